@@ -1,0 +1,319 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (build container only).
+
+TEST INFRASTRUCTURE.  Imports the reference's unmodified Util.py / Losses.py /
+Model.py from /root/reference on CPU and records input/output vectors.  The
+reference never travels to the GPU box; only the vectors written here do.
+
+Two import-time obstacles are bridged before the import, exactly as recorded in
+SURVEY.md section 8(c):
+  * ``torchvision`` is not installed -> an in-memory module object whose
+    ``transforms.*`` are no-ops and whose ``models.vgg16`` returns the standard
+    VGG-16 'D' layer list built from ``torch.nn`` (seeded random weights; the
+    pretrained weights are a network download and are not available).  No
+    arithmetic on the hot path comes from torchvision: convolution, pooling,
+    ReLU are ``torch.nn``.
+  * ``DataLists.call_on_load`` reads VOC files that do not exist -> a module
+    object with empty lists (plus one generated PNG so that
+    ``Losses.inference`` can read an image size, Losses.py:87).
+Consequently network parity is pinned on seeded random weights and
+"torchvision VGG-16 layout" itself is unpinned.
+
+Usage (build container):  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+"""
+import contextlib
+import io
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, "tests", "golden")
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, HERE)
+import ssd_oracle as O  # noqa: E402
+
+IMG_W, IMG_H = 500, 375
+IMG_PATH = "/tmp/_ssd_golden_blank.png"
+
+
+def _install_stand_ins():
+    tv = types.ModuleType("torchvision")
+    tr = types.ModuleType("torchvision.transforms")
+    ft = types.ModuleType("torchvision.transforms.functional")
+    md = types.ModuleType("torchvision.models")
+
+    class _NoOp:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, x):
+            return x
+    for n in ("Compose", "Resize", "ToTensor", "Normalize"):
+        setattr(tr, n, _NoOp)
+
+    def vgg16(pretrained=False, **kw):
+        cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"]
+        layers, cin = [], 3
+        for v in cfg:
+            if v == "M":
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+            else:
+                layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+                cin = v
+        m = nn.Module()
+        m.features = nn.Sequential(*layers)
+        m.avgpool = nn.AdaptiveAvgPool2d((7, 7))
+        m.classifier = nn.Sequential(nn.Linear(512 * 7 * 7, 4096), nn.ReLU(True), nn.Dropout(),
+                                     nn.Linear(4096, 4096), nn.ReLU(True), nn.Dropout(),
+                                     nn.Linear(4096, 1000))
+        return m
+    md.vgg16 = vgg16
+    tr.functional = ft
+    tv.transforms = tr
+    tv.models = md
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tr,
+                        "torchvision.transforms.functional": ft, "torchvision.models": md})
+    from PIL import Image
+    Image.new("RGB", (IMG_W, IMG_H)).save(IMG_PATH)
+    dl = types.ModuleType("DataLists")
+    dl.call_on_load = lambda: None
+    for n in ("all_images", "all_multi_labels", "all_multi_bboxes", "all_difficulties"):
+        setattr(dl, n, {"train": [IMG_PATH], "test": [IMG_PATH]})
+    sys.modules["DataLists"] = dl
+    sys.path.insert(0, REF)
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        yield
+
+
+# ---------------------------------------------------------------------------
+# synthetic ground truth -- numpy PCG64 is stable across
+# platforms, so tests regenerate inputs from the seed instead of storing them.
+# ---------------------------------------------------------------------------
+def synth_gt(rng, bs, max_extra=7):
+    boxes, classes = [], []
+    for _ in range(bs):
+        n = 1 + min(int(rng.poisson(1.4)), max_extra)
+        x1 = rng.uniform(0, .6, n); y1 = rng.uniform(0, .6, n)
+        w = rng.uniform(.08, .6, n); h = rng.uniform(.08, .6, n)
+        b = np.stack([x1, y1, np.minimum(x1 + w, 1.), np.minimum(y1 + h, 1.)], 1).astype(np.float32)
+        boxes.append(b)
+        classes.append(rng.integers(0, 20, n).astype(np.float32))
+    return boxes, classes
+
+
+def edge_cases(pri_xyxy):
+    """Hand-made matching cases for the tie rules."""
+    f = np.float32
+    cases = []
+    # 1. a tiny GT that overlaps nothing by >= .5, next to a large one (forced match only)
+    cases.append(([np.array([[.30, .30, .33, .34], [.1, .1, .8, .9]], f)], [np.array([3., 7.], f)]))
+    # 2. duplicate GT boxes with different classes (ties: first index for per-prior argmax,
+    #    last GT wins the forced match)
+    cases.append(([np.array([[.2, .2, .6, .7], [.2, .2, .6, .7], [.5, .5, .9, .9]], f)],
+                  [np.array([1., 2., 3.], f)]))
+    # 3. two different GT whose best prior is the same prior (collision -> last wins)
+    p = pri_xyxy[8000]
+    cases.append(([np.stack([p + f(.004), p - f(.003)]).astype(f).clip(0, 1)], [np.array([5., 9.], f)]))
+    # 4. boxes touching / spanning the image border, and a whole-image box
+    cases.append(([np.array([[0., 0., .25, .3], [.7, .65, 1., 1.], [0., 0., 1., 1.]], f)],
+                  [np.array([0., 19., 10.], f)]))
+    # 5. GT exactly equal to prior boxes (IoU == 1 exactly) in a 2-image batch;
+    #    second image's GT is disjoint from most priors (all-zero IoU columns)
+    cases.append(([pri_xyxy[[100, 6000]].clip(0, 1).astype(f), np.array([[.9, .9, .95, .95]], f)],
+                  [np.array([4., 6.], f), np.array([11.], f)]))
+    # 6. many GT in one image, one in the other (ragged batch)
+    rng = np.random.default_rng(77)
+    b, c = synth_gt(rng, 1, max_extra=7)
+    many = np.concatenate([b[0]] + [synth_gt(rng, 1)[0][0] for _ in range(4)])[:12]
+    cases.append(([many, np.array([[.4, .4, .6, .6]], f)],
+                  [rng.integers(0, 20, many.shape[0]).astype(f), np.array([2.], f)]))
+    return cases
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    _install_stand_ins()
+    with quiet():
+        import Util as RU          # noqa: F401  (reference)
+        import Losses as RL        # reference
+        import Model as RM         # reference
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+
+    # ---- 1. priors ---------------------------------------------------------
+    pri = RL.ancs_xywh.numpy().astype(np.float32)
+    pri_xyxy = RL.ancs_xyxy.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "priors_ssd300.npz"), cxcywh=pri, xyxy=pri_xyxy)
+
+    # ---- 2. box coders + IoU -----------------------------------------------
+    rng = np.random.default_rng(5)
+    a = np.sort(rng.uniform(0, 1, (40, 2, 2)).astype(np.float32), axis=1).reshape(40, 4)[:, [0, 1, 2, 3]]
+    a = np.stack([np.minimum(a[:, 0], a[:, 2]), np.minimum(a[:, 1], a[:, 3]),
+                  np.maximum(a[:, 0], a[:, 2]) + np.float32(.01), np.maximum(a[:, 1], a[:, 3]) + np.float32(.01)], 1)
+    sub = pri_xyxy[rng.integers(0, 8732, 300)]
+    iou = RU.get_jaccard_tensor1(torch.from_numpy(a), torch.from_numpy(sub)).numpy()
+    g = rng.standard_normal((300, 4)).astype(np.float32)
+    psub = pri[rng.integers(0, 8732, 300)]
+    dec = RU.gcxgcy_to_cxcy(torch.from_numpy(g), torch.from_numpy(psub)).numpy()
+    enc = RU.get_offsets_coords(torch.from_numpy(dec), torch.from_numpy(psub)).numpy()
+    np.savez_compressed(os.path.join(GOLD, "boxmath.npz"), a=a, b=sub, iou=iou, g=g, pri=psub, dec=dec,
+                        enc=enc, a_xywh=RU.xyxy_to_xywh(torch.from_numpy(a)).numpy(),
+                        a_back=RU.xywh_to_xyxy(RU.xyxy_to_xywh(torch.from_numpy(a))).numpy())
+
+    # ---- 3. matching + loss cases --------------------------------------------
+    captured = {}
+    orig_enc = RL.get_offsets_coords
+
+    def spy(cxcy, priors_cxcy):                    # wraps, does not replace, Util.py:98-102
+        out = orig_enc(cxcy, priors_cxcy)
+        captured["gt"] = cxcy.detach().clone().numpy()
+        captured["enc"] = out.detach().clone().numpy()
+        return out
+    RL.get_offsets_coords = spy
+
+    cases = [(b, c, 1000 + i) for i, (b, c) in enumerate(edge_cases(pri_xyxy))]
+    for i, bs in enumerate([1, 2, 2, 3, 4, 4, 8, 8, 2, 3, 5, 6]):
+        r = np.random.default_rng(2000 + i)
+        b, c = synth_gt(r, bs)
+        cases.append((b, c, 2000 + i))
+    store = {"n_cases": np.int64(len(cases))}
+    for ci, (boxes, classes, seed) in enumerate(cases):
+        bs = len(boxes)
+        r = np.random.default_rng(seed)
+        loc = r.standard_normal((bs, 8732, 4), dtype=np.float32)
+        conf = (r.standard_normal((bs, 8732, 21), dtype=np.float32) * np.float32(2.0))
+        lt = torch.from_numpy(loc).requires_grad_(True)
+        ct = torch.from_numpy(conf).requires_grad_(True)
+        with quiet():
+            l_loc, l_conf = RL.ssd((lt, ct), [torch.from_numpy(c) for c in classes],
+                                   [torch.from_numpy(b) for b in boxes])
+        cls = RL.obj_forEach_prior___.numpy().astype(np.int8)        # Losses.py:172-173
+        (l_loc + l_conf).backward()
+        dloc = lt.grad.numpy(); dconf = ct.grad.numpy()
+        rows = np.random.default_rng(seed + 7).integers(0, bs * 8732, 400)
+        touched = np.nonzero(np.abs(dconf.reshape(-1, 21)).sum(1) > 0)[0]
+        p = f"c{ci}_"
+        store[p + "seed"] = np.int64(seed)
+        store[p + "counts"] = np.asarray([b.shape[0] for b in boxes], np.int64)
+        store[p + "boxes"] = np.concatenate(boxes).astype(np.float32)
+        store[p + "classes"] = np.concatenate(classes).astype(np.float32)
+        store[p + "cls"] = cls
+        store[p + "gt_pos"] = captured["gt"].astype(np.float32)
+        store[p + "enc_pos"] = captured["enc"].astype(np.float32)
+        store[p + "loc_loss"] = np.float32(l_loc.item())
+        store[p + "conf_loss"] = np.float32(l_conf.item())
+        store[p + "dloc_pos"] = dloc[cls != 20].astype(np.float32)
+        store[p + "dloc_abs_sum"] = np.float64(np.abs(dloc).astype(np.float64).sum())
+        store[p + "dconf_rows"] = rows
+        store[p + "dconf_vals"] = dconf.reshape(-1, 21)[rows].astype(np.float32)
+        store[p + "dconf_touched"] = touched.astype(np.int64)
+        store[p + "dconf_abs_sum"] = np.float64(np.abs(dconf).astype(np.float64).sum())
+    RL.get_offsets_coords = orig_enc
+    np.savez_compressed(os.path.join(GOLD, "match_loss.npz"), **store)
+
+    # ---- 4. decode + NMS cases -------------------------------------------------
+    store = {}
+    n_ok = 0
+    seed = 3000
+    want = [dict(scale=3.0, top_k=200), dict(scale=3.0, top_k=200), dict(scale=2.0, top_k=200),
+            dict(scale=4.0, top_k=50), dict(scale=1.2, top_k=200), dict(scale=0.1, top_k=200)]
+    while n_ok < len(want):
+        cfg = want[n_ok]
+        r = np.random.default_rng(seed)
+        seed += 1
+        l_ = (r.standard_normal((8732, 4), dtype=np.float32) * np.float32(0.5))
+        c_ = (r.standard_normal((8732, 21), dtype=np.float32) * np.float32(cfg["scale"]))
+        # margins: keep every prob away from the score threshold and every candidate-pair IoU away
+        # from the NMS threshold, so ulp-level differences in exp() cannot flip a decision.
+        pr = torch.softmax(torch.from_numpy(c_).double(), 1).numpy()
+        if np.min(np.abs(pr[:, :20] - 0.2)) < 2e-6:
+            continue
+        bx = O.xywh_to_xyxy(O.decode_offsets(l_, pri))
+        ok = True
+        for c in range(20):
+            idx = np.nonzero(pr[:, c] >= 0.2)[0]
+            if idx.size < 2:
+                continue
+            sp = np.sort(pr[idx, c])
+            if np.min(np.diff(sp)) < 1e-7:
+                ok = False; break
+            io = O.iou_matrix(bx[idx], bx[idx]).astype(np.float64)
+            if np.min(np.abs(io - 0.45)) < 2e-6:
+                ok = False; break
+        if not ok:
+            continue
+        with quiet():
+            out = RL.inference(torch.from_numpy(l_), torch.from_numpy(c_), 0, top_k=cfg["top_k"],
+                               phase="train", toDraw=False)
+        p = f"n{n_ok}_"
+        store[p + "seed"] = np.int64(seed - 1)
+        store[p + "scale"] = np.float32(cfg["scale"])
+        store[p + "top_k"] = np.int64(cfg["top_k"])
+        if isinstance(out[0], list):
+            store[p + "boxes"] = np.zeros((0, 4), np.float32)
+            store[p + "classes"] = np.zeros((0,), np.int64)
+            store[p + "probs"] = np.zeros((0,), np.float32)
+        else:
+            store[p + "boxes"] = out[0].numpy().astype(np.float32)
+            store[p + "classes"] = out[1].numpy().astype(np.int64)
+            store[p + "probs"] = out[2].numpy().astype(np.float32)
+        n_ok += 1
+    store["n_cases"] = np.int64(n_ok)
+    store["img_wh"] = np.asarray([IMG_W, IMG_H], np.int64)
+    np.savez_compressed(os.path.join(GOLD, "nms.npz"), **store)
+
+    # ---- 5. network forward / train step ----------------------------------------
+    params = O.ssd300_random_params(seed=0)
+    with quiet():
+        net = RM.SSD_300()
+    names = dict(net.named_parameters())
+    missing = [k for k in params if k not in names]
+    assert not missing, missing                     # our names == reference names
+    with torch.no_grad():
+        for k, v in params.items():
+            assert tuple(names[k].shape) == tuple(v.shape), (k, names[k].shape, v.shape)
+            names[k].copy_(v)
+    net.train()
+    r = np.random.default_rng(4242)
+    bs = 2
+    x = r.standard_normal((bs, 3, 300, 300), dtype=np.float32)
+    boxes, classes = synth_gt(np.random.default_rng(4243), bs)
+    loc, conf = net(torch.from_numpy(x))
+    with quiet():
+        l_loc, l_conf = RL.ssd((loc, conf), [torch.from_numpy(c) for c in classes],
+                               [torch.from_numpy(b) for b in boxes])
+    net.zero_grad()
+    (l_loc + l_conf).backward()
+    pidx = np.random.default_rng(4244).integers(0, 8732, 512)
+    store = dict(x_seed=np.int64(4242), gt_seed=np.int64(4243), param_seed=np.int64(0), bs=np.int64(bs),
+                 prior_idx=pidx, loc_s=loc.detach().numpy()[:, pidx], conf_s=conf.detach().numpy()[:, pidx],
+                 loc_sum=np.float64(loc.detach().double().sum()), loc_abs=np.float64(loc.detach().double().abs().sum()),
+                 conf_sum=np.float64(conf.detach().double().sum()), conf_abs=np.float64(conf.detach().double().abs().sum()),
+                 loc_loss=np.float32(l_loc.item()), conf_loss=np.float32(l_conf.item()))
+    gnames = sorted(k for k in params)
+    store["grad_names"] = np.asarray(gnames)
+    store["grad_l2"] = np.asarray([float(names[k].grad.double().norm()) for k in gnames], np.float64)
+    store["grad_sum"] = np.asarray([float(names[k].grad.double().sum()) for k in gnames], np.float64)
+    for k in ("model.features.0.weight", "model.features.21.bias", "c_11_cl.weight", "seq10.2.weight",
+              "rescaling_conv_4_3", "c_4_bb.bias"):
+        store["g_" + k] = names[k].grad.numpy().astype(np.float32)
+    n_named = len(list(net.named_parameters()))
+    store["ref_named_parameters"] = np.int64(n_named)
+    np.savez_compressed(os.path.join(GOLD, "network.npz"), **store)
+    print("golden fixtures written to", GOLD)
+    for f in sorted(os.listdir(GOLD)):
+        print(f"  {f}: {os.path.getsize(os.path.join(GOLD, f))} bytes")
+
+
+if __name__ == "__main__":
+    main()

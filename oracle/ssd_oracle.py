@@ -1,0 +1,413 @@
+"""CPU oracle for the SSD300 hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a CPU restatement (numpy for the box / index arithmetic, plain
+torch-CPU ops for the floating-point network and the log-softmax) of the
+algorithms on the reference's hot path.  It exists so that the HIP kernels in
+``objectdetection_ssd_amd/csrc`` can be checked on the GPU box, where
+``/root/reference`` does not exist.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+it; the product package never does.
+
+Pinning: ``oracle/gen_golden.py`` runs the reference's own ``Util.py`` /
+``Losses.py`` / ``Model.py`` (imported unmodified in the build container) on
+seeded inputs and commits the input/output vectors under ``tests/golden``;
+``tests/test_oracle_golden.py`` checks every function here against them.
+The reference has no tests or golden vectors of its own.
+
+Every function cites the reference file:line it restates (paths relative to
+the reference repository root).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+P_SSD300 = 8732
+N_CLASSES = 21          # 20 VOC classes + background
+BG_CLASS = 20           # Losses.py:171,179 -- background is the LAST class
+
+# ---------------------------------------------------------------------------
+# priors  (Util.py:105-137)
+# ---------------------------------------------------------------------------
+_GRIDS = (38, 19, 10, 5, 3, 1)
+_SCALES = (0.1, 0.2, 0.375, 0.55, 0.725, 0.9)
+# literal .333, not 1/3  (Util.py:114-116)
+_RATIOS = ((1., 2., .5), (1., 2., 3., .5, .333), (1., 2., 3., .5, .333),
+           (1., 2., 3., .5, .333), (1., 2., .5), (1., 2., .5))
+ANCHORS_PER_CELL = (4, 6, 6, 6, 4, 4)
+SCALE_OFFSETS = (0, 5776, 7942, 8542, 8692, 8728)
+
+
+def create_priors_ssd300() -> np.ndarray:
+    """(8732,4) f32 cx,cy,w,h.  Util.py:105-137.
+
+    Row-major over the grid (cy outer, cx inner, Util.py:122-126); for every
+    ratio ``a`` a box (s*sqrt(a), s/sqrt(a)); immediately after a == 1 the
+    extra square box of scale sqrt(s_k*s_{k+1}) (1.0 for the last grid).
+    Computed in python doubles, rounded to f32, then clamped to [0,1] on
+    cx,cy,w,h (Util.py:135-136).
+    """
+    rows = []
+    for k, g in enumerate(_GRIDS):
+        s = _SCALES[k]
+        s_next = math.sqrt(s * _SCALES[k + 1]) if k + 1 < len(_SCALES) else 1.0
+        for i in range(g):
+            for j in range(g):
+                cx = (j + 0.5) / float(g)
+                cy = (i + 0.5) / float(g)
+                for a in _RATIOS[k]:
+                    rows.append((cx, cy, s * math.sqrt(a), s / math.sqrt(a)))
+                    if a == 1.:
+                        rows.append((cx, cy, s_next, s_next))
+    pri = np.asarray(rows, dtype=np.float64).astype(np.float32)
+    np.clip(pri, 0.0, 1.0, out=pri)
+    assert pri.shape == (P_SSD300, 4)
+    return pri
+
+
+def xywh_to_xyxy(b: np.ndarray) -> np.ndarray:
+    """Util.py:93-96 (f32: c - wh/2, c + wh/2)."""
+    b = np.asarray(b, dtype=np.float32)
+    half = b[:, 2:] / np.float32(2.)
+    return np.concatenate([b[:, :2] - half, b[:, :2] + half], axis=1).astype(np.float32)
+
+
+def xyxy_to_xywh(b: np.ndarray) -> np.ndarray:
+    """Util.py:57-63: ((x2+x1)/2, (y2+y1)/2, x2-x1, y2-y1) in f32."""
+    b = np.asarray(b, dtype=np.float32)
+    x1, y1, x2, y2 = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
+    two = np.float32(2.)
+    return np.stack([(x2 + x1) / two, (y2 + y1) / two, x2 - x1, y2 - y1], axis=1).astype(np.float32)
+
+
+def encode_offsets(cxcywh: np.ndarray, pri: np.ndarray) -> np.ndarray:
+    """Util.py:98-102 get_offsets_coords: (c - pc)/(pwh/10), log(wh/pwh)*5."""
+    c = np.asarray(cxcywh, np.float32)
+    p = np.asarray(pri, np.float32)
+    g_c = (c[:, :2] - p[:, :2]) / (p[:, 2:] / np.float32(10))
+    g_wh = np.log(c[:, 2:] / p[:, 2:]).astype(np.float32) * np.float32(5)
+    return np.concatenate([g_c, g_wh], axis=1).astype(np.float32)
+
+
+def decode_offsets(g: np.ndarray, pri: np.ndarray) -> np.ndarray:
+    """Util.py:86-91 gcxgcy_to_cxcy: g_c*pwh/10 + pc, exp(g_wh/5)*pwh."""
+    g = np.asarray(g, np.float32)
+    p = np.asarray(pri, np.float32)
+    c = g[:, :2] * p[:, 2:] / np.float32(10) + p[:, :2]
+    wh = np.exp(g[:, 2:] / np.float32(5)).astype(np.float32) * p[:, 2:]
+    return np.concatenate([c, wh], axis=1).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------
+# IoU (Util.py:252-265 find_intersection, Util.py:288-301 get_jaccard_tensor1)
+# ---------------------------------------------------------------------------
+def iou_matrix(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """(n1,4),(n2,4) xyxy -> (n1,n2) f32.
+
+    inter = clamp(min(hi) - max(lo), 0) product; area = (x2-x1)*(y2-y1);
+    iou = inter / ((area1 + area2) - inter); no epsilon (0/0 -> NaN).
+    Only +,-,*,/,min,max: reproducible bit-for-bit in IEEE f32 as long as no
+    fused multiply-add is formed.
+    """
+    a = np.asarray(a, np.float32)
+    b = np.asarray(b, np.float32)
+    lo = np.maximum(a[:, None, :2], b[None, :, :2])
+    hi = np.minimum(a[:, None, 2:], b[None, :, 2:])
+    d = np.maximum(hi - lo, np.float32(0))
+    inter = d[:, :, 0] * d[:, :, 1]
+    a1 = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    a2 = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    union = (a1[:, None] + a2[None, :]) - inter
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return (inter / union).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------
+# matching (Losses.py:119-134 ssd, Losses.py:150-179 ssd1_)
+# ---------------------------------------------------------------------------
+def match_priors(boxes: Sequence[np.ndarray], classes: Sequence[np.ndarray],
+                 pri_xyxy: np.ndarray):
+    """Batched prior<->GT matching.
+
+    boxes[i]: (n_i,4) f32 xyxy in 0..1, classes[i]: (n_i,) values 0..19.
+    Returns obj (bs,P) int64 = GLOBAL index into cat(boxes); cls (bs,P) int64
+    (20 = background); overlap (bs,P) f32 (after the forced 1.0).
+
+    * best GT per prior is taken over the image's own rows only, first index
+      on ties (Losses.py:152-155);
+    * best prior per GT is taken over all priors, first index on ties
+      (Losses.py:157);
+    * forced matches are written in GT order so on collisions the LAST GT of
+      the image wins (Losses.py:164-167);
+    * threshold: overlap < 0.5 -> background (Losses.py:171).
+    An image without GT makes the reference raise (max over an empty dim); so
+    do we.
+    """
+    bs = len(boxes)
+    counts = [int(np.asarray(b).shape[0]) for b in boxes]
+    if any(c == 0 for c in counts):
+        raise ValueError("every image needs at least one ground-truth box")
+    start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    allb = np.concatenate([np.asarray(b, np.float32).reshape(-1, 4) for b in boxes], 0)
+    allc = np.concatenate([np.asarray(c, np.float32).reshape(-1) for c in classes], 0)
+    iou = iou_matrix(allb, pri_xyxy)                       # (N,P)
+    P = pri_xyxy.shape[0]
+    obj = np.zeros((bs, P), np.int64)
+    overlap = np.zeros((bs, P), np.float32)
+    prior_for_obj = np.argmax(iou, axis=1)                 # first index on ties
+    for i in range(bs):
+        s, e = start[i], start[i + 1]
+        sub = iou[s:e]
+        obj[i] = np.argmax(sub, axis=0) + s                # first index on ties
+        overlap[i] = sub.max(axis=0)
+        for k in range(s, e):                              # sequential: last k wins
+            obj[i, prior_for_obj[k]] = k
+            overlap[i, prior_for_obj[k]] = np.float32(1.)
+    cls = allc[obj].astype(np.float32)
+    cls[overlap < np.float32(0.5)] = BG_CLASS
+    return obj, cls.astype(np.int64), overlap, allb, start
+
+
+def _log_softmax_rows(x: np.ndarray) -> np.ndarray:
+    import torch
+    return torch.log_softmax(torch.from_numpy(np.ascontiguousarray(x, np.float32)), dim=-1).numpy()
+
+
+def multibox_loss(loc: np.ndarray, conf: np.ndarray, boxes, classes,
+                  pri_cxcywh: np.ndarray | None = None, neg_pos_ratio: int = 3,
+                  want_grads: bool = True):
+    """Losses.py:119-199.  Returns dict with loc_loss, conf_loss (f32 scalars),
+    and -- restated analytically, checked against the reference's autograd in
+    gen_golden.py -- dloc, dconf = d(loc_loss + conf_loss)/d(loc|conf).
+
+    loc_loss  = mean over ALL n_pos*4 elements of |pred - g|   (nn.L1Loss, :147,:182)
+    conf_loss = (sum of top-(3*n_pos_i) negative CE per image + sum positive CE) / n_pos_total  (:184-197)
+    """
+    loc = np.asarray(loc, np.float32)
+    conf = np.asarray(conf, np.float32)
+    bs, P, C = conf.shape
+    if pri_cxcywh is None:
+        pri_cxcywh = create_priors_ssd300()
+    pri_xyxy = xywh_to_xyxy(pri_cxcywh)
+    obj, cls, overlap, allb, _ = match_priors(boxes, classes, pri_xyxy)
+    pos = cls != BG_CLASS
+    n_pos = int(pos.sum())
+    gt_cxcywh = xyxy_to_xywh(allb)[obj]                   # (bs,P,4)
+    pri_rep = np.broadcast_to(pri_cxcywh[None], (bs, P, 4))
+    g = encode_offsets(gt_cxcywh[pos], pri_rep[pos])     # (n_pos,4)
+    diff = loc[pos] - g
+    loc_loss = np.float32(np.abs(diff).astype(np.float64).sum() / (n_pos * 4))
+
+    logp = _log_softmax_rows(conf.reshape(-1, C)).reshape(bs, P, C)
+    cce = -np.take_along_axis(logp, cls[..., None], axis=2)[..., 0]   # (bs,P)
+    neg = cce.copy()
+    neg[pos] = 0.
+    k = neg_pos_ratio * pos.sum(axis=1)
+    order = np.argsort(-neg, axis=1, kind="stable")
+    hn_mask = np.zeros_like(pos)
+    hn_sum = 0.0
+    for i in range(bs):
+        sel = order[i, :min(int(k[i]), P)]
+        hn_mask[i, sel] = True
+        hn_sum += float(neg[i, sel].astype(np.float64).sum())
+    conf_loss = np.float32((hn_sum + float(cce[pos].astype(np.float64).sum())) / n_pos)
+    out = dict(loc_loss=loc_loss, conf_loss=conf_loss, obj=obj, cls=cls, pos=pos,
+               n_pos=n_pos, cce=cce, hn_mask=hn_mask, enc=g, overlap=overlap)
+    if want_grads:
+        dloc = np.zeros_like(loc)
+        dloc[pos] = np.sign(diff) / np.float32(n_pos * 4)
+        sel = pos | hn_mask
+        sm = np.exp(logp)
+        onehot = np.zeros_like(sm)
+        np.put_along_axis(onehot, cls[..., None], 1.0, axis=2)
+        dconf = ((sm - onehot) * sel[..., None] / np.float32(n_pos)).astype(np.float32)
+        out.update(dloc=dloc.astype(np.float32), dconf=dconf)
+    return out
+
+
+# ---------------------------------------------------------------------------
+# decode + per-class NMS + top-k (Losses.py:11-98 inference)
+# ---------------------------------------------------------------------------
+def decode_nms(l_: np.ndarray, c_: np.ndarray, w: float, h: float, top_k: int = 200,
+               min_score: float = 0.2, iou_threshold: float = 0.45,
+               pri_cxcywh: np.ndarray | None = None):
+    """Returns (boxes (K,4) f32 pixels xyxy, classes (K,) int64, probs (K,) f32,
+    prior_ids (K,) int64).  K == 0 -> empty arrays (the reference returns
+    three empty lists, Losses.py:62-63).
+
+    Per class 0..19 (never background, :27): candidates prob >= min_score (:32);
+    sorted by prob descending, lower prior index first on ties (:38, CPU
+    behaviour); greedy suppression with IoU >= iou_threshold (:44-55); kept
+    boxes concatenated class-major (:71-73); only if more than top_k survive,
+    a global descending sort keeps the first top_k (:77-81); boxes scaled by
+    (w,h,w,h) (:89).
+    """
+    if pri_cxcywh is None:
+        pri_cxcywh = create_priors_ssd300()
+    l_ = np.asarray(l_, np.float32)
+    c_ = np.asarray(c_, np.float32)
+    boxes_cxcywh = decode_offsets(l_, pri_cxcywh)
+    import torch
+    probs = torch.softmax(torch.from_numpy(c_), dim=1).numpy()
+    kb, kc, kp, ki = [], [], [], []
+    for c in range(N_CLASSES - 1):
+        pc = probs[:, c]
+        cand = np.nonzero(pc >= np.float32(min_score))[0]
+        if cand.size == 0:
+            continue
+        order = cand[np.argsort(-pc[cand], kind="stable")]
+        bx = xywh_to_xyxy(boxes_cxcywh[order])
+        iou = iou_matrix(bx, bx)
+        n = order.size
+        suppressed = np.zeros(n, bool)
+        for i in range(n):
+            if suppressed[i]:
+                continue
+            suppressed |= iou[i] >= np.float32(iou_threshold)
+            suppressed[i] = False
+        keep = ~suppressed
+        kb.append(bx[keep]); kp.append(pc[order][keep]); ki.append(order[keep])
+        kc.append(np.full(int(keep.sum()), c, np.int64))
+    if not kb:
+        z = np.zeros
+        return z((0, 4), np.float32), z((0,), np.int64), z((0,), np.float32), z((0,), np.int64)
+    kb = np.concatenate(kb); kc = np.concatenate(kc); kp = np.concatenate(kp); ki = np.concatenate(ki)
+    if kb.shape[0] > top_k:
+        o = np.argsort(-kp, kind="stable")[:top_k]
+        kb, kc, kp, ki = kb[o], kc[o], kp[o], ki[o]
+    scale = np.asarray([w, h, w, h], np.float32)[None]
+    return (kb * scale).astype(np.float32), kc, kp.astype(np.float32), ki
+
+
+# ---------------------------------------------------------------------------
+# SSD_300 network (Model.py:128-235) as a functional torch-CPU forward
+# ---------------------------------------------------------------------------
+# (name, cin, cout, k, stride, pad, dil, relu) in execution order; pools are
+# interleaved by name.  VGG indices follow torchvision's vgg16 'D' features
+# list that Model.py:136-141 slices.
+VGG_CONV_IDX = (0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28)
+VGG_CH = (3, 64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512)
+HEADS = (("c_4", 512, 4), ("c_7", 1024, 6), ("c_8", 512, 6),
+         ("c_9", 256, 6), ("c_10", 256, 4), ("c_11", 256, 4))
+AUX = (("seq8", 1024, 256, 512, 2, 1), ("seq9", 512, 128, 256, 2, 1),
+       ("seq10", 256, 128, 256, 1, 0), ("seq11", 256, 128, 256, 1, 0))
+
+
+def ssd300_param_shapes() -> Dict[str, Tuple[int, ...]]:
+    """Names follow the reference's named_parameters() for the tensors the
+    forward actually uses."""
+    sh: Dict[str, Tuple[int, ...]] = {"rescaling_conv_4_3": (1, 512, 1, 1)}
+    for li, idx in enumerate(VGG_CONV_IDX):
+        sh[f"model.features.{idx}.weight"] = (VGG_CH[li + 1], VGG_CH[li], 3, 3)
+        sh[f"model.features.{idx}.bias"] = (VGG_CH[li + 1],)
+    sh["conv_fc6.weight"] = (1024, 512, 3, 3); sh["conv_fc6.bias"] = (1024,)
+    sh["conv_fc7.weight"] = (1024, 1024, 1, 1); sh["conv_fc7.bias"] = (1024,)
+    for name, cin, mid, cout, _, _ in AUX:
+        sh[f"{name}.0.weight"] = (mid, cin, 1, 1); sh[f"{name}.0.bias"] = (mid,)
+        sh[f"{name}.2.weight"] = (cout, mid, 3, 3); sh[f"{name}.2.bias"] = (cout,)
+    for name, cin, a in HEADS:
+        sh[f"{name}_bb.weight"] = (4 * a, cin, 3, 3); sh[f"{name}_bb.bias"] = (4 * a,)
+        sh[f"{name}_cl.weight"] = (21 * a, cin, 3, 3); sh[f"{name}_cl.bias"] = (21 * a,)
+    return sh
+
+
+def ssd300_random_params(seed: int = 0):
+    """Seeded parameters with O(1) activations (He-normal fan-in for the ReLU
+    stack, Xavier-uniform + zero bias for aux/head convs as Model.py:190-200,
+    rescale 20 as Model.py:133).  Pretrained VGG weights are not available
+    offline, so parity is on these."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for name, shape in ssd300_param_shapes().items():
+        if name == "rescaling_conv_4_3":
+            t = torch.full(shape, 20.0)
+        elif name.endswith(".bias"):
+            backbone = name.startswith("model.") or name.startswith("conv_fc")
+            t = (torch.randn(shape, generator=g) * 0.05) if backbone else torch.zeros(shape)
+        else:
+            fan_in = shape[1] * shape[2] * shape[3]
+            fan_out = shape[0] * shape[2] * shape[3]
+            if name.startswith("model.") or name.startswith("conv_fc"):
+                t = torch.randn(shape, generator=g) * math.sqrt(2.0 / fan_in)
+            else:
+                bound = math.sqrt(6.0 / (fan_in + fan_out))
+                t = (torch.rand(shape, generator=g) * 2 - 1) * bound
+        out[name] = t.float()
+    return out
+
+
+def ssd300_forward(x, params, return_features: bool = False):
+    """x (bs,3,300,300) f32 NCHW torch tensor -> loc (bs,8732,4), conf (bs,8732,21).
+
+    Model.py:203-235: conv1_1..conv4_3 with 2x2/s2 pools (third one
+    ceil_mode, :137); L2-norm over channels * gamma, no epsilon (:206-209);
+    pool4 2x2/s2, conv5_x, pool5 3x3/s1/p1 (:140-143); fc6 3x3 dilation 4
+    padding 4, fc7 1x1 (:149,:159); aux blocks 1x1 -> 3x3 (s2p1,s2p1,s1p0,s1p0)
+    (:163-166); six head pairs, NHWC-flattened and concatenated in order
+    4,7,8,9,10,11 (:212-235).
+    """
+    import torch
+    import torch.nn.functional as F
+    feats = {}
+    h = x
+    pools_after = {2: False, 4: False, 7: True, 10: False}   # conv ordinal -> ceil_mode
+    for li, idx in enumerate(VGG_CONV_IDX):
+        h = F.relu(F.conv2d(h, params[f"model.features.{idx}.weight"],
+                            params[f"model.features.{idx}.bias"], padding=1))
+        n = li + 1
+        if n == 10:
+            feats["conv4_3"] = h
+        if n in pools_after:
+            h = F.max_pool2d(h, 2, 2, ceil_mode=pools_after[n])
+    h = F.max_pool2d(h, 3, 1, padding=1)
+    c43 = feats["conv4_3"]
+    norm = c43.pow(2).sum(dim=1, keepdim=True).sqrt()
+    c43n = c43 / norm * params["rescaling_conv_4_3"]
+    h = F.relu(F.conv2d(h, params["conv_fc6.weight"], params["conv_fc6.bias"], padding=4, dilation=4))
+    h = F.relu(F.conv2d(h, params["conv_fc7.weight"], params["conv_fc7.bias"]))
+    srcs = [c43n, h]
+    for name, _, _, _, stride, pad in AUX:
+        h = F.relu(F.conv2d(h, params[f"{name}.0.weight"], params[f"{name}.0.bias"]))
+        h = F.relu(F.conv2d(h, params[f"{name}.2.weight"], params[f"{name}.2.bias"], stride=stride, padding=pad))
+        srcs.append(h)
+    bs = x.shape[0]
+    locs, confs = [], []
+    for (name, _, _), s in zip(HEADS, srcs):
+        bb = F.conv2d(s, params[f"{name}_bb.weight"], params[f"{name}_bb.bias"], padding=1)
+        cl = F.conv2d(s, params[f"{name}_cl.weight"], params[f"{name}_cl.bias"], padding=1)
+        locs.append(bb.permute(0, 2, 3, 1).reshape(bs, -1, 4))
+        confs.append(cl.permute(0, 2, 3, 1).reshape(bs, -1, 21))
+    loc, conf = torch.cat(locs, 1), torch.cat(confs, 1)
+    if return_features:
+        return loc, conf, srcs
+    return loc, conf
+
+
+def multibox_loss_torch(loc, conf, boxes, classes, pri_cxcywh=None):
+    """Differentiable torch-CPU form of multibox_loss (same selection logic,
+    matching done by match_priors) used as the CPU train-step baseline."""
+    import torch
+    import torch.nn.functional as F
+    if pri_cxcywh is None:
+        pri_cxcywh = create_priors_ssd300()
+    bs, P, C = conf.shape
+    obj, cls, _, allb, _ = match_priors([b.detach().cpu().numpy() for b in boxes],
+                                        [c.detach().cpu().numpy() for c in classes],
+                                        xywh_to_xyxy(pri_cxcywh))
+    pos_np = cls != BG_CLASS
+    g = encode_offsets(xyxy_to_xywh(allb)[obj][pos_np],
+                       np.broadcast_to(pri_cxcywh[None], (bs, P, 4))[pos_np])
+    pos = torch.from_numpy(pos_np)
+    cls_t = torch.from_numpy(cls)
+    loc_loss = (loc[pos] - torch.from_numpy(g)).abs().mean()
+    cce = F.cross_entropy(conf.reshape(-1, C), cls_t.reshape(-1), reduction="none").view(bs, P)
+    neg = cce.clone()
+    neg[pos] = 0.
+    neg_sorted, _ = neg.sort(dim=1, descending=True)
+    k = 3 * pos.sum(dim=1, keepdim=True)
+    hn = torch.arange(P)[None, :] < k
+    conf_loss = (neg_sorted[hn].sum() + cce[pos].sum()) / pos.sum().float()
+    return loc_loss, conf_loss

@@ -1,0 +1,116 @@
+"""Pins oracle/ssd_oracle.py to vectors produced by the reference itself
+(tests/golden, written by oracle/gen_golden.py in the build container)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ssd_oracle as O
+from helpers import nms_case, split_case, synth_gt
+
+
+def test_priors_bit_exact(gold_dir):
+    z = np.load(os.path.join(gold_dir, "priors_ssd300.npz"))
+    pri = O.create_priors_ssd300()
+    assert pri.dtype == np.float32 and pri.shape == (8732, 4)
+    assert np.array_equal(pri, z["cxcywh"])
+    assert np.array_equal(O.xywh_to_xyxy(pri), z["xyxy"])
+    # SURVEY 8(a) A6 probes
+    assert np.allclose(pri[0], [.013158, .013158, .1, .1], atol=1e-6)
+    assert np.allclose(pri[-1], [.5, .5, .6364, 1.0], atol=1e-4)
+    offs = np.cumsum([0] + [g * g * a for g, a in zip((38, 19, 10, 5, 3, 1), O.ANCHORS_PER_CELL)])
+    assert tuple(offs[:-1]) == O.SCALE_OFFSETS and offs[-1] == 8732
+
+
+def test_boxmath_bit_exact(gold_dir):
+    z = np.load(os.path.join(gold_dir, "boxmath.npz"))
+    assert np.array_equal(O.iou_matrix(z["a"], z["b"]), z["iou"])
+    assert np.array_equal(O.xyxy_to_xywh(z["a"]), z["a_xywh"])
+    assert np.array_equal(O.xywh_to_xyxy(O.xyxy_to_xywh(z["a"])), z["a_back"])
+    # exp/log are libm-dependent: tolerance, not bit equality
+    np.testing.assert_allclose(O.decode_offsets(z["g"], z["pri"]), z["dec"], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(O.encode_offsets(z["dec"], z["pri"]), z["enc"], rtol=1e-5, atol=2e-5)
+
+
+def _n_cases(gold_dir):
+    return int(np.load(os.path.join(gold_dir, "match_loss.npz"))["n_cases"])
+
+
+@pytest.mark.parametrize("ci", range(18))
+def test_match_and_loss_vs_reference(gold_dir, ci):
+    z = np.load(os.path.join(gold_dir, "match_loss.npz"))
+    assert int(z["n_cases"]) == 18
+    boxes, classes, loc, conf, p = split_case(z, ci)
+    out = O.multibox_loss(loc, conf, boxes, classes)
+    # integer outputs: bit-exact
+    assert np.array_equal(out["cls"].astype(np.int8), z[p + "cls"])
+    pos = out["pos"]
+    allb = np.concatenate(boxes)
+    assert np.array_equal(O.xyxy_to_xywh(allb)[out["obj"]][pos], z[p + "gt_pos"])
+    np.testing.assert_allclose(out["enc"], z[p + "enc_pos"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(out["loc_loss"], z[p + "loc_loss"], rtol=2e-6)
+    np.testing.assert_allclose(out["conf_loss"], z[p + "conf_loss"], rtol=2e-6)
+    np.testing.assert_allclose(out["dloc"][pos], z[p + "dloc_pos"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(np.abs(out["dloc"]).astype(np.float64).sum(), z[p + "dloc_abs_sum"], rtol=1e-6)
+    rows = z[p + "dconf_rows"]
+    np.testing.assert_allclose(out["dconf"].reshape(-1, 21)[rows], z[p + "dconf_vals"], rtol=1e-4, atol=1e-8)
+    touched = np.nonzero(np.abs(out["dconf"].reshape(-1, 21)).sum(1) > 0)[0]
+    assert np.array_equal(touched, z[p + "dconf_touched"])          # same hard-negative set
+    np.testing.assert_allclose(np.abs(out["dconf"]).astype(np.float64).sum(), z[p + "dconf_abs_sum"], rtol=1e-5)
+
+
+def test_match_rejects_empty_image(priors):
+    with pytest.raises(ValueError):
+        O.match_priors([np.zeros((0, 4), np.float32)], [np.zeros((0,), np.float32)], O.xywh_to_xyxy(priors))
+
+
+@pytest.mark.parametrize("ni", range(6))
+def test_nms_vs_reference(gold_dir, ni):
+    z = np.load(os.path.join(gold_dir, "nms.npz"))
+    assert int(z["n_cases"]) == 6
+    l_, c_, top_k, p = nms_case(z, ni)
+    w, h = [int(v) for v in z["img_wh"]]
+    boxes, classes, probs, ids = O.decode_nms(l_, c_, w, h, top_k=top_k)
+    assert boxes.shape == z[p + "boxes"].shape
+    assert np.array_equal(classes, z[p + "classes"])
+    np.testing.assert_allclose(probs, z[p + "probs"], rtol=1e-6)
+    np.testing.assert_allclose(boxes, z[p + "boxes"], rtol=1e-5, atol=1e-3)
+    if ni == 5:
+        assert boxes.shape[0] == 0          # nothing reaches min_score: reference returns three empty lists
+
+
+def test_network_forward_and_step_vs_reference(gold_dir):
+    z = np.load(os.path.join(gold_dir, "network.npz"))
+    assert int(z["ref_named_parameters"]) == 77
+    params = {k: v.requires_grad_(True) for k, v in O.ssd300_random_params(int(z["param_seed"])).items()}
+    assert len(params) == 71 and sum(v.numel() for v in params.values()) == 26285486
+    bs = int(z["bs"])
+    x = np.random.default_rng(int(z["x_seed"])).standard_normal((bs, 3, 300, 300), dtype=np.float32)
+    boxes, classes = synth_gt(np.random.default_rng(int(z["gt_seed"])), bs)
+    torch.set_num_threads(8)
+    loc, conf = O.ssd300_forward(torch.from_numpy(x), params)
+    assert loc.shape == (bs, 8732, 4) and conf.shape == (bs, 8732, 21)
+    idx = z["prior_idx"]
+    np.testing.assert_allclose(loc.detach().numpy()[:, idx], z["loc_s"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(conf.detach().numpy()[:, idx], z["conf_s"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(float(loc.detach().double().abs().sum()), z["loc_abs"], rtol=1e-5)
+    np.testing.assert_allclose(float(conf.detach().double().abs().sum()), z["conf_abs"], rtol=1e-5)
+    # numpy loss on the torch outputs == reference loss
+    out = O.multibox_loss(loc.detach().numpy(), conf.detach().numpy(), boxes, classes, want_grads=False)
+    np.testing.assert_allclose(out["loc_loss"], z["loc_loss"], rtol=1e-5)
+    np.testing.assert_allclose(out["conf_loss"], z["conf_loss"], rtol=1e-5)
+    # differentiable form + autograd == reference backward
+    l1, l2 = O.multibox_loss_torch(loc, conf, [torch.from_numpy(b) for b in boxes],
+                                   [torch.from_numpy(c) for c in classes])
+    np.testing.assert_allclose(l1.item(), z["loc_loss"], rtol=1e-5)
+    np.testing.assert_allclose(l2.item(), z["conf_loss"], rtol=1e-5)
+    (l1 + l2).backward()
+    names = [str(n) for n in z["grad_names"]]
+    l2n = np.asarray([float(params[k].grad.double().norm()) for k in names])
+    np.testing.assert_allclose(l2n, z["grad_l2"], rtol=2e-4)
+    for k in ("model.features.0.weight", "model.features.21.bias", "c_11_cl.weight", "seq10.2.weight",
+              "rescaling_conv_4_3", "c_4_bb.bias"):
+        g = params[k].grad.numpy()
+        ref = z["g_" + k]
+        np.testing.assert_allclose(g, ref, rtol=1e-3, atol=1e-5 * max(1.0, float(np.abs(ref).max())))
