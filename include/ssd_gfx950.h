@@ -1,0 +1,144 @@
+/*
+ * ssd_gfx950.h -- C ABI of libssd_gfx950.so: the MI355X (gfx950) SSD300 hot path.
+ *
+ * The reference (nitishsaDire/objectDetection_ssd) has no native layer: its hot
+ * path is Python calling ATen ops.  This header is the boundary a maintainer
+ * binds instead (ctypes stub in INTEGRATION.md).  Every entry point names the
+ * reference call site it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain pointers + sizes, no framework types; all pointers are DEVICE
+ *     pointers unless a parameter is documented as host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - functions only enqueue work: they never allocate, synchronise or throw;
+ *   - return 0 on success or a negative ssd_status code;
+ *   - activations are NHWC f32; "packed" head buffers are [N*H*W][ld] f32.
+ */
+#ifndef SSD_GFX950_H
+#define SSD_GFX950_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSD_ABI_VERSION 1
+
+enum ssd_status {
+    SSD_OK = 0,
+    SSD_ERR_BAD_SHAPE = -1,   /* unsupported / inconsistent dimensions            */
+    SSD_ERR_WORKSPACE = -2,   /* workspace too small                              */
+    SSD_ERR_NULL = -3,        /* required pointer is NULL                         */
+    SSD_ERR_LAUNCH = -4,      /* hipGetLastError() != hipSuccess after enqueue    */
+    SSD_ERR_ALIGN = -5        /* pointer / leading dimension not 16-byte aligned  */
+};
+
+int ssd_abi_version(void);
+const char* ssd_status_string(int status);
+
+/* Geometry of one convolution, forward sense.  (torch.nn.Conv2d arguments of
+ * Model.py:135-184: kernel R x S, stride, padding, dilation.) */
+typedef struct ssd_conv_geom {
+    int32_t N, H, W, Ci;      /* input  NHWC                                     */
+    int32_t Ho, Wo, Co;       /* output NHWC                                     */
+    int32_t R, S;             /* taps                                            */
+    int32_t stride, pad, dil;
+} ssd_conv_geom;
+
+/* ---- weight layouts --------------------------------------------------------
+ * nn.Conv2d keeps OIHW.  The kernels read K-contiguous rows:
+ *   forward : [Co_pad][R*S][Ci]   (rows >= Co zero)
+ *   dgrad   : [Ci][R*S][Co_pad]   (columns >= Co zero)
+ * Replaces nothing in the reference (ATen re-lays weights internally). */
+int ssd_weight_oihw_to_ohwi(const float* w_oihw, float* w_ohwi, int Co, int Ci, int R, int S, int Co_pad, void* stream);
+int ssd_weight_oihw_to_ihwo(const float* w_oihw, float* w_ihwo, int Co, int Ci, int R, int S, int Co_pad, void* stream);
+
+/* ---- convolution (Model.py:135-184 nn.Conv2d + nn.ReLU; autograd of them,
+ * train_function.py:94) ------------------------------------------------------
+ * y[m][n] = act( sum_{tap,c} x[pix(m,tap)][c] * w[n][tap][c] + bias[n] ),  m = (n,ho,wo).
+ * Ci % 32 == 0 required (conv1_1 has its own entry below).  ldy = row stride of y
+ * in floats (>= Co).  relu: 0/1. */
+int ssd_conv2d_fwd(const float* x, const float* w_ohwi, const float* bias, float* y, int ldy,
+                   const ssd_conv_geom* g, int relu, void* stream);
+
+/* dx[pix][c] (+)= sum_{tap,n} dy[opix(pix,tap)][n] * w[n][c][tap];  then, if
+ * relu_mask != NULL, dx = relu_mask > 0 ? dx : 0 (relu_mask = the post-ReLU
+ * activation that produced x).  dy rows have stride ldy (>= Co_pad, pad columns
+ * zero), Co_pad % 32 == 0. */
+int ssd_conv2d_dgrad(const float* dy, int ldy, const float* w_ihwo, int Co_pad, float* dx,
+                     const float* relu_mask, int accumulate, const ssd_conv_geom* g, void* stream);
+
+/* dw_oihw[n][c][r][s] = sum_m dy[m][n] * x[pix(m,tap)][c];  dbias[n] = sum_m dy[m][n]
+ * (dbias may be NULL).  Deterministic: split-K partial slabs in `workspace`, then a
+ * fixed-order reduction. */
+size_t ssd_conv2d_wgrad_workspace(const ssd_conv_geom* g);
+int ssd_conv2d_wgrad(const float* x, const float* dy, int ldy, float* dw_oihw, float* dbias,
+                     const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream);
+
+/* conv1_1 (Model.py:136 features[0]: Conv2d(3,64,3,padding=1)+ReLU): reads the
+ * caller's NCHW image batch directly (Dataset.py:39 layout), writes NHWC. */
+int ssd_conv_first_fwd(const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc,
+                       int N, int H, int W, int Co, int relu, void* stream);
+size_t ssd_conv_first_wgrad_workspace(int N, int H, int W, int Co);
+int ssd_conv_first_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_oihw, float* dbias,
+                         int N, int H, int W, int Co, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- max pooling (Model.py:137,142 nn.MaxPool2d incl. ceil_mode; features[4,9,23]) ----
+ * argmax: uint8 window-relative index (r*k+s) of the first maximum, for backward. */
+int ssd_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int N, int H, int W, int C,
+                    int k, int stride, int pad, int Ho, int Wo, void* stream);
+/* dx (+)= routed dy; if relu_mask != NULL dx = relu_mask > 0 ? dx : 0. */
+int ssd_maxpool_bwd(const float* dy, const uint8_t* argmax, float* dx, const float* relu_mask, int accumulate,
+                    int N, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo, void* stream);
+
+/* ---- conv4_3 L2 normalisation (Model.py:206-209): y = x / sqrt(sum_c x^2) * gamma_c, no epsilon */
+int ssd_l2norm_fwd(const float* x, const float* gamma, float* y, int M, int C, void* stream);
+size_t ssd_l2norm_bwd_workspace(int M, int C);
+int ssd_l2norm_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma,
+                   int M, int C, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- head output <-> (bs,P,4)/(bs,P,21) (Model.py:212-235 permute+view+cat) ------------
+ * packed[m][0:4A] = loc channels, packed[m][4A:25A] = conf channels of pixel m=(n,h,w);
+ * prior index = prior_off + (h*W+w)*A + a. */
+int ssd_heads_scatter(const float* packed, int ld, float* loc, float* conf, int N, int HW, int A,
+                      int prior_off, int P, int n_classes, void* stream);
+int ssd_heads_gather(const float* dloc, const float* dconf, float* packed, int ld, int N, int HW, int A,
+                     int prior_off, int P, int n_classes, void* stream);
+
+/* ---- MultiBox loss (Losses.py:119-199 ssd + ssd1_; Util.py:57-63,98-102,252-301) -------
+ * gt_boxes (n_gt,4) xyxy f32, gt_classes (n_gt) f32 values 0..19, img_start (bs+1) int32
+ * prefix offsets into them (every image needs >= 1 box: checked by the caller on the host,
+ * the reference raises there).  priors_cxcywh/priors_xyxy (P,4).
+ * Outputs: losses[0]=loc_loss, losses[1]=conf_loss, losses[2]=n_pos (as float);
+ *          obj (bs,P) int32 global GT index; cls (bs,P) int32 (bg_class = n_classes-1);
+ *          dloc/dconf = d(loc_loss+conf_loss)/d(loc|conf) (may both be NULL: forward only).
+ * norm_mode 0: reference normalisation (divide by batch n_pos).
+ * norm_mode 1: un-normalised sums (loc: sum|d|/4, conf: sum CE) and gradients of those,
+ *              for data-parallel runs that divide by the global n_pos after the all-reduce. */
+size_t ssd_multibox_loss_workspace(int bs, int P, int n_gt);
+int ssd_multibox_loss(const float* loc, const float* conf, const float* gt_boxes, const float* gt_classes,
+                      const int32_t* img_start, int bs, int n_gt, const float* priors_cxcywh,
+                      const float* priors_xyxy, int P, int n_classes, float iou_threshold, int neg_pos_ratio,
+                      int norm_mode, float* losses, int32_t* obj, int32_t* cls, float* dloc, float* dconf,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- decode + per-class NMS + top-k (Losses.py:11-98 inference; Util.py:86-96) ----------
+ * l_ (P,4), c_ (P,n_classes) of ONE image.  Outputs (capacity top_k): boxes (top_k,4) xyxy
+ * scaled by (img_w,img_h,img_w,img_h), classes int64, probs f32, prior_ids int32, count int32[1]. */
+size_t ssd_decode_nms_workspace(int P, int n_classes);
+int ssd_decode_nms(const float* l_, const float* c_, const float* priors_cxcywh, int P, int n_classes,
+                   float min_score, float iou_threshold, int top_k, float img_w, float img_h,
+                   float* boxes, int64_t* classes, float* probs, int32_t* prior_ids, int32_t* count,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- fused SGD (train.py:53-55: momentum .9, weight decay 5e-4; bias lr 2x) on a flat buffer;
+ * grad_scale multiplies the gradient first (1/n_pos_global in data-parallel runs). */
+int ssd_sgd_momentum(float* param, const float* grad, float* momentum_buf, size_t n, float lr, float momentum,
+                     float weight_decay, const float* grad_scale_dev, int first_step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSD_GFX950_H */

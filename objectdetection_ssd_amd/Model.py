@@ -1,0 +1,341 @@
+"""`Model.SSD_300` with the reference's constructor, attribute / parameter names and
+`forward(x) -> (loc (bs,8732,4), conf (bs,8732,21))` contract (reference
+Model.py:128-235), computed by the gfx950 kernels of libssd_gfx950.so.
+
+The module tree exists to own the `nn.Parameter`s under the reference's
+state-dict names (so `train.py`'s optimizer groups, `.to(device)`,
+`state_dict()` and checkpoints keep working); none of the `nn.Conv2d` /
+`nn.MaxPool2d` modules is ever called.  `forward` hands the parameters to
+`_Engine`, which runs the network as a flat list of NHWC ops through the C ABI
+and, under autograd, supplies an explicit backward (dgrad / wgrad / pool /
+L2-norm kernels) through one `torch.autograd.Function`.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .Util import ANCHORS_PER_CELL, subsampling
+
+N_CLASSES = 21
+_VGG_CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M")
+
+
+class _VGG16(nn.Module):
+    """Layer list of VGG-16 'D' (what `torchvision.models.vgg16()` builds and reference
+    Model.py:131-157 slices by index).  Pretrained weights are a network download in
+    the reference; here the layers are initialised like torchvision's untrained model
+    and `load_state_dict` accepts the torchvision key names (`features.N.weight`, ...)."""
+
+    def __init__(self):
+        super().__init__()
+        layers: List[nn.Module] = []
+        cin = 3
+        for v in _VGG_CFG:
+            if v == "M":
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+            else:
+                layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+                cin = v
+        self.features = nn.Sequential(*layers)
+        self.avgpool = nn.AdaptiveAvgPool2d((7, 7))
+        self.classifier = nn.Sequential(nn.Linear(512 * 7 * 7, 4096), nn.ReLU(True), nn.Dropout(),
+                                        nn.Linear(4096, 4096), nn.ReLU(True), nn.Dropout(), nn.Linear(4096, 1000))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0, 0.01)
+                nn.init.constant_(m.bias, 0)
+
+
+# ------------------------------------------------------------------------------------------
+# op list
+# ------------------------------------------------------------------------------------------
+def _conv(p, x, y, ci, co, k=3, s=1, pad=1, dil=1, relu=True):
+    return dict(op="conv", p=p, x=x, y=y, ci=ci, co=co, k=k, s=s, pad=pad, dil=dil, relu=relu)
+
+
+def _pool(x, y, k=2, s=2, pad=0, ceil=False):
+    return dict(op="pool", x=x, y=y, k=k, s=s, pad=pad, ceil=ceil)
+
+
+def _head(p, x, scale, ci):
+    return dict(op="head", p=p, x=x, scale=scale, ci=ci, a=ANCHORS_PER_CELL[scale])
+
+
+def build_ops() -> List[dict]:
+    """SSD300 as a flat op list (reference Model.py:203-235).  Order matters only where a
+    tensor has two consumers: in reverse order the consumer that cannot accumulate
+    (L2-norm backward) must deliver its gradient first."""
+    f = "model.features."
+    o = [dict(op="conv_first", p=f + "0", x="x", y="a1_1"),
+         _conv(f + "2", "a1_1", "a1_2", 64, 64), _pool("a1_2", "p1"),
+         _conv(f + "5", "p1", "a2_1", 64, 128), _conv(f + "7", "a2_1", "a2_2", 128, 128), _pool("a2_2", "p2"),
+         _conv(f + "10", "p2", "a3_1", 128, 256), _conv(f + "12", "a3_1", "a3_2", 256, 256),
+         _conv(f + "14", "a3_2", "a3_3", 256, 256), _pool("a3_3", "p3", ceil=True),            # Model.py:137
+         _conv(f + "17", "p3", "a4_1", 256, 512), _conv(f + "19", "a4_1", "a4_2", 512, 512),
+         _conv(f + "21", "a4_2", "a4_3", 512, 512),
+         _pool("a4_3", "p4"),
+         dict(op="l2norm", p="rescaling_conv_4_3", x="a4_3", y="n4_3"),                         # Model.py:206-209
+         _head("c_4", "n4_3", 0, 512),
+         _conv(f + "24", "p4", "a5_1", 512, 512), _conv(f + "26", "a5_1", "a5_2", 512, 512),
+         _conv(f + "28", "a5_2", "a5_3", 512, 512), _pool("a5_3", "p5", k=3, s=1, pad=1, ceil=True),   # Model.py:142
+         _conv("conv_fc6", "p5", "a6", 512, 1024, k=3, pad=4, dil=4),                            # Model.py:149
+         _conv("conv_fc7", "a6", "a7", 1024, 1024, k=1, pad=0),
+         _head("c_7", "a7", 1, 1024)]
+    prev = "a7"
+    for i, (name, cin, mid, cout, s, pad) in enumerate((("seq8", 1024, 256, 512, 2, 1), ("seq9", 512, 128, 256, 2, 1),
+                                                        ("seq10", 256, 128, 256, 1, 0), ("seq11", 256, 128, 256, 1, 0))):
+        n = 8 + i
+        o.append(_conv(f"{name}.0", prev, f"a{n}a", cin, mid, k=1, pad=0))
+        o.append(_conv(f"{name}.2", f"a{n}a", f"a{n}", mid, cout, k=3, s=s, pad=pad))
+        o.append(_head(f"c_{n}", f"a{n}", 2 + i, cout))
+        prev = f"a{n}"
+    return o
+
+
+def param_names(op_list: List[dict]) -> List[str]:
+    names = []
+    for op in op_list:
+        if op["op"] in ("conv", "conv_first"):
+            names += [op["p"] + ".weight", op["p"] + ".bias"]
+        elif op["op"] == "l2norm":
+            names.append(op["p"])
+        elif op["op"] == "head":
+            names += [op["p"] + "_bb.weight", op["p"] + "_bb.bias", op["p"] + "_cl.weight", op["p"] + "_cl.bias"]
+    return names
+
+
+class _Engine:
+    """Runs the op list on the current HIP stream.  Holds only caches (re-laid-out weights)."""
+
+    def __init__(self):
+        self.ops = build_ops()
+        self.names = param_names(self.ops)
+        self._wcache: Dict[str, tuple] = {}
+        self.consumers: Dict[str, int] = {}
+        for op in self.ops:
+            self.consumers[op["x"]] = self.consumers.get(op["x"], 0) + 1
+        self.relu_out = {op["y"] for op in self.ops if op["op"] == "conv_first" or (op["op"] == "conv" and op["relu"])}
+
+    # -- weights ----------------------------------------------------------------------------
+    def _layouts(self, key: str, tensors, co_pad: int, need_bwd: bool):
+        """Cached [Co_pad][T][Ci] / [Ci][T][Co_pad] copies, refreshed when a parameter changes."""
+        sig = tuple((t.data_ptr(), t._version) for t in tensors)
+        ent = self._wcache.get(key)
+        if ent is None or ent[0] != sig:
+            w = tensors[0] if len(tensors) == 1 else torch.cat(list(tensors), 0)
+            ent = [sig, w.detach().contiguous(), None, None]
+            ent[2] = ops.weight_ohwi(ent[1], co_pad)
+            self._wcache[key] = ent
+        if need_bwd and ent[3] is None:
+            ent[3] = ops.weight_ihwo(ent[1], co_pad)
+        return ent[2], ent[3]
+
+    # -- forward ----------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, P: Dict[str, torch.Tensor], save: bool):
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError(f"SSD_300 expects (bs,3,H,W) NCHW input, got {tuple(x.shape)}")
+        if x.dtype != torch.float32:
+            raise ValueError("SSD_300 expects float32 input")
+        if not x.is_cuda:
+            raise RuntimeError("SSD_300 runs on the gfx950 HIP kernels only: move the model and the input to the GPU "
+                               "(there is no CPU fallback)")
+        x = x.contiguous()
+        bs = x.shape[0]
+        T = {"x": x}
+        aux = {}
+        heads = []
+        for op in self.ops:
+            kind = op["op"]
+            if kind == "conv_first":
+                T[op["y"]] = ops.conv_first_fwd(x, P[op["p"] + ".weight"].detach(), P[op["p"] + ".bias"].detach(), relu=True)
+            elif kind == "conv":
+                xin = T[op["x"]]
+                g = ops.make_geom(bs, xin.shape[1], xin.shape[2], op["ci"], op["co"], op["k"], op["s"], op["pad"], op["dil"])
+                wf, _ = self._layouts(op["p"], (P[op["p"] + ".weight"],), op["co"], False)
+                T[op["y"]] = ops.conv2d_fwd(xin, wf, P[op["p"] + ".bias"].detach(), g, op["relu"])
+                aux[op["y"]] = g
+            elif kind == "pool":
+                y, am = ops.maxpool_fwd(T[op["x"]], op["k"], op["s"], op["pad"], op["ceil"], want_argmax=save)
+                T[op["y"]] = y
+                aux[op["y"]] = am
+            elif kind == "l2norm":
+                T[op["y"]] = ops.l2norm_fwd(T[op["x"]], P[op["p"]].detach().reshape(-1))
+            elif kind == "head":
+                xin = T[op["x"]]
+                a = op["a"]
+                co = a * (4 + N_CLASSES)
+                g = ops.make_geom(bs, xin.shape[1], xin.shape[2], op["ci"], co, 3, 1, 1, 1)
+                pre = op["p"]
+                wf, _ = self._layouts(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]), ops.pad32(co), False)
+                bias = torch.cat((P[pre + "_bb.bias"].detach(), P[pre + "_cl.bias"].detach()))
+                packed = ops.conv2d_fwd(xin, wf, bias, g, False, ld=ops.pad32(co))
+                heads.append((op, packed, g))
+        P_total = sum(g.Ho * g.Wo * op["a"] for op, _, g in heads)
+        loc = torch.empty((bs, P_total, 4), device=x.device, dtype=torch.float32)
+        conf = torch.empty((bs, P_total, N_CLASSES), device=x.device, dtype=torch.float32)
+        off = 0
+        offs = {}
+        for op, packed, g in heads:
+            ops.heads_scatter(packed, ops.pad32(g.Co), loc, conf, bs, g.Ho * g.Wo, op["a"], off)
+            offs[op["p"]] = (off, g)
+            off += g.Ho * g.Wo * op["a"]
+        saved = dict(T=T, aux=aux, offs=offs, bs=bs) if save else None
+        return loc, conf, saved
+
+    # -- backward ---------------------------------------------------------------------------
+    def backward(self, saved, dloc: torch.Tensor, dconf: torch.Tensor, P: Dict[str, torch.Tensor], need: Dict[str, bool]):
+        T, aux, offs, bs = saved["T"], saved["aux"], saved["offs"], saved["bs"]
+        dloc = dloc.contiguous()
+        dconf = dconf.contiguous()
+        G: Dict[str, torch.Tensor] = {}
+        arrived: Dict[str, int] = {}
+        grads: Dict[str, torch.Tensor] = {}
+
+        def deliver(name, fn):
+            """fn(dx, accumulate, mask) -> dx; mask only when this is the last contribution to a post-ReLU tensor."""
+            k = arrived.get(name, 0)
+            last = k + 1 == self.consumers[name]
+            mask = T[name] if (last and name in self.relu_out) else None
+            G[name] = fn(G.get(name), k > 0, mask)
+            arrived[name] = k + 1
+
+        for op in reversed(self.ops):
+            kind = op["op"]
+            if kind == "head":
+                pre = op["p"]
+                off, g = offs[pre]
+                co_pad = ops.pad32(g.Co)
+                dy = ops.heads_gather(dloc, dconf, co_pad, bs, g.Ho * g.Wo, op["a"], off)
+                xin = T[op["x"]]
+                a4 = 4 * op["a"]
+                if any(need[pre + s] for s in ("_bb.weight", "_bb.bias", "_cl.weight", "_cl.bias")):
+                    dw, db = ops.conv2d_wgrad(xin, dy, g, co_pad, True)
+                    grads[pre + "_bb.weight"], grads[pre + "_cl.weight"] = dw[:a4], dw[a4:]
+                    grads[pre + "_bb.bias"], grads[pre + "_cl.bias"] = db[:a4], db[a4:]
+                _, wb = self._layouts(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]), co_pad, True)
+                deliver(op["x"], lambda dx, acc, mask: ops.conv2d_dgrad(dy, wb, g, dx, mask, acc))
+            elif kind == "conv":
+                dy = G.pop(op["y"])
+                g = aux[op["y"]]
+                xin = T[op["x"]]
+                if need[op["p"] + ".weight"] or need[op["p"] + ".bias"]:
+                    dw, db = ops.conv2d_wgrad(xin, dy, g, g.Co, True)
+                    grads[op["p"] + ".weight"], grads[op["p"] + ".bias"] = dw, db
+                _, wb = self._layouts(op["p"], (P[op["p"] + ".weight"],), op["co"], True)
+                deliver(op["x"], lambda dx, acc, mask: ops.conv2d_dgrad(dy, wb, g, dx, mask, acc))
+            elif kind == "pool":
+                dy = G.pop(op["y"])
+                xin = T[op["x"]]
+                am = aux[op["y"]]
+                deliver(op["x"], lambda dx, acc, mask: ops.maxpool_bwd(dy, am, tuple(xin.shape), op["k"], op["s"], op["pad"],
+                                                                       dx, mask, acc))
+            elif kind == "l2norm":
+                dy = G.pop(op["y"])
+                xin = T[op["x"]]
+                gamma = P[op["p"]].detach().reshape(-1)
+                box = {}
+
+                def run(dx, acc, mask, xin=xin, gamma=gamma, dy=dy, box=box):
+                    if acc or mask is not None:
+                        raise RuntimeError("L2-norm backward must deliver the first, non-final gradient of its input")
+                    dx, box["dg"] = ops.l2norm_bwd(xin, gamma, dy)
+                    return dx
+                deliver(op["x"], run)
+                grads[op["p"]] = box["dg"].reshape(P[op["p"]].shape)
+            elif kind == "conv_first":
+                dy = G.pop(op["y"])
+                if need[op["p"] + ".weight"] or need[op["p"] + ".bias"]:
+                    dw, db = ops.conv_first_wgrad(T["x"], dy, True)
+                    grads[op["p"] + ".weight"], grads[op["p"] + ".bias"] = dw, db
+        return grads
+
+
+class _SSD300Function(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, engine, *params):
+        P = dict(zip(engine.names, params))
+        loc, conf, saved = engine.forward(x, P, save=True)
+        ctx.engine = engine
+        ctx.saved = saved
+        ctx.params = params
+        return loc, conf
+
+    @staticmethod
+    def backward(ctx, dloc, dconf):
+        eng = ctx.engine
+        P = dict(zip(eng.names, ctx.params))
+        need = {n: bool(f) for n, f in zip(eng.names, ctx.needs_input_grad[2:])}
+        grads = eng.backward(ctx.saved, dloc, dconf, P, need)
+        ctx.saved = None
+        return (None, None) + tuple(grads.get(n) if need[n] else None for n in eng.names)
+
+
+class SSD_300(nn.Module):
+    """Drop-in for reference Model.py:128-235 (same no-argument constructor, same parameter names)."""
+
+    def __init__(self):
+        super().__init__()
+        self.model = _VGG16()                                              # Model.py:131 (no download here)
+        self.rescaling_conv_4_3 = nn.Parameter(torch.full((1, 512, 1, 1), 20.))   # Model.py:132-133
+        feats = self.model.features
+        self.conv_4_3 = nn.Sequential(*feats[0:16], nn.MaxPool2d(2, 2, 0, 1, ceil_mode=True), *feats[17:23])
+        self.seq5 = nn.Sequential(*feats[23:30], nn.MaxPool2d(3, 1, 1, 1, ceil_mode=True))
+        # fc6 / fc7 as convolutions by sub-sampling the classifier weights (Model.py:145-161)
+        cls0, cls3 = self.model.classifier[0], self.model.classifier[3]
+        self.fc6 = subsampling(cls0.weight.detach().view(4096, 512, 7, 7), [4, None, 3, 3])
+        self.fc6_b = subsampling(cls0.bias.detach(), [4])
+        self.fc7 = subsampling(cls3.weight.detach().view(4096, 4096, 1, 1), [4, 4, None, None])
+        self.fc7_b = subsampling(cls3.bias.detach(), [4])
+        self.conv_fc6 = nn.Conv2d(512, 1024, 3, padding=4, dilation=4)
+        self.conv_fc6.weight = nn.Parameter(self.fc6.clone())
+        self.conv_fc6.bias = nn.Parameter(self.fc6_b.clone())
+        self.conv_fc7 = nn.Conv2d(1024, 1024, 1)
+        self.conv_fc7.weight = nn.Parameter(self.fc7.clone())
+        self.conv_fc7.bias = nn.Parameter(self.fc7_b.clone())
+        self.seq7 = nn.Sequential(self.conv_fc6, nn.ReLU(), self.conv_fc7, nn.ReLU())
+        self.seq8 = nn.Sequential(nn.Conv2d(1024, 256, 1), nn.ReLU(), nn.Conv2d(256, 512, 3, 2, padding=1), nn.ReLU())
+        self.seq9 = nn.Sequential(nn.Conv2d(512, 128, 1), nn.ReLU(), nn.Conv2d(128, 256, 3, 2, padding=1), nn.ReLU())
+        self.seq10 = nn.Sequential(nn.Conv2d(256, 128, 1), nn.ReLU(), nn.Conv2d(128, 256, 3, 1), nn.ReLU())
+        self.seq11 = nn.Sequential(nn.Conv2d(256, 128, 1), nn.ReLU(), nn.Conv2d(128, 256, 3, 1), nn.ReLU())
+        for name, cin, a in (("c_4", 512, 4), ("c_7", 1024, 6), ("c_8", 512, 6), ("c_9", 256, 6), ("c_10", 256, 4),
+                             ("c_11", 256, 4)):
+            setattr(self, name + "_bb", nn.Conv2d(cin, 4 * a, 3, padding=1))
+            setattr(self, name + "_cl", nn.Conv2d(cin, N_CLASSES * a, 3, padding=1))
+        self.initialization()
+        self._engine = _Engine()
+
+    def get_norm(self):
+        return torch.norm(self.fc6) + torch.norm(self.fc6_b) + torch.norm(self.fc7) + torch.norm(self.fc7_b)
+
+    def initialization(self):
+        """Xavier-uniform weights / zero biases for the aux and head convolutions (Model.py:190-200)."""
+        for name in ("seq8", "seq9", "seq10", "seq11"):
+            seq = getattr(self, name)
+            self.initialize(seq[0])
+            self.initialize(seq[2])
+        for name in ("c_4", "c_7", "c_8", "c_9", "c_10", "c_11"):
+            self.initialize(getattr(self, name + "_bb"))
+            self.initialize(getattr(self, name + "_cl"))
+
+    def initialize(self, c):
+        nn.init.xavier_uniform_(c.weight)
+        nn.init.constant_(c.bias, 0.)
+
+    def _forward_params(self) -> Dict[str, torch.Tensor]:
+        named = dict(self.named_parameters())
+        return {n: named[n] for n in self._engine.names}
+
+    def forward(self, x):
+        P = self._forward_params()
+        eng = self._engine
+        if torch.is_grad_enabled() and any(p.requires_grad for p in P.values()):
+            return _SSD300Function.apply(x, eng, *[P[n] for n in eng.names])
+        loc, conf, _ = eng.forward(x, P, save=False)
+        return loc, conf

@@ -1,0 +1,82 @@
+"""Host-side mirror of the box utilities the hot path imports from the
+reference's Util.py (names and argument meaning kept; bodies are ours).
+
+Only what `Losses.py` / `train_function.py` pull in through `from Util import *`
+for the SSD300 path lives here: prior boxes, box coders, IoU, the class table
+and `device`.  Dataset lists, augmentation and drawing are out of scope
+(SURVEY.md section 2, rows 13-18).
+"""
+from __future__ import annotations
+
+from math import sqrt
+
+import torch
+
+use_cuda = torch.cuda.is_available()
+device = torch.device("cuda" if use_cuda else "cpu")
+
+# reference Util.py:26-27 -- background is the last entry
+class_to_label = ['aeroplane', 'bicycle', 'bird', 'boat', 'bottle', 'bus', 'car', 'cat', 'chair', 'cow',
+                  'diningtable', 'dog', 'horse', 'motorbike', 'person', 'pottedplant', 'sheep', 'sofa', 'train',
+                  'tvmonitor', 'bg']
+label_to_class = {name: i for i, name in enumerate(class_to_label)}
+
+# filled by callers that have a dataset (reference: DataLists.py); empty here
+all_images = {"train": [], "test": []}
+
+_GRID = (38, 19, 10, 5, 3, 1)
+_SCALE = (0.1, 0.2, 0.375, 0.55, 0.725, 0.9)
+_RATIO = ((1., 2., .5), (1., 2., 3., .5, .333), (1., 2., 3., .5, .333), (1., 2., 3., .5, .333), (1., 2., .5), (1., 2., .5))
+ANCHORS_PER_CELL = (4, 6, 6, 6, 4, 4)
+
+
+def create_priors_ssd300() -> torch.Tensor:
+    """(8732,4) f32 cx,cy,w,h  (reference Util.py:105-137): per grid cell, row-major,
+    boxes (s*sqrt(a), s/sqrt(a)) for each ratio with the sqrt(s_k*s_k+1) square right
+    after a == 1; double arithmetic, rounded to f32, clamped to [0,1]."""
+    out = []
+    for k, g in enumerate(_GRID):
+        s = _SCALE[k]
+        extra = sqrt(s * _SCALE[k + 1]) if k + 1 < len(_SCALE) else 1.
+        for row in range(g):
+            cy = (row + 0.5) / float(g)
+            for col in range(g):
+                cx = (col + 0.5) / float(g)
+                for a in _RATIO[k]:
+                    out.append([cx, cy, s * sqrt(a), s / sqrt(a)])
+                    if a == 1.:
+                        out.append([cx, cy, extra, extra])
+    return torch.tensor(out, dtype=torch.float64).to(torch.float32).clamp_(0, 1)
+
+
+def xywh_to_xyxy(box: torch.Tensor) -> torch.Tensor:
+    """reference Util.py:93-96"""
+    return torch.cat((box[:, :2] - box[:, 2:] / 2., box[:, :2] + box[:, 2:] / 2.), dim=1)
+
+
+def xyxy_to_xywh(box: torch.Tensor) -> torch.Tensor:
+    """reference Util.py:57-63 (without its host round trip)"""
+    return torch.stack(((box[:, 2] + box[:, 0]) / 2., (box[:, 3] + box[:, 1]) / 2.,
+                        box[:, 2] - box[:, 0], box[:, 3] - box[:, 1]), dim=1)
+
+
+def gcxgcy_to_cxcy(gcxgcy: torch.Tensor, priors_cxcy: torch.Tensor) -> torch.Tensor:
+    """reference Util.py:86-91"""
+    priors_cxcy = priors_cxcy.to(gcxgcy.device)
+    return torch.cat([gcxgcy[:, :2] * priors_cxcy[:, 2:] / 10 + priors_cxcy[:, :2],
+                      torch.exp(gcxgcy[:, 2:] / 5) * priors_cxcy[:, 2:]], 1)
+
+
+def get_offsets_coords(cxcy: torch.Tensor, priors_cxcy: torch.Tensor) -> torch.Tensor:
+    """reference Util.py:98-102"""
+    priors_cxcy = priors_cxcy.to(cxcy.device)
+    return torch.cat([(cxcy[:, :2] - priors_cxcy[:, :2]) / (priors_cxcy[:, 2:] / 10),
+                      torch.log(cxcy[:, 2:] / priors_cxcy[:, 2:]) * 5], 1)
+
+
+def subsampling(x: torch.Tensor, step) -> torch.Tensor:
+    """keep every step[d]-th entry along dim d (None = keep all); reference Util.py:555-560"""
+    for d, s in enumerate(step):
+        if s is not None:
+            x = x.index_select(d, torch.arange(0, x.shape[d], s, device=x.device))
+    return x

@@ -1,0 +1,84 @@
+"""ctypes binding of libssd_gfx950.so (C ABI in include/ssd_gfx950.h).
+
+The shared library is the only compute path: if it cannot be loaded the import
+fails loudly -- there is no CPU or eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libssd_gfx950.so")
+
+SSD_ABI_VERSION = 1
+
+
+class ConvGeom(C.Structure):
+    """struct ssd_conv_geom"""
+    _fields_ = [(n, C.c_int32) for n in ("N", "H", "W", "Ci", "Ho", "Wo", "Co", "R", "S", "stride", "pad", "dil")]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+_Z = C.c_size_t
+_G = C.POINTER(ConvGeom)
+
+# name -> (restype, argtypes); must list every symbol declared in include/ssd_gfx950.h
+SIGNATURES = {
+    "ssd_abi_version": (_I, []),
+    "ssd_status_string": (C.c_char_p, [_I]),
+    "ssd_weight_oihw_to_ohwi": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "ssd_weight_oihw_to_ihwo": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "ssd_conv2d_fwd": (_I, [_P, _P, _P, _P, _I, _G, _I, _P]),
+    "ssd_conv2d_dgrad": (_I, [_P, _I, _P, _I, _P, _P, _I, _G, _P]),
+    "ssd_conv2d_wgrad_workspace": (_Z, [_G]),
+    "ssd_conv2d_wgrad": (_I, [_P, _P, _I, _P, _P, _G, _P, _Z, _P]),
+    "ssd_conv_first_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ssd_conv_first_wgrad_workspace": (_Z, [_I, _I, _I, _I]),
+    "ssd_conv_first_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
+    "ssd_maxpool_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ssd_maxpool_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ssd_l2norm_fwd": (_I, [_P, _P, _P, _I, _I, _P]),
+    "ssd_l2norm_bwd_workspace": (_Z, [_I, _I]),
+    "ssd_l2norm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _Z, _P]),
+    "ssd_heads_scatter": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ssd_heads_gather": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ssd_multibox_loss_workspace": (_Z, [_I, _I, _I]),
+    "ssd_multibox_loss": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _I, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "ssd_decode_nms_workspace": (_Z, [_I, _I]),
+    "ssd_decode_nms": (_I, [_P, _P, _P, _I, _I, _F, _F, _I, _F, _F, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "ssd_sgd_momentum": (_I, [_P, _P, _P, _Z, _F, _F, _F, _P, _I, _P]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load (building first if the .so is absent and hipcc is present)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        from . import build as _build          # raises if hipcc is missing
+        _build.build()
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:                      # pragma: no cover
+        raise RuntimeError(f"cannot load {LIB_PATH}: {e}.  The gfx950 HIP extension is the only compute "
+                           f"path of this package; build it with `python -m objectdetection_ssd_amd.build`.") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)               # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ssd_abi_version() != SSD_ABI_VERSION:
+        raise RuntimeError("libssd_gfx950.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = load().ssd_status_string(status).decode()
+        raise RuntimeError(f"libssd_gfx950 {what}: {msg} (status {status})")

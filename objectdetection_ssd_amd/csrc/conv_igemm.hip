@@ -1,0 +1,253 @@
+// Implicit-GEMM convolution on the f32 MFMA (v_mfma_f32_32x32x2_f32), NHWC.
+//
+// Replaces nn.Conv2d(+ReLU) forward (Model.py:135-184) and its autograd
+// data-gradient (train_function.py:94).  One kernel serves both directions:
+//
+//   out[m][n] = epi( sum_tap sum_c  A[gather(m,tap)][c] * Wt[n][tap][c] )
+//
+// forward : A = x,  Wt = [Co_pad][T][Ci], gather = (oh*stride - pad + r*dil, ...)
+// dgrad   : A = dy, Wt = [Ci][T][Co_pad], gather = ((ih + pad - r*dil)/stride, ...) when divisible
+//
+// Tiling: 256 threads = 4 waves; block tile BM x BN, K step 32 (always inside one
+// tap because every channel count on the path is a multiple of 32); each wave owns
+// TM x TN accumulators of 32x32.  A and B tiles sit in LDS as [row][k] with a
+// 36-float row stride: the global side reads whole 128-B channel runs per 8 lanes,
+// the MFMA side reads 16 B per lane (ds_read_b128, conflict-free at stride 36) and
+// feeds four 32x32x2 MFMAs per read.  The k order inside a K step is permuted
+// (lane half h takes k = 8q+4h+e): A and B use the same permutation, so the sum is
+// the same set of products.
+#include "common.h"
+
+namespace {
+
+struct IgemmParams {
+    const float* __restrict__ a;
+    const float* __restrict__ w;
+    const float* __restrict__ bias;
+    float* __restrict__ out;
+    const float* __restrict__ mask;
+    int Ha, Wa, Ca;          // A-side spatial size and channels (= K per tap)
+    int Ho, Wo;              // output spatial size
+    int Nout;                // valid output channels (store mask)
+    int Nrows;               // valid weight rows (load mask)
+    int ldo;                 // output row stride
+    int R, S;
+    int sm, sd;              // output coord multiplier; divisor (dgrad of strided conv)
+    int off, dstep;          // tap 0 offset; per-tap step
+    int M;                   // N*Ho*Wo
+    int tiles_m, tiles_n;
+    int relu, accumulate;
+};
+
+constexpr int BK = 32;
+constexpr int LDS_LD = 36;
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;
+    static_assert(WM * WN == 4, "4 waves");
+    __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDS_LD];
+    float* As = lds;
+    float* Bs = lds + BM * LDS_LD;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int lid = xcd_swizzle(blockIdx.x, nblk);
+    const int tile_m = lid / p.tiles_n, tile_n = lid % p.tiles_n;   // n fastest: neighbours share A rows
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int chunk = tid & 7, row0 = tid >> 3;
+
+    // ---- per-thread A rows: decompose m once --------------------------------
+    int a_oh[A_ROWS], a_ow[A_ROWS];
+    size_t a_img[A_ROWS];
+    bool a_ok[A_ROWS];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int j = 0; j < A_ROWS; ++j) {
+        const int m = m0 + row0 + 32 * j;
+        a_ok[j] = m < p.M;
+        const int mm = a_ok[j] ? m : 0;
+        const int n = mm / HoWo, rem = mm - n * HoWo;
+        a_oh[j] = rem / p.Wo;
+        a_ow[j] = rem - a_oh[j] * p.Wo;
+        a_img[j] = (size_t)n * p.Ha * p.Wa * p.Ca;
+    }
+    const int T = p.R * p.S;
+    const float* b_ptr[B_ROWS];
+    bool b_ok[B_ROWS];
+#pragma unroll
+    for (int j = 0; j < B_ROWS; ++j) {
+        const int n = n0 + row0 + 32 * j;
+        b_ok[j] = n < p.Nrows;
+        b_ptr[j] = p.w + (size_t)(b_ok[j] ? n : 0) * T * p.Ca + chunk * 4;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int kc = p.Ca / BK;          // K steps per tap
+    const int KT = T * kc;
+    f32x4 ra[A_ROWS], rb[B_ROWS];
+
+    auto load_tile = [&](int kt) {
+        const int t = kt / kc, c0 = (kt - t * kc) * BK + chunk * 4;
+        const int r = t / p.S, s = t - r * p.S;
+        const int dh = p.off + r * p.dstep, dw = p.off + s * p.dstep;
+#pragma unroll
+        for (int j = 0; j < A_ROWS; ++j) {
+            int th = a_oh[j] * p.sm + dh, tw = a_ow[j] * p.sm + dw;
+            bool ok = a_ok[j] && th >= 0 && tw >= 0;
+            if (p.sd > 1) {
+                ok = ok && (th % p.sd == 0) && (tw % p.sd == 0);
+                th /= p.sd;
+                tw /= p.sd;
+            }
+            ok = ok && th < p.Ha && tw < p.Wa;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4*>(p.a + a_img[j] + ((size_t)th * p.Wa + tw) * p.Ca + c0);
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < B_ROWS; ++j) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b_ok[j]) v = *reinterpret_cast<const f32x4*>(b_ptr[j] + (size_t)kt * BK);
+            rb[j] = v;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_ROWS; ++j)
+            *reinterpret_cast<f32x4*>(&As[(row0 + 32 * j) * LDS_LD + chunk * 4]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < B_ROWS; ++j)
+            *reinterpret_cast<f32x4*>(&Bs[(row0 + 32 * j) * LDS_LD + chunk * 4]) = rb[j];
+    };
+
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+
+    const int lr = lane & 31, lh = lane >> 5;
+    const float* a_rd = As + (wm * TM * 32 + lr) * LDS_LD + lh * 4;
+    const float* b_rd = Bs + (wn * TN * 32 + lr) * LDS_LD + lh * 4;
+
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) load_tile(kt + 1);       // global loads stay in flight under the MFMAs
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(a_rd + i * 32 * LDS_LD + q * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(b_rd + j * 32 * LDS_LD + q * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (kt + 1 < KT) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) --------
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + lr;
+            const bool n_ok = n < p.Nout;
+            const float bv = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (n_ok && m < p.M) {
+                    const size_t idx = (size_t)m * p.ldo + n;
+                    float v = acc[i][j][r] + bv;
+                    if (p.accumulate) v += p.out[idx];
+                    if (p.relu) v = v < 0.f ? 0.f : v;            // NaN stays NaN, like torch.relu
+                    if (p.mask != nullptr) v = p.mask[idx] > 0.f ? v : 0.f;
+                    p.out[idx] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_igemm(IgemmParams& p, hipStream_t st) {
+    p.tiles_m = ssd_cdiv(p.M, BM);
+    p.tiles_n = ssd_cdiv(p.Nout, BN);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
+int dispatch_igemm(IgemmParams& p, hipStream_t st) {
+    // Tile choice: wide-N tiles when there are enough blocks to fill 256 CUs a few
+    // times over, smaller tiles for the deep / small layers so the grid still covers
+    // the chip.
+    const long blocks_128 = (long)ssd_cdiv(p.M, 128) * ssd_cdiv(p.Nout, 128);
+    if (p.Nout <= 64) {
+        if (p.M >= 256 * 512) return launch_igemm<256, 64, 4, 1>(p, st);
+        return launch_igemm<64, 64, 2, 2>(p, st);
+    }
+    if (blocks_128 >= 512) return launch_igemm<128, 128, 2, 2>(p, st);
+    return launch_igemm<64, 64, 2, 2>(p, st);
+}
+
+int check_geom(const ssd_conv_geom* g) {
+    if (g == nullptr) return SSD_ERR_NULL;
+    if (g->N <= 0 || g->H <= 0 || g->W <= 0 || g->Ci <= 0 || g->Co <= 0 || g->R <= 0 || g->S <= 0 ||
+        g->stride <= 0 || g->dil <= 0 || g->pad < 0)
+        return SSD_ERR_BAD_SHAPE;
+    const int ho = (g->H + 2 * g->pad - g->dil * (g->R - 1) - 1) / g->stride + 1;
+    const int wo = (g->W + 2 * g->pad - g->dil * (g->S - 1) - 1) / g->stride + 1;
+    if (ho != g->Ho || wo != g->Wo || ho <= 0 || wo <= 0) return SSD_ERR_BAD_SHAPE;
+    if ((long)g->N * g->Ho * g->Wo >= (1L << 31) || (long)g->N * g->H * g->W >= (1L << 31)) return SSD_ERR_BAD_SHAPE;
+    return SSD_OK;
+}
+
+}  // namespace
+
+extern "C" int ssd_conv2d_fwd(const float* x, const float* w_ohwi, const float* bias, float* y, int ldy,
+                              const ssd_conv_geom* g, int relu, void* stream) {
+    if (int e = check_geom(g)) return e;
+    if (!x || !w_ohwi || !y) return SSD_ERR_NULL;
+    if (g->Ci % 32 != 0 || ldy < g->Co) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(x) || !ssd_aligned16(w_ohwi)) return SSD_ERR_ALIGN;
+    IgemmParams p{};
+    p.a = x; p.w = w_ohwi; p.bias = bias; p.out = y; p.mask = nullptr;
+    p.Ha = g->H; p.Wa = g->W; p.Ca = g->Ci; p.Ho = g->Ho; p.Wo = g->Wo;
+    p.Nout = g->Co; p.Nrows = g->Co; p.ldo = ldy; p.R = g->R; p.S = g->S;
+    p.sm = g->stride; p.sd = 1; p.off = -g->pad; p.dstep = g->dil;
+    p.M = g->N * g->Ho * g->Wo; p.relu = relu; p.accumulate = 0;
+    return dispatch_igemm(p, (hipStream_t)stream);
+}
+
+extern "C" int ssd_conv2d_dgrad(const float* dy, int ldy, const float* w_ihwo, int Co_pad, float* dx,
+                                const float* relu_mask, int accumulate, const ssd_conv_geom* g, void* stream) {
+    if (int e = check_geom(g)) return e;
+    if (!dy || !w_ihwo || !dx) return SSD_ERR_NULL;
+    if (Co_pad % 32 != 0 || Co_pad < g->Co || ldy != Co_pad || g->Ci % 4 != 0) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(dy) || !ssd_aligned16(w_ihwo)) return SSD_ERR_ALIGN;
+    IgemmParams p{};
+    p.a = dy; p.w = w_ihwo; p.bias = nullptr; p.out = dx; p.mask = relu_mask;
+    p.Ha = g->Ho; p.Wa = g->Wo; p.Ca = Co_pad; p.Ho = g->H; p.Wo = g->W;
+    p.Nout = g->Ci; p.Nrows = g->Ci; p.ldo = g->Ci; p.R = g->R; p.S = g->S;
+    p.sm = 1; p.sd = g->stride; p.off = g->pad; p.dstep = -g->dil;
+    p.M = g->N * g->H * g->W; p.relu = 0; p.accumulate = accumulate;
+    return dispatch_igemm(p, (hipStream_t)stream);
+}

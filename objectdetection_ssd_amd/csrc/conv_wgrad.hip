@@ -1,0 +1,253 @@
+// Weight gradient of nn.Conv2d (autograd of Model.py:135-184, train_function.py:94).
+//
+//   dW[n][tap][c] = sum_m dy[m][n] * x[gather(m,tap)][c],     db[n] = sum_m dy[m][n]
+//
+// GEMM with the pixel index m as the reduction dimension (up to 2.9 M at bs=32), so
+// the grid is (split-K chunk, tap, n-tile, c-tile) and every block writes an f32
+// partial tile into a slab; a second kernel adds the slabs in a fixed order and
+// writes OIHW, which keeps the result bitwise reproducible (no float atomics).
+// LDS tiles are [pixel][channel] exactly as they arrive from NHWC memory; the MFMA
+// operands (A = dy^T, B = x) are read one float per lane with consecutive lanes on
+// consecutive channels (ds_read_b32, conflict-free).
+#include "common.h"
+
+namespace {
+
+struct WgradParams {
+    const float* __restrict__ x;
+    const float* __restrict__ dy;
+    float* __restrict__ slab;        // [nsplit][Co][T][Ci]
+    float* __restrict__ bias_slab;   // [nsplit][Co] or null
+    int H, W, Ci, Ho, Wo, Co, ldy;
+    int R, S, stride, pad, dil;
+    int M, m_per_split, nsplit;
+    int tiles_co, tiles_ci;
+};
+
+constexpr int WBK = 32;   // pixels per K step
+
+// BT = tile edge (both n and c), 4 waves as 2x2, each wave (BT/2)x(BT/2).
+template <int BT>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+    constexpr int TT = BT / 64;                 // 32x32 accumulators per wave per dim
+    constexpr int CHUNKS = BT / 4;              // float4 chunks per tile row
+    constexpr int ROWS_PER_PASS = 256 / CHUNKS; // pixel rows loaded per pass
+    constexpr int PASSES = WBK / ROWS_PER_PASS;
+    __shared__ __attribute__((aligned(16))) float lds[2 * WBK * BT];
+    __shared__ float bias_red[256 * 4];
+    float* Ys = lds;
+    float* Xs = lds + WBK * BT;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int T = p.R * p.S;
+    // block id -> (split, co tile, ci tile, tap); tap fastest so the T blocks that re-read the
+    // same dy / x chunk are neighbours in one XCD's L2.
+    const int per_split = T * p.tiles_co * p.tiles_ci;
+    const int nblk = per_split * p.nsplit;
+    int lid = xcd_swizzle(blockIdx.x, nblk);
+    const int split = lid / per_split;
+    lid -= split * per_split;
+    const int t = lid % T;
+    lid /= T;
+    const int tile_ci = lid % p.tiles_ci, tile_co = lid / p.tiles_ci;
+    const int co0 = tile_co * BT, ci0 = tile_ci * BT;
+    const int r = t / p.S, s = t - r * p.S;
+    const int dh = r * p.dil - p.pad, dw = s * p.dil - p.pad;
+
+    const int chunk = tid % CHUNKS, prow = tid / CHUNKS;
+    const int m_begin = split * p.m_per_split;
+    const int m_end = min(p.M, m_begin + p.m_per_split);
+    const bool y_col_ok = co0 + chunk * 4 < p.ldy;     // columns Co..ldy-1 of dy are zero padding (ldy % 4 == 0)
+    const bool x_col_ok = ci0 + chunk * 4 < p.Ci;
+    const bool do_bias = p.bias_slab != nullptr && t == 0 && tile_ci == 0;
+    const int HoWo = p.Ho * p.Wo;
+
+    f32x16 acc[TT][TT];
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+        for (int j = 0; j < TT; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 ry[PASSES], rx[PASSES];
+    auto load_tile = [&](int mb) {
+#pragma unroll
+        for (int j = 0; j < PASSES; ++j) {
+            const int m = mb + prow + ROWS_PER_PASS * j;
+            f32x4 vy = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
+            if (m < m_end) {
+                if (y_col_ok) vy = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.ldy + co0 + chunk * 4);
+                const int n = m / HoWo, rem = m - n * HoWo;
+                const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+                const int ih = oh * p.stride + dh, iw = ow * p.stride + dw;
+                if (x_col_ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                    vx = *reinterpret_cast<const f32x4*>(p.x + (((size_t)n * p.H + ih) * p.W + iw) * p.Ci + ci0 + chunk * 4);
+            }
+            ry[j] = vy;
+            rx[j] = vx;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < PASSES; ++j) {
+            const int row = prow + ROWS_PER_PASS * j;
+            *reinterpret_cast<f32x4*>(&Ys[row * BT + chunk * 4]) = ry[j];
+            *reinterpret_cast<f32x4*>(&Xs[row * BT + chunk * 4]) = rx[j];
+            if (do_bias) bsum += ry[j];
+        }
+    };
+
+    const int lr = lane & 31, lh = lane >> 5;
+    if (m_begin < m_end) {
+        load_tile(m_begin);
+        store_tile();
+        __syncthreads();
+        for (int mb = m_begin; mb < m_end; mb += WBK) {
+            const bool more = mb + WBK < m_end;
+            if (more) load_tile(mb + WBK);
+#pragma unroll
+            for (int kk = 0; kk < WBK / 2; ++kk) {
+                float af[TT], bf[TT];
+#pragma unroll
+                for (int i = 0; i < TT; ++i) af[i] = Ys[(2 * kk + lh) * BT + (wm * TT + i) * 32 + lr];
+#pragma unroll
+                for (int j = 0; j < TT; ++j) bf[j] = Xs[(2 * kk + lh) * BT + (wn * TT + j) * 32 + lr];
+#pragma unroll
+                for (int i = 0; i < TT; ++i)
+#pragma unroll
+                    for (int j = 0; j < TT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+            if (more) {
+                store_tile();
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- partial tile -> slab[split][co][t][ci] -------------------------------------------
+    float* slab = p.slab + (size_t)split * p.Co * T * p.Ci;
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            const int ci = ci0 + (wn * TT + j) * 32 + lr;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int co = co0 + (wm * TT + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+                if (co < p.Co && ci < p.Ci) slab[((size_t)co * T + t) * p.Ci + ci] = acc[i][j][q];
+            }
+        }
+    if (do_bias) {   // uniform per block
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bias_red[tid * 4 + e] = bsum[e];
+        __syncthreads();
+        if (tid < CHUNKS) {
+            f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < ROWS_PER_PASS; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tot[e] += bias_red[(q * CHUNKS + tid) * 4 + e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = co0 + tid * 4 + e;
+                if (co < p.Co) p.bias_slab[(size_t)split * p.Co + co] = tot[e];
+            }
+        }
+    }
+}
+
+// out_oihw[co][ci][t] = sum_split slab[split][co][t][ci]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Co, int Ci, int T,
+                                    int nsplit) {
+    const size_t total = (size_t)Co * T * Ci;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * total + i];
+        const int ci = (int)(i % Ci);
+        const size_t rest = i / Ci;
+        const int t = (int)(rest % T), co = (int)(rest / T);
+        dw[((size_t)co * Ci + ci) * T + t] = s;
+    }
+}
+
+__global__ void bias_reduce_kernel(const float* __restrict__ slab, float* __restrict__ db, int Co, int nsplit) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Co) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * Co + i];
+        db[i] = s;
+    }
+}
+
+struct WgradPlan {
+    int bt, tiles_co, tiles_ci, nsplit, m_per_split;
+    size_t slab_floats, bias_floats;
+};
+
+WgradPlan plan_wgrad(const ssd_conv_geom* g) {
+    WgradPlan pl;
+    const int T = g->R * g->S;
+    const int M = g->N * g->Ho * g->Wo;
+    pl.bt = (g->Co > 64 && g->Ci > 64) ? 128 : 64;
+    pl.tiles_co = ssd_cdiv(g->Co, pl.bt);
+    pl.tiles_ci = ssd_cdiv(g->Ci, pl.bt);
+    const int per_split = T * pl.tiles_co * pl.tiles_ci;
+    // aim for ~4 blocks per CU, at least 8 K steps per block, at most 256 slabs
+    int ns = ssd_cdiv(256 * 4, per_split);
+    const int max_by_m = M / (WBK * 8) > 0 ? M / (WBK * 8) : 1;
+    if (ns > max_by_m) ns = max_by_m;
+    if (ns > 256) ns = 256;
+    if (ns < 1) ns = 1;
+    int mps = ssd_cdiv(M, ns);
+    mps = ssd_cdiv(mps, WBK) * WBK;
+    pl.m_per_split = mps;
+    pl.nsplit = ssd_cdiv(M, mps);
+    pl.slab_floats = (size_t)pl.nsplit * g->Co * T * g->Ci;
+    pl.bias_floats = (size_t)pl.nsplit * g->Co;
+    return pl;
+}
+
+}  // namespace
+
+extern "C" size_t ssd_conv2d_wgrad_workspace(const ssd_conv_geom* g) {
+    if (g == nullptr) return 0;
+    const WgradPlan pl = plan_wgrad(g);
+    return (pl.slab_floats + pl.bias_floats) * sizeof(float) + 256;
+}
+
+extern "C" int ssd_conv2d_wgrad(const float* x, const float* dy, int ldy, float* dw_oihw, float* dbias,
+                                const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!g || !x || !dy || !dw_oihw || !workspace) return SSD_ERR_NULL;
+    if (g->Ci % 4 != 0 || ldy % 4 != 0 || ldy < g->Co) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(x) || !ssd_aligned16(dy) || !ssd_aligned16(workspace)) return SSD_ERR_ALIGN;
+    if (workspace_bytes < ssd_conv2d_wgrad_workspace(g)) return SSD_ERR_WORKSPACE;
+    const WgradPlan pl = plan_wgrad(g);
+    hipStream_t st = (hipStream_t)stream;
+    WgradParams p{};
+    p.x = x; p.dy = dy;
+    p.slab = reinterpret_cast<float*>(workspace);
+    p.bias_slab = dbias ? p.slab + pl.slab_floats : nullptr;
+    p.H = g->H; p.W = g->W; p.Ci = g->Ci; p.Ho = g->Ho; p.Wo = g->Wo; p.Co = g->Co; p.ldy = ldy;
+    p.R = g->R; p.S = g->S; p.stride = g->stride; p.pad = g->pad; p.dil = g->dil;
+    p.M = g->N * g->Ho * g->Wo; p.m_per_split = pl.m_per_split; p.nsplit = pl.nsplit;
+    p.tiles_co = pl.tiles_co; p.tiles_ci = pl.tiles_ci;
+    const int T = g->R * g->S;
+    const int nblk = T * pl.tiles_co * pl.tiles_ci * pl.nsplit;
+    if (pl.bt == 128) hipLaunchKernelGGL(wgrad_kernel<128>, dim3(nblk), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(wgrad_kernel<64>, dim3(nblk), dim3(256), 0, st, p);
+    SSD_CHECK_LAUNCH();
+    const size_t total = (size_t)g->Co * T * g->Ci;
+    const int rb = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, p.slab, dw_oihw, g->Co, g->Ci, T, pl.nsplit);
+    SSD_CHECK_LAUNCH();
+    if (dbias) {
+        hipLaunchKernelGGL(bias_reduce_kernel, dim3(ssd_cdiv(g->Co, 256)), dim3(256), 0, st, p.bias_slab, dbias, g->Co,
+                           pl.nsplit);
+        SSD_CHECK_LAUNCH();
+    }
+    return SSD_OK;
+}

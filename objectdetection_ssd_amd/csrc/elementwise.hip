@@ -1,0 +1,539 @@
+// HBM-bound NHWC kernels around the convolutions: weight re-layout, conv1_1,
+// max pooling, conv4_3 L2 normalisation, head scatter/gather, fused SGD.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// weight layouts
+// ---------------------------------------------------------------------------------------
+__global__ void oihw_to_ohwi_kernel(const float* __restrict__ w, float* __restrict__ o, int Co, int Ci, int T, int Co_pad) {
+    const size_t total = (size_t)Co_pad * T * Ci;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Ci);
+        const size_t rest = i / Ci;
+        const int t = (int)(rest % T), co = (int)(rest / T);
+        o[i] = co < Co ? w[((size_t)co * Ci + ci) * T + t] : 0.f;
+    }
+}
+__global__ void oihw_to_ihwo_kernel(const float* __restrict__ w, float* __restrict__ o, int Co, int Ci, int T, int Co_pad) {
+    const size_t total = (size_t)Ci * T * Co_pad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Co_pad);
+        const size_t rest = i / Co_pad;
+        const int t = (int)(rest % T), ci = (int)(rest / T);
+        o[i] = co < Co ? w[((size_t)co * Ci + ci) * T + t] : 0.f;
+    }
+}
+
+inline int grid_for(size_t total, int block = 256, int cap = 4096) {
+    size_t b = (total + block - 1) / block;
+    return (int)(b > (size_t)cap ? cap : (b == 0 ? 1 : b));
+}
+
+// ---------------------------------------------------------------------------------------
+// conv1_1: Conv2d(3, Co, 3, padding=1) + ReLU reading NCHW, writing NHWC.
+// One thread = one output pixel x 16 output channels (4 threads per pixel so a wave
+// writes 16 pixels x 256 B contiguous); the 27 input taps sit in registers, weights
+// in LDS as [tap*3+c][Co] (all lanes of a quarter read the same address: broadcast).
+// ---------------------------------------------------------------------------------------
+template <int CO>
+__global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ y,
+                                                             int N, int H, int W, int relu) {
+    __shared__ __attribute__((aligned(16))) float ws[27 * CO];
+    __shared__ float bs[CO];
+    for (int i = threadIdx.x; i < 27 * CO; i += 256) {
+        const int co = i % CO, k = i / CO;          // k = (r*3+s)*3 + c
+        const int c = k % 3, t = k / 3;
+        ws[i] = w[((size_t)co * 3 + c) * 9 + t];
+    }
+    for (int i = threadIdx.x; i < CO; i += 256) bs[i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+    constexpr int Q = CO / 16;                       // threads per pixel
+    const size_t npix = (size_t)N * H * W;
+    const size_t HW = (size_t)H * W;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < npix * Q; g += (size_t)gridDim.x * 256) {
+        const size_t pix = g / Q;
+        const int q = (int)(g % Q);
+        const int n = (int)(pix / HW);
+        const int rem = (int)(pix - (size_t)n * HW);
+        const int oh = rem / W, ow = rem - oh * W;
+        float v[27];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int ih = oh + r - 1, iw = ow + s - 1;
+                const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < W;
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    v[(r * 3 + s) * 3 + c] = ok ? x[((size_t)n * 3 + c) * HW + (size_t)ih * W + iw] : 0.f;
+            }
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = bs[q * 16 + j];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            const float* wr = ws + k * CO + q * 16;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = fmaf(v[k], wr[j], acc[j]);
+        }
+        f32x4* dst = reinterpret_cast<f32x4*>(y + pix * CO + q * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = acc[j * 4 + e];
+                o[e] = relu ? (t < 0.f ? 0.f : t) : t;
+            }
+            dst[j] = o;
+        }
+    }
+}
+
+// conv1_1 weight gradient: dW[co][c][t] = sum_pix dy[pix][co] * xcol[pix][t*3+c].
+// Each block walks a slice of pixels in 64-pixel steps: the dy tile [64][CO] and the im2col
+// tile [64][27] go to LDS; the 64 co x 27 k = 1728 outputs are spread as 256 threads x 7
+// (co = tid&63, k = (tid>>6) + 4j), so a wave reads consecutive dy channels and one
+// broadcast im2col value per FMA.  HBM-bound on reading dy (N*H*W*64 floats).
+template <int CO>
+__global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ slab, float* __restrict__ bias_slab,
+                                                               int N, int H, int W, int pix_per_block) {
+    static_assert(CO == 64, "conv1_1 has 64 output channels");
+    constexpr int PB = 64;
+    __shared__ float ys[PB][CO + 1];
+    __shared__ float xs[PB][28];
+    const int tid = threadIdx.x;
+    const int co = tid & 63, kq = tid >> 6;
+    const size_t HW = (size_t)H * W;
+    const size_t npix = (size_t)N * HW;
+    const size_t p_begin = (size_t)blockIdx.x * pix_per_block;
+    const size_t p_end = p_begin + pix_per_block < npix ? p_begin + pix_per_block : npix;
+    float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float bacc = 0.f;
+    for (size_t pb = p_begin; pb < p_end; pb += PB) {
+        // dy tile: 64 pixels x 64 channels = 4096 floats, 16 per thread, coalesced
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int e = tid + 256 * j;
+            const int pr = e >> 6, c = e & 63;
+            const size_t pix = pb + pr;
+            ys[pr][c] = pix < p_end ? dy[pix * CO + c] : 0.f;
+        }
+        // im2col tile: 64 pixels x 27
+        for (int e = tid; e < PB * 27; e += 256) {
+            const int pr = e / 27, k = e - pr * 27;
+            const size_t pix = pb + pr;
+            float v = 0.f;
+            if (pix < p_end) {
+                const int n = (int)(pix / HW);
+                const int rem = (int)(pix - (size_t)n * HW);
+                const int oh = rem / W, ow = rem - oh * W;
+                const int c = k % 3, t = k / 3;
+                const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
+                if (ih >= 0 && ih < H && iw >= 0 && iw < W) v = x[((size_t)n * 3 + c) * HW + (size_t)ih * W + iw];
+            }
+            xs[pr][k] = v;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int pr = 0; pr < PB; ++pr) {
+            const float d = ys[pr][co];
+            if (kq == 0) bacc += d;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int k = kq + 4 * j;
+                if (k < 27) acc[j] = fmaf(d, xs[pr][k], acc[j]);
+            }
+        }
+        __syncthreads();
+    }
+    float* out = slab + (size_t)blockIdx.x * CO * 27;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int k = kq + 4 * j;                  // k = t*3 + c
+        if (k < 27) out[co * 27 + (k % 3) * 9 + k / 3] = acc[j];   // OIHW order inside the slab
+    }
+    if (kq == 0 && bias_slab) bias_slab[(size_t)blockIdx.x * CO + co] = bacc;
+}
+
+__global__ void slab_sum_kernel(const float* __restrict__ slab, float* __restrict__ out, int n, int nslab) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        float s = 0.f;
+        for (int k = 0; k < nslab; ++k) s += slab[(size_t)k * n + i];
+        out[i] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// max pooling, NHWC, 4 channels per thread
+// ---------------------------------------------------------------------------------------
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ am, int N,
+                                   int H, int W, int C, int k, int stride, int pad, int Ho, int Wo) {
+    const int C4 = C >> 2;
+    const size_t total = (size_t)N * Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        size_t rest = i / C4;
+        const int ow = (int)(rest % Wo);
+        rest /= Wo;
+        const int oh = (int)(rest % Ho), n = (int)(rest / Ho);
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+        bool first = true;
+        for (int r = 0; r < k; ++r) {
+            const int ih = oh * stride - pad + r;
+            if (ih < 0 || ih >= H) continue;
+            for (int s = 0; s < k; ++s) {
+                const int iw = ow * stride - pad + s;
+                if (iw < 0 || iw >= W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)n * H + ih) * W + iw) * C + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // torch: take v if (v > best) or isnan(v); the first valid element seeds the max
+                    if (first || v[e] > best[e] || v[e] != v[e]) {
+                        best[e] = v[e];
+                        bi[e] = r * k + s;
+                    }
+                }
+                first = false;
+            }
+        }
+        *reinterpret_cast<f32x4*>(y + i * 4) = best;
+        if (am) {
+            uint32_t packed = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+            *reinterpret_cast<uint32_t*>(am + i * 4) = packed;
+        }
+    }
+}
+
+// gather form: every input element sums dy over the windows whose argmax it is
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ am, float* __restrict__ dx,
+                                   const float* __restrict__ mask, int accumulate, int N, int H, int W, int C, int k,
+                                   int stride, int pad, int Ho, int Wo) {
+    const int C4 = C >> 2;
+    const size_t total = (size_t)N * H * W * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        size_t rest = i / C4;
+        const int iw = (int)(rest % W);
+        rest /= W;
+        const int ih = (int)(rest % H), n = (int)(rest / H);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < k; ++r) {
+            const int th = ih + pad - r;
+            if (th < 0 || th % stride != 0) continue;
+            const int oh = th / stride;
+            if (oh >= Ho) continue;
+            for (int s = 0; s < k; ++s) {
+                const int tw = iw + pad - s;
+                if (tw < 0 || tw % stride != 0) continue;
+                const int ow = tw / stride;
+                if (ow >= Wo) continue;
+                const size_t o = (((size_t)n * Ho + oh) * Wo + ow) * C + c4 * 4;
+                const uint32_t a = *reinterpret_cast<const uint32_t*>(am + o);
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dy + o);
+                const uint32_t me = (uint32_t)(r * k + s);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (((a >> (8 * e)) & 0xffu) == me) g[e] += d[e];
+            }
+        }
+        f32x4* dst = reinterpret_cast<f32x4*>(dx + i * 4);
+        if (accumulate) g += *dst;
+        if (mask) {
+            const f32x4 m = *reinterpret_cast<const f32x4*>(mask + i * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
+        }
+        *dst = g;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// L2 norm over channels: one wave per pixel, C = 512 -> 8 floats per lane
+// ---------------------------------------------------------------------------------------
+template <int VPL>   // float4 vectors per lane: C = 64*4*VPL
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         float* __restrict__ y, int M) {
+    const int lane = threadIdx.x & 63;
+    const int C = 256 * VPL;
+    for (int m = blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += gridDim.x * 4) {
+        f32x4 v[VPL];
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            v[j] = *reinterpret_cast<const f32x4*>(x + (size_t)m * C + (j * 64 + lane) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ss += v[j][e] * v[j][e];
+        }
+        ss = wave_sum(ss);
+        const float nrm = sqrtf(ss);               // no epsilon: Model.py:207
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + (j * 64 + lane) * 4);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = v[j][e] / nrm * g[e];
+            *reinterpret_cast<f32x4*>(y + (size_t)m * C + (j * 64 + lane) * 4) = o;
+        }
+    }
+}
+
+// u = x/|x|, gdy = gamma*dy:  dx = (gdy - u*(u.gdy))/|x| ;  dgamma_c = sum_m dy_c*u_c (per-block partials)
+template <int VPL>
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ dy, float* __restrict__ dx,
+                                                         float* __restrict__ dg_slab, int M) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = 256 * VPL;
+    __shared__ float red[4][256 * VPL];
+    f32x4 dg[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) dg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
+        f32x4 v[VPL], d[VPL];
+        float ss = 0.f, dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            const size_t o = (size_t)m * C + (j * 64 + lane) * 4;
+            v[j] = *reinterpret_cast<const f32x4*>(x + o);
+            d[j] = *reinterpret_cast<const f32x4*>(dy + o);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + (j * 64 + lane) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ss += v[j][e] * v[j][e];
+                dot += v[j][e] * d[j][e] * g[e];
+            }
+        }
+        ss = wave_sum(ss);
+        dot = wave_sum(dot);
+        const float inv = 1.f / sqrtf(ss);
+        const float coef = dot * inv * inv * inv;          // (x.gdy)/|x|^3
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + (j * 64 + lane) * 4);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = g[e] * d[j][e] * inv - v[j][e] * coef;
+                dg[j][e] += d[j][e] * v[j][e] * inv;
+            }
+            *reinterpret_cast<f32x4*>(dx + (size_t)m * C + (j * 64 + lane) * 4) = o;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VPL; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave][(j * 64 + lane) * 4 + e] = dg[j][e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256)
+        dg_slab[(size_t)blockIdx.x * C + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+
+// ---------------------------------------------------------------------------------------
+// heads: packed [N*HW][ld] <-> loc (N,P,4) / conf (N,P,ncls)
+// ---------------------------------------------------------------------------------------
+__global__ void heads_scatter_kernel(const float* __restrict__ packed, int ld, float* __restrict__ loc,
+                                     float* __restrict__ conf, int N, int HW, int A, int prior_off, int P, int ncls) {
+    const int cw = A * (4 + ncls);
+    const size_t total = (size_t)N * HW * cw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cw);
+        const size_t m = i / cw;
+        const int n = (int)(m / HW), pix = (int)(m % HW);
+        const float v = packed[m * ld + c];
+        const size_t pbase = (size_t)n * P + prior_off + (size_t)pix * A;
+        if (c < 4 * A) loc[pbase * 4 + c] = v;
+        else conf[pbase * ncls + (c - 4 * A)] = v;
+    }
+}
+__global__ void heads_gather_kernel(const float* __restrict__ dloc, const float* __restrict__ dconf,
+                                    float* __restrict__ packed, int ld, int N, int HW, int A, int prior_off, int P,
+                                    int ncls) {
+    const int cw = A * (4 + ncls);
+    const size_t total = (size_t)N * HW * ld;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % ld);
+        const size_t m = i / ld;
+        const int n = (int)(m / HW), pix = (int)(m % HW);
+        const size_t pbase = (size_t)n * P + prior_off + (size_t)pix * A;
+        float v = 0.f;                                  // pad columns cw..ld-1 are written as zero
+        if (c < 4 * A) v = dloc[pbase * 4 + c];
+        else if (c < cw) v = dconf[pbase * ncls + (c - 4 * A)];
+        packed[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// SGD with momentum and weight decay (torch.optim.SGD semantics, train.py:53-55):
+//   g = grad*scale + wd*p ; buf = first ? g : mom*buf + g ; p -= lr*buf
+// ---------------------------------------------------------------------------------------
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, size_t n, float lr,
+                           float mom, float wd, const float* __restrict__ scale, int first) {
+    const float sc = scale ? *scale : 1.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float w = p[i];
+        const float d = g[i] * sc + wd * w;
+        const float b = first ? d : mom * buf[i] + d;
+        buf[i] = b;
+        p[i] = w - lr * b;
+    }
+}
+
+}  // namespace
+
+extern "C" int ssd_abi_version(void) { return SSD_ABI_VERSION; }
+
+extern "C" const char* ssd_status_string(int s) {
+    switch (s) {
+        case SSD_OK: return "ok";
+        case SSD_ERR_BAD_SHAPE: return "unsupported or inconsistent shape";
+        case SSD_ERR_WORKSPACE: return "workspace too small";
+        case SSD_ERR_NULL: return "required pointer is NULL";
+        case SSD_ERR_LAUNCH: return "kernel launch failed (hipGetLastError)";
+        case SSD_ERR_ALIGN: return "pointer or leading dimension not 16-byte aligned";
+        default: return "unknown status";
+    }
+}
+
+extern "C" int ssd_weight_oihw_to_ohwi(const float* w, float* o, int Co, int Ci, int R, int S, int Co_pad, void* stream) {
+    if (!w || !o) return SSD_ERR_NULL;
+    if (Co <= 0 || Ci <= 0 || R <= 0 || S <= 0 || Co_pad < Co) return SSD_ERR_BAD_SHAPE;
+    const size_t total = (size_t)Co_pad * R * S * Ci;
+    hipLaunchKernelGGL(oihw_to_ohwi_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w, o, Co, Ci, R * S, Co_pad);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+extern "C" int ssd_weight_oihw_to_ihwo(const float* w, float* o, int Co, int Ci, int R, int S, int Co_pad, void* stream) {
+    if (!w || !o) return SSD_ERR_NULL;
+    if (Co <= 0 || Ci <= 0 || R <= 0 || S <= 0 || Co_pad < Co) return SSD_ERR_BAD_SHAPE;
+    const size_t total = (size_t)Co_pad * R * S * Ci;
+    hipLaunchKernelGGL(oihw_to_ihwo_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w, o, Co, Ci, R * S, Co_pad);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
+extern "C" int ssd_conv_first_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Co,
+                                  int relu, void* stream) {
+    if (!x || !w || !y) return SSD_ERR_NULL;
+    if (Co != 64 || N <= 0 || H <= 0 || W <= 0) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(y)) return SSD_ERR_ALIGN;
+    const size_t work = (size_t)N * H * W * (Co / 16);
+    hipLaunchKernelGGL(conv_first_fwd_kernel<64>, dim3(grid_for(work, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, N, H, W, relu);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
+static int conv_first_blocks(int N, int H, int W, int* pix_per_block) {
+    const size_t npix = (size_t)N * H * W;
+    size_t ppb = (npix + 1023) / 1024;
+    ppb = (ppb + 63) / 64 * 64;
+    if (ppb < 64) ppb = 64;
+    *pix_per_block = (int)ppb;
+    return (int)((npix + ppb - 1) / ppb);
+}
+extern "C" size_t ssd_conv_first_wgrad_workspace(int N, int H, int W, int Co) {
+    int ppb;
+    const int nb = conv_first_blocks(N, H, W, &ppb);
+    return (size_t)nb * Co * 28 * sizeof(float) + 256;
+}
+extern "C" int ssd_conv_first_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N, int H, int W, int Co,
+                                    void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !dy || !dw || !ws) return SSD_ERR_NULL;
+    if (Co != 64 || N <= 0 || H <= 0 || W <= 0) return SSD_ERR_BAD_SHAPE;
+    if (ws_bytes < ssd_conv_first_wgrad_workspace(N, H, W, Co)) return SSD_ERR_WORKSPACE;
+    int ppb;
+    const int nb = conv_first_blocks(N, H, W, &ppb);
+    float* slab = reinterpret_cast<float*>(ws);
+    float* bslab = slab + (size_t)nb * Co * 27;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv_first_wgrad_kernel<64>, dim3(nb), dim3(256), 0, st, x, dy, slab, dbias ? bslab : nullptr, N, H, W, ppb);
+    SSD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(ssd_cdiv(Co * 27, 256)), dim3(256), 0, st, slab, dw, Co * 27, nb);
+    SSD_CHECK_LAUNCH();
+    if (dbias) {
+        hipLaunchKernelGGL(slab_sum_kernel, dim3(1), dim3(256), 0, st, bslab, dbias, Co, nb);
+        SSD_CHECK_LAUNCH();
+    }
+    return SSD_OK;
+}
+
+extern "C" int ssd_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int N, int H, int W, int C, int k, int stride,
+                               int pad, int Ho, int Wo, void* stream) {
+    if (!x || !y) return SSD_ERR_NULL;
+    if (C % 4 != 0 || k <= 0 || k > 15 || stride <= 0 || pad < 0 || 2 * pad > k || Ho <= 0 || Wo <= 0) return SSD_ERR_BAD_SHAPE;
+    // every window must contain at least one valid element (torch guarantees this for its own Ho/Wo)
+    if ((Ho - 1) * stride - pad >= H || (Wo - 1) * stride - pad >= W) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(x) || !ssd_aligned16(y)) return SSD_ERR_ALIGN;
+    const size_t total = (size_t)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, N, H, W, C, k, stride, pad, Ho, Wo);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+extern "C" int ssd_maxpool_bwd(const float* dy, const uint8_t* argmax, float* dx, const float* relu_mask, int accumulate,
+                               int N, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo, void* stream) {
+    if (!dy || !argmax || !dx) return SSD_ERR_NULL;
+    if (C % 4 != 0 || k <= 0 || k > 15 || stride <= 0 || pad < 0) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(dy) || !ssd_aligned16(dx)) return SSD_ERR_ALIGN;
+    const size_t total = (size_t)N * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx, relu_mask, accumulate, N, H, W, C, k, stride, pad, Ho, Wo);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
+extern "C" int ssd_l2norm_fwd(const float* x, const float* gamma, float* y, int M, int C, void* stream) {
+    if (!x || !gamma || !y) return SSD_ERR_NULL;
+    if (C != 512 || M <= 0) return SSD_ERR_BAD_SHAPE;
+    const int blocks = ssd_cdiv(M, 4) > 2048 ? 2048 : ssd_cdiv(M, 4);
+    hipLaunchKernelGGL(l2norm_fwd_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, y, M);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+static int l2norm_bwd_blocks(int M) { const int b = ssd_cdiv(M, 4); return b > 512 ? 512 : b; }
+extern "C" size_t ssd_l2norm_bwd_workspace(int M, int C) { return (size_t)l2norm_bwd_blocks(M) * C * sizeof(float) + 256; }
+extern "C" int ssd_l2norm_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, int M, int C,
+                              void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !gamma || !dy || !dx || !dgamma || !ws) return SSD_ERR_NULL;
+    if (C != 512 || M <= 0) return SSD_ERR_BAD_SHAPE;
+    if (ws_bytes < ssd_l2norm_bwd_workspace(M, C)) return SSD_ERR_WORKSPACE;
+    const int blocks = l2norm_bwd_blocks(M);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(l2norm_bwd_kernel<2>, dim3(blocks), dim3(256), 0, st, x, gamma, dy, dx, reinterpret_cast<float*>(ws), M);
+    SSD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(ssd_cdiv(C, 256)), dim3(256), 0, st, reinterpret_cast<const float*>(ws), dgamma, C, blocks);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
+extern "C" int ssd_heads_scatter(const float* packed, int ld, float* loc, float* conf, int N, int HW, int A, int prior_off,
+                                 int P, int ncls, void* stream) {
+    if (!packed || !loc || !conf) return SSD_ERR_NULL;
+    if (ld < A * (4 + ncls) || prior_off < 0 || prior_off + HW * A > P) return SSD_ERR_BAD_SHAPE;
+    const size_t total = (size_t)N * HW * A * (4 + ncls);
+    hipLaunchKernelGGL(heads_scatter_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, packed, ld, loc, conf, N, HW, A, prior_off, P, ncls);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+extern "C" int ssd_heads_gather(const float* dloc, const float* dconf, float* packed, int ld, int N, int HW, int A,
+                                int prior_off, int P, int ncls, void* stream) {
+    if (!packed || !dloc || !dconf) return SSD_ERR_NULL;
+    if (ld < A * (4 + ncls) || prior_off < 0 || prior_off + HW * A > P) return SSD_ERR_BAD_SHAPE;
+    const size_t total = (size_t)N * HW * ld;
+    hipLaunchKernelGGL(heads_gather_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dloc, dconf, packed, ld, N, HW, A, prior_off, P, ncls);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
+extern "C" int ssd_sgd_momentum(float* param, const float* grad, float* buf, size_t n, float lr, float momentum,
+                                float weight_decay, const float* grad_scale_dev, int first_step, void* stream) {
+    if (!param || !grad || !buf) return SSD_ERR_NULL;
+    if (n == 0) return SSD_OK;
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, param, grad, buf, n, lr, momentum, weight_decay, grad_scale_dev, first_step);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}

@@ -1,0 +1,277 @@
+// Decode + softmax + per-class NMS + cross-class top-k for one image
+// (Losses.py:11-98 inference; Util.py:86-96 gcxgcy_to_cxcy, xywh_to_xyxy; Util.py:252-301 IoU).
+//
+//   D1 decode_softmax  thread per prior: box (cxcywh -> xyxy), class probabilities (class-major copy)
+//   D2 compact         block per class: candidates prob >= min_score -> 64-bit keys
+//                      (prob bits << 32 | ~prior index): descending key order = descending
+//                      prob, lower prior index first on ties (the CPU sort order)
+//   D3 rank_scatter    rank of every candidate = number of larger keys (keys are unique), so
+//                      the sort is a scatter; all classes and candidates in parallel
+//   D4 nms             block per class, greedy in sorted order: a kept box marks every later
+//                      box with IoU >= threshold; suppression flags live in LDS
+//   D5 offsets         class-major offsets of the kept boxes
+//   D6 emit            if more than top_k survive, rank by prob (stable on the class-major
+//                      position) and keep ranks < top_k; scale boxes by (w,h,w,h)
+// IoU uses the same contraction-free f32 sequence as the matcher.
+#include "common.h"
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int NB_T = 1024;
+
+__device__ __forceinline__ float iou_boxes(const f32x4 a, const f32x4 b) {
+    const float lx = fmaxf(a[0], b[0]), ly = fmaxf(a[1], b[1]);
+    const float hx = fminf(a[2], b[2]), hy = fminf(a[3], b[3]);
+    const float dx = fmaxf(hx - lx, 0.f), dy = fmaxf(hy - ly, 0.f);
+    const float inter = dx * dy;
+    const float a1 = (a[2] - a[0]) * (a[3] - a[1]);
+    const float a2 = (b[2] - b[0]) * (b[3] - b[1]);
+    return inter / ((a1 + a2) - inter);
+}
+
+struct NmsWs {
+    float* boxes;        // [P][4] xyxy
+    float* probs_t;      // [C-1][P]
+    uint64_t* keys;      // [C-1][P] unsorted candidate keys
+    int32_t* cand_cnt;   // [C-1]
+    float* s_boxes;      // [C-1][P][4] sorted
+    float* s_prob;       // [C-1][P]
+    int32_t* s_idx;      // [C-1][P]
+    int32_t* kept_pos;   // [C-1][P] sorted positions of kept boxes, in order
+    int32_t* kept_cnt;   // [C-1]
+    int32_t* offsets;    // [C] class-major exclusive offsets, [C-1] = total
+    size_t bytes;
+};
+
+NmsWs carve(void* ws, int P, int C) {
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    char* b = reinterpret_cast<char*>(ws);
+    size_t o = 0;
+    const size_t K = (size_t)(C - 1) * P;
+    NmsWs w;
+    w.boxes = reinterpret_cast<float*>(b + o); o += up((size_t)P * 16);
+    w.probs_t = reinterpret_cast<float*>(b + o); o += up(K * 4);
+    w.keys = reinterpret_cast<uint64_t*>(b + o); o += up(K * 8);
+    w.cand_cnt = reinterpret_cast<int32_t*>(b + o); o += up((size_t)C * 4);
+    w.s_boxes = reinterpret_cast<float*>(b + o); o += up(K * 16);
+    w.s_prob = reinterpret_cast<float*>(b + o); o += up(K * 4);
+    w.s_idx = reinterpret_cast<int32_t*>(b + o); o += up(K * 4);
+    w.kept_pos = reinterpret_cast<int32_t*>(b + o); o += up(K * 4);
+    w.kept_cnt = reinterpret_cast<int32_t*>(b + o); o += up((size_t)C * 4);
+    w.offsets = reinterpret_cast<int32_t*>(b + o); o += up((size_t)(C + 1) * 4);
+    w.bytes = o;
+    return w;
+}
+
+__global__ void decode_softmax_kernel(const float* __restrict__ l_, const float* __restrict__ c_, const float* __restrict__ pri,
+                                      int P, int C, float* __restrict__ boxes, float* __restrict__ probs_t) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(l_ + (size_t)p * 4);
+    const f32x4 pr = *reinterpret_cast<const f32x4*>(pri + (size_t)p * 4);
+    // Util.py:89-91: g_c * p_wh / 10 + p_c ; exp(g_wh / 5) * p_wh
+    const float cx = g[0] * pr[2] / 10.f + pr[0], cy = g[1] * pr[3] / 10.f + pr[1];
+    const float w = expf(g[2] / 5.f) * pr[2], h = expf(g[3] / 5.f) * pr[3];
+    // Util.py:93-96: c - wh/2, c + wh/2
+    f32x4 b;
+    b[0] = cx - w / 2.f; b[1] = cy - h / 2.f; b[2] = cx + w / 2.f; b[3] = cy + h / 2.f;
+    *reinterpret_cast<f32x4*>(boxes + (size_t)p * 4) = b;
+    const float* x = c_ + (size_t)p * C;
+    float m = x[0];
+    for (int q = 1; q < C; ++q) m = fmaxf(m, x[q]);
+    float se = 0.f;
+    for (int q = 0; q < C; ++q) se += expf(x[q] - m);
+    for (int q = 0; q < C - 1; ++q) probs_t[(size_t)q * P + p] = expf(x[q] - m) / se;
+}
+
+__global__ __launch_bounds__(NB_T) void compact_kernel(const float* __restrict__ probs_t, int P, float min_score,
+                                                       uint64_t* __restrict__ keys, int32_t* __restrict__ cand_cnt) {
+    __shared__ int cnt;
+    const int c = blockIdx.x;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    for (int p = threadIdx.x; p < P; p += NB_T) {
+        const float v = probs_t[(size_t)c * P + p];
+        if (v >= min_score) {                                   // Losses.py:32 (NaN fails, as in torch)
+            const int pos = atomicAdd(&cnt, 1);
+            keys[(size_t)c * P + pos] = ((uint64_t)__float_as_uint(v) << 32) | (uint64_t)(0xffffffffu - (uint32_t)p);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) cand_cnt[c] = cnt;
+}
+
+__global__ __launch_bounds__(256) void rank_scatter_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ cand_cnt,
+                                                           const float* __restrict__ boxes, int P, float* __restrict__ s_boxes,
+                                                           float* __restrict__ s_prob, int32_t* __restrict__ s_idx) {
+    __shared__ uint64_t tile[256];
+    const int c = blockIdx.y;
+    const int n = cand_cnt[c];
+    if (blockIdx.x * 256 >= n) return;                          // uniform per block
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const uint64_t* kc = keys + (size_t)c * P;
+    const uint64_t mine = i < n ? kc[i] : 0;
+    int rank = 0;
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int j = j0 + threadIdx.x;
+        tile[threadIdx.x] = j < n ? kc[j] : 0;
+        __syncthreads();
+        const int lim = min(256, n - j0);
+        for (int t = 0; t < lim; ++t) rank += tile[t] > mine;
+        __syncthreads();
+    }
+    if (i < n) {
+        const int p = (int)(0xffffffffu - (uint32_t)(mine & 0xffffffffu));
+        const size_t o = (size_t)c * P + rank;
+        *reinterpret_cast<f32x4*>(s_boxes + o * 4) = *reinterpret_cast<const f32x4*>(boxes + (size_t)p * 4);
+        s_prob[o] = __uint_as_float((uint32_t)(mine >> 32));
+        s_idx[o] = p;
+    }
+}
+
+__global__ __launch_bounds__(NB_T) void nms_kernel(const float* __restrict__ s_boxes, const int32_t* __restrict__ cand_cnt, int P,
+                                                   float thr, int32_t* __restrict__ kept_pos, int32_t* __restrict__ kept_cnt) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t sup[];     // P flags
+    __shared__ int wave_tot[NB_T / 64];
+    __shared__ int running;
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = cand_cnt[c];
+    const float* bx = s_boxes + (size_t)c * P * 4;
+    for (int j = tid; j < n; j += NB_T) sup[j] = 0;
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+        if (sup[i]) continue;                                   // uniform: every thread reads the same flag
+        const f32x4 a = *reinterpret_cast<const f32x4*>(bx + (size_t)i * 4);
+        for (int j = i + 1 + tid; j < n; j += NB_T) {
+            if (!sup[j]) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(bx + (size_t)j * 4);
+                if (iou_boxes(a, b) >= thr) sup[j] = 1;         // Losses.py:51 (NaN >= thr is false)
+            }
+        }
+        __syncthreads();
+    }
+    // ordered compaction of the survivors
+    if (tid == 0) running = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < n; j0 += NB_T) {
+        const int j = j0 + tid;
+        const int keep = (j < n && !sup[j]) ? 1 : 0;
+        int incl = keep;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int off = running;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        if (keep) kept_pos[(size_t)c * P + off + incl - 1] = j;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < NB_T / 64; ++w) t += wave_tot[w];
+            running += t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) kept_cnt[c] = running;
+}
+
+__global__ void offsets_kernel(const int32_t* __restrict__ kept_cnt, int C1, int32_t* __restrict__ offsets) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int o = 0;
+        for (int c = 0; c < C1; ++c) { offsets[c] = o; o += kept_cnt[c]; }
+        offsets[C1] = o;
+    }
+}
+
+struct EmitArgs {
+    const float* s_boxes; const float* s_prob; const int32_t* s_idx; const int32_t* kept_pos; const int32_t* kept_cnt;
+    const int32_t* offsets; int P, C1, top_k; float w, h;
+    float* boxes; int64_t* classes; float* probs; int32_t* prior_ids; int32_t* count;
+};
+
+// thread per (class, kept slot).  Output slot = class-major position when everything fits, else the
+// rank by (prob desc, class-major position asc); only ranks < top_k are written.
+__global__ __launch_bounds__(256) void emit_kernel(const EmitArgs a) {
+    const int c = blockIdx.y;
+    const int n = a.kept_cnt[c];
+    const int total = a.offsets[a.C1];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.count = total > a.top_k ? a.top_k : total;
+    if (blockIdx.x * 256 >= n) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int pos = a.kept_pos[(size_t)c * a.P + i];
+    const size_t src = (size_t)c * a.P + pos;
+    const float pr = a.s_prob[src];
+    const int gpos = a.offsets[c] + i;
+    int slot = gpos;
+    if (total > a.top_k) {
+        const uint32_t mine = __float_as_uint(pr);
+        int rank = 0;
+        for (int c2 = 0; c2 < a.C1; ++c2) {
+            const int n2 = a.kept_cnt[c2];
+            const int base = a.offsets[c2];
+            for (int j = 0; j < n2; ++j) {
+                const uint32_t o = __float_as_uint(a.s_prob[(size_t)c2 * a.P + a.kept_pos[(size_t)c2 * a.P + j]]);
+                rank += (o > mine) || (o == mine && base + j < gpos);
+            }
+        }
+        slot = rank;
+    }
+    if (slot < a.top_k) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(a.s_boxes + src * 4);
+        f32x4 o;
+        o[0] = b[0] * a.w; o[1] = b[1] * a.h; o[2] = b[2] * a.w; o[3] = b[3] * a.h;    // Losses.py:89
+        *reinterpret_cast<f32x4*>(a.boxes + (size_t)slot * 4) = o;
+        a.classes[slot] = c;
+        a.probs[slot] = pr;
+        a.prior_ids[slot] = a.s_idx[src];
+    }
+}
+
+}  // namespace
+
+extern "C" size_t ssd_decode_nms_workspace(int P, int n_classes) {
+    if (P <= 0 || n_classes < 2) return 0;
+    return carve(nullptr, P, n_classes).bytes;
+}
+
+extern "C" int ssd_decode_nms(const float* l_, const float* c_, const float* priors_cxcywh, int P, int n_classes,
+                              float min_score, float iou_threshold, int top_k, float img_w, float img_h, float* boxes,
+                              int64_t* classes, float* probs, int32_t* prior_ids, int32_t* count, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    if (!l_ || !c_ || !priors_cxcywh || !boxes || !classes || !probs || !prior_ids || !count || !workspace) return SSD_ERR_NULL;
+    if (P <= 0 || P > 100000 || n_classes < 2 || n_classes > 256 || top_k <= 0) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(l_) || !ssd_aligned16(priors_cxcywh) || !ssd_aligned16(boxes) || !ssd_aligned16(workspace)) return SSD_ERR_ALIGN;
+    if (workspace_bytes < ssd_decode_nms_workspace(P, n_classes)) return SSD_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const NmsWs w = carve(workspace, P, n_classes);
+    const int C1 = n_classes - 1;
+    hipLaunchKernelGGL(decode_softmax_kernel, dim3(ssd_cdiv(P, 256)), dim3(256), 0, st, l_, c_, priors_cxcywh, P, n_classes, w.boxes, w.probs_t);
+    SSD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(compact_kernel, dim3(C1), dim3(NB_T), 0, st, w.probs_t, P, min_score, w.keys, w.cand_cnt);
+    SSD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(rank_scatter_kernel, dim3(ssd_cdiv(P, 256), C1), dim3(256), 0, st, w.keys, w.cand_cnt, w.boxes, P, w.s_boxes, w.s_prob, w.s_idx);
+    SSD_CHECK_LAUNCH();
+    const size_t lds = ((size_t)P + 15) / 16 * 16;
+    if (lds > 48 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+                return SSD_ERR_LAUNCH;
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(nms_kernel, dim3(C1), dim3(NB_T), lds, st, w.s_boxes, w.cand_cnt, P, iou_threshold, w.kept_pos, w.kept_cnt);
+    SSD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(64), 0, st, w.kept_cnt, C1, w.offsets);
+    SSD_CHECK_LAUNCH();
+    EmitArgs ea{w.s_boxes, w.s_prob, w.s_idx, w.kept_pos, w.kept_cnt, w.offsets, P, C1, top_k, img_w, img_h,
+                boxes, classes, probs, prior_ids, count};
+    hipLaunchKernelGGL(emit_kernel, dim3(ssd_cdiv(P, 256), C1), dim3(256), 0, st, ea);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}

@@ -1,0 +1,321 @@
+"""torch-tensor front ends of the C ABI (device memory + streams are torch's; the
+arithmetic is libssd_gfx950.so's).  Every wrapper validates what the kernels
+assume (device, dtype, contiguity, shapes) before enqueueing -- a wrong shape
+must never reach a hand-written kernel.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvGeom, check
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: the gfx950 path needs a device tensor (got {t.device}); there is no CPU fallback")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def conv_out_hw(h: int, w: int, k: int, stride: int, pad: int, dil: int) -> Tuple[int, int]:
+    return ((h + 2 * pad - dil * (k - 1) - 1) // stride + 1, (w + 2 * pad - dil * (k - 1) - 1) // stride + 1)
+
+
+def make_geom(n, h, w, ci, co, k, stride, pad, dil) -> ConvGeom:
+    ho, wo = conv_out_hw(h, w, k, stride, pad, dil)
+    return ConvGeom(n, h, w, ci, ho, wo, co, k, k, stride, pad, dil)
+
+
+def pad32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+# ---- weights ---------------------------------------------------------------------------
+def weight_ohwi(w_oihw: torch.Tensor, co_pad: Optional[int] = None) -> torch.Tensor:
+    _req(w_oihw, "weight")
+    co, ci, r, s = w_oihw.shape
+    co_pad = co if co_pad is None else co_pad
+    out = torch.empty((co_pad, r * s, ci), device=w_oihw.device, dtype=torch.float32)
+    check(_lib.load().ssd_weight_oihw_to_ohwi(w_oihw.data_ptr(), out.data_ptr(), co, ci, r, s, co_pad, _stream()), "weight_ohwi")
+    return out
+
+
+def weight_ihwo(w_oihw: torch.Tensor, co_pad: Optional[int] = None) -> torch.Tensor:
+    _req(w_oihw, "weight")
+    co, ci, r, s = w_oihw.shape
+    co_pad = pad32(co) if co_pad is None else co_pad
+    out = torch.empty((ci, r * s, co_pad), device=w_oihw.device, dtype=torch.float32)
+    check(_lib.load().ssd_weight_oihw_to_ihwo(w_oihw.data_ptr(), out.data_ptr(), co, ci, r, s, co_pad, _stream()), "weight_ihwo")
+    return out
+
+
+# ---- convolution -----------------------------------------------------------------------
+def conv2d_fwd(x: torch.Tensor, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], g: ConvGeom, relu: bool,
+               ld: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x (N,H,W,Ci) -> (N,Ho,Wo,ld) (ld defaults to Co; columns Co..ld-1 are left untouched)."""
+    _req(x, "x"); _req(w_ohwi, "w_ohwi")
+    if tuple(x.shape) != (g.N, g.H, g.W, g.Ci):
+        raise ValueError(f"x shape {tuple(x.shape)} != geometry {(g.N, g.H, g.W, g.Ci)}")
+    if w_ohwi.shape[0] < g.Co or w_ohwi.shape[1] != g.R * g.S or w_ohwi.shape[2] != g.Ci:
+        raise ValueError("w_ohwi shape does not match geometry")
+    if bias is not None:
+        _req(bias, "bias")
+        if bias.numel() != g.Co:
+            raise ValueError("bias length")
+    ld = g.Co if ld is None else ld
+    if out is None:
+        out = torch.empty((g.N, g.Ho, g.Wo, ld), device=x.device, dtype=torch.float32) if ld == g.Co else \
+            torch.zeros((g.N, g.Ho, g.Wo, ld), device=x.device, dtype=torch.float32)
+    else:
+        _req(out, "out")
+        if out.numel() != g.N * g.Ho * g.Wo * ld:
+            raise ValueError("out size")
+    check(_lib.load().ssd_conv2d_fwd(x.data_ptr(), w_ohwi.data_ptr(), _ptr(bias), out.data_ptr(), ld, C.byref(g),
+                                     int(relu), _stream()), "conv2d_fwd")
+    return out
+
+
+def conv2d_dgrad(dy: torch.Tensor, w_ihwo: torch.Tensor, g: ConvGeom, dx: Optional[torch.Tensor] = None,
+                 relu_mask: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    _req(dy, "dy"); _req(w_ihwo, "w_ihwo")
+    co_pad = w_ihwo.shape[2]
+    if dy.numel() != g.N * g.Ho * g.Wo * co_pad:
+        raise ValueError(f"dy has {dy.numel()} elements, geometry wants {g.N * g.Ho * g.Wo * co_pad}")
+    if w_ihwo.shape[0] != g.Ci or w_ihwo.shape[1] != g.R * g.S or co_pad % 32 != 0 or co_pad < g.Co:
+        raise ValueError("w_ihwo shape does not match geometry")
+    if dx is None:
+        if accumulate:
+            raise ValueError("accumulate needs an existing dx")
+        dx = torch.empty((g.N, g.H, g.W, g.Ci), device=dy.device, dtype=torch.float32)
+    _req(dx, "dx")
+    if dx.numel() != g.N * g.H * g.W * g.Ci:
+        raise ValueError("dx size")
+    if relu_mask is not None:
+        _req(relu_mask, "relu_mask")
+        if relu_mask.numel() != dx.numel():
+            raise ValueError("relu_mask size")
+    check(_lib.load().ssd_conv2d_dgrad(dy.data_ptr(), co_pad, w_ihwo.data_ptr(), co_pad, dx.data_ptr(), _ptr(relu_mask),
+                                       int(accumulate), C.byref(g), _stream()), "conv2d_dgrad")
+    return dx
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:
+    """Grow-only scratch buffer per (device, stream, tag); contents are dead between calls."""
+    key = (str(device), _stream(), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), device=device, dtype=torch.uint8)
+        _ws_cache[key] = buf
+    return buf
+
+
+def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, g: ConvGeom, ldy: int, want_bias: bool = True):
+    """-> (dw (Co,Ci,R,S) OIHW, dbias (Co,) or None)."""
+    _req(x, "x"); _req(dy, "dy")
+    if tuple(x.shape) != (g.N, g.H, g.W, g.Ci):
+        raise ValueError("x shape does not match geometry")
+    if dy.numel() != g.N * g.Ho * g.Wo * ldy or ldy < g.Co:
+        raise ValueError("dy size does not match geometry")
+    lib = _lib.load()
+    nbytes = lib.ssd_conv2d_wgrad_workspace(C.byref(g))
+    ws = workspace(nbytes, x.device)
+    dw = torch.empty((g.Co, g.Ci, g.R, g.S), device=x.device, dtype=torch.float32)
+    db = torch.empty((g.Co,), device=x.device, dtype=torch.float32) if want_bias else None
+    check(lib.ssd_conv2d_wgrad(x.data_ptr(), dy.data_ptr(), ldy, dw.data_ptr(), _ptr(db), C.byref(g), ws.data_ptr(),
+                               ws.numel(), _stream()), "conv2d_wgrad")
+    return dw, db
+
+
+def conv_first_fwd(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], relu: bool = True) -> torch.Tensor:
+    _req(x_nchw, "x"); _req(w, "w")
+    n, c, h, wd = x_nchw.shape
+    if c != 3 or tuple(w.shape[1:]) != (3, 3, 3):
+        raise ValueError("conv_first expects (N,3,H,W) input and (Co,3,3,3) weights")
+    co = w.shape[0]
+    if bias is not None:
+        _req(bias, "bias")
+    y = torch.empty((n, h, wd, co), device=x_nchw.device, dtype=torch.float32)
+    check(_lib.load().ssd_conv_first_fwd(x_nchw.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), n, h, wd, co, int(relu),
+                                         _stream()), "conv_first_fwd")
+    return y
+
+
+def conv_first_wgrad(x_nchw: torch.Tensor, dy: torch.Tensor, want_bias: bool = True):
+    _req(x_nchw, "x"); _req(dy, "dy")
+    n, c, h, wd = x_nchw.shape
+    co = dy.shape[-1]
+    if c != 3 or dy.numel() != n * h * wd * co:
+        raise ValueError("conv_first_wgrad shapes")
+    lib = _lib.load()
+    ws = workspace(lib.ssd_conv_first_wgrad_workspace(n, h, wd, co), x_nchw.device)
+    dw = torch.empty((co, 3, 3, 3), device=dy.device, dtype=torch.float32)
+    db = torch.empty((co,), device=dy.device, dtype=torch.float32) if want_bias else None
+    check(lib.ssd_conv_first_wgrad(x_nchw.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db), n, h, wd, co, ws.data_ptr(),
+                                   ws.numel(), _stream()), "conv_first_wgrad")
+    return dw, db
+
+
+# ---- pooling / norm ----------------------------------------------------------------------
+def pool_out(h: int, k: int, stride: int, pad: int, ceil_mode: bool) -> int:
+    num = h + 2 * pad - k
+    o = (-(-num // stride) if ceil_mode else num // stride) + 1
+    if ceil_mode and (o - 1) * stride >= h + pad:      # torch: last window must start inside the input or left pad
+        o -= 1
+    return o
+
+
+def maxpool_fwd(x: torch.Tensor, k: int, stride: int, pad: int, ceil_mode: bool, want_argmax: bool = True):
+    _req(x, "x")
+    n, h, w, c = x.shape
+    ho, wo = pool_out(h, k, stride, pad, ceil_mode), pool_out(w, k, stride, pad, ceil_mode)
+    y = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.float32)
+    am = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.uint8) if want_argmax else None
+    check(_lib.load().ssd_maxpool_fwd(x.data_ptr(), y.data_ptr(), _ptr(am), n, h, w, c, k, stride, pad, ho, wo, _stream()),
+          "maxpool_fwd")
+    return y, am
+
+
+def maxpool_bwd(dy: torch.Tensor, argmax: torch.Tensor, in_shape, k: int, stride: int, pad: int,
+                dx: Optional[torch.Tensor] = None, relu_mask: Optional[torch.Tensor] = None, accumulate: bool = False):
+    _req(dy, "dy"); _req(argmax, "argmax", torch.uint8)
+    n, h, w, c = in_shape
+    _, ho, wo, c2 = dy.shape
+    if c2 != c or tuple(argmax.shape) != tuple(dy.shape):
+        raise ValueError("maxpool_bwd shapes")
+    if dx is None:
+        if accumulate:
+            raise ValueError("accumulate needs an existing dx")
+        dx = torch.empty((n, h, w, c), device=dy.device, dtype=torch.float32)
+    _req(dx, "dx")
+    if dx.numel() != n * h * w * c:
+        raise ValueError("dx size")
+    if relu_mask is not None:
+        _req(relu_mask, "relu_mask")
+        if relu_mask.numel() != dx.numel():
+            raise ValueError("relu_mask size")
+    check(_lib.load().ssd_maxpool_bwd(dy.data_ptr(), argmax.data_ptr(), dx.data_ptr(), _ptr(relu_mask), int(accumulate),
+                                      n, h, w, c, k, stride, pad, ho, wo, _stream()), "maxpool_bwd")
+    return dx
+
+
+def l2norm_fwd(x: torch.Tensor, gamma: torch.Tensor) -> torch.Tensor:
+    _req(x, "x"); _req(gamma, "gamma")
+    c = x.shape[-1]
+    if gamma.numel() != c:
+        raise ValueError("gamma length")
+    y = torch.empty_like(x)
+    check(_lib.load().ssd_l2norm_fwd(x.data_ptr(), gamma.data_ptr(), y.data_ptr(), x.numel() // c, c, _stream()), "l2norm_fwd")
+    return y
+
+
+def l2norm_bwd(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, dx: Optional[torch.Tensor] = None):
+    _req(x, "x"); _req(gamma, "gamma"); _req(dy, "dy")
+    c = x.shape[-1]
+    m = x.numel() // c
+    if dy.numel() != x.numel():
+        raise ValueError("dy size")
+    lib = _lib.load()
+    ws = workspace(lib.ssd_l2norm_bwd_workspace(m, c), x.device)
+    dx = torch.empty_like(x) if dx is None else _req(dx, "dx")
+    dg = torch.empty((c,), device=x.device, dtype=torch.float32)
+    check(lib.ssd_l2norm_bwd(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), dx.data_ptr(), dg.data_ptr(), m, c,
+                             ws.data_ptr(), ws.numel(), _stream()), "l2norm_bwd")
+    return dx, dg
+
+
+# ---- heads ---------------------------------------------------------------------------------
+def heads_scatter(packed: torch.Tensor, ld: int, loc: torch.Tensor, conf: torch.Tensor, n: int, hw: int, a: int,
+                  prior_off: int) -> None:
+    _req(packed, "packed"); _req(loc, "loc"); _req(conf, "conf")
+    p, ncls = conf.shape[1], conf.shape[2]
+    if packed.numel() != n * hw * ld or tuple(loc.shape) != (n, p, 4) or conf.shape[0] != n:
+        raise ValueError("heads_scatter shapes")
+    check(_lib.load().ssd_heads_scatter(packed.data_ptr(), ld, loc.data_ptr(), conf.data_ptr(), n, hw, a, prior_off, p, ncls,
+                                        _stream()), "heads_scatter")
+
+
+def heads_gather(dloc: torch.Tensor, dconf: torch.Tensor, ld: int, n: int, hw: int, a: int, prior_off: int) -> torch.Tensor:
+    _req(dloc, "dloc"); _req(dconf, "dconf")
+    p, ncls = dconf.shape[1], dconf.shape[2]
+    if tuple(dloc.shape) != (n, p, 4) or dconf.shape[0] != n:
+        raise ValueError("heads_gather shapes")
+    packed = torch.empty((n * hw, ld), device=dloc.device, dtype=torch.float32)
+    check(_lib.load().ssd_heads_gather(dloc.data_ptr(), dconf.data_ptr(), packed.data_ptr(), ld, n, hw, a, prior_off, p, ncls,
+                                       _stream()), "heads_gather")
+    return packed
+
+
+# ---- loss / decode ----------------------------------------------------------------------------
+def multibox_loss(loc, conf, gt_boxes, gt_classes, img_start, priors_cxcywh, priors_xyxy, iou_threshold=0.5,
+                  neg_pos_ratio=3, norm_mode=0, want_grads=True):
+    """-> dict(losses (3,), obj (bs,P) i32, cls (bs,P) i32, dloc, dconf)."""
+    _req(loc, "loc"); _req(conf, "conf"); _req(gt_boxes, "gt_boxes"); _req(gt_classes, "gt_classes")
+    _req(img_start, "img_start", torch.int32); _req(priors_cxcywh, "priors"); _req(priors_xyxy, "priors_xyxy")
+    bs, p, ncls = conf.shape
+    n_gt = gt_boxes.shape[0]
+    if tuple(loc.shape) != (bs, p, 4) or tuple(gt_boxes.shape) != (n_gt, 4) or gt_classes.numel() != n_gt or \
+            img_start.numel() != bs + 1 or tuple(priors_cxcywh.shape) != (p, 4) or tuple(priors_xyxy.shape) != (p, 4):
+        raise ValueError("multibox_loss shapes")
+    lib = _lib.load()
+    ws = workspace(lib.ssd_multibox_loss_workspace(bs, p, n_gt), loc.device, "loss")
+    dev = loc.device
+    losses = torch.empty((3,), device=dev, dtype=torch.float32)
+    obj = torch.empty((bs, p), device=dev, dtype=torch.int32)
+    cls = torch.empty((bs, p), device=dev, dtype=torch.int32)
+    dloc = torch.empty_like(loc) if want_grads else None
+    dconf = torch.empty_like(conf) if want_grads else None
+    check(lib.ssd_multibox_loss(loc.data_ptr(), conf.data_ptr(), gt_boxes.data_ptr(), gt_classes.data_ptr(), img_start.data_ptr(),
+                                bs, n_gt, priors_cxcywh.data_ptr(), priors_xyxy.data_ptr(), p, ncls, float(iou_threshold),
+                                int(neg_pos_ratio), int(norm_mode), losses.data_ptr(), obj.data_ptr(), cls.data_ptr(),
+                                _ptr(dloc), _ptr(dconf), ws.data_ptr(), ws.numel(), _stream()), "multibox_loss")
+    return dict(losses=losses, obj=obj, cls=cls, dloc=dloc, dconf=dconf)
+
+
+def decode_nms(l_, c_, priors_cxcywh, img_w, img_h, top_k=200, min_score=0.2, iou_threshold=0.45):
+    """-> (boxes (top_k,4), classes (top_k,) i64, probs (top_k,), prior_ids (top_k,) i32, count (1,) i32), all device."""
+    _req(l_, "l_"); _req(c_, "c_"); _req(priors_cxcywh, "priors")
+    p, ncls = c_.shape
+    if tuple(l_.shape) != (p, 4) or tuple(priors_cxcywh.shape) != (p, 4):
+        raise ValueError("decode_nms shapes")
+    lib = _lib.load()
+    ws = workspace(lib.ssd_decode_nms_workspace(p, ncls), l_.device, "nms")
+    dev = l_.device
+    boxes = torch.zeros((top_k, 4), device=dev, dtype=torch.float32)
+    classes = torch.zeros((top_k,), device=dev, dtype=torch.int64)
+    probs = torch.zeros((top_k,), device=dev, dtype=torch.float32)
+    ids = torch.zeros((top_k,), device=dev, dtype=torch.int32)
+    count = torch.zeros((1,), device=dev, dtype=torch.int32)
+    check(lib.ssd_decode_nms(l_.data_ptr(), c_.data_ptr(), priors_cxcywh.data_ptr(), p, ncls, float(min_score),
+                             float(iou_threshold), int(top_k), float(img_w), float(img_h), boxes.data_ptr(), classes.data_ptr(),
+                             probs.data_ptr(), ids.data_ptr(), count.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "decode_nms")
+    return boxes, classes, probs, ids, count
+
+
+def sgd_momentum_(param, grad, buf, lr, momentum, weight_decay, grad_scale=None, first_step=False):
+    _req(param, "param"); _req(grad, "grad"); _req(buf, "buf")
+    if grad.numel() != param.numel() or buf.numel() != param.numel():
+        raise ValueError("sgd sizes")
+    if grad_scale is not None:
+        _req(grad_scale, "grad_scale")
+    check(_lib.load().ssd_sgd_momentum(param.data_ptr(), grad.data_ptr(), buf.data_ptr(), param.numel(), float(lr), float(momentum),
+                                       float(weight_decay), _ptr(grad_scale), int(first_step), _stream()), "sgd_momentum")

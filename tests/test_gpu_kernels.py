@@ -1,0 +1,224 @@
+"""GPU parity tests of the individual gfx950 kernels, through the C ABI
+(objectdetection_ssd_amd.ops -> libssd_gfx950.so).  Floating-point kernels are
+compared with plain torch-CPU f32 ops of the same mathematical op; tolerance:
+|a-b| <= 1e-4 * max(1, max|ref|) (north_star: loc/conf/loss within 1e-4 fp32).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _close(got, ref, tol=1e-4, what=""):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((got - ref).abs().max())
+    assert err <= tol * scale, f"{what}: max err {err:.3e} > {tol * scale:.3e} (scale {scale:.3g})"
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def _nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+CONV_CASES = [
+    # n, h, w, ci, co, k, stride, pad, dil      (what it exercises)
+    (2, 19, 19, 64, 64, 3, 1, 1, 1),       # 64x64 tile, M=722 ragged
+    (1, 38, 38, 128, 256, 3, 1, 1, 1),     # 64x64 tile
+    (4, 64, 64, 64, 512, 3, 1, 1, 1),      # 128x128 tile (>=512 blocks)
+    (2, 256, 256, 32, 64, 3, 1, 1, 1),     # 256x64 tile
+    (1, 19, 19, 512, 1024, 3, 1, 4, 4),    # fc6: dilation 4
+    (2, 19, 19, 1024, 256, 1, 1, 0, 1),    # 1x1
+    (2, 19, 19, 256, 512, 3, 2, 1, 1),     # stride 2 pad 1 -> 10x10
+    (3, 10, 10, 128, 256, 3, 2, 1, 1),     # stride 2 -> 5x5
+    (2, 5, 5, 128, 256, 3, 1, 0, 1),       # pad 0 -> 3x3
+    (2, 3, 3, 128, 256, 3, 1, 0, 1),       # -> 1x1
+    (2, 38, 38, 512, 100, 3, 1, 1, 1),     # head: Co=100 (not a tile multiple)
+    (2, 19, 19, 1024, 150, 3, 1, 1, 1),    # head: Co=150
+]
+
+
+def _conv_data(case, seed=0):
+    n, h, w, ci, co, k, s, p, d = case
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, k, k, generator=g) * (2.0 / (ci * k * k)) ** 0.5
+    b = torch.randn(co, generator=g) * 0.1
+    return x, wt, b
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("relu", [True, False])
+def test_conv2d_fwd(case, relu):
+    from objectdetection_ssd_amd import ops
+    n, h, w, ci, co, k, s, p, d = case
+    dev = _dev()
+    x, wt, b = _conv_data(case)
+    ref = F.conv2d(x, wt, b, stride=s, padding=p, dilation=d)
+    if relu:
+        ref = F.relu(ref)
+    g = ops.make_geom(n, h, w, ci, co, k, s, p, d)
+    ld = ops.pad32(co)
+    wf = ops.weight_ohwi(wt.to(dev), ld)
+    y = ops.conv2d_fwd(_nhwc(x).to(dev), wf, b.to(dev), g, relu, ld=ld)
+    torch.cuda.synchronize()
+    assert y.shape == (n, g.Ho, g.Wo, ld)
+    _close(y[..., :co], _nhwc(ref), what=f"conv fwd {case}")
+    if ld != co:
+        assert float(y[..., co:].abs().max()) == 0.0        # pad columns untouched
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_dgrad_and_wgrad(case):
+    from objectdetection_ssd_amd import ops
+    n, h, w, ci, co, k, s, p, d = case
+    dev = _dev()
+    x, wt, b = _conv_data(case, seed=1)
+    x.requires_grad_(True); wt.requires_grad_(True); b.requires_grad_(True)
+    y = F.conv2d(x, wt, b, stride=s, padding=p, dilation=d)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(2))
+    y.backward(dy)
+    g = ops.make_geom(n, h, w, ci, co, k, s, p, d)
+    ld = ops.pad32(co)
+    dy_p = torch.zeros(n, g.Ho, g.Wo, ld)
+    dy_p[..., :co] = _nhwc(dy)
+    dy_d = dy_p.to(dev)
+    wb = ops.weight_ihwo(wt.detach().to(dev), ld)
+    x_d = _nhwc(x.detach()).to(dev)
+    # plain dgrad
+    dx = ops.conv2d_dgrad(dy_d, wb, g)
+    _close(dx, _nhwc(x.grad), what=f"dgrad {case}")
+    # accumulate + relu mask
+    prev = torch.randn(dx.shape, generator=torch.Generator().manual_seed(3)).to(dev)
+    mask = torch.randn(dx.shape, generator=torch.Generator().manual_seed(4)).clamp_min(0).to(dev)
+    dx2 = ops.conv2d_dgrad(dy_d, wb, g, dx=prev.clone(), relu_mask=mask, accumulate=True)
+    ref2 = (_nhwc(x.grad) + prev.cpu()) * (mask.cpu() > 0)
+    _close(dx2, ref2, what=f"dgrad acc+mask {case}")
+    # wgrad + bias grad (deterministic: two runs are bitwise equal)
+    dw, db = ops.conv2d_wgrad(x_d, dy_d, g, ld, True)
+    dw_b, db_b = ops.conv2d_wgrad(x_d, dy_d, g, ld, True)
+    torch.cuda.synchronize()
+    _close(dw, wt.grad, tol=2e-4, what=f"wgrad {case}")
+    _close(db, b.grad, tol=2e-4, what=f"bias grad {case}")
+    assert torch.equal(dw, dw_b) and torch.equal(db, db_b)
+
+
+def test_conv_first_fwd_and_wgrad():
+    from objectdetection_ssd_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    for (n, h, w) in ((2, 75, 75), (1, 300, 300), (3, 33, 47)):
+        x = torch.randn(n, 3, h, w, generator=g)
+        wt = (torch.randn(64, 3, 3, 3, generator=g) * 0.27).requires_grad_(True)
+        b = (torch.randn(64, generator=g) * 0.1).requires_grad_(True)
+        y = F.relu(F.conv2d(x, wt, b, padding=1))
+        dy = torch.randn(y.shape, generator=g) * (y > 0)
+        y.backward(dy)
+        yd = ops.conv_first_fwd(x.to(dev), wt.detach().to(dev), b.detach().to(dev), relu=True)
+        _close(yd, _nhwc(y), what="conv_first fwd")
+        dw, db = ops.conv_first_wgrad(x.to(dev), _nhwc(dy).to(dev), True)
+        _close(dw, wt.grad, tol=2e-4, what="conv_first wgrad")
+        _close(db, b.grad, tol=2e-4, what="conv_first bias grad")
+
+
+POOLS = [(2, 2, 0, False, 300), (2, 2, 0, False, 75), (2, 2, 0, True, 75), (2, 2, 0, False, 38), (3, 1, 1, True, 19)]
+
+
+@pytest.mark.parametrize("k,s,p,ceil,hw", POOLS)
+def test_maxpool_fwd_bwd(k, s, p, ceil, hw):
+    from objectdetection_ssd_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(6)
+    n, c = 2, 64
+    x = F.relu(torch.randn(n, c, hw, hw, generator=g)).requires_grad_(True)   # post-ReLU: many tied zeros
+    y = F.max_pool2d(x, k, s, p, ceil_mode=ceil)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    yd, am = ops.maxpool_fwd(_nhwc(x.detach()).to(dev), k, s, p, ceil)
+    assert yd.shape == _nhwc(y).shape
+    assert torch.equal(yd.cpu(), _nhwc(y.detach()))                       # max is exact
+    xd = _nhwc(x.detach()).to(dev)
+    # with the ReLU mask the routing of tied zeros cannot matter
+    dx = ops.maxpool_bwd(_nhwc(dy).to(dev), am, tuple(xd.shape), k, s, p, relu_mask=xd)
+    ref = _nhwc(x.grad * (x.detach() > 0))
+    _close(dx, ref, tol=1e-6, what="maxpool bwd + mask")
+    prev = torch.randn(ref.shape, generator=g)
+    dx2 = ops.maxpool_bwd(_nhwc(dy).to(dev), am, tuple(xd.shape), k, s, p, dx=prev.to(dev), relu_mask=xd, accumulate=True)
+    _close(dx2, (_nhwc(x.grad) + prev) * (_nhwc(x.detach()) > 0), tol=1e-6, what="maxpool bwd acc")
+    # without mask and without ties: exact torch routing
+    x2 = torch.randn(n, c, hw, hw, generator=g).requires_grad_(True)
+    y2 = F.max_pool2d(x2, k, s, p, ceil_mode=ceil)
+    y2.backward(dy)
+    _, am2 = ops.maxpool_fwd(_nhwc(x2.detach()).to(dev), k, s, p, ceil)
+    dx3 = ops.maxpool_bwd(_nhwc(dy).to(dev), am2, tuple(xd.shape), k, s, p)
+    _close(dx3, _nhwc(x2.grad), tol=1e-6, what="maxpool bwd plain")
+
+
+def test_l2norm_fwd_bwd():
+    from objectdetection_ssd_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(7)
+    x = F.relu(torch.randn(2, 512, 38, 38, generator=g)).requires_grad_(True)
+    gamma = (20 + torch.randn(1, 512, 1, 1, generator=g)).requires_grad_(True)
+    y = x / x.pow(2).sum(dim=1, keepdim=True).sqrt() * gamma                # Model.py:207-209
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xd = _nhwc(x.detach()).to(dev)
+    gd = gamma.detach().reshape(-1).to(dev)
+    yd = ops.l2norm_fwd(xd, gd)
+    _close(yd, _nhwc(y), tol=1e-5, what="l2norm fwd")
+    dx, dg = ops.l2norm_bwd(xd, gd, _nhwc(dy).to(dev))
+    _close(dx, _nhwc(x.grad), tol=1e-4, what="l2norm dx")
+    _close(dg, gamma.grad.reshape(-1), tol=2e-4, what="l2norm dgamma")
+
+
+def test_heads_scatter_gather_roundtrip():
+    from objectdetection_ssd_amd import ops
+    dev = _dev()
+    n, hw, a, P = 2, 25, 6, 8732
+    ld = ops.pad32(a * 25)
+    g = torch.Generator().manual_seed(8)
+    packed = torch.randn(n * hw, ld, generator=g).to(dev)
+    loc = torch.zeros(n, P, 4, device=dev)
+    conf = torch.zeros(n, P, 21, device=dev)
+    off = 8542
+    ops.heads_scatter(packed, ld, loc, conf, n, hw, a, off)
+    pc = packed.cpu().view(n, hw, ld)
+    ref_loc = pc[:, :, :4 * a].reshape(n, hw * a, 4)                        # Model.py:212 permute+view
+    ref_conf = pc[:, :, 4 * a:25 * a].reshape(n, hw * a, 21)
+    assert torch.equal(loc.cpu()[:, off:off + hw * a], ref_loc)
+    assert torch.equal(conf.cpu()[:, off:off + hw * a], ref_conf)
+    assert float(loc.cpu()[:, :off].abs().max()) == 0.0
+    back = ops.heads_gather(loc, conf, ld, n, hw, a, off)
+    exp = packed.clone()
+    exp[:, 25 * a:] = 0
+    assert torch.equal(back, exp)
+
+
+def test_sgd_momentum_matches_torch():
+    from objectdetection_ssd_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    p0 = torch.randn(100003, generator=g)
+    p_ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([p_ref], lr=1e-2, momentum=0.9, weight_decay=5e-4)
+    p = p0.clone().to(dev)
+    buf = torch.zeros_like(p)
+    for step in range(3):
+        gr = torch.randn(100003, generator=g)
+        p_ref.grad = gr.clone()
+        opt.step()
+        ops.sgd_momentum_(p, gr.to(dev), buf, 1e-2, 0.9, 5e-4, first_step=(step == 0))
+    _close(p, p_ref.detach(), tol=1e-6, what="sgd")

@@ -1,0 +1,233 @@
+"""GPU parity of the assembled hot path against the oracle and the reference-generated
+golden vectors: matching (bit-exact), MultiBox loss + gradients, NMS decode
+(bit-exact keep sets), SSD_300 forward / train step, and size-independent
+properties at BASELINE.json's full batch size.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ssd_oracle as O
+from helpers import nms_case, split_case, synth_gt
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(DEV) if dtype is None else t.to(DEV, dtype)
+
+
+# ---------------------------------------------------------------------------------------------
+# matching + loss
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ci", range(18))
+def test_ssd_loss_vs_golden_and_oracle(gold_dir, ci):
+    from objectdetection_ssd_amd import Losses
+    z = np.load(os.path.join(gold_dir, "match_loss.npz"))
+    boxes, classes, loc, conf, p = split_case(z, ci)
+    lt = _t(loc).requires_grad_(True)
+    ct = _t(conf).requires_grad_(True)
+    l_loc, l_conf = Losses.ssd((lt, ct), [_t(c) for c in classes], [_t(b) for b in boxes])
+    (l_loc + l_conf).backward()
+    torch.cuda.synchronize()
+    cls = Losses.last_match["cls"].cpu().numpy()
+    obj = Losses.last_match["obj"].cpu().numpy()
+    # integer outputs: bit-exact against the reference
+    assert np.array_equal(cls.astype(np.int8), z[p + "cls"])
+    pos = cls != 20
+    allb = np.concatenate(boxes)
+    assert np.array_equal(O.xyxy_to_xywh(allb)[obj][pos], z[p + "gt_pos"])          # matched GT of every positive
+    ora = O.multibox_loss(loc, conf, boxes, classes)
+    assert np.array_equal(obj[pos], ora["obj"][pos])
+    # floating point: 1e-4 (north_star)
+    assert abs(l_loc.item() - float(z[p + "loc_loss"])) <= 1e-4 * max(1, abs(float(z[p + "loc_loss"])))
+    assert abs(l_conf.item() - float(z[p + "conf_loss"])) <= 1e-4 * max(1, abs(float(z[p + "conf_loss"])))
+    dloc = lt.grad.cpu().numpy()
+    dconf = ct.grad.cpu().numpy()
+    np.testing.assert_allclose(dloc, ora["dloc"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(dloc[pos], z[p + "dloc_pos"], rtol=1e-5, atol=1e-8)
+    touched = np.nonzero(np.abs(dconf.reshape(-1, 21)).sum(1) > 0)[0]
+    assert np.array_equal(touched, z[p + "dconf_touched"])                          # same hard-negative set
+    np.testing.assert_allclose(dconf, ora["dconf"], rtol=1e-3, atol=1e-6)
+    rows = z[p + "dconf_rows"]
+    np.testing.assert_allclose(dconf.reshape(-1, 21)[rows], z[p + "dconf_vals"], rtol=1e-3, atol=1e-6)
+
+
+def test_ssd_loss_is_deterministic_and_rejects_bad_input():
+    from objectdetection_ssd_amd import Losses
+    rng = np.random.default_rng(11)
+    boxes, classes = synth_gt(rng, 4)
+    loc = _t(rng.standard_normal((4, 8732, 4), dtype=np.float32))
+    conf = _t(rng.standard_normal((4, 8732, 21), dtype=np.float32))
+    a = Losses.ssd((loc, conf), [_t(c) for c in classes], [_t(b) for b in boxes])
+    b = Losses.ssd((loc, conf), [_t(c) for c in classes], [_t(b) for b in boxes])
+    assert a[0].item() == b[0].item() and a[1].item() == b[1].item()
+    with pytest.raises(ValueError):
+        Losses.ssd((loc, conf), [_t(c) for c in classes[:3]] + [torch.zeros(0, device=DEV)],
+                   [_t(b) for b in boxes[:3]] + [torch.zeros(0, 4, device=DEV)])
+    with pytest.raises(RuntimeError):
+        Losses.ssd((loc.cpu(), conf.cpu()), classes, boxes)
+
+
+def test_loss_norm_mode_1_is_unnormalised_sum():
+    """data-parallel form: sums / gradients before the division by n_pos."""
+    from objectdetection_ssd_amd import Losses
+    rng = np.random.default_rng(12)
+    boxes, classes = synth_gt(rng, 3)
+    loc = _t(rng.standard_normal((3, 8732, 4), dtype=np.float32))
+    conf = _t(rng.standard_normal((3, 8732, 21), dtype=np.float32))
+    cl = [_t(c) for c in classes]
+    bx = [_t(b) for b in boxes]
+    l0 = loc.clone().requires_grad_(True); c0 = conf.clone().requires_grad_(True)
+    a = Losses.ssd((l0, c0), cl, bx)
+    (a[0] + a[1]).backward()
+    n_pos = float(Losses.last_match["n_pos"].item())
+    l1 = loc.clone().requires_grad_(True); c1 = conf.clone().requires_grad_(True)
+    b = Losses.ssd((l1, c1), cl, bx, norm_mode=1)
+    (b[0] + b[1]).backward()
+    assert abs(b[0].item() / n_pos - a[0].item()) <= 1e-5 * max(1, a[0].item())
+    assert abs(b[1].item() / n_pos - a[1].item()) <= 1e-5 * max(1, a[1].item())
+    torch.testing.assert_close(l1.grad / n_pos, l0.grad, rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(c1.grad / n_pos, c0.grad, rtol=1e-5, atol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------
+# decode + NMS
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ni", range(6))
+def test_inference_vs_golden(gold_dir, ni):
+    from objectdetection_ssd_amd import Losses
+    z = np.load(os.path.join(gold_dir, "nms.npz"))
+    l_, c_, top_k, p = nms_case(z, ni)
+    w, h = [int(v) for v in z["img_wh"]]
+    out = Losses.inference(_t(l_), _t(c_), (w, h), top_k=top_k, toDraw=False)
+    ob, oc, op_, oi = O.decode_nms(l_, c_, w, h, top_k=top_k)
+    if z[p + "boxes"].shape[0] == 0:
+        assert out == ([], [], [])
+        return
+    boxes, classes, probs = [t.cpu().numpy() for t in out]
+    ids = Losses.inference.last_prior_ids.cpu().numpy()
+    assert boxes.shape == z[p + "boxes"].shape
+    # keep set on ORIGINAL prior ids, bit-exact (SURVEY section 7 "hard parts")
+    assert np.array_equal(ids, oi)
+    assert np.array_equal(classes, z[p + "classes"])
+    np.testing.assert_allclose(probs, z[p + "probs"], rtol=1e-5)
+    np.testing.assert_allclose(boxes, z[p + "boxes"], rtol=1e-5, atol=1e-3)
+
+
+def test_inference_worst_case_all_candidates():
+    """every prior is a candidate of one class with identical boxes -> one survivor per class"""
+    from objectdetection_ssd_amd import Losses
+    l_ = torch.zeros(8732, 4, device=DEV)
+    c_ = torch.full((8732, 21), -10.0, device=DEV)
+    c_[:, 3] = 10.0
+    boxes, classes, probs = Losses.inference(l_, c_, (300, 300), toDraw=False)
+    ob, oc, op_, oi = O.decode_nms(l_.cpu().numpy(), c_.cpu().numpy(), 300, 300)
+    assert np.array_equal(Losses.inference.last_prior_ids.cpu().numpy(), oi)
+    assert np.array_equal(classes.cpu().numpy(), oc)
+    assert boxes.shape[0] == ob.shape[0] <= 200
+
+
+# ---------------------------------------------------------------------------------------------
+# network
+# ---------------------------------------------------------------------------------------------
+def _load_params(net, params):
+    named = dict(net.named_parameters())
+    with torch.no_grad():
+        for k, v in params.items():
+            named[k].copy_(v)
+
+
+@pytest.fixture(scope="module")
+def golden_net(gold_dir):
+    from objectdetection_ssd_amd import Model
+    z = np.load(os.path.join(gold_dir, "network.npz"))
+    params = O.ssd300_random_params(int(z["param_seed"]))
+    net = Model.SSD_300()
+    _load_params(net, params)
+    net = net.to(DEV)
+    return net, params, z
+
+
+def test_ssd300_forward_vs_reference_golden(golden_net):
+    net, params, z = golden_net
+    bs = int(z["bs"])
+    x = np.random.default_rng(int(z["x_seed"])).standard_normal((bs, 3, 300, 300), dtype=np.float32)
+    net.eval()
+    with torch.no_grad():
+        loc, conf = net(_t(x))
+    assert loc.shape == (bs, 8732, 4) and conf.shape == (bs, 8732, 21)
+    idx = z["prior_idx"]
+    loc_c, conf_c = loc.cpu().numpy(), conf.cpu().numpy()
+    for got, ref, nm in ((loc_c[:, idx], z["loc_s"], "loc"), (conf_c[:, idx], z["conf_s"], "conf")):
+        err = np.abs(got - ref).max()
+        assert err <= 1e-4 * max(1.0, np.abs(ref).max()), f"{nm}: {err}"
+    assert abs(np.abs(loc_c).astype(np.float64).sum() - float(z["loc_abs"])) <= 1e-4 * float(z["loc_abs"])
+    assert abs(np.abs(conf_c).astype(np.float64).sum() - float(z["conf_abs"])) <= 1e-4 * float(z["conf_abs"])
+    # full tensors against the oracle network
+    with torch.no_grad():
+        lo, co = O.ssd300_forward(torch.from_numpy(x), params)
+    assert np.abs(loc_c - lo.numpy()).max() <= 1e-4 * max(1.0, float(lo.abs().max()))
+    assert np.abs(conf_c - co.numpy()).max() <= 1e-4 * max(1.0, float(co.abs().max()))
+
+
+def test_ssd300_train_step_vs_reference_golden(golden_net):
+    """forward + ssd loss + backward through every kernel: losses and all 71 gradients."""
+    from objectdetection_ssd_amd import Losses
+    net, params, z = golden_net
+    bs = int(z["bs"])
+    x = np.random.default_rng(int(z["x_seed"])).standard_normal((bs, 3, 300, 300), dtype=np.float32)
+    boxes, classes = synth_gt(np.random.default_rng(int(z["gt_seed"])), bs)
+    net.train()
+    net.zero_grad()
+    loc, conf = net(_t(x))
+    l1, l2 = Losses.ssd((loc, conf), [_t(c) for c in classes], [_t(b) for b in boxes])
+    (l1 + l2).backward()
+    torch.cuda.synchronize()
+    assert abs(l1.item() - float(z["loc_loss"])) <= 1e-4 * max(1, float(z["loc_loss"]))       # loss delta vs CPU
+    assert abs(l2.item() - float(z["conf_loss"])) <= 1e-4 * max(1, float(z["conf_loss"]))
+    named = dict(net.named_parameters())
+    names = [str(n) for n in z["grad_names"]]
+    bad = []
+    for k, ref_l2, ref_sum in zip(names, z["grad_l2"], z["grad_sum"]):
+        g = named[k].grad
+        assert g is not None, k
+        got = float(g.double().norm())
+        if abs(got - ref_l2) > 1e-3 * max(ref_l2, 1e-6):
+            bad.append((k, got, float(ref_l2)))
+    assert not bad, bad
+    for k in ("model.features.0.weight", "model.features.21.bias", "c_11_cl.weight", "seq10.2.weight",
+              "rescaling_conv_4_3", "c_4_bb.bias"):
+        ref = z["g_" + k]
+        got = named[k].grad.cpu().numpy()
+        tol = 1e-3 * max(float(np.abs(ref).max()), 1e-6)
+        assert np.abs(got - ref).max() <= tol, (k, np.abs(got - ref).max(), tol)
+    # dead VGG classifier receives nothing
+    assert named["model.classifier.0.weight"].grad is None
+
+
+def test_full_batch_properties():
+    """BASELINE config 2 size (bs=32): finite outputs, batch independence (image i of a batch ==
+    the same image alone), per-image matching independence, loss reproducible."""
+    from objectdetection_ssd_amd import Losses, Model
+    torch.manual_seed(0)
+    net = Model.SSD_300().to(DEV).eval()
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(32, 3, 300, 300, generator=g).to(DEV)
+    with torch.no_grad():
+        loc, conf = net(x)
+        loc1, conf1 = net(x[5:6].contiguous())
+    assert torch.isfinite(loc).all() and torch.isfinite(conf).all()
+    assert (loc[5:6] - loc1).abs().max().item() <= 1e-4 * max(1.0, loc1.abs().max().item())
+    assert (conf[5:6] - conf1).abs().max().item() <= 1e-4 * max(1.0, conf1.abs().max().item())
+    boxes, classes = synth_gt(np.random.default_rng(99), 32)
+    bx = [_t(b) for b in boxes]; cl = [_t(c) for c in classes]
+    l = Losses.ssd((loc, conf), cl, bx)
+    cls_all = Losses.last_match["cls"].clone()
+    Losses.ssd((loc[7:8].contiguous(), conf[7:8].contiguous()), cl[7:8], bx[7:8])
+    assert torch.equal(Losses.last_match["cls"][0], cls_all[7])
+    assert torch.isfinite(l[0]) and torch.isfinite(l[1])

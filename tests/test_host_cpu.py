@@ -1,0 +1,121 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol the header declares,
+host-side mirrors agree with the oracle, the drop-in surface has the reference's names, and the
+product path refuses to run without the GPU instead of falling back."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import ssd_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from objectdetection_ssd_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "ssd_gfx950.h")).read()
+    declared = set(re.findall(r"\b(ssd_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"ssd_status"}
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ssd_abi_version() == 1
+    assert lib.ssd_status_string(-2) == b"workspace too small"
+
+
+def test_workspace_queries_need_no_gpu():
+    import ctypes as C
+    from objectdetection_ssd_amd import _lib, ops
+    lib = _lib.load()
+    g = ops.make_geom(32, 300, 300, 64, 64, 3, 1, 1, 1)
+    assert (g.Ho, g.Wo) == (300, 300)
+    assert 0 < lib.ssd_conv2d_wgrad_workspace(C.byref(g)) < 1 << 30
+    assert lib.ssd_multibox_loss_workspace(32, 8732, 90) > 32 * 8732 * 5
+    assert lib.ssd_decode_nms_workspace(8732, 21) > 0
+    assert ops.pool_out(75, 2, 2, 0, True) == 38 and ops.pool_out(75, 2, 2, 0, False) == 37
+    assert ops.pool_out(19, 3, 1, 1, True) == 19 and ops.pool_out(300, 2, 2, 0, False) == 150
+
+
+def test_host_priors_and_coders_match_oracle():
+    from objectdetection_ssd_amd import Losses, Util
+    pri = O.create_priors_ssd300()
+    assert np.array_equal(Losses.ancs_xywh.numpy(), pri)
+    assert np.array_equal(Losses.ancs_xyxy.numpy(), O.xywh_to_xyxy(pri))
+    r = np.random.default_rng(0)
+    g = r.standard_normal((50, 4)).astype(np.float32)
+    p = pri[r.integers(0, 8732, 50)]
+    np.testing.assert_allclose(Util.gcxgcy_to_cxcy(torch.from_numpy(g), torch.from_numpy(p)).numpy(),
+                               O.decode_offsets(g, p), rtol=1e-6)
+    assert Util.class_to_label[20] == "bg" and len(Util.class_to_label) == 21
+
+
+def test_ssd300_module_surface_matches_reference_names(gold_dir):
+    from objectdetection_ssd_amd import Model
+    z = np.load(os.path.join(gold_dir, "network.npz"))
+    net = Model.SSD_300()
+    named = dict(net.named_parameters())
+    assert len(named) == int(z["ref_named_parameters"]) == 77
+    shapes = O.ssd300_param_shapes()
+    assert set(net._engine.names) == set(shapes)
+    for k, s in shapes.items():
+        assert tuple(named[k].shape) == s, k
+    biases = [n for n in named if n.endswith(".bias")]
+    assert len(biases) == 38                                       # train.py:46-51 2x-lr group
+    sd = net.state_dict()
+    for alias in ("conv_4_3.0.weight", "seq5.1.weight", "seq7.0.weight", "seq7.2.bias", "model.classifier.0.weight"):
+        assert alias in sd, alias
+    assert torch.equal(sd["seq7.0.weight"], sd["conv_fc6.weight"])
+    assert float(net.rescaling_conv_4_3.mean()) == 20.0
+    # op list geometry: 8732 priors, offsets as SURVEY 8(a) A5
+    from objectdetection_ssd_amd import ops
+    hw = {"x": 300}
+    offs, off = [], 0
+    for op in net._engine.ops:
+        if op["op"] == "conv_first":
+            hw[op["y"]] = hw[op["x"]]
+        elif op["op"] == "conv":
+            hw[op["y"]] = ops.conv_out_hw(hw[op["x"]], hw[op["x"]], op["k"], op["s"], op["pad"], op["dil"])[0]
+        elif op["op"] == "pool":
+            hw[op["y"]] = ops.pool_out(hw[op["x"]], op["k"], op["s"], op["pad"], op["ceil"])
+        elif op["op"] == "l2norm":
+            hw[op["y"]] = hw[op["x"]]
+        elif op["op"] == "head":
+            offs.append(off)
+            off += hw[op["x"]] ** 2 * op["a"]
+    assert tuple(offs) == O.SCALE_OFFSETS and off == 8732
+
+
+def test_product_path_refuses_cpu_tensors():
+    from objectdetection_ssd_amd import Losses, Model, ops
+    net = Model.SSD_300()
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 3, 300, 300))
+    with pytest.raises(RuntimeError):
+        Losses.ssd((torch.zeros(1, 8732, 4), torch.zeros(1, 8732, 21)), [torch.zeros(1)], [torch.tensor([[0., 0., 1., 1.]])])
+    with pytest.raises(RuntimeError):
+        Losses.inference(torch.zeros(8732, 4), torch.zeros(8732, 21), (300, 300), toDraw=False)
+    with pytest.raises(RuntimeError):
+        ops.l2norm_fwd(torch.zeros(4, 512), torch.ones(512))
+    with pytest.raises(ValueError):
+        Losses.ssd((torch.zeros(1, 8732, 4), torch.zeros(1, 8732, 21)), [torch.zeros(0)], [torch.zeros(0, 4)])
+
+
+def test_dropin_module_names():
+    import sys
+    import objectdetection_ssd_amd as pkg
+    saved = {k: sys.modules.get(k) for k in ("Model", "Losses", "Util")}
+    try:
+        pkg.install_dropin()
+        from Losses import ancs_xywh, ancs_xyxy, device, inference, ssd  # noqa: F401
+        from Model import SSD_300  # noqa: F401
+        from Util import class_to_label  # noqa: F401
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
