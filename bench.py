@@ -1,0 +1,203 @@
+"""bench.py -- SSD300-VGG16 train step throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = Model.SSD_300 forward + Losses.ssd (match, loss) + backward through every
+kernel + ONE gradient all-reduce over RCCL (N > 1) + fused SGD, on one batch of 32
+synthetic 300x300 images per GPU (BASELINE.json configs[1]; weak scaling), f32.
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline     -- the dominant kernel (by summed time) of the step, timed per launch with HIP
+                  events on the stream the kernels run on, against the f32-MFMA peak;
+  cpu_baseline -- the oracle's torch-CPU restatement of the same step on this box's host cores
+                  (rank 0, N=1 only, bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+PER_GPU_BATCH = 32
+TRAIN_GFLOP_PER_IMAGE = 187.930        # BASELINE.md section 3 (fwd + dgrad + wgrad, no dgrad for conv1_1)
+PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md chip-level parameters
+
+
+def synth_batch(bs: int, seed: int, dev):
+    """randn images; 1 + min(Poisson(1.4), 7) boxes per image."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(bs, 3, 300, 300, generator=g)
+    rng = np.random.default_rng(seed)
+    boxes, classes = [], []
+    for _ in range(bs):
+        n = 1 + min(int(rng.poisson(1.4)), 7)
+        x1 = rng.uniform(0, .6, n); y1 = rng.uniform(0, .6, n)
+        w = rng.uniform(.08, .6, n); h = rng.uniform(.08, .6, n)
+        b = np.stack([x1, y1, np.minimum(x1 + w, 1.), np.minimum(y1 + h, 1.)], 1).astype(np.float32)
+        boxes.append(torch.from_numpy(b).to(dev))
+        classes.append(torch.from_numpy(rng.integers(0, 20, n).astype(np.float32)).to(dev))
+    return x.to(dev), classes, boxes
+
+
+def cpu_baseline(bs: int = 4, iters: int = 2, max_threads: int = 16):
+    """Oracle (CPU restatement of the reference path, plain torch-CPU ops) timed on the host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ssd_oracle as O
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    cores = max(1, min(cores, max_threads))      # the box's CPU share for one GPU is 16 cores; 256 threads thrash
+    torch.set_num_threads(cores)
+    params = {k: v.requires_grad_(True) for k, v in O.ssd300_random_params(0).items()}
+    opt = torch.optim.SGD(list(params.values()), lr=1e-4, momentum=0.9, weight_decay=5e-4)
+    x, classes, boxes = synth_batch(bs, 1234, "cpu")
+    times = []
+    for it in range(iters + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loc, conf = O.ssd300_forward(x, params)
+        l1, l2 = O.multibox_loss_torch(loc, conf, boxes, classes)
+        (l1 + l2).backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times[1:]))
+    return {"value": round(bs / t, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle torch-CPU train step (fwd+loss+bwd+SGD), bs={bs}, median of {iters} after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="images per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="print the per-launch table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the gfx950 HIP extension is the only compute path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    from objectdetection_ssd_amd import Losses, Model
+    from objectdetection_ssd_amd.ddp import FlatSGDDataParallel
+
+    torch.manual_seed(0)                                   # same initial weights on every rank
+    net = Model.SSD_300().to(dev).train()
+    trainer = FlatSGDDataParallel(net, lr=1e-4, momentum=0.9, weight_decay=5e-4)
+    trainer.broadcast_parameters(0)
+    bs = args.batch
+    x, classes, boxes = synth_batch(bs, 1234 + rank, dev)
+
+    def step():
+        trainer.zero_grad()
+        loc, conf = net(x)
+        l1, l2 = Losses.ssd((loc, conf), classes, boxes, norm_mode=1)     # un-normalised sums (ddp.py)
+        (l1 + l2).backward()
+        trainer.reduce_and_step(Losses.last_match["n_pos"])
+        return l1, l2
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        l1, l2 = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms = elapsed / args.steps * 1e3
+    ips = bs * world * args.steps / elapsed
+    n_pos = float(trainer.flat_grad[trainer.n].item())
+    loss = (float(l1.item()) + float(l2.item())) / max(float(Losses.last_match["n_pos"].item()), 1.0)
+
+    out = {"metric": "images/sec SSD300-VGG16 train step", "value": round(ips, 2), "unit": "images/sec",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"SSD300-VGG16 train step (fwd + MultiBox loss + bwd + all-reduce + SGD), "
+                                  f"batch {bs}/GPU, 300x300x3, 21 classes, 8732 priors (BASELINE configs[1])",
+                      "global_batch": bs * world, "per_gpu_batch": bs, "parallelism": f"dp{world}",
+                      "train_gflop_per_image": TRAIN_GFLOP_PER_IMAGE,
+                      "step_tflops_per_gpu": round(TRAIN_GFLOP_PER_IMAGE * ips / world / 1e3, 2),
+                      "step_frac_of_f32_mfma_peak": round(TRAIN_GFLOP_PER_IMAGE * ips / world / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+                      "last_loss_per_rank": round(loss, 5), "n_pos_global_last": n_pos}}
+
+    # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream -----------------
+    if not args.no_roofline and rank != 0:
+        for _ in range(3):                 # keep the collectives of rank 0's profiling steps matched
+            step()
+    if not args.no_roofline and rank == 0:
+        eng = net._engine
+        agg = {}
+        rows = []
+        for _ in range(3):
+            eng.prof = []
+            step()
+            torch.cuda.synchronize()
+            for label, tag, flops, e0, e1 in eng.prof:
+                dt = e0.elapsed_time(e1) * 1e-3
+                a = agg.setdefault(tag, [0.0, 0.0, 0])
+                a[0] += dt; a[1] += flops; a[2] += 1
+                rows.append((label, tag, flops, dt))
+            eng.prof = None
+        tag, (tsum, fsum, n) = max(agg.items(), key=lambda kv: kv[1][0])
+        ach = fsum / tsum / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": tag + ", ...>", "achieved": round(ach, 2),
+                           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                           "traffic": None, "launches_timed": n, "avg_launch_ms": round(tsum / n * 1e3, 4),
+                           "avg_launch_gflop": round(fsum / n / 1e9, 3),
+                           "all_conv_kernels_tflops": round(sum(a[1] for a in agg.values()) / sum(a[0] for a in agg.values()) / 1e12, 2),
+                           "by_kernel": {k: {"ms_per_step": round(a[0] / 3 * 1e3, 3), "tflops": round(a[1] / a[0] / 1e12, 2),
+                                             "launches_per_step": a[2] // 3} for k, a in sorted(agg.items())}}
+        if args.layers:
+            seen = set()
+            for label, tag, flops, dt in rows:
+                if label in seen:
+                    continue
+                seen.add(label)
+                print(f"{label:32s} {tag:28s} {flops / 1e9:9.2f} GF {dt * 1e3:8.3f} ms {flops / dt / 1e12:7.2f} TF/s", file=sys.stderr)
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

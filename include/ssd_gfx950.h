@@ -77,6 +77,12 @@ size_t ssd_conv2d_wgrad_workspace(const ssd_conv_geom* g);
 int ssd_conv2d_wgrad(const float* x, const float* dy, int ldy, float* dw_oihw, float* dbias,
                      const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Introspection for profiling: which tile configuration the dispatcher picks (direction 0 = forward,
+ * 1 = dgrad), and the wgrad tile edge / split-K factor.  Used by bench.py to attribute HIP-event
+ * timings to kernel instantiations; no effect on results. */
+int ssd_conv2d_igemm_tile(const ssd_conv_geom* g, int direction, int* bm, int* bn);
+int ssd_conv2d_wgrad_tile(const ssd_conv_geom* g, int* bt, int* nsplit);
+
 /* conv1_1 (Model.py:136 features[0]: Conv2d(3,64,3,padding=1)+ReLU): reads the
  * caller's NCHW image batch directly (Dataset.py:39 layout), writes NHWC. */
 int ssd_conv_first_fwd(const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc,

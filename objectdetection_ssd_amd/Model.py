@@ -122,6 +122,18 @@ class _Engine:
         for op in self.ops:
             self.consumers[op["x"]] = self.consumers.get(op["x"], 0) + 1
         self.relu_out = {op["y"] for op in self.ops if op["op"] == "conv_first" or (op["op"] == "conv" and op["relu"])}
+        self.prof = None          # bench.py: list collecting (label, kernel tag, flops, start event, end event)
+
+    def _timed(self, label, tag, flops, fn):
+        """Run fn(); when profiling, bracket it with HIP events on the current stream."""
+        if self.prof is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.prof.append((label, tag, flops, e0, e1))
+        return out
 
     # -- weights ----------------------------------------------------------------------------
     def _layouts(self, key: str, tensors, co_pad: int, need_bwd: bool):
@@ -154,12 +166,15 @@ class _Engine:
         for op in self.ops:
             kind = op["op"]
             if kind == "conv_first":
-                T[op["y"]] = ops.conv_first_fwd(x, P[op["p"] + ".weight"].detach(), P[op["p"] + ".bias"].detach(), relu=True)
+                T[op["y"]] = self._timed("fwd " + op["p"], "conv_first_fwd_kernel", 2.0 * bs * x.shape[2] * x.shape[3] * 64 * 27,
+                                         lambda: ops.conv_first_fwd(x, P[op["p"] + ".weight"].detach(), P[op["p"] + ".bias"].detach(), relu=True))
             elif kind == "conv":
                 xin = T[op["x"]]
                 g = ops.make_geom(bs, xin.shape[1], xin.shape[2], op["ci"], op["co"], op["k"], op["s"], op["pad"], op["dil"])
                 wf, _ = self._layouts(op["p"], (P[op["p"] + ".weight"],), op["co"], False)
-                T[op["y"]] = ops.conv2d_fwd(xin, wf, P[op["p"] + ".bias"].detach(), g, op["relu"])
+                bias = P[op["p"] + ".bias"].detach()
+                T[op["y"]] = self._timed("fwd " + op["p"], ops.igemm_tile(g, 0) if self.prof is not None else "", ops.conv_flops(g),
+                                         lambda: ops.conv2d_fwd(xin, wf, bias, g, op["relu"]))
                 aux[op["y"]] = g
             elif kind == "pool":
                 y, am = ops.maxpool_fwd(T[op["x"]], op["k"], op["s"], op["pad"], op["ceil"], want_argmax=save)
@@ -175,7 +190,8 @@ class _Engine:
                 pre = op["p"]
                 wf, _ = self._layouts(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]), ops.pad32(co), False)
                 bias = torch.cat((P[pre + "_bb.bias"].detach(), P[pre + "_cl.bias"].detach()))
-                packed = ops.conv2d_fwd(xin, wf, bias, g, False, ld=ops.pad32(co))
+                packed = self._timed("fwd " + pre, ops.igemm_tile(g, 0) if self.prof is not None else "", ops.conv_flops(g),
+                                     lambda: ops.conv2d_fwd(xin, wf, bias, g, False, ld=ops.pad32(co)))
                 heads.append((op, packed, g))
         P_total = sum(g.Ho * g.Wo * op["a"] for op, _, g in heads)
         loc = torch.empty((bs, P_total, 4), device=x.device, dtype=torch.float32)
@@ -216,20 +232,26 @@ class _Engine:
                 xin = T[op["x"]]
                 a4 = 4 * op["a"]
                 if any(need[pre + s] for s in ("_bb.weight", "_bb.bias", "_cl.weight", "_cl.bias")):
-                    dw, db = ops.conv2d_wgrad(xin, dy, g, co_pad, True)
+                    dw, db = self._timed("wgrad " + pre, ops.wgrad_tile(g) if self.prof is not None else "", ops.conv_flops(g),
+                                         lambda: ops.conv2d_wgrad(xin, dy, g, co_pad, True))
                     grads[pre + "_bb.weight"], grads[pre + "_cl.weight"] = dw[:a4], dw[a4:]
                     grads[pre + "_bb.bias"], grads[pre + "_cl.bias"] = db[:a4], db[a4:]
                 _, wb = self._layouts(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]), co_pad, True)
-                deliver(op["x"], lambda dx, acc, mask: ops.conv2d_dgrad(dy, wb, g, dx, mask, acc))
+                deliver(op["x"], lambda dx, acc, mask: self._timed(
+                    "dgrad " + pre, ops.igemm_tile(g, 1) if self.prof is not None else "", ops.conv_flops(g),
+                    lambda: ops.conv2d_dgrad(dy, wb, g, dx, mask, acc)))
             elif kind == "conv":
                 dy = G.pop(op["y"])
                 g = aux[op["y"]]
                 xin = T[op["x"]]
                 if need[op["p"] + ".weight"] or need[op["p"] + ".bias"]:
-                    dw, db = ops.conv2d_wgrad(xin, dy, g, g.Co, True)
+                    dw, db = self._timed("wgrad " + op["p"], ops.wgrad_tile(g) if self.prof is not None else "", ops.conv_flops(g),
+                                         lambda: ops.conv2d_wgrad(xin, dy, g, g.Co, True))
                     grads[op["p"] + ".weight"], grads[op["p"] + ".bias"] = dw, db
                 _, wb = self._layouts(op["p"], (P[op["p"] + ".weight"],), op["co"], True)
-                deliver(op["x"], lambda dx, acc, mask: ops.conv2d_dgrad(dy, wb, g, dx, mask, acc))
+                deliver(op["x"], lambda dx, acc, mask: self._timed(
+                    "dgrad " + op["p"], ops.igemm_tile(g, 1) if self.prof is not None else "", ops.conv_flops(g),
+                    lambda: ops.conv2d_dgrad(dy, wb, g, dx, mask, acc)))
             elif kind == "pool":
                 dy = G.pop(op["y"])
                 xin = T[op["x"]]
@@ -252,7 +274,8 @@ class _Engine:
             elif kind == "conv_first":
                 dy = G.pop(op["y"])
                 if need[op["p"] + ".weight"] or need[op["p"] + ".bias"]:
-                    dw, db = ops.conv_first_wgrad(T["x"], dy, True)
+                    dw, db = self._timed("wgrad " + op["p"], "conv_first_wgrad_kernel", 2.0 * dy.numel() * 27,
+                                         lambda: ops.conv_first_wgrad(T["x"], dy, True))
                     grads[op["p"] + ".weight"], grads[op["p"] + ".bias"] = dw, db
         return grads
 

@@ -195,17 +195,21 @@ int launch_igemm(IgemmParams& p, hipStream_t st) {
     return SSD_OK;
 }
 
+// Tile choice: wide tiles when there are enough blocks to fill 256 CUs a few times over,
+// smaller tiles for the deep / small layers so the grid still covers the chip.
+enum Tile { T256x64, T128x128, T64x64 };
+Tile pick_tile(int M, int Nout) {
+    const long blocks_128 = (long)ssd_cdiv(M, 128) * ssd_cdiv(Nout, 128);
+    if (Nout <= 64) return M >= 256 * 512 ? T256x64 : T64x64;
+    return blocks_128 >= 512 ? T128x128 : T64x64;
+}
+
 int dispatch_igemm(IgemmParams& p, hipStream_t st) {
-    // Tile choice: wide-N tiles when there are enough blocks to fill 256 CUs a few
-    // times over, smaller tiles for the deep / small layers so the grid still covers
-    // the chip.
-    const long blocks_128 = (long)ssd_cdiv(p.M, 128) * ssd_cdiv(p.Nout, 128);
-    if (p.Nout <= 64) {
-        if (p.M >= 256 * 512) return launch_igemm<256, 64, 4, 1>(p, st);
-        return launch_igemm<64, 64, 2, 2>(p, st);
+    switch (pick_tile(p.M, p.Nout)) {
+        case T256x64: return launch_igemm<256, 64, 4, 1>(p, st);
+        case T128x128: return launch_igemm<128, 128, 2, 2>(p, st);
+        default: return launch_igemm<64, 64, 2, 2>(p, st);
     }
-    if (blocks_128 >= 512) return launch_igemm<128, 128, 2, 2>(p, st);
-    return launch_igemm<64, 64, 2, 2>(p, st);
 }
 
 int check_geom(const ssd_conv_geom* g) {
@@ -250,4 +254,17 @@ extern "C" int ssd_conv2d_dgrad(const float* dy, int ldy, const float* w_ihwo, i
     p.sm = 1; p.sd = g->stride; p.off = g->pad; p.dstep = -g->dil;
     p.M = g->N * g->H * g->W; p.relu = 0; p.accumulate = accumulate;
     return dispatch_igemm(p, (hipStream_t)stream);
+}
+
+extern "C" int ssd_conv2d_igemm_tile(const ssd_conv_geom* g, int direction, int* bm, int* bn) {
+    if (int e = check_geom(g)) return e;
+    if (!bm || !bn || (direction != 0 && direction != 1)) return SSD_ERR_NULL;
+    const int M = direction == 0 ? g->N * g->Ho * g->Wo : g->N * g->H * g->W;
+    const int Nout = direction == 0 ? g->Co : g->Ci;
+    switch (pick_tile(M, Nout)) {
+        case T256x64: *bm = 256; *bn = 64; break;
+        case T128x128: *bm = 128; *bn = 128; break;
+        default: *bm = 64; *bn = 64; break;
+    }
+    return SSD_OK;
 }

@@ -251,3 +251,11 @@ extern "C" int ssd_conv2d_wgrad(const float* x, const float* dy, int ldy, float*
     }
     return SSD_OK;
 }
+
+extern "C" int ssd_conv2d_wgrad_tile(const ssd_conv_geom* g, int* bt, int* nsplit) {
+    if (!g || !bt || !nsplit) return SSD_ERR_NULL;
+    const WgradPlan pl = plan_wgrad(g);
+    *bt = pl.bt;
+    *nsplit = pl.nsplit;
+    return SSD_OK;
+}

@@ -1,0 +1,99 @@
+"""Data-parallel train step around the hot path: flat parameter / gradient buffers,
+ONE gradient all-reduce per step over RCCL (torch.distributed backend "nccl"), fused SGD.
+
+The reference has no distributed code; this is the build
+addition BASELINE.json's north_star asks for.  Images are sharded by rank, weights
+replicated.  Both losses normalise by the batch-GLOBAL number of positive priors
+(reference Losses.py:182,197), so each rank back-propagates the un-normalised sums
+(`Losses.ssd(..., norm_mode=1)`), appends its n_pos to the flat gradient buffer,
+the buffer is all-reduced once, and the fused SGD kernel multiplies the gradient by
+1 / n_pos_global -- the same arithmetic as the reference at the global batch size,
+with a single collective.
+
+SGD follows train.py:44-55: momentum 0.9, weight decay 5e-4, biases at 2x lr (weight
+decay applies to both groups, as torch.optim.SGD does there).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+class FlatSGDDataParallel:
+    def __init__(self, model, lr: float = 1e-4, momentum: float = 0.9, weight_decay: float = 5e-4,
+                 bias_lr_mult: float = 2.0, process_group=None):
+        self.model = model
+        self.lr, self.momentum, self.wd, self.bias_mult = lr, momentum, weight_decay, bias_lr_mult
+        self.group = process_group
+        named = dict(model.named_parameters())
+        names = [n for n in model._engine.names if named[n].requires_grad]
+        # weights first, biases second: two contiguous segments = two SGD launches (train.py:46-51 groups)
+        self.w_names = [n for n in names if not n.endswith(".bias")]
+        self.b_names = [n for n in names if n.endswith(".bias")]
+        self.names = self.w_names + self.b_names
+        self.params: List[torch.nn.Parameter] = [named[n] for n in self.names]
+        dev = self.params[0].device      # flat buffers live where the model lives (the SGD kernel itself is GPU-only)
+        sizes = [p.numel() for p in self.params]
+        slots = [(s + 3) // 4 * 4 for s in sizes]              # every parameter starts 16-byte aligned
+        self.n_w = sum(slots[:len(self.w_names)])
+        self.n = sum(slots)
+        pad = (-(self.n + 1)) % 64
+        self.flat_param = torch.zeros(self.n, device=dev, dtype=torch.float32)
+        self.flat_grad = torch.zeros(self.n + 1 + pad, device=dev, dtype=torch.float32)     # [grads | n_pos | pad]
+        self.flat_mom = torch.zeros(self.n, device=dev, dtype=torch.float32)
+        self.inv_npos = torch.ones(1, device=dev, dtype=torch.float32)
+        self.grad_views = []
+        off = 0
+        with torch.no_grad():
+            for p, sz, slot in zip(self.params, sizes, slots):
+                view = self.flat_param[off:off + sz].view_as(p)
+                view.copy_(p.data)
+                p.data = view                                  # parameters now live in the flat buffer
+                self.grad_views.append(self.flat_grad[off:off + sz].view_as(p))
+                off += slot
+        self.steps = 0
+        model._engine._wcache.clear()
+
+    @property
+    def world(self) -> int:
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def broadcast_parameters(self, src: int = 0) -> None:
+        if self.world > 1:
+            dist.broadcast(self.flat_param, src, group=self.group)
+            self.model._engine._wcache.clear()
+
+    def zero_grad(self) -> None:
+        for p in self.params:
+            p.grad = None
+
+    def reduce_gradients(self, n_pos: torch.Tensor) -> None:
+        """Pack this rank's gradients (of the UN-normalised loss sums) and its positive-prior count
+        (`Losses.last_match['n_pos']`) into the flat buffer and all-reduce it once; afterwards
+        `flat_grad[:n] * inv_npos` is the gradient of the reference loss at the global batch."""
+        grads = [p.grad for p in self.params]
+        if any(g is None for g in grads):
+            missing = [n for n, g in zip(self.names, grads) if g is None]
+            raise RuntimeError(f"parameters without gradient: {missing[:4]}...")
+        torch._foreach_copy_(self.grad_views, grads)
+        self.flat_grad[self.n:self.n + 1].copy_(n_pos.reshape(1))
+        if self.world > 1:
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)    # the one collective per step
+        torch.reciprocal(self.flat_grad[self.n:self.n + 1], out=self.inv_npos)
+
+    def apply_sgd(self) -> None:
+        first = self.steps == 0
+        ops.sgd_momentum_(self.flat_param[:self.n_w], self.flat_grad[:self.n_w], self.flat_mom[:self.n_w],
+                          self.lr, self.momentum, self.wd, self.inv_npos, first)
+        ops.sgd_momentum_(self.flat_param[self.n_w:], self.flat_grad[self.n_w:self.n], self.flat_mom[self.n_w:],
+                          self.lr * self.bias_mult, self.momentum, self.wd, self.inv_npos, first)
+        self.steps += 1
+        self.model._engine._wcache.clear()        # parameters changed in place: re-lay weights next forward
+
+    def reduce_and_step(self, n_pos: torch.Tensor) -> None:
+        self.reduce_gradients(n_pos)
+        self.apply_sgd()

@@ -47,6 +47,23 @@ def pad32(c: int) -> int:
     return (c + 31) // 32 * 32
 
 
+def igemm_tile(g: ConvGeom, direction: int) -> str:
+    bm, bn = C.c_int(0), C.c_int(0)
+    check(_lib.load().ssd_conv2d_igemm_tile(C.byref(g), direction, C.byref(bm), C.byref(bn)), "igemm_tile")
+    return f"igemm_kernel<{bm.value}, {bn.value}"
+
+
+def wgrad_tile(g: ConvGeom) -> str:
+    bt, ns = C.c_int(0), C.c_int(0)
+    check(_lib.load().ssd_conv2d_wgrad_tile(C.byref(g), C.byref(bt), C.byref(ns)), "wgrad_tile")
+    return f"wgrad_kernel<{bt.value}>"
+
+
+def conv_flops(g: ConvGeom) -> float:
+    """algorithmic FLOPs of one pass (fwd, dgrad or wgrad all cost 2*M*Co*K)"""
+    return 2.0 * g.N * g.Ho * g.Wo * g.Co * g.R * g.S * g.Ci
+
+
 # ---- weights ---------------------------------------------------------------------------
 def weight_ohwi(w_oihw: torch.Tensor, co_pad: Optional[int] = None) -> torch.Tensor:
     _req(w_oihw, "weight")

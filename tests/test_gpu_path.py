@@ -70,7 +70,7 @@ def test_ssd_loss_is_deterministic_and_rejects_bad_input():
         Losses.ssd((loc, conf), [_t(c) for c in classes[:3]] + [torch.zeros(0, device=DEV)],
                    [_t(b) for b in boxes[:3]] + [torch.zeros(0, 4, device=DEV)])
     with pytest.raises(RuntimeError):
-        Losses.ssd((loc.cpu(), conf.cpu()), classes, boxes)
+        Losses.ssd((loc.cpu(), conf.cpu()), [torch.from_numpy(c) for c in classes], [torch.from_numpy(b) for b in boxes])
 
 
 def test_loss_norm_mode_1_is_unnormalised_sum():
@@ -192,22 +192,66 @@ def test_ssd300_train_step_vs_reference_golden(golden_net):
     assert abs(l2.item() - float(z["conf_loss"])) <= 1e-4 * max(1, float(z["conf_loss"]))
     named = dict(net.named_parameters())
     names = [str(n) for n in z["grad_names"]]
+    # Gradient tolerance: the reference's own f32 CPU backward is 1.8e-3 (relative L2) away from an f64
+    # evaluation on conv1_1 and 1e-4..1e-3 on the backbone (tools/grad_err.py, measured), so "equal to the
+    # reference" cannot be tighter than that; test_train_step_gradients_vs_f64_oracle holds the kernels to the
+    # f64 truth instead.
     bad = []
-    for k, ref_l2, ref_sum in zip(names, z["grad_l2"], z["grad_sum"]):
+    for k, ref_l2 in zip(names, z["grad_l2"]):
         g = named[k].grad
         assert g is not None, k
         got = float(g.double().norm())
-        if abs(got - ref_l2) > 1e-3 * max(ref_l2, 1e-6):
+        if abs(got - ref_l2) > 2e-3 * max(ref_l2, 1e-6):
             bad.append((k, got, float(ref_l2)))
     assert not bad, bad
     for k in ("model.features.0.weight", "model.features.21.bias", "c_11_cl.weight", "seq10.2.weight",
               "rescaling_conv_4_3", "c_4_bb.bias"):
-        ref = z["g_" + k]
-        got = named[k].grad.cpu().numpy()
-        tol = 1e-3 * max(float(np.abs(ref).max()), 1e-6)
-        assert np.abs(got - ref).max() <= tol, (k, np.abs(got - ref).max(), tol)
+        ref = z["g_" + k].astype(np.float64)
+        got = named[k].grad.cpu().numpy().astype(np.float64)
+        rel = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-12)
+        assert rel <= 5e-3, (k, rel)
     # dead VGG classifier receives nothing
     assert named["model.classifier.0.weight"].grad is None
+
+
+def test_train_step_gradients_vs_f64_oracle(golden_net):
+    """Every gradient of the train step against an f64 CPU evaluation of the oracle network, on ground truth
+    with large boxes so that all six scales (incl. the 3x3 and 1x1 maps) carry positives."""
+    from objectdetection_ssd_amd import Losses
+    net, params, _ = golden_net
+    bs = 2
+    x = np.random.default_rng(515).standard_normal((bs, 3, 300, 300), dtype=np.float32)
+    # one GT per prior scale (.1 .2 .375 .55 .725 .9): the forced match gives each scale a positive
+    boxes = [np.array([[.05, .05, .95, .95], [.1, .3, .475, .675], [.40, .40, .50, .52]], np.float32),
+             np.array([[.0, .1, .9, 1.], [.55, .5, .75, .7], [.2, .2, .75, .75], [.15, .1, .875, .825]], np.float32)]
+    classes = [np.array([1., 5., 12.], np.float32), np.array([7., 0., 19., 3.], np.float32)]
+    P64 = {k: v.double().requires_grad_(True) for k, v in params.items()}
+    loc64, conf64 = O.ssd300_forward(torch.from_numpy(x).double(), P64)
+    a1, a2 = O.multibox_loss_torch(loc64, conf64, [torch.from_numpy(b) for b in boxes], [torch.from_numpy(c) for c in classes])
+    (a1 + a2).backward()
+    net.train()
+    net.zero_grad()
+    loc, conf = net(_t(x))
+    l1, l2 = Losses.ssd((loc, conf), [_t(c) for c in classes], [_t(b) for b in boxes])
+    (l1 + l2).backward()
+    assert abs(l1.item() - a1.item()) <= 1e-4 * max(1, a1.item())
+    assert abs(l2.item() - a2.item()) <= 1e-4 * max(1, a2.item())
+    assert float((loc.detach().cpu().double() - loc64.detach()).abs().max()) <= 1e-4 * max(1, float(loc64.abs().max()))
+    assert float((conf.detach().cpu().double() - conf64.detach()).abs().max()) <= 1e-4 * max(1, float(conf64.abs().max()))
+    named = dict(net.named_parameters())
+    bad = []
+    for k, p64 in P64.items():
+        ref = p64.grad
+        assert float(ref.norm()) > 0, f"{k}: scale not exercised"
+        rel = float((named[k].grad.cpu().double() - ref).norm() / ref.norm())
+        # f32 activations that differ by an ulp flip a few ReLU / max-pool decisions out of ~1e8; each flip is a
+        # discrete change of one gradient path, so the relative L2 distance to the f64 truth grows towards the
+        # input (measured: <=2e-5 from conv5 up, ~1e-4 at conv3, 2e-3..4e-3 at conv1; the reference's own f32 CPU
+        # backward sits at 1.8e-3 on conv1_1, tools/grad_err.py).
+        lim = 1e-2 if k.startswith("model.features") else 2e-3
+        if rel > lim:
+            bad.append((k, rel))
+    assert not bad, bad
 
 
 def test_full_batch_properties():
