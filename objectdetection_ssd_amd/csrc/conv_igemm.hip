@@ -17,6 +17,8 @@
 // (lane half h takes k = 8q+4h+e): A and B use the same permutation, so the sum is
 // the same set of products.
 #include "common.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -26,6 +28,7 @@ struct IgemmParams {
     const float* __restrict__ bias;
     float* __restrict__ out;
     const float* __restrict__ mask;
+    unsigned a_bytes, w_bytes; // extents for the buffer descriptors (hardware range check -> 0)
     int Ha, Wa, Ca;          // A-side spatial size and channels (= K per tap)
     int Ho, Wo;              // output spatial size
     int Nout;                // valid output channels (store mask)
@@ -41,15 +44,26 @@ struct IgemmParams {
 
 constexpr int BK = 32;
 constexpr int LDS_LD = 36;
+constexpr unsigned OOB = 0xFFFFFF00u;    // beyond any descriptor extent: the load returns 0
 
-template <int BM, int BN, int WM, int WN>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t srd, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)voff, (int)soff, 0));
+}
+
+// The K loop walks taps (r,s) outermost and 32-channel chunks innermost.  Per tap every thread
+// recomputes the byte offset of its A rows once (or OOB when the tap falls outside the image:
+// the buffer range check then returns zeros, no branch); inside a tap only a scalar offset moves.
+// NBUF = 2: the next tile is written into the other LDS stage while this one is multiplied
+// (one barrier per K step); NBUF = 1 keeps a single stage (two barriers) where LDS is scarce.
+template <int BM, int BN, int WM, int WN, int NBUF>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;
+    constexpr int STAGE = (BM + BN) * LDS_LD;
     static_assert(WM * WN == 4, "4 waves");
-    __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDS_LD];
-    float* As = lds;
-    float* Bs = lds + BM * LDS_LD;
+    __shared__ __attribute__((aligned(16))) float lds[NBUF * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -59,30 +73,47 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int chunk = tid & 7, row0 = tid >> 3;
 
+    const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+
     // ---- per-thread A rows: decompose m once --------------------------------
-    int a_oh[A_ROWS], a_ow[A_ROWS];
-    size_t a_img[A_ROWS];
-    bool a_ok[A_ROWS];
+    int a_h[A_ROWS], a_w[A_ROWS];
+    unsigned a_base[A_ROWS], voff_a[A_ROWS];
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int j = 0; j < A_ROWS; ++j) {
         const int m = m0 + row0 + 32 * j;
-        a_ok[j] = m < p.M;
-        const int mm = a_ok[j] ? m : 0;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
         const int n = mm / HoWo, rem = mm - n * HoWo;
-        a_oh[j] = rem / p.Wo;
-        a_ow[j] = rem - a_oh[j] * p.Wo;
-        a_img[j] = (size_t)n * p.Ha * p.Wa * p.Ca;
+        const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+        a_h[j] = ok ? oh * p.sm + p.off : -(1 << 24);       // never in range for a row past M
+        a_w[j] = ow * p.sm + p.off;
+        a_base[j] = (unsigned)n * (unsigned)(p.Ha * p.Wa * p.Ca) * 4u + chunk * 16u;
     }
     const int T = p.R * p.S;
-    const float* b_ptr[B_ROWS];
-    bool b_ok[B_ROWS];
+    unsigned voff_b[B_ROWS];
 #pragma unroll
     for (int j = 0; j < B_ROWS; ++j) {
         const int n = n0 + row0 + 32 * j;
-        b_ok[j] = n < p.Nrows;
-        b_ptr[j] = p.w + (size_t)(b_ok[j] ? n : 0) * T * p.Ca + chunk * 4;
+        voff_b[j] = n < p.Nrows ? ((unsigned)n * (unsigned)(T * p.Ca)) * 4u + chunk * 16u : OOB;
     }
+
+    auto tap_offsets = [&](int r, int s) {
+        const int dh = r * p.dstep, dw = s * p.dstep;
+#pragma unroll
+        for (int j = 0; j < A_ROWS; ++j) {
+            int th = a_h[j] + dh, tw = a_w[j] + dw;
+            bool ok = th >= 0 && tw >= 0;
+            if (p.sd > 1) {                                  // dgrad of a strided conv (uniform branch)
+                ok = ok && (th % p.sd == 0) && (tw % p.sd == 0);
+                th /= p.sd;
+                tw /= p.sd;
+            }
+            ok = ok && th < p.Ha && tw < p.Wa;
+            voff_a[j] = ok ? a_base[j] + (unsigned)((th * p.Wa + tw) * p.Ca) * 4u : OOB;
+        }
+    };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -95,33 +126,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const int kc = p.Ca / BK;          // K steps per tap
     const int KT = T * kc;
     f32x4 ra[A_ROWS], rb[B_ROWS];
+    int c_nxt = 0, r_nxt = 0, s_nxt = 0;
+    unsigned soff_a = 0, soff_b = 0;
+    tap_offsets(0, 0);
 
-    auto load_tile = [&](int kt) {
-        const int t = kt / kc, c0 = (kt - t * kc) * BK + chunk * 4;
-        const int r = t / p.S, s = t - r * p.S;
-        const int dh = p.off + r * p.dstep, dw = p.off + s * p.dstep;
+    auto issue_loads = [&]() {
 #pragma unroll
-        for (int j = 0; j < A_ROWS; ++j) {
-            int th = a_oh[j] * p.sm + dh, tw = a_ow[j] * p.sm + dw;
-            bool ok = a_ok[j] && th >= 0 && tw >= 0;
-            if (p.sd > 1) {
-                ok = ok && (th % p.sd == 0) && (tw % p.sd == 0);
-                th /= p.sd;
-                tw /= p.sd;
-            }
-            ok = ok && th < p.Ha && tw < p.Wa;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(p.a + a_img[j] + ((size_t)th * p.Wa + tw) * p.Ca + c0);
-            ra[j] = v;
-        }
+        for (int j = 0; j < A_ROWS; ++j) ra[j] = buf_load16(srd_a, voff_a[j], soff_a);
 #pragma unroll
-        for (int j = 0; j < B_ROWS; ++j) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (b_ok[j]) v = *reinterpret_cast<const f32x4*>(b_ptr[j] + (size_t)kt * BK);
-            rb[j] = v;
+        for (int j = 0; j < B_ROWS; ++j) rb[j] = buf_load16(srd_w, voff_b[j], soff_b);
+        soff_a += BK * 4;
+        soff_b += BK * 4;
+        if (++c_nxt == kc) {                                 // next tile starts a new tap
+            c_nxt = 0;
+            soff_a = 0;
+            if (++s_nxt == p.S) { s_nxt = 0; ++r_nxt; }
+            tap_offsets(r_nxt, s_nxt);
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](float* stage) {
+        float* As = stage;
+        float* Bs = stage + BM * LDS_LD;
 #pragma unroll
         for (int j = 0; j < A_ROWS; ++j)
             *reinterpret_cast<f32x4*>(&As[(row0 + 32 * j) * LDS_LD + chunk * 4]) = ra[j];
@@ -130,23 +155,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             *reinterpret_cast<f32x4*>(&Bs[(row0 + 32 * j) * LDS_LD + chunk * 4]) = rb[j];
     };
 
-    load_tile(0);
-    store_tile();
+    const int lr = lane & 31, lh = lane >> 5;
+    const int a_rd = (wm * TM * 32 + lr) * LDS_LD + lh * 4;
+    const int b_rd = BM * LDS_LD + (wn * TN * 32 + lr) * LDS_LD + lh * 4;
+
+    issue_loads();
+    store_tile(lds);
     __syncthreads();
 
-    const int lr = lane & 31, lh = lane >> 5;
-    const float* a_rd = As + (wm * TM * 32 + lr) * LDS_LD + lh * 4;
-    const float* b_rd = Bs + (wn * TN * 32 + lr) * LDS_LD + lh * 4;
-
+    int cur = 0;
     for (int kt = 0; kt < KT; ++kt) {
-        if (kt + 1 < KT) load_tile(kt + 1);       // global loads stay in flight under the MFMAs
+        const bool more = kt + 1 < KT;
+        if (more) issue_loads();                  // global loads stay in flight under the MFMAs
+        const float* stage = lds + (NBUF == 2 ? cur * STAGE : 0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(a_rd + i * 32 * LDS_LD + q * 8);
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(stage + a_rd + i * 32 * LDS_LD + q * 8);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(b_rd + j * 32 * LDS_LD + q * 8);
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(stage + b_rd + j * 32 * LDS_LD + q * 8);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -155,10 +183,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
-        if (kt + 1 < KT) {
-            store_tile();
+        if (NBUF == 2) {
+            if (more) store_tile(lds + (cur ^ 1) * STAGE);   // other stage: last read one iteration ago
             __syncthreads();
+            cur ^= 1;
+        } else {
+            __syncthreads();
+            if (more) {
+                store_tile(lds);
+                __syncthreads();
+            }
         }
     }
 
@@ -186,19 +220,34 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NBUF>
 int launch_igemm(IgemmParams& p, hipStream_t st) {
     p.tiles_m = ssd_cdiv(p.M, BM);
     p.tiles_n = ssd_cdiv(p.Nout, BN);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, NBUF>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
 }
 
 // Tile choice: wide tiles when there are enough blocks to fill 256 CUs a few times over,
 // smaller tiles for the deep / small layers so the grid still covers the chip.
-enum Tile { T256x64, T128x128, T64x64 };
+// SSD_IGEMM_TILE=256x64|128x128|128x64|64x64 forces one configuration (tuning aid).
+enum Tile { T256x64, T128x128, T128x64, T64x64, TAUTO };
+Tile forced_tile() {
+    static const Tile t = [] {
+        const char* e = getenv("SSD_IGEMM_TILE");
+        if (!e) return TAUTO;
+        if (!strcmp(e, "256x64")) return T256x64;
+        if (!strcmp(e, "128x128")) return T128x128;
+        if (!strcmp(e, "128x64")) return T128x64;
+        if (!strcmp(e, "64x64")) return T64x64;
+        return TAUTO;
+    }();
+    return t;
+}
 Tile pick_tile(int M, int Nout) {
+    const Tile f = forced_tile();
+    if (f != TAUTO) return f;
     const long blocks_128 = (long)ssd_cdiv(M, 128) * ssd_cdiv(Nout, 128);
     if (Nout <= 64) return M >= 256 * 512 ? T256x64 : T64x64;
     return blocks_128 >= 512 ? T128x128 : T64x64;
@@ -206,9 +255,10 @@ Tile pick_tile(int M, int Nout) {
 
 int dispatch_igemm(IgemmParams& p, hipStream_t st) {
     switch (pick_tile(p.M, p.Nout)) {
-        case T256x64: return launch_igemm<256, 64, 4, 1>(p, st);
-        case T128x128: return launch_igemm<128, 128, 2, 2>(p, st);
-        default: return launch_igemm<64, 64, 2, 2>(p, st);
+        case T256x64: return launch_igemm<256, 64, 4, 1, 1>(p, st);
+        case T128x128: return launch_igemm<128, 128, 2, 2, 2>(p, st);
+        case T128x64: return launch_igemm<128, 64, 4, 1, 2>(p, st);
+        default: return launch_igemm<64, 64, 2, 2, 2>(p, st);
     }
 }
 
@@ -234,6 +284,11 @@ extern "C" int ssd_conv2d_fwd(const float* x, const float* w_ohwi, const float* 
     if (!ssd_aligned16(x) || !ssd_aligned16(w_ohwi)) return SSD_ERR_ALIGN;
     IgemmParams p{};
     p.a = x; p.w = w_ohwi; p.bias = bias; p.out = y; p.mask = nullptr;
+    {
+        const size_t ab = (size_t)g->N * g->H * g->W * g->Ci * 4, wb = (size_t)g->Co * g->R * g->S * g->Ci * 4;
+        if (ab >= 0xF0000000ull || wb >= 0xF0000000ull) return SSD_ERR_BAD_SHAPE;   // 32-bit buffer offsets
+        p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+    }
     p.Ha = g->H; p.Wa = g->W; p.Ca = g->Ci; p.Ho = g->Ho; p.Wo = g->Wo;
     p.Nout = g->Co; p.Nrows = g->Co; p.ldo = ldy; p.R = g->R; p.S = g->S;
     p.sm = g->stride; p.sd = 1; p.off = -g->pad; p.dstep = g->dil;
@@ -249,6 +304,11 @@ extern "C" int ssd_conv2d_dgrad(const float* dy, int ldy, const float* w_ihwo, i
     if (!ssd_aligned16(dy) || !ssd_aligned16(w_ihwo)) return SSD_ERR_ALIGN;
     IgemmParams p{};
     p.a = dy; p.w = w_ihwo; p.bias = nullptr; p.out = dx; p.mask = relu_mask;
+    {
+        const size_t ab = (size_t)g->N * g->Ho * g->Wo * Co_pad * 4, wb = (size_t)g->Ci * g->R * g->S * Co_pad * 4;
+        if (ab >= 0xF0000000ull || wb >= 0xF0000000ull) return SSD_ERR_BAD_SHAPE;
+        p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+    }
     p.Ha = g->Ho; p.Wa = g->Wo; p.Ca = Co_pad; p.Ho = g->H; p.Wo = g->W;
     p.Nout = g->Ci; p.Nrows = g->Ci; p.ldo = g->Ci; p.R = g->R; p.S = g->S;
     p.sm = 1; p.sd = g->stride; p.off = g->pad; p.dstep = -g->dil;
@@ -264,6 +324,7 @@ extern "C" int ssd_conv2d_igemm_tile(const ssd_conv_geom* g, int direction, int*
     switch (pick_tile(M, Nout)) {
         case T256x64: *bm = 256; *bn = 64; break;
         case T128x128: *bm = 128; *bn = 128; break;
+        case T128x64: *bm = 128; *bn = 64; break;
         default: *bm = 64; *bn = 64; break;
     }
     return SSD_OK;

@@ -18,6 +18,7 @@ struct WgradParams {
     const float* __restrict__ dy;
     float* __restrict__ slab;        // [nsplit][Co][T][Ci]
     float* __restrict__ bias_slab;   // [nsplit][Co] or null
+    unsigned x_bytes, dy_bytes;
     int H, W, Ci, Ho, Wo, Co, ldy;
     int R, S, stride, pad, dil;
     int M, m_per_split, nsplit;
@@ -25,18 +26,24 @@ struct WgradParams {
 };
 
 constexpr int WBK = 32;   // pixels per K step
+constexpr unsigned OOB = 0xFFFFFF00u;
+
+__device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t srd, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)voff, (int)soff, 0));
+}
 
 // BT = tile edge (both n and c), 4 waves as 2x2, each wave (BT/2)x(BT/2).
+// Both LDS stages hold [pixel][channel] rows as they come from NHWC memory.  Within a wave's
+// 64-channel span MFMA tile i takes channels 2*lane+i, so one ds_read_b64 feeds both tiles.
 template <int BT>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     constexpr int TT = BT / 64;                 // 32x32 accumulators per wave per dim
     constexpr int CHUNKS = BT / 4;              // float4 chunks per tile row
     constexpr int ROWS_PER_PASS = 256 / CHUNKS; // pixel rows loaded per pass
     constexpr int PASSES = WBK / ROWS_PER_PASS;
-    __shared__ __attribute__((aligned(16))) float lds[2 * WBK * BT];
+    constexpr int STAGE = 2 * WBK * BT;
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
     __shared__ float bias_red[256 * 4];
-    float* Ys = lds;
-    float* Xs = lds + WBK * BT;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -63,6 +70,23 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     const bool do_bias = p.bias_slab != nullptr && t == 0 && tile_ci == 0;
     const int HoWo = p.Ho * p.Wo;
 
+    const __amdgpu_buffer_rsrc_t srd_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
+
+    // per-thread pixel rows: coordinates advance by WBK pixels per K step (no division in the loop)
+    int pn[PASSES], poh[PASSES], pow_[PASSES], pm[PASSES];
+#pragma unroll
+    for (int j = 0; j < PASSES; ++j) {
+        const int m = m_begin + prow + ROWS_PER_PASS * j;
+        pm[j] = m;
+        const int mm = m < p.M ? m : 0;
+        pn[j] = mm / HoWo;
+        const int rem = mm - pn[j] * HoWo;
+        poh[j] = rem / p.Wo;
+        pow_[j] = rem - poh[j] * p.Wo;
+    }
+    const unsigned y_col = (unsigned)(co0 + chunk * 4) * 4u, x_col = (unsigned)(ci0 + chunk * 4) * 4u;
+
     f32x16 acc[TT][TT];
 #pragma unroll
     for (int i = 0; i < TT; ++i)
@@ -73,24 +97,28 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
 
     f32x4 ry[PASSES], rx[PASSES];
-    auto load_tile = [&](int mb) {
+    auto issue_loads = [&]() {
 #pragma unroll
         for (int j = 0; j < PASSES; ++j) {
-            const int m = mb + prow + ROWS_PER_PASS * j;
-            f32x4 vy = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
-            if (m < m_end) {
-                if (y_col_ok) vy = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.ldy + co0 + chunk * 4);
-                const int n = m / HoWo, rem = m - n * HoWo;
-                const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
-                const int ih = oh * p.stride + dh, iw = ow * p.stride + dw;
-                if (x_col_ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
-                    vx = *reinterpret_cast<const f32x4*>(p.x + (((size_t)n * p.H + ih) * p.W + iw) * p.Ci + ci0 + chunk * 4);
+            const bool in = pm[j] < m_end;
+            const unsigned vy = (in && y_col_ok) ? (unsigned)pm[j] * (unsigned)p.ldy * 4u + y_col : OOB;
+            const int ih = poh[j] * p.stride + dh, iw = pow_[j] * p.stride + dw;
+            const bool xin = in && x_col_ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            const unsigned vx = xin ? (unsigned)((pn[j] * p.H + ih) * p.W + iw) * (unsigned)p.Ci * 4u + x_col : OOB;
+            ry[j] = buf_load16(srd_y, vy, 0);
+            rx[j] = buf_load16(srd_x, vx, 0);
+            // advance this row by WBK pixels
+            pm[j] += WBK;
+            pow_[j] += WBK;
+            while (pow_[j] >= p.Wo) {
+                pow_[j] -= p.Wo;
+                if (++poh[j] == p.Ho) { poh[j] = 0; ++pn[j]; }
             }
-            ry[j] = vy;
-            rx[j] = vx;
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](float* stage) {
+        float* Ys = stage;
+        float* Xs = stage + WBK * BT;
 #pragma unroll
         for (int j = 0; j < PASSES; ++j) {
             const int row = prow + ROWS_PER_PASS * j;
@@ -101,44 +129,52 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     };
 
     const int lr = lane & 31, lh = lane >> 5;
+    // operand read offsets: row (2kk+lh), channels wave_span + TT*lr + i
+    const int y_rd = lh * BT + wm * (BT / 2) + TT * lr;
+    const int x_rd = WBK * BT + lh * BT + wn * (BT / 2) + TT * lr;
     if (m_begin < m_end) {
-        load_tile(m_begin);
-        store_tile();
+        issue_loads();
+        store_tile(lds);
         __syncthreads();
+        int cur = 0;
         for (int mb = m_begin; mb < m_end; mb += WBK) {
             const bool more = mb + WBK < m_end;
-            if (more) load_tile(mb + WBK);
+            if (more) issue_loads();
+            const float* stage = lds + cur * STAGE;
 #pragma unroll
             for (int kk = 0; kk < WBK / 2; ++kk) {
                 float af[TT], bf[TT];
-#pragma unroll
-                for (int i = 0; i < TT; ++i) af[i] = Ys[(2 * kk + lh) * BT + (wm * TT + i) * 32 + lr];
-#pragma unroll
-                for (int j = 0; j < TT; ++j) bf[j] = Xs[(2 * kk + lh) * BT + (wn * TT + j) * 32 + lr];
+                if (TT == 2) {
+                    const float2 a2 = *reinterpret_cast<const float2*>(stage + y_rd + 2 * kk * BT);
+                    const float2 b2 = *reinterpret_cast<const float2*>(stage + x_rd + 2 * kk * BT);
+                    af[0] = a2.x; af[TT - 1] = a2.y; bf[0] = b2.x; bf[TT - 1] = b2.y;
+                } else {
+                    af[0] = stage[y_rd + 2 * kk * BT];
+                    bf[0] = stage[x_rd + 2 * kk * BT];
+                }
 #pragma unroll
                 for (int i = 0; i < TT; ++i)
 #pragma unroll
                     for (int j = 0; j < TT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
+            if (more) store_tile(lds + (cur ^ 1) * STAGE);
             __syncthreads();
-            if (more) {
-                store_tile();
-                __syncthreads();
-            }
+            cur ^= 1;
         }
     }
 
-    // ---- partial tile -> slab[split][co][t][ci] -------------------------------------------
+    // ---- partial tile -> slab[split][co][t][ci]; accumulator (i,j), row q -> channel TT*row + i ------
     float* slab = p.slab + (size_t)split * p.Co * T * p.Ci;
 #pragma unroll
     for (int i = 0; i < TT; ++i)
 #pragma unroll
         for (int j = 0; j < TT; ++j) {
-            const int ci = ci0 + (wn * TT + j) * 32 + lr;
+            const int ci = ci0 + wn * (BT / 2) + TT * lr + j;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const int co = co0 + (wm * TT + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+                const int row = (q & 3) + 8 * (q >> 2) + 4 * lh;
+                const int co = co0 + wm * (BT / 2) + TT * row + i;
                 if (co < p.Co && ci < p.Ci) slab[((size_t)co * T + t) * p.Ci + ci] = acc[i][j][q];
             }
         }
@@ -229,6 +265,11 @@ extern "C" int ssd_conv2d_wgrad(const float* x, const float* dy, int ldy, float*
     hipStream_t st = (hipStream_t)stream;
     WgradParams p{};
     p.x = x; p.dy = dy;
+    {
+        const size_t xb = (size_t)g->N * g->H * g->W * g->Ci * 4, yb = (size_t)g->N * g->Ho * g->Wo * ldy * 4;
+        if (xb >= 0xF0000000ull || yb >= 0xF0000000ull) return SSD_ERR_BAD_SHAPE;   // 32-bit buffer offsets
+        p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)yb;
+    }
     p.slab = reinterpret_cast<float*>(workspace);
     p.bias_slab = dbias ? p.slab + pl.slab_floats : nullptr;
     p.H = g->H; p.W = g->W; p.Ci = g->Ci; p.Ho = g->Ho; p.Wo = g->Wo; p.Co = g->Co; p.ldy = ldy;
