@@ -1,0 +1,107 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the flat-buffer gradient exchange (ddp.py) and of the
+data-parallel loss normalisation checked against the oracle at the global batch."""
+import os
+import socket
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+import ssd_oracle as O
+from helpers import synth_gt
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _Tiny(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Conv2d(3, 5, 3)          # 135 + 5 params: slots are padded to multiples of 4
+        self.b = nn.Conv2d(5, 7, 1)
+        self.g = nn.Parameter(torch.ones(1, 6, 1, 1))
+        self._engine = types.SimpleNamespace(names=["a.weight", "a.bias", "b.weight", "b.bias", "g"], _wcache={"x": 1})
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from objectdetection_ssd_amd.ddp import FlatSGDDataParallel
+        torch.manual_seed(0)
+        net = _Tiny()
+        if rank == 1:                               # ranks start different; broadcast must fix that
+            with torch.no_grad():
+                for p in net.parameters():
+                    p.add_(1.0)
+        tr = FlatSGDDataParallel(net, lr=0.1)
+        assert tr.names == ["a.weight", "b.weight", "g", "a.bias", "b.bias"]      # weights | biases segments
+        assert tr.n_w == 136 + 36 + 8 and tr.n == tr.n_w + 8 + 8
+        tr.broadcast_parameters(0)
+        assert net._engine._wcache == {}
+        # --- data-parallel loss: each rank handles its own images with un-normalised sums ----------------
+        boxes, classes = synth_gt(np.random.default_rng(5), 4)
+        r = np.random.default_rng(6)
+        loc = r.standard_normal((4, 8732, 4), dtype=np.float32)
+        conf = r.standard_normal((4, 8732, 21), dtype=np.float32)
+        sl = slice(2 * rank, 2 * rank + 2)
+        mine = O.multibox_loss(loc[sl], conf[sl], boxes[sl], classes[sl])
+        n_pos = float(mine["n_pos"])
+        g = torch.Generator().manual_seed(100 + rank)
+        for p in tr.params:                          # stand-in for backward of the un-normalised loss
+            p.grad = torch.randn(p.shape, generator=g)
+        local = [p.grad.clone() for p in tr.params]
+        tr.reduce_gradients(torch.tensor(n_pos))
+        sums = torch.tensor([float(mine["loc_loss"]) * n_pos, float(mine["conf_loss"]) * n_pos, n_pos], dtype=torch.float64)
+        dist.all_reduce(sums)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, [t.numpy() for t in local])
+        q.put((rank, tr.flat_param.clone().numpy(), [v.clone().numpy() for v in tr.grad_views], float(tr.inv_npos),
+               float(tr.flat_grad[tr.n]), sums.numpy(), gathered))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_allreduce_and_global_normalisation_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, par0, g0, inv0, np0, sums0, gath), (_, par1, g1, inv1, np1, sums1, _) = out
+    assert np.array_equal(par0, par1)                                 # broadcast made the replicas identical
+    for a, b in zip(g0, g1):
+        assert np.array_equal(a, b)                                   # every rank holds the same reduced gradient
+    for k, a in enumerate(g0):
+        np.testing.assert_allclose(a, gath[0][k] + gath[1][k], rtol=1e-6)     # = sum over ranks
+    # the one extra element carries n_pos: global normaliser, identical on both ranks
+    boxes, classes = synth_gt(np.random.default_rng(5), 4)
+    r = np.random.default_rng(6)
+    loc = r.standard_normal((4, 8732, 4), dtype=np.float32)
+    conf = r.standard_normal((4, 8732, 21), dtype=np.float32)
+    ref = O.multibox_loss(loc, conf, boxes, classes)                  # the reference's loss at the GLOBAL batch
+    assert np0 == np1 == float(ref["n_pos"])
+    assert abs(inv0 - 1.0 / ref["n_pos"]) < 1e-9 and inv0 == inv1
+    np.testing.assert_allclose(sums0[0] / sums0[2], ref["loc_loss"], rtol=1e-5)
+    np.testing.assert_allclose(sums0[1] / sums0[2], ref["conf_loss"], rtol=1e-5)
+    # per-image gradients: un-normalised local gradient * 1/n_pos_global == global-batch gradient
+    for rank in range(2):
+        sl = slice(2 * rank, 2 * rank + 2)
+        mine = O.multibox_loss(loc[sl], conf[sl], boxes[sl], classes[sl])
+        np.testing.assert_allclose(mine["dloc"] * mine["n_pos"] * inv0, ref["dloc"][sl], rtol=1e-5, atol=1e-9)
+        # hard-negative mining is per image (Losses.py:189-194), so the selection does not depend on the shard
+        np.testing.assert_allclose(mine["dconf"] * mine["n_pos"] * inv0, ref["dconf"][sl], rtol=1e-5, atol=1e-9)
