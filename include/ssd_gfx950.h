@@ -82,6 +82,11 @@ int ssd_conv2d_wgrad(const float* x, const float* dy, int ldy, float* dw_oihw, f
  * timings to kernel instantiations; no effect on results. */
 int ssd_conv2d_igemm_tile(const ssd_conv_geom* g, int direction, int* bm, int* bn);
 int ssd_conv2d_wgrad_tile(const ssd_conv_geom* g, int* bt, int* nsplit);
+/* Tuning aids (process-global, not thread-safe, results unchanged): force the igemm tile
+ * (0 = 256x64, 1 = 128x128, 2 = 128x64, 3 = 64x64) / LDS stage count (1|2), and the wgrad tile edge
+ * (64|128) / stage count / split-K target in blocks per CU.  -1 = automatic. */
+int ssd_tune_set_igemm(int tile, int nbuf);
+int ssd_tune_set_wgrad(int bt, int nbuf, int blocks_per_cu);
 
 /* conv1_1 (Model.py:136 features[0]: Conv2d(3,64,3,padding=1)+ReLU): reads the
  * caller's NCHW image batch directly (Dataset.py:39 layout), writes NHWC. */

@@ -37,6 +37,8 @@ SIGNATURES = {
     "ssd_conv2d_wgrad": (_I, [_P, _P, _I, _P, _P, _G, _P, _Z, _P]),
     "ssd_conv2d_igemm_tile": (_I, [_G, _I, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ssd_conv2d_wgrad_tile": (_I, [_G, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ssd_tune_set_igemm": (_I, [_I, _I]),
+    "ssd_tune_set_wgrad": (_I, [_I, _I, _I]),
     "ssd_conv_first_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ssd_conv_first_wgrad_workspace": (_Z, [_I, _I, _I, _I]),
     "ssd_conv_first_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),

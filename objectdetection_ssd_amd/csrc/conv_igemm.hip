@@ -232,33 +232,31 @@ int launch_igemm(IgemmParams& p, hipStream_t st) {
 // Tile choice: wide tiles when there are enough blocks to fill 256 CUs a few times over,
 // smaller tiles for the deep / small layers so the grid still covers the chip.
 // SSD_IGEMM_TILE=256x64|128x128|128x64|64x64 forces one configuration (tuning aid).
-enum Tile { T256x64, T128x128, T128x64, T64x64, TAUTO };
-Tile forced_tile() {
-    static const Tile t = [] {
-        const char* e = getenv("SSD_IGEMM_TILE");
-        if (!e) return TAUTO;
-        if (!strcmp(e, "256x64")) return T256x64;
-        if (!strcmp(e, "128x128")) return T128x128;
-        if (!strcmp(e, "128x64")) return T128x64;
-        if (!strcmp(e, "64x64")) return T64x64;
-        return TAUTO;
-    }();
-    return t;
-}
-Tile pick_tile(int M, int Nout) {
-    const Tile f = forced_tile();
-    if (f != TAUTO) return f;
-    const long blocks_128 = (long)ssd_cdiv(M, 128) * ssd_cdiv(Nout, 128);
-    if (Nout <= 64) return M >= 256 * 512 ? T256x64 : T64x64;
-    return blocks_128 >= 512 ? T128x128 : T64x64;
+enum Tile { T256x64 = 0, T128x128 = 1, T128x64 = 2, T64x64 = 3, TAUTO = -1 };
+int g_force_tile = TAUTO, g_force_nbuf = -1;      // tuning aid (ssd_tune_set); -1 = automatic
+
+struct TileChoice { Tile tile; int nbuf; };
+TileChoice pick_tile(int M, int Nout) {
+    // Measured on MI355X at bs=32 (tools/conv_bench.py, gpurun_out/convbench1.log): on every layer of the
+    // network the 64x64 tile with ONE LDS stage (18 KB, 70 registers -> 7 blocks per CU) beats the wider
+    // tiles and the double-buffered variants (125-141 vs 95-130 TFLOP/s): with a 64-cycle MFMA, occupancy
+    // hides the barrier and staging better than a second stage does, and small tiles quantise better.
+    TileChoice c;
+    (void)M; (void)Nout;
+    c.tile = T64x64;
+    if (g_force_tile != TAUTO) c.tile = (Tile)g_force_tile;
+    c.nbuf = 1;
+    if (g_force_nbuf == 1 || g_force_nbuf == 2) c.nbuf = g_force_nbuf;
+    return c;
 }
 
 int dispatch_igemm(IgemmParams& p, hipStream_t st) {
-    switch (pick_tile(p.M, p.Nout)) {
-        case T256x64: return launch_igemm<256, 64, 4, 1, 1>(p, st);
-        case T128x128: return launch_igemm<128, 128, 2, 2, 2>(p, st);
-        case T128x64: return launch_igemm<128, 64, 4, 1, 2>(p, st);
-        default: return launch_igemm<64, 64, 2, 2, 2>(p, st);
+    const TileChoice c = pick_tile(p.M, p.Nout);
+    switch (c.tile) {
+        case T256x64: return c.nbuf == 2 ? launch_igemm<256, 64, 4, 1, 2>(p, st) : launch_igemm<256, 64, 4, 1, 1>(p, st);
+        case T128x128: return c.nbuf == 2 ? launch_igemm<128, 128, 2, 2, 2>(p, st) : launch_igemm<128, 128, 2, 2, 1>(p, st);
+        case T128x64: return c.nbuf == 2 ? launch_igemm<128, 64, 4, 1, 2>(p, st) : launch_igemm<128, 64, 4, 1, 1>(p, st);
+        default: return c.nbuf == 2 ? launch_igemm<64, 64, 2, 2, 2>(p, st) : launch_igemm<64, 64, 2, 2, 1>(p, st);
     }
 }
 
@@ -321,11 +319,19 @@ extern "C" int ssd_conv2d_igemm_tile(const ssd_conv_geom* g, int direction, int*
     if (!bm || !bn || (direction != 0 && direction != 1)) return SSD_ERR_NULL;
     const int M = direction == 0 ? g->N * g->Ho * g->Wo : g->N * g->H * g->W;
     const int Nout = direction == 0 ? g->Co : g->Ci;
-    switch (pick_tile(M, Nout)) {
+    switch (pick_tile(M, Nout).tile) {
         case T256x64: *bm = 256; *bn = 64; break;
         case T128x128: *bm = 128; *bn = 128; break;
         case T128x64: *bm = 128; *bn = 64; break;
         default: *bm = 64; *bn = 64; break;
     }
+    return SSD_OK;
+}
+
+// Tuning aid: force the igemm tile (0 = 256x64, 1 = 128x128, 2 = 128x64, 3 = 64x64) and LDS stage count; -1 = automatic.
+extern "C" int ssd_tune_set_igemm(int tile, int nbuf) {
+    if (tile < -1 || tile > 3 || nbuf < -1 || nbuf > 2 || nbuf == 0) return SSD_ERR_BAD_SHAPE;
+    g_force_tile = tile;
+    g_force_nbuf = nbuf;
     return SSD_OK;
 }

@@ -35,14 +35,14 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t srd, unsigned
 // BT = tile edge (both n and c), 4 waves as 2x2, each wave (BT/2)x(BT/2).
 // Both LDS stages hold [pixel][channel] rows as they come from NHWC memory.  Within a wave's
 // 64-channel span MFMA tile i takes channels 2*lane+i, so one ds_read_b64 feeds both tiles.
-template <int BT>
+template <int BT, int NBUF>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     constexpr int TT = BT / 64;                 // 32x32 accumulators per wave per dim
     constexpr int CHUNKS = BT / 4;              // float4 chunks per tile row
     constexpr int ROWS_PER_PASS = 256 / CHUNKS; // pixel rows loaded per pass
     constexpr int PASSES = WBK / ROWS_PER_PASS;
     constexpr int STAGE = 2 * WBK * BT;
-    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) float lds[NBUF * STAGE];
     __shared__ float bias_red[256 * 4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -97,22 +97,34 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
 
     f32x4 ry[PASSES], rx[PASSES];
+    const bool wide = p.Wo >= WBK;               // a 32-pixel step wraps at most one image row
+    const unsigned ldy4 = (unsigned)p.ldy * 4u, ci4 = (unsigned)p.Ci * 4u;
     auto issue_loads = [&]() {
 #pragma unroll
         for (int j = 0; j < PASSES; ++j) {
             const bool in = pm[j] < m_end;
-            const unsigned vy = (in && y_col_ok) ? (unsigned)pm[j] * (unsigned)p.ldy * 4u + y_col : OOB;
+            const unsigned vy = (in && y_col_ok) ? (unsigned)pm[j] * ldy4 + y_col : OOB;
             const int ih = poh[j] * p.stride + dh, iw = pow_[j] * p.stride + dw;
-            const bool xin = in && x_col_ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-            const unsigned vx = xin ? (unsigned)((pn[j] * p.H + ih) * p.W + iw) * (unsigned)p.Ci * 4u + x_col : OOB;
+            const bool xin = in && x_col_ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            const unsigned vx = xin ? (unsigned)((pn[j] * p.H + ih) * p.W + iw) * ci4 + x_col : OOB;
             ry[j] = buf_load16(srd_y, vy, 0);
             rx[j] = buf_load16(srd_x, vx, 0);
-            // advance this row by WBK pixels
+            // advance this row by WBK pixels (branch-free when the map is at least 32 wide)
             pm[j] += WBK;
-            pow_[j] += WBK;
-            while (pow_[j] >= p.Wo) {
-                pow_[j] -= p.Wo;
-                if (++poh[j] == p.Ho) { poh[j] = 0; ++pn[j]; }
+            if (wide) {
+                pow_[j] += WBK;
+                const bool w1 = pow_[j] >= p.Wo;
+                pow_[j] -= w1 ? p.Wo : 0;
+                poh[j] += w1 ? 1 : 0;
+                const bool w2 = poh[j] >= p.Ho;
+                poh[j] = w2 ? 0 : poh[j];
+                pn[j] += w2 ? 1 : 0;
+            } else {
+                const int mm = pm[j] < p.M ? pm[j] : 0;
+                pn[j] = mm / HoWo;
+                const int rem = mm - pn[j] * HoWo;
+                poh[j] = rem / p.Wo;
+                pow_[j] = rem - poh[j] * p.Wo;
             }
         }
     };
@@ -140,27 +152,45 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
         for (int mb = m_begin; mb < m_end; mb += WBK) {
             const bool more = mb + WBK < m_end;
             if (more) issue_loads();
-            const float* stage = lds + cur * STAGE;
-#pragma unroll
-            for (int kk = 0; kk < WBK / 2; ++kk) {
-                float af[TT], bf[TT];
+            const float* stage = lds + (NBUF == 2 ? cur * STAGE : 0);
+            // operands of k-pair kk+1 are read from LDS before the MFMAs of k-pair kk are issued
+            float an[TT], bn[TT];
+            auto rd = [&](int kk) {
                 if (TT == 2) {
                     const float2 a2 = *reinterpret_cast<const float2*>(stage + y_rd + 2 * kk * BT);
                     const float2 b2 = *reinterpret_cast<const float2*>(stage + x_rd + 2 * kk * BT);
-                    af[0] = a2.x; af[TT - 1] = a2.y; bf[0] = b2.x; bf[TT - 1] = b2.y;
+                    an[0] = a2.x; an[TT - 1] = a2.y; bn[0] = b2.x; bn[TT - 1] = b2.y;
                 } else {
-                    af[0] = stage[y_rd + 2 * kk * BT];
-                    bf[0] = stage[x_rd + 2 * kk * BT];
+                    an[0] = stage[y_rd + 2 * kk * BT];
+                    bn[0] = stage[x_rd + 2 * kk * BT];
                 }
+            };
+            rd(0);
+#pragma unroll
+            for (int kk = 0; kk < WBK / 2; ++kk) {
+                float af[TT], bf[TT];
+#pragma unroll
+                for (int i = 0; i < TT; ++i) { af[i] = an[i]; bf[i] = bn[i]; }
+                if (kk + 1 < WBK / 2) rd(kk + 1);
 #pragma unroll
                 for (int i = 0; i < TT; ++i)
 #pragma unroll
                     for (int j = 0; j < TT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);        // 2 LDS reads (next k-pair) ...
+                __builtin_amdgcn_sched_group_barrier(0x008, TT * TT, 0);  // ... then this k-pair's MFMAs
             }
-            if (more) store_tile(lds + (cur ^ 1) * STAGE);
-            __syncthreads();
-            cur ^= 1;
+            if (NBUF == 2) {
+                if (more) store_tile(lds + (cur ^ 1) * STAGE);
+                __syncthreads();
+                cur ^= 1;
+            } else {
+                __syncthreads();
+                if (more) {
+                    store_tile(lds);
+                    __syncthreads();
+                }
+            }
         }
     }
 
@@ -219,8 +249,10 @@ __global__ void bias_reduce_kernel(const float* __restrict__ slab, float* __rest
     }
 }
 
+int g_force_bt = -1, g_force_wnbuf = -1, g_force_blocks_per_cu = -1;   // tuning aid (ssd_tune_set_wgrad)
+
 struct WgradPlan {
-    int bt, tiles_co, tiles_ci, nsplit, m_per_split;
+    int bt, nbuf, tiles_co, tiles_ci, nsplit, m_per_split;
     size_t slab_floats, bias_floats;
 };
 
@@ -229,11 +261,16 @@ WgradPlan plan_wgrad(const ssd_conv_geom* g) {
     const int T = g->R * g->S;
     const int M = g->N * g->Ho * g->Wo;
     pl.bt = (g->Co > 64 && g->Ci > 64) ? 128 : 64;
+    if (g_force_bt == 64 || g_force_bt == 128) pl.bt = g_force_bt;
+    pl.nbuf = (g_force_wnbuf == 1 || g_force_wnbuf == 2) ? g_force_wnbuf : 1;
+    // measured (tools/conv_bench.py): BT=128 peaks at ~9 blocks per CU of split-K work (3 resident x 3 rounds),
+    // BT=64 at ~16; one LDS stage beats two (occupancy).
+    const int target_per_cu = g_force_blocks_per_cu > 0 ? g_force_blocks_per_cu : (pl.bt == 128 ? 9 : 16);
     pl.tiles_co = ssd_cdiv(g->Co, pl.bt);
     pl.tiles_ci = ssd_cdiv(g->Ci, pl.bt);
     const int per_split = T * pl.tiles_co * pl.tiles_ci;
     // aim for ~4 blocks per CU, at least 8 K steps per block, at most 256 slabs
-    int ns = ssd_cdiv(256 * 4, per_split);
+    int ns = ssd_cdiv(256 * target_per_cu, per_split);
     const int max_by_m = M / (WBK * 8) > 0 ? M / (WBK * 8) : 1;
     if (ns > max_by_m) ns = max_by_m;
     if (ns > 256) ns = 256;
@@ -278,8 +315,13 @@ extern "C" int ssd_conv2d_wgrad(const float* x, const float* dy, int ldy, float*
     p.tiles_co = pl.tiles_co; p.tiles_ci = pl.tiles_ci;
     const int T = g->R * g->S;
     const int nblk = T * pl.tiles_co * pl.tiles_ci * pl.nsplit;
-    if (pl.bt == 128) hipLaunchKernelGGL(wgrad_kernel<128>, dim3(nblk), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(wgrad_kernel<64>, dim3(nblk), dim3(256), 0, st, p);
+    if (pl.bt == 128) {
+        if (pl.nbuf == 2) hipLaunchKernelGGL((wgrad_kernel<128, 2>), dim3(nblk), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((wgrad_kernel<128, 1>), dim3(nblk), dim3(256), 0, st, p);
+    } else {
+        if (pl.nbuf == 2) hipLaunchKernelGGL((wgrad_kernel<64, 2>), dim3(nblk), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((wgrad_kernel<64, 1>), dim3(nblk), dim3(256), 0, st, p);
+    }
     SSD_CHECK_LAUNCH();
     const size_t total = (size_t)g->Co * T * g->Ci;
     const int rb = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
@@ -298,5 +340,13 @@ extern "C" int ssd_conv2d_wgrad_tile(const ssd_conv_geom* g, int* bt, int* nspli
     const WgradPlan pl = plan_wgrad(g);
     *bt = pl.bt;
     *nsplit = pl.nsplit;
+    return SSD_OK;
+}
+
+// Tuning aid: force tile edge (64/128), LDS stage count (1/2) and split-K target in blocks per CU; -1 = automatic.
+extern "C" int ssd_tune_set_wgrad(int bt, int nbuf, int blocks_per_cu) {
+    g_force_bt = bt;
+    g_force_wnbuf = nbuf;
+    g_force_blocks_per_cu = blocks_per_cu;
     return SSD_OK;
 }

@@ -1,0 +1,64 @@
+"""Per-layer conv micro-benchmark over tile / stage variants (tuning aid; GPU only).
+usage: python tools/conv_bench.py [fwd|dgrad|wgrad|all]"""
+import ctypes as C, os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from objectdetection_ssd_amd import ops, _lib
+lib = _lib.load()
+BS = 32
+LAYERS = [  # name, H, Ci, Co, k, s, pad, dil
+    ("conv1_2", 300, 64, 64, 3, 1, 1, 1), ("conv2_1", 150, 64, 128, 3, 1, 1, 1), ("conv2_2", 150, 128, 128, 3, 1, 1, 1),
+    ("conv3_1", 75, 128, 256, 3, 1, 1, 1), ("conv3_2", 75, 256, 256, 3, 1, 1, 1), ("conv4_1", 38, 256, 512, 3, 1, 1, 1),
+    ("conv4_2", 38, 512, 512, 3, 1, 1, 1), ("conv5_1", 19, 512, 512, 3, 1, 1, 1), ("fc6", 19, 512, 1024, 3, 1, 4, 4),
+    ("fc7", 19, 1024, 1024, 1, 1, 0, 1), ("c_4", 38, 512, 100, 3, 1, 1, 1), ("c_7", 19, 1024, 150, 3, 1, 1, 1),
+    ("seq8.2", 19, 256, 512, 3, 2, 1, 1),
+]
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    dev = torch.device("cuda")
+    ig_var = [(-1, -1, "auto"), (1, 2, "128x128/2"), (1, 1, "128x128/1"), (0, 1, "256x64/1"), (0, 2, "256x64/2"),
+              (2, 2, "128x64/2"), (2, 1, "128x64/1"), (3, 2, "64x64/2"), (3, 1, "64x64/1")]
+    wg_var = [(-1, -1, -1, "auto"), (128, 1, 3, "128/1/3"), (128, 1, 6, "128/1/6"), (128, 1, 9, "128/1/9"), (128, 1, 12, "128/1/12"),
+              (64, 1, 4, "64/1/4"), (64, 1, 8, "64/1/8"), (64, 1, 12, "64/1/12"), (64, 1, 16, "64/1/16"), (64, 1, 24, "64/1/24")]
+    for name, H, ci, co, k, s, pad, dil in LAYERS:
+        g = ops.make_geom(BS, H, H, ci, co, k, s, pad, dil)
+        ld = ops.pad32(co)
+        x = torch.randn(BS, H, H, ci, device=dev)
+        w = torch.randn(co, ci, k, k, device=dev) * 0.05
+        b = torch.randn(co, device=dev)
+        wf, wb = ops.weight_ohwi(w, ld), ops.weight_ihwo(w, ld)
+        dy = torch.randn(BS, g.Ho, g.Wo, ld, device=dev)
+        if ld != co: dy[..., co:] = 0
+        dx = torch.empty(BS, H, H, ci, device=dev)
+        fl = ops.conv_flops(g)
+        if which in ("fwd", "all"):
+            row = []
+            for t, nb, lab in ig_var:
+                lib.ssd_tune_set_igemm(t, nb)
+                ms = timeit(lambda: ops.conv2d_fwd(x, wf, b, g, True, ld=ld, out=dy))
+                row.append(f"{lab}:{fl / ms / 1e9:6.1f}")
+            print(f"fwd   {name:8s} " + "  ".join(row), flush=True)
+        if which in ("dgrad", "all"):
+            row = []
+            for t, nb, lab in ig_var:
+                lib.ssd_tune_set_igemm(t, nb)
+                ms = timeit(lambda: ops.conv2d_dgrad(dy, wb, g, dx, x, False))
+                row.append(f"{lab}:{fl / ms / 1e9:6.1f}")
+            print(f"dgrad {name:8s} " + "  ".join(row), flush=True)
+        lib.ssd_tune_set_igemm(-1, -1)
+        if which in ("wgrad", "all"):
+            row = []
+            for bt, nb, bpc, lab in wg_var:
+                lib.ssd_tune_set_wgrad(bt, nb, bpc)
+                ms = timeit(lambda: ops.conv2d_wgrad(x, dy, g, ld, True))
+                row.append(f"{lab}:{fl / ms / 1e9:6.1f}")
+            print(f"wgrad {name:8s} " + "  ".join(row), flush=True)
+        lib.ssd_tune_set_wgrad(-1, -1, -1)
+main()
