@@ -88,13 +88,10 @@ int ssd_conv2d_wgrad_tile(const ssd_conv_geom* g, int* bt, int* nsplit);
 int ssd_tune_set_igemm(int tile, int nbuf);
 int ssd_tune_set_wgrad(int bt, int nbuf, int blocks_per_cu);
 
-/* conv1_1 (Model.py:136 features[0]: Conv2d(3,64,3,padding=1)+ReLU): reads the
- * caller's NCHW image batch directly (Dataset.py:39 layout), writes NHWC. */
-int ssd_conv_first_fwd(const float* x_nchw, const float* w_oihw, const float* bias, float* y_nhwc,
-                       int N, int H, int W, int Co, int relu, void* stream);
-size_t ssd_conv_first_wgrad_workspace(int N, int H, int W, int Co);
-int ssd_conv_first_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_oihw, float* dbias,
-                         int N, int H, int W, int Co, void* workspace, size_t workspace_bytes, void* stream);
+/* conv1_1 (Model.py:136 features[0]: Conv2d(3,64,3,padding=1)+ReLU, Ci = 3): im2col of the caller's
+ * NCHW image batch (Dataset.py:39 layout) into [N*H*W][32] rows (k = (r*3+s)*3 + c, columns 27..31
+ * zero); forward / wgrad are then the 1x1 cases of ssd_conv2d_fwd / ssd_conv2d_wgrad with Ci = 32. */
+int ssd_im2col_first(const float* x_nchw, float* out, int N, int H, int W, void* stream);
 
 /* ---- max pooling (Model.py:137,142 nn.MaxPool2d incl. ceil_mode; features[4,9,23]) ----
  * argmax: uint8 window-relative index (r*k+s) of the first maximum, for backward. */

@@ -166,8 +166,20 @@ class _Engine:
         for op in self.ops:
             kind = op["op"]
             if kind == "conv_first":
-                T[op["y"]] = self._timed("fwd " + op["p"], "conv_first_fwd_kernel", 2.0 * bs * x.shape[2] * x.shape[3] * 64 * 27,
-                                         lambda: ops.conv_first_fwd(x, P[op["p"] + ".weight"].detach(), P[op["p"] + ".bias"].detach(), relu=True))
+                # conv1_1 as im2col (K = 27 -> 32) + the 1x1 MFMA convolution
+                col = ops.im2col_first(x)
+                g = ops.make_geom(bs, x.shape[2], x.shape[3], 32, 64, 1, 1, 0, 1)
+                wkey = P[op["p"] + ".weight"]
+                sig = (wkey.data_ptr(), wkey._version)
+                ent = self._wcache.get(op["p"])
+                if ent is None or ent[0] != sig:
+                    ent = [sig, None, ops.first_weight_rows(wkey), None]
+                    self._wcache[op["p"]] = ent
+                bias = P[op["p"] + ".bias"].detach()
+                T[op["y"]] = self._timed("fwd " + op["p"], ops.igemm_tile(g, 0) if self.prof is not None else "", 2.0 * bs * g.Ho * g.Wo * 64 * 27,
+                                         lambda: ops.conv2d_fwd(col, ent[2], bias, g, True))
+                T["x_col"] = col
+                aux[op["y"]] = g
             elif kind == "conv":
                 xin = T[op["x"]]
                 g = ops.make_geom(bs, xin.shape[1], xin.shape[2], op["ci"], op["co"], op["k"], op["s"], op["pad"], op["dil"])
@@ -274,9 +286,11 @@ class _Engine:
             elif kind == "conv_first":
                 dy = G.pop(op["y"])
                 if need[op["p"] + ".weight"] or need[op["p"] + ".bias"]:
-                    dw, db = self._timed("wgrad " + op["p"], "conv_first_wgrad_kernel", 2.0 * dy.numel() * 27,
-                                         lambda: ops.conv_first_wgrad(T["x"], dy, True))
-                    grads[op["p"] + ".weight"], grads[op["p"] + ".bias"] = dw, db
+                    g = aux[op["y"]]
+                    col = T["x_col"]
+                    dw, db = self._timed("wgrad " + op["p"], ops.wgrad_tile(g) if self.prof is not None else "", 2.0 * dy.numel() * 27,
+                                         lambda: ops.conv2d_wgrad(col, dy, g, g.Co, True))
+                    grads[op["p"] + ".weight"], grads[op["p"] + ".bias"] = ops.first_weight_grad(dw), db
         return grads
 
 

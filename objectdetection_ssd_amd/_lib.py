@@ -39,9 +39,7 @@ SIGNATURES = {
     "ssd_conv2d_wgrad_tile": (_I, [_G, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ssd_tune_set_igemm": (_I, [_I, _I]),
     "ssd_tune_set_wgrad": (_I, [_I, _I, _I]),
-    "ssd_conv_first_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "ssd_conv_first_wgrad_workspace": (_Z, [_I, _I, _I, _I]),
-    "ssd_conv_first_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
+    "ssd_im2col_first": (_I, [_P, _P, _I, _I, _I, _P]),
     "ssd_maxpool_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ssd_maxpool_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ssd_l2norm_fwd": (_I, [_P, _P, _P, _I, _I, _P]),

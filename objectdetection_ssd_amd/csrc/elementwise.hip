@@ -1,4 +1,4 @@
-// HBM-bound NHWC kernels around the convolutions: weight re-layout, conv1_1,
+// HBM-bound NHWC kernels around the convolutions: weight re-layout, conv1_1 im2col,
 // max pooling, conv4_3 L2 normalisation, head scatter/gather, fused SGD.
 #include "common.h"
 
@@ -32,132 +32,31 @@ inline int grid_for(size_t total, int block = 256, int cap = 4096) {
 }
 
 // ---------------------------------------------------------------------------------------
-// conv1_1: Conv2d(3, Co, 3, padding=1) + ReLU reading NCHW, writing NHWC.
-// One thread = one output pixel x 16 output channels (4 threads per pixel so a wave
-// writes 16 pixels x 256 B contiguous); the 27 input taps sit in registers, weights
-// in LDS as [tap*3+c][Co] (all lanes of a quarter read the same address: broadcast).
+// conv1_1 (Model.py:136 features[0], Ci = 3): im2col so that the MFMA kernels can take it
 // ---------------------------------------------------------------------------------------
-template <int CO>
-__global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                             const float* __restrict__ bias, float* __restrict__ y,
-                                                             int N, int H, int W, int relu) {
-    __shared__ __attribute__((aligned(16))) float ws[27 * CO];
-    __shared__ float bs[CO];
-    for (int i = threadIdx.x; i < 27 * CO; i += 256) {
-        const int co = i % CO, k = i / CO;          // k = (r*3+s)*3 + c
-        const int c = k % 3, t = k / 3;
-        ws[i] = w[((size_t)co * 3 + c) * 9 + t];
-    }
-    for (int i = threadIdx.x; i < CO; i += 256) bs[i] = bias ? bias[i] : 0.f;
-    __syncthreads();
-    constexpr int Q = CO / 16;                       // threads per pixel
-    const size_t npix = (size_t)N * H * W;
+// im2col of the 3-channel NCHW input for conv1_1: out[pix][k], k = (r*3+s)*3 + c for k < 27, zero for 27..31.
+// 8 threads per pixel, each writes one 16-byte chunk (4 k values) -> 128 contiguous bytes per pixel.
+__global__ __launch_bounds__(256) void im2col_first_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int H, int W) {
     const size_t HW = (size_t)H * W;
-    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < npix * Q; g += (size_t)gridDim.x * 256) {
-        const size_t pix = g / Q;
-        const int q = (int)(g % Q);
+    const size_t total = (size_t)N * HW * 8;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
+        const size_t pix = g >> 3;
+        const int q = (int)(g & 7);
         const int n = (int)(pix / HW);
         const int rem = (int)(pix - (size_t)n * HW);
         const int oh = rem / W, ow = rem - oh * W;
-        float v[27];
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const int ih = oh + r - 1, iw = ow + s - 1;
-                const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < W;
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    v[(r * 3 + s) * 3 + c] = ok ? x[((size_t)n * 3 + c) * HW + (size_t)ih * W + iw] : 0.f;
-            }
-        float acc[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = bs[q * 16 + j];
-#pragma unroll
-        for (int k = 0; k < 27; ++k) {
-            const float* wr = ws + k * CO + q * 16;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) acc[j] = fmaf(v[k], wr[j], acc[j]);
-        }
-        f32x4* dst = reinterpret_cast<f32x4*>(y + pix * CO + q * 16);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = acc[j * 4 + e];
-                o[e] = relu ? (t < 0.f ? 0.f : t) : t;
-            }
-            dst[j] = o;
-        }
-    }
-}
-
-// conv1_1 weight gradient: dW[co][c][t] = sum_pix dy[pix][co] * xcol[pix][t*3+c].
-// Each block walks a slice of pixels in 64-pixel steps: the dy tile [64][CO] and the im2col
-// tile [64][27] go to LDS; the 64 co x 27 k = 1728 outputs are spread as 256 threads x 7
-// (co = tid&63, k = (tid>>6) + 4j), so a wave reads consecutive dy channels and one
-// broadcast im2col value per FMA.  HBM-bound on reading dy (N*H*W*64 floats).
-template <int CO>
-__global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                               float* __restrict__ slab, float* __restrict__ bias_slab,
-                                                               int N, int H, int W, int pix_per_block) {
-    static_assert(CO == 64, "conv1_1 has 64 output channels");
-    constexpr int PB = 64;
-    __shared__ float ys[PB][CO + 1];
-    __shared__ float xs[PB][28];
-    const int tid = threadIdx.x;
-    const int co = tid & 63, kq = tid >> 6;
-    const size_t HW = (size_t)H * W;
-    const size_t npix = (size_t)N * HW;
-    const size_t p_begin = (size_t)blockIdx.x * pix_per_block;
-    const size_t p_end = p_begin + pix_per_block < npix ? p_begin + pix_per_block : npix;
-    float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float bacc = 0.f;
-    for (size_t pb = p_begin; pb < p_end; pb += PB) {
-        // dy tile: 64 pixels x 64 channels = 4096 floats, 16 per thread, coalesced
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int e = tid + 256 * j;
-            const int pr = e >> 6, c = e & 63;
-            const size_t pix = pb + pr;
-            ys[pr][c] = pix < p_end ? dy[pix * CO + c] : 0.f;
-        }
-        // im2col tile: 64 pixels x 27
-        for (int e = tid; e < PB * 27; e += 256) {
-            const int pr = e / 27, k = e - pr * 27;
-            const size_t pix = pb + pr;
-            float v = 0.f;
-            if (pix < p_end) {
-                const int n = (int)(pix / HW);
-                const int rem = (int)(pix - (size_t)n * HW);
-                const int oh = rem / W, ow = rem - oh * W;
+        for (int e = 0; e < 4; ++e) {
+            const int k = q * 4 + e;
+            if (k < 27) {
                 const int c = k % 3, t = k / 3;
                 const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
-                if (ih >= 0 && ih < H && iw >= 0 && iw < W) v = x[((size_t)n * 3 + c) * HW + (size_t)ih * W + iw];
-            }
-            xs[pr][k] = v;
-        }
-        __syncthreads();
-#pragma unroll 8
-        for (int pr = 0; pr < PB; ++pr) {
-            const float d = ys[pr][co];
-            if (kq == 0) bacc += d;
-#pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                const int k = kq + 4 * j;
-                if (k < 27) acc[j] = fmaf(d, xs[pr][k], acc[j]);
+                if (ih >= 0 && ih < H && iw >= 0 && iw < W) v[e] = x[((size_t)n * 3 + c) * HW + (size_t)ih * W + iw];
             }
         }
-        __syncthreads();
+        *reinterpret_cast<f32x4*>(out + g * 4) = v;
     }
-    float* out = slab + (size_t)blockIdx.x * CO * 27;
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        const int k = kq + 4 * j;                  // k = t*3 + c
-        if (k < 27) out[co * 27 + (k % 3) * 9 + k / 3] = acc[j];   // OIHW order inside the slab
-    }
-    if (kq == 0 && bias_slab) bias_slab[(size_t)blockIdx.x * CO + co] = bacc;
 }
 
 __global__ void slab_sum_kernel(const float* __restrict__ slab, float* __restrict__ out, int n, int nslab) {
@@ -418,48 +317,13 @@ extern "C" int ssd_weight_oihw_to_ihwo(const float* w, float* o, int Co, int Ci,
     return SSD_OK;
 }
 
-extern "C" int ssd_conv_first_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Co,
-                                  int relu, void* stream) {
-    if (!x || !w || !y) return SSD_ERR_NULL;
-    if (Co != 64 || N <= 0 || H <= 0 || W <= 0) return SSD_ERR_BAD_SHAPE;
-    if (!ssd_aligned16(y)) return SSD_ERR_ALIGN;
-    const size_t work = (size_t)N * H * W * (Co / 16);
-    hipLaunchKernelGGL(conv_first_fwd_kernel<64>, dim3(grid_for(work, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, N, H, W, relu);
+extern "C" int ssd_im2col_first(const float* x_nchw, float* out, int N, int H, int W, void* stream) {
+    if (!x_nchw || !out) return SSD_ERR_NULL;
+    if (N <= 0 || H <= 0 || W <= 0) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(out)) return SSD_ERR_ALIGN;
+    const size_t total = (size_t)N * H * W * 8;
+    hipLaunchKernelGGL(im2col_first_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x_nchw, out, N, H, W);
     SSD_CHECK_LAUNCH();
-    return SSD_OK;
-}
-
-static int conv_first_blocks(int N, int H, int W, int* pix_per_block) {
-    const size_t npix = (size_t)N * H * W;
-    size_t ppb = (npix + 1023) / 1024;
-    ppb = (ppb + 63) / 64 * 64;
-    if (ppb < 64) ppb = 64;
-    *pix_per_block = (int)ppb;
-    return (int)((npix + ppb - 1) / ppb);
-}
-extern "C" size_t ssd_conv_first_wgrad_workspace(int N, int H, int W, int Co) {
-    int ppb;
-    const int nb = conv_first_blocks(N, H, W, &ppb);
-    return (size_t)nb * Co * 28 * sizeof(float) + 256;
-}
-extern "C" int ssd_conv_first_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N, int H, int W, int Co,
-                                    void* ws, size_t ws_bytes, void* stream) {
-    if (!x || !dy || !dw || !ws) return SSD_ERR_NULL;
-    if (Co != 64 || N <= 0 || H <= 0 || W <= 0) return SSD_ERR_BAD_SHAPE;
-    if (ws_bytes < ssd_conv_first_wgrad_workspace(N, H, W, Co)) return SSD_ERR_WORKSPACE;
-    int ppb;
-    const int nb = conv_first_blocks(N, H, W, &ppb);
-    float* slab = reinterpret_cast<float*>(ws);
-    float* bslab = slab + (size_t)nb * Co * 27;
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv_first_wgrad_kernel<64>, dim3(nb), dim3(256), 0, st, x, dy, slab, dbias ? bslab : nullptr, N, H, W, ppb);
-    SSD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(slab_sum_kernel, dim3(ssd_cdiv(Co * 27, 256)), dim3(256), 0, st, slab, dw, Co * 27, nb);
-    SSD_CHECK_LAUNCH();
-    if (dbias) {
-        hipLaunchKernelGGL(slab_sum_kernel, dim3(1), dim3(256), 0, st, bslab, dbias, Co, nb);
-        SSD_CHECK_LAUNCH();
-    }
     return SSD_OK;
 }
 

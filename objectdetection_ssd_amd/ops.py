@@ -163,33 +163,28 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, g: ConvGeom, ldy: int, want_
     return dw, db
 
 
-def conv_first_fwd(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], relu: bool = True) -> torch.Tensor:
-    _req(x_nchw, "x"); _req(w, "w")
-    n, c, h, wd = x_nchw.shape
-    if c != 3 or tuple(w.shape[1:]) != (3, 3, 3):
-        raise ValueError("conv_first expects (N,3,H,W) input and (Co,3,3,3) weights")
-    co = w.shape[0]
-    if bias is not None:
-        _req(bias, "bias")
-    y = torch.empty((n, h, wd, co), device=x_nchw.device, dtype=torch.float32)
-    check(_lib.load().ssd_conv_first_fwd(x_nchw.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), n, h, wd, co, int(relu),
-                                         _stream()), "conv_first_fwd")
-    return y
+def im2col_first(x_nchw: torch.Tensor) -> torch.Tensor:
+    """(N,3,H,W) NCHW -> (N,H,W,32) rows of the 27 taps (k = (r*3+s)*3 + c) + 5 zero columns."""
+    _req(x_nchw, "x")
+    n, c, h, w = x_nchw.shape
+    if c != 3:
+        raise ValueError("im2col_first expects 3 input channels")
+    out = torch.empty((n, h, w, 32), device=x_nchw.device, dtype=torch.float32)
+    check(_lib.load().ssd_im2col_first(x_nchw.data_ptr(), out.data_ptr(), n, h, w, _stream()), "im2col_first")
+    return out
 
 
-def conv_first_wgrad(x_nchw: torch.Tensor, dy: torch.Tensor, want_bias: bool = True):
-    _req(x_nchw, "x"); _req(dy, "dy")
-    n, c, h, wd = x_nchw.shape
-    co = dy.shape[-1]
-    if c != 3 or dy.numel() != n * h * wd * co:
-        raise ValueError("conv_first_wgrad shapes")
-    lib = _lib.load()
-    ws = workspace(lib.ssd_conv_first_wgrad_workspace(n, h, wd, co), x_nchw.device)
-    dw = torch.empty((co, 3, 3, 3), device=dy.device, dtype=torch.float32)
-    db = torch.empty((co,), device=dy.device, dtype=torch.float32) if want_bias else None
-    check(lib.ssd_conv_first_wgrad(x_nchw.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db), n, h, wd, co, ws.data_ptr(),
-                                   ws.numel(), _stream()), "conv_first_wgrad")
-    return dw, db
+def first_weight_rows(w_oihw: torch.Tensor) -> torch.Tensor:
+    """(Co,3,3,3) OIHW -> (Co,1,32): rows ordered like im2col_first's columns, zero padded."""
+    co = w_oihw.shape[0]
+    rows = w_oihw.detach().permute(0, 2, 3, 1).reshape(co, 27)              # [co][(r,s),c]
+    return torch.nn.functional.pad(rows, (0, 5)).reshape(co, 1, 32).contiguous()
+
+
+def first_weight_grad(dw_rows: torch.Tensor) -> torch.Tensor:
+    """inverse of first_weight_rows for the gradient: (Co,32,1,1) -> (Co,3,3,3) OIHW"""
+    co = dw_rows.shape[0]
+    return dw_rows.reshape(co, 32)[:, :27].reshape(co, 3, 3, 3).permute(0, 3, 1, 2).contiguous()
 
 
 # ---- pooling / norm ----------------------------------------------------------------------

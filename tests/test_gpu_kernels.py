@@ -115,24 +115,6 @@ def test_conv2d_dgrad_and_wgrad(case):
     assert torch.equal(dw, dw_b) and torch.equal(db, db_b)
 
 
-def test_conv_first_fwd_and_wgrad():
-    from objectdetection_ssd_amd import ops
-    dev = _dev()
-    g = torch.Generator().manual_seed(5)
-    for (n, h, w) in ((2, 75, 75), (1, 300, 300), (3, 33, 47)):
-        x = torch.randn(n, 3, h, w, generator=g)
-        wt = (torch.randn(64, 3, 3, 3, generator=g) * 0.27).requires_grad_(True)
-        b = (torch.randn(64, generator=g) * 0.1).requires_grad_(True)
-        y = F.relu(F.conv2d(x, wt, b, padding=1))
-        dy = torch.randn(y.shape, generator=g) * (y > 0)
-        y.backward(dy)
-        yd = ops.conv_first_fwd(x.to(dev), wt.detach().to(dev), b.detach().to(dev), relu=True)
-        _close(yd, _nhwc(y), what="conv_first fwd")
-        dw, db = ops.conv_first_wgrad(x.to(dev), _nhwc(dy).to(dev), True)
-        _close(dw, wt.grad, tol=2e-4, what="conv_first wgrad")
-        _close(db, b.grad, tol=2e-4, what="conv_first bias grad")
-
-
 POOLS = [(2, 2, 0, False, 300), (2, 2, 0, False, 75), (2, 2, 0, True, 75), (2, 2, 0, False, 38), (3, 1, 1, True, 19)]
 
 
@@ -222,3 +204,26 @@ def test_sgd_momentum_matches_torch():
         opt.step()
         ops.sgd_momentum_(p, gr.to(dev), buf, 1e-2, 0.9, 5e-4, first_step=(step == 0))
     _close(p, p_ref.detach(), tol=1e-6, what="sgd")
+
+
+def test_conv_first_via_im2col():
+    """conv1_1 = im2col (K 27->32) + 1x1 MFMA conv; wgrad through the same buffer"""
+    from objectdetection_ssd_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(15)
+    n, h, w = 2, 60, 77
+    x = torch.randn(n, 3, h, w, generator=g)
+    wt = (torch.randn(64, 3, 3, 3, generator=g) * 0.27).requires_grad_(True)
+    b = (torch.randn(64, generator=g) * 0.1).requires_grad_(True)
+    y = F.relu(F.conv2d(x, wt, b, padding=1))
+    dy = torch.randn(y.shape, generator=g) * (y > 0)
+    y.backward(dy)
+    col = ops.im2col_first(x.to(dev))
+    ref_col = F.unfold(x, 3, padding=1).view(n, 3, 9, h, w).permute(0, 3, 4, 2, 1).reshape(n, h, w, 27)   # [(r,s)][c]
+    assert torch.equal(col[..., :27].cpu(), ref_col) and float(col[..., 27:].abs().max()) == 0.0
+    geom = ops.make_geom(n, h, w, 32, 64, 1, 1, 0, 1)
+    yd = ops.conv2d_fwd(col, ops.first_weight_rows(wt.detach().to(dev)), b.detach().to(dev), geom, True)
+    _close(yd, _nhwc(y), what="conv1_1 via im2col")
+    dw, db = ops.conv2d_wgrad(col, _nhwc(dy).to(dev), geom, 64, True)
+    _close(ops.first_weight_grad(dw), wt.grad, tol=2e-4, what="conv1_1 wgrad via im2col")
+    _close(db, b.grad, tol=2e-4, what="conv1_1 bias grad via im2col")
