@@ -260,20 +260,24 @@ WgradPlan plan_wgrad(const ssd_conv_geom* g) {
     WgradPlan pl;
     const int T = g->R * g->S;
     const int M = g->N * g->Ho * g->Wo;
+    // 128x128 tiles when both channel counts fill them; 64x64 otherwise (also for Co = 150, where
+    // two 128-row tiles would be 41 % padding against 22 % with three 64-row tiles)
     pl.bt = (g->Co > 64 && g->Ci > 64) ? 128 : 64;
+    if (pl.bt == 128 && ssd_cdiv(g->Co, 128) * 128 * 100 > ssd_cdiv(g->Co, 64) * 64 * 115) pl.bt = 64;
     if (g_force_bt == 64 || g_force_bt == 128) pl.bt = g_force_bt;
     pl.nbuf = (g_force_wnbuf == 1 || g_force_wnbuf == 2) ? g_force_wnbuf : 1;
     // measured (tools/conv_bench.py): BT=128 peaks at ~9 blocks per CU of split-K work (3 resident x 3 rounds),
-    // BT=64 at ~16; one LDS stage beats two (occupancy).
-    const int target_per_cu = g_force_blocks_per_cu > 0 ? g_force_blocks_per_cu : (pl.bt == 128 ? 9 : 16);
+    // BT=64 at ~18; one LDS stage beats two (occupancy).  A variant that loaded the MFMA operands straight
+    // from global memory into registers (no LDS, no barrier) measured 15-25 % slower and was dropped.
+    const int target_per_cu = g_force_blocks_per_cu > 0 ? g_force_blocks_per_cu : (pl.bt == 128 ? 9 : 18);
     pl.tiles_co = ssd_cdiv(g->Co, pl.bt);
     pl.tiles_ci = ssd_cdiv(g->Ci, pl.bt);
     const int per_split = T * pl.tiles_co * pl.tiles_ci;
-    // aim for ~4 blocks per CU, at least 8 K steps per block, at most 256 slabs
+    // split-K so that the grid is a few rounds of resident blocks; at least 8 K steps per block, at most 1024 slabs
     int ns = ssd_cdiv(256 * target_per_cu, per_split);
     const int max_by_m = M / (WBK * 8) > 0 ? M / (WBK * 8) : 1;
     if (ns > max_by_m) ns = max_by_m;
-    if (ns > 256) ns = 256;
+    if (ns > 1024) ns = 1024;
     if (ns < 1) ns = 1;
     int mps = ssd_cdiv(M, ns);
     mps = ssd_cdiv(mps, WBK) * WBK;

@@ -227,3 +227,48 @@ def test_conv_first_via_im2col():
     dw, db = ops.conv2d_wgrad(col, _nhwc(dy).to(dev), geom, 64, True)
     _close(ops.first_weight_grad(dw), wt.grad, tol=2e-4, what="conv1_1 wgrad via im2col")
     _close(db, b.grad, tol=2e-4, what="conv1_1 bias grad via im2col")
+
+
+VARIANT_CASES = [(2, 19, 19, 64, 64, 3, 1, 1, 1), (2, 38, 38, 128, 256, 3, 1, 1, 1), (2, 19, 19, 256, 100, 3, 1, 1, 1),
+                 (2, 10, 10, 128, 256, 3, 2, 1, 1), (3, 5, 5, 128, 256, 3, 1, 0, 1), (2, 19, 19, 512, 160, 1, 1, 0, 1)]
+
+
+@pytest.mark.parametrize("case", VARIANT_CASES)
+def test_every_kernel_variant(case):
+    """every instantiated tile / stage variant of the igemm and wgrad kernels (the dispatcher's choice is a
+    speed matter only: results must not depend on it)"""
+    from objectdetection_ssd_amd import _lib, ops
+    lib = _lib.load()
+    n, h, w, ci, co, k, s, p, d = case
+    dev = _dev()
+    x, wt, b = _conv_data(case, seed=21)
+    x.requires_grad_(True); wt.requires_grad_(True); b.requires_grad_(True)
+    y = F.conv2d(x, wt, b, stride=s, padding=p, dilation=d)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(22))
+    y.backward(dy)
+    g = ops.make_geom(n, h, w, ci, co, k, s, p, d)
+    ld = ops.pad32(co)
+    x_d = _nhwc(x.detach()).to(dev)
+    dy_p = torch.zeros(n, g.Ho, g.Wo, ld)
+    dy_p[..., :co] = _nhwc(dy)
+    dy_d = dy_p.to(dev)
+    wf = ops.weight_ohwi(wt.detach().to(dev), ld)
+    wb = ops.weight_ihwo(wt.detach().to(dev), ld)
+    try:
+        for tile in range(4):
+            for nbuf in (1, 2):
+                assert lib.ssd_tune_set_igemm(tile, nbuf) == 0
+                yd = ops.conv2d_fwd(x_d, wf, b.detach().to(dev), g, False, ld=ld)
+                _close(yd[..., :co], _nhwc(y), what=f"fwd tile {tile} nbuf {nbuf} {case}")
+                dx = ops.conv2d_dgrad(dy_d, wb, g)
+                _close(dx, _nhwc(x.grad), what=f"dgrad tile {tile} nbuf {nbuf} {case}")
+        lib.ssd_tune_set_igemm(-1, -1)
+        for bt, nbuf in ((64, 1), (64, 2), (128, 1), (128, 2)):
+            for bpc in (-1, 1, 40):
+                lib.ssd_tune_set_wgrad(bt, nbuf, bpc)
+                dw, db = ops.conv2d_wgrad(x_d, dy_d, g, ld, True)
+                _close(dw, wt.grad, tol=2e-4, what=f"wgrad bt {bt} nbuf {nbuf} bpc {bpc} {case}")
+                _close(db, b.grad, tol=2e-4, what=f"bias bt {bt} nbuf {nbuf} bpc {bpc} {case}")
+    finally:
+        lib.ssd_tune_set_igemm(-1, -1)
+        lib.ssd_tune_set_wgrad(-1, -1, -1)

@@ -22,12 +22,19 @@ def timeit(fn, n=5):
     return e0.elapsed_time(e1) / n
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
+    vonly = sys.argv[3].split(",") if len(sys.argv) > 3 else None
     dev = torch.device("cuda")
     ig_var = [(-1, -1, "auto"), (1, 2, "128x128/2"), (1, 1, "128x128/1"), (0, 1, "256x64/1"), (0, 2, "256x64/2"),
               (2, 2, "128x64/2"), (2, 1, "128x64/1"), (3, 2, "64x64/2"), (3, 1, "64x64/1")]
-    wg_var = [(-1, -1, -1, "auto"), (128, 1, 3, "128/1/3"), (128, 1, 6, "128/1/6"), (128, 1, 9, "128/1/9"), (128, 1, 12, "128/1/12"),
-              (64, 1, 4, "64/1/4"), (64, 1, 8, "64/1/8"), (64, 1, 12, "64/1/12"), (64, 1, 16, "64/1/16"), (64, 1, 24, "64/1/24")]
+    wg_var = [(-1, -1, -1, "auto"), (128, 1, 9, "128/1/9"), (64, 1, 18, "64/1/18"),
+              (64, 1, 12, "64/1/12"), (128, 1, 6, "128/1/6")]
+    if vonly:
+        ig_var = [v for v in ig_var if v[2] in vonly]
+        wg_var = [v for v in wg_var if v[3] in vonly]
     for name, H, ci, co, k, s, pad, dil in LAYERS:
+        if only and name not in only:
+            continue
         g = ops.make_geom(BS, H, H, ci, co, k, s, pad, dil)
         ld = ops.pad32(co)
         x = torch.randn(BS, H, H, ci, device=dev)
