@@ -268,7 +268,9 @@ WgradPlan plan_wgrad(const ssd_conv_geom* g) {
     pl.nbuf = (g_force_wnbuf == 1 || g_force_wnbuf == 2) ? g_force_wnbuf : 1;
     // measured (tools/conv_bench.py): BT=128 peaks at ~9 blocks per CU of split-K work (3 resident x 3 rounds),
     // BT=64 at ~18; one LDS stage beats two (occupancy).  A variant that loaded the MFMA operands straight
-    // from global memory into registers (no LDS, no barrier) measured 15-25 % slower and was dropped.
+    // from global memory into registers (no LDS, no barrier) and one that split each K step across the
+    // block's waves (one ds_read_b64 per two MFMAs at the 64x64 granularity) both measured 10-25 % slower
+    // than these and were dropped.
     const int target_per_cu = g_force_blocks_per_cu > 0 ? g_force_blocks_per_cu : (pl.bt == 128 ? 9 : 18);
     pl.tiles_co = ssd_cdiv(g->Co, pl.bt);
     pl.tiles_ci = ssd_cdiv(g->Ci, pl.bt);
