@@ -226,6 +226,150 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// All nine taps in one block (3x3, stride 1, dilation 1, padding 1 -- every VGG conv and every head).
+// The K dimension is walked in 4x8-pixel output patches: per patch the dy tile [32 px][64 co] and the
+// x HALO tile [6x10 px][64 ci] are staged in LDS once, and each of the nine taps multiplies the same dy
+// operand with the halo shifted by (r,s) -- an immediate LDS offset.  Against one-tap-per-block this
+// loads dy once instead of nine times and x 1.9x instead of 9x, and amortises the two barriers of a
+// K step over 144 MFMAs per wave instead of 16.  4 waves as 2x2, each 32x32 per tap: nine accumulators.
+// ---------------------------------------------------------------------------------------------
+constexpr int PH = 4, PW = 8, HH = PH + 2, HW = PW + 2, HPIX = HH * HW;   // patch 4x8, halo 6x10 = 60 pixels
+
+__global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const WgradParams p) {
+    constexpr int BT = 64, CHUNKS = 16, RPP = 16;
+    __shared__ __attribute__((aligned(16))) float Ys[PH * PW * BT];
+    __shared__ __attribute__((aligned(16))) float Xs[HPIX * BT];
+    __shared__ float bias_red[256 * 4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+    // block -> (split, co tile, ci tile); ci fastest so neighbours share the dy patch stream in L2
+    const int per_split = p.tiles_co * p.tiles_ci;
+    const int nblk = per_split * p.nsplit;
+    int lid = xcd_swizzle(blockIdx.x, nblk);
+    const int split = lid / per_split;
+    lid -= split * per_split;
+    const int tile_ci = lid % p.tiles_ci, tile_co = lid / p.tiles_ci;
+    const int co0 = tile_co * BT, ci0 = tile_ci * BT;
+    const int npw = (p.Wo + PW - 1) / PW, nph = (p.Ho + PH - 1) / PH;
+    const int per_img = npw * nph;
+    const int npatch = per_img * (p.M / (p.Ho * p.Wo));
+    const int pb = split * p.m_per_split;                       // here: patches per split
+    const int pe = min(npatch, pb + p.m_per_split);
+
+    const int chunk = tid % CHUNKS, prow = tid / CHUNKS;
+    const bool y_col_ok = co0 + chunk * 4 < p.ldy;
+    const bool x_col_ok = ci0 + chunk * 4 < p.Ci;
+    const bool do_bias = p.bias_slab != nullptr && tile_ci == 0;
+    const unsigned y_col = (unsigned)(co0 + chunk * 4) * 4u, x_col = (unsigned)(ci0 + chunk * 4) * 4u;
+    const unsigned ldy4 = (unsigned)p.ldy * 4u, ci4 = (unsigned)p.Ci * 4u;
+
+    const __amdgpu_buffer_rsrc_t srd_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
+
+    // this thread's pixels inside a patch / halo (fixed for the whole kernel)
+    int ypy[2], ypx[2], xhy[4], xhx[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int q = prow + RPP * j; ypy[j] = q / PW; ypx[j] = q % PW; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int q = prow + RPP * j; xhy[j] = q / HW; xhx[j] = q % HW; }   // q >= 60: unused
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ry[2], rx[4];
+
+    auto issue_loads = [&](int patch) {
+        const int n = patch / per_img, rem = patch - n * per_img;          // uniform: scalar unit
+        const int oh0 = (rem / npw) * PH, ow0 = (rem % npw) * PW;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int oh = oh0 + ypy[j], ow = ow0 + ypx[j];
+            const bool ok = y_col_ok && oh < p.Ho && ow < p.Wo;
+            const unsigned v = ok ? (unsigned)((n * p.Ho + oh) * p.Wo + ow) * ldy4 + y_col : OOB;
+            ry[j] = buf_load16(srd_y, v, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ih = oh0 + xhy[j] - 1, iw = ow0 + xhx[j] - 1;
+            const bool ok = x_col_ok && (prow + RPP * j) < HPIX && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            const unsigned v = ok ? (unsigned)((n * p.H + ih) * p.W + iw) * ci4 + x_col : OOB;
+            rx[j] = buf_load16(srd_x, v, 0);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            *reinterpret_cast<f32x4*>(&Ys[(prow + RPP * j) * BT + chunk * 4]) = ry[j];
+            if (do_bias) bsum += ry[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (prow + RPP * j < HPIX) *reinterpret_cast<f32x4*>(&Xs[(prow + RPP * j) * BT + chunk * 4]) = rx[j];
+    };
+
+    // operand addresses: k-pair kk covers patch pixels 2kk, 2kk+1 (lane half lh): py = kk>>2, px = 2(kk&3)+lh
+    const float* y_rd = Ys + lh * BT + wm * 32 + lr;
+    const float* x_rd = Xs + lh * BT + wn * 32 + lr;
+    if (pb < pe) {
+        issue_loads(pb);
+        store_tile();
+        __syncthreads();
+        for (int patch = pb; patch < pe; ++patch) {
+            const bool more = patch + 1 < pe;
+            if (more) issue_loads(patch + 1);
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const float a = y_rd[2 * kk * BT];
+                const int hbase = ((kk >> 2) * HW + 2 * (kk & 3)) * BT;
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int s2 = 0; s2 < 3; ++s2) {
+                        const float b = x_rd[hbase + (r * HW + s2) * BT];
+                        acc[r * 3 + s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[r * 3 + s2], 0, 0, 0);
+                    }
+            }
+            __syncthreads();
+            if (more) {
+                store_tile();
+                __syncthreads();
+            }
+        }
+    }
+
+    float* slab = p.slab + (size_t)split * p.Co * 9 * p.Ci;
+    const int ci = ci0 + wn * 32 + lr;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int co = co0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+            if (co < p.Co && ci < p.Ci) slab[((size_t)co * 9 + t) * p.Ci + ci] = acc[t][q];
+        }
+    if (do_bias) {   // uniform per block
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bias_red[tid * 4 + e] = bsum[e];
+        __syncthreads();
+        if (tid < CHUNKS) {
+            f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < RPP; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tot[e] += bias_red[(q * CHUNKS + tid) * 4 + e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = co0 + tid * 4 + e;
+                if (co < p.Co) p.bias_slab[(size_t)split * p.Co + co] = tot[e];
+            }
+        }
+    }
+}
+
 // out_oihw[co][ci][t] = sum_split slab[split][co][t][ci]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Co, int Ci, int T,
                                     int nsplit) {
@@ -252,14 +396,39 @@ __global__ void bias_reduce_kernel(const float* __restrict__ slab, float* __rest
 int g_force_bt = -1, g_force_wnbuf = -1, g_force_blocks_per_cu = -1;   // tuning aid (ssd_tune_set_wgrad)
 
 struct WgradPlan {
-    int bt, nbuf, tiles_co, tiles_ci, nsplit, m_per_split;
+    int bt, nbuf, fused, tiles_co, tiles_ci, nsplit, m_per_split;
     size_t slab_floats, bias_floats;
 };
+
+int g_force_fused = -1;          // tuning aid: 0 = never use the fused 3x3 kernel, 1 = whenever applicable
 
 WgradPlan plan_wgrad(const ssd_conv_geom* g) {
     WgradPlan pl;
     const int T = g->R * g->S;
     const int M = g->N * g->Ho * g->Wo;
+    // fused nine-tap kernel: measured 117-130 TFLOP/s on conv1_2..conv4_3 against 92-123 for one tap per block;
+    // below ~30 pixels per side the 4x8 patch grid wastes >= 25 % of the MFMAs (19x19 -> 5x3 patches) and the
+    // 128-wide kernel is as fast, so small maps keep the old path unless forced.
+    pl.fused = g->R == 3 && g->S == 3 && g->stride == 1 && g->dil == 1 && g->pad == 1 && g_force_fused != 0 &&
+               (g_force_fused == 1 || (g->Ho >= 30 && g->Wo >= 30));
+    if (pl.fused) {
+        pl.bt = 64; pl.nbuf = 1;
+        pl.tiles_co = ssd_cdiv(g->Co, 64);
+        pl.tiles_ci = ssd_cdiv(g->Ci, 64);
+        const int npatch = g->N * ssd_cdiv(g->Ho, PH) * ssd_cdiv(g->Wo, PW);
+        const int per_split = pl.tiles_co * pl.tiles_ci;
+        const int bpc = g_force_blocks_per_cu > 0 ? g_force_blocks_per_cu : 2;       // exactly the 2 resident blocks per CU: no tail round
+        int ns = ssd_cdiv(256 * bpc, per_split);
+        const int max_by_m = npatch / 4 > 0 ? npatch / 4 : 1;                        // at least 4 patches per block
+        if (ns > max_by_m) ns = max_by_m;
+        if (ns > 1024) ns = 1024;
+        if (ns < 1) ns = 1;
+        pl.m_per_split = ssd_cdiv(npatch, ns);                                       // patches per split
+        pl.nsplit = ssd_cdiv(npatch, pl.m_per_split);
+        pl.slab_floats = (size_t)pl.nsplit * g->Co * T * g->Ci;
+        pl.bias_floats = (size_t)pl.nsplit * g->Co;
+        return pl;
+    }
     // 128x128 tiles when both channel counts fill them; 64x64 otherwise (also for Co = 150, where
     // two 128-row tiles would be 41 % padding against 22 % with three 64-row tiles)
     pl.bt = (g->Co > 64 && g->Ci > 64) ? 128 : 64;
@@ -321,7 +490,9 @@ extern "C" int ssd_conv2d_wgrad(const float* x, const float* dy, int ldy, float*
     p.tiles_co = pl.tiles_co; p.tiles_ci = pl.tiles_ci;
     const int T = g->R * g->S;
     const int nblk = T * pl.tiles_co * pl.tiles_ci * pl.nsplit;
-    if (pl.bt == 128) {
+    if (pl.fused) {
+        hipLaunchKernelGGL(wgrad3x3_kernel, dim3(pl.tiles_co * pl.tiles_ci * pl.nsplit), dim3(256), 0, st, p);
+    } else if (pl.bt == 128) {
         if (pl.nbuf == 2) hipLaunchKernelGGL((wgrad_kernel<128, 2>), dim3(nblk), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((wgrad_kernel<128, 1>), dim3(nblk), dim3(256), 0, st, p);
     } else {
@@ -344,13 +515,14 @@ extern "C" int ssd_conv2d_wgrad(const float* x, const float* dy, int ldy, float*
 extern "C" int ssd_conv2d_wgrad_tile(const ssd_conv_geom* g, int* bt, int* nsplit) {
     if (!g || !bt || !nsplit) return SSD_ERR_NULL;
     const WgradPlan pl = plan_wgrad(g);
-    *bt = pl.bt;
+    *bt = pl.fused ? 3 : pl.bt;
     *nsplit = pl.nsplit;
     return SSD_OK;
 }
 
 // Tuning aid: force tile edge (64/128), LDS stage count (1/2) and split-K target in blocks per CU; -1 = automatic.
 extern "C" int ssd_tune_set_wgrad(int bt, int nbuf, int blocks_per_cu) {
+    g_force_fused = bt == 3 ? 1 : (bt == 64 || bt == 128 ? 0 : -1);       // bt = 3 selects the fused 3x3 kernel
     g_force_bt = bt;
     g_force_wnbuf = nbuf;
     g_force_blocks_per_cu = blocks_per_cu;

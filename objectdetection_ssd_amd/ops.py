@@ -56,7 +56,7 @@ def igemm_tile(g: ConvGeom, direction: int) -> str:
 def wgrad_tile(g: ConvGeom) -> str:
     bt, ns = C.c_int(0), C.c_int(0)
     check(_lib.load().ssd_conv2d_wgrad_tile(C.byref(g), C.byref(bt), C.byref(ns)), "wgrad_tile")
-    return f"wgrad_kernel<{bt.value}"
+    return "wgrad3x3_kernel" if bt.value == 3 else f"wgrad_kernel<{bt.value}"
 
 
 def conv_flops(g: ConvGeom) -> float:

@@ -263,7 +263,7 @@ def test_every_kernel_variant(case):
                 dx = ops.conv2d_dgrad(dy_d, wb, g)
                 _close(dx, _nhwc(x.grad), what=f"dgrad tile {tile} nbuf {nbuf} {case}")
         lib.ssd_tune_set_igemm(-1, -1)
-        for bt, nbuf in ((64, 1), (64, 2), (128, 1), (128, 2)):
+        for bt, nbuf in ((3, 1), (64, 1), (64, 2), (128, 1), (128, 2)):
             for bpc in (-1, 1, 40):
                 lib.ssd_tune_set_wgrad(bt, nbuf, bpc)
                 dw, db = ops.conv2d_wgrad(x_d, dy_d, g, ld, True)

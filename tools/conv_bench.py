@@ -28,7 +28,7 @@ def main():
     ig_var = [(-1, -1, "auto"), (1, 2, "128x128/2"), (1, 1, "128x128/1"), (0, 1, "256x64/1"), (0, 2, "256x64/2"),
               (2, 2, "128x64/2"), (2, 1, "128x64/1"), (3, 2, "64x64/2"), (3, 1, "64x64/1")]
     wg_var = [(-1, -1, -1, "auto"), (128, 1, 9, "128/1/9"), (64, 1, 18, "64/1/18"),
-              (64, 1, 12, "64/1/12"), (128, 1, 6, "128/1/6")]
+              (3, 1, 1, "f3/1"), (3, 1, 2, "f3/2"), (3, 1, 3, "f3/3")]
     if vonly:
         ig_var = [v for v in ig_var if v[2] in vonly]
         wg_var = [v for v in wg_var if v[3] in vonly]
