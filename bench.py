@@ -181,9 +181,16 @@ def main():
             eng.prof = None
         tag, (tsum, fsum, n) = max(agg.items(), key=lambda kv: kv[1][0])
         ach = fsum / tsum / 1e12
+        traffic = None            # HBM bytes per launch from the committed PMC passes (cannot be collected live)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if tj["kernel"] == tag:
+                traffic = tj["bytes_per_launch"]
+        except Exception:
+            pass
         out["roofline"] = {"bound": "mfma", "kernel": tag + ", ...>", "achieved": round(ach, 2),
                            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                           "traffic": None, "launches_timed": n, "avg_launch_ms": round(tsum / n * 1e3, 4),
+                           "traffic": traffic, "traffic_unit": "bytes per launch (profiles/r01_traffic.json)", "launches_timed": n, "avg_launch_ms": round(tsum / n * 1e3, 4),
                            "avg_launch_gflop": round(fsum / n / 1e9, 3),
                            "all_conv_kernels_tflops": round(sum(a[1] for a in agg.values()) / sum(a[0] for a in agg.values()) / 1e12, 2),
                            "by_kernel": {k: {"ms_per_step": round(a[0] / 3 * 1e3, 3), "tflops": round(a[1] / a[0] / 1e12, 2),
