@@ -370,13 +370,20 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const WgradParams p) {
     }
 }
 
-// out_oihw[co][ci][t] = sum_split slab[split][co][t][ci]
+// out_oihw[co][ci][t] = sum_split slab[split][co][t][ci].  The split loop is unrolled into eight independent
+// partial sums (loads in flight instead of one dependent load per ~1 us); the association order is fixed, so
+// the result stays bitwise reproducible.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Co, int Ci, int T,
                                     int nsplit) {
     const size_t total = (size_t)Co * T * Ci;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * total + i];
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 8 <= nsplit; k += 8)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += slab[(size_t)(k + u) * total + i];
+        for (int u = 0; k < nsplit; ++k, ++u) a[u] += slab[(size_t)k * total + i];
+        const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
         const int ci = (int)(i % Ci);
         const size_t rest = i / Ci;
         const int t = (int)(rest % T), co = (int)(rest / T);
@@ -384,13 +391,14 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
     }
 }
 
-__global__ void bias_reduce_kernel(const float* __restrict__ slab, float* __restrict__ db, int Co, int nsplit) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < Co) {
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * Co + i];
-        db[i] = s;
-    }
+// db[co] = sum_split slab[split][co]: one wave per channel, lanes stride over the splits, fixed shuffle tree
+__global__ __launch_bounds__(256) void bias_reduce_kernel(const float* __restrict__ slab, float* __restrict__ db, int Co, int nsplit) {
+    const int co = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (co >= Co) return;
+    float s = 0.f;
+    for (int k = lane; k < nsplit; k += 64) s += slab[(size_t)k * Co + co];
+    s = wave_sum(s);
+    if (lane == 0) db[co] = s;
 }
 
 int g_force_bt = -1, g_force_wnbuf = -1, g_force_blocks_per_cu = -1;   // tuning aid (ssd_tune_set_wgrad)
@@ -505,7 +513,7 @@ extern "C" int ssd_conv2d_wgrad(const float* x, const float* dy, int ldy, float*
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, p.slab, dw_oihw, g->Co, g->Ci, T, pl.nsplit);
     SSD_CHECK_LAUNCH();
     if (dbias) {
-        hipLaunchKernelGGL(bias_reduce_kernel, dim3(ssd_cdiv(g->Co, 256)), dim3(256), 0, st, p.bias_slab, dbias, g->Co,
+        hipLaunchKernelGGL(bias_reduce_kernel, dim3(ssd_cdiv(g->Co, 4)), dim3(256), 0, st, p.bias_slab, dbias, g->Co,
                            pl.nsplit);
         SSD_CHECK_LAUNCH();
     }

@@ -275,3 +275,100 @@ def test_full_batch_properties():
     Losses.ssd((loc[7:8].contiguous(), conf[7:8].contiguous()), cl[7:8], bx[7:8])
     assert torch.equal(Losses.last_match["cls"][0], cls_all[7])
     assert torch.isfinite(l[0]) and torch.isfinite(l[1])
+
+
+def _sgd_groups(named):
+    """train.py:44-55: biases at 2x lr, everything else at lr; momentum .9, weight decay 5e-4"""
+    named = list(named)
+    biases = [p for n, p in named if p.requires_grad and n.endswith(".bias")]
+    others = [p for n, p in named if p.requires_grad and not n.endswith(".bias")]
+    return biases, others
+
+
+def test_training_loop_as_train_function_vs_cpu_oracle(gold_dir):
+    """The caller's loop (train_function.py:59-95: zero_grad, cnn(inputs), ssd(...), loss1+loss2, .item(),
+    backward, optimizer.step with train.py's SGD groups) for three iterations on the GPU path against the same
+    loop on the CPU oracle: the loss trajectory must agree step by step."""
+    from objectdetection_ssd_amd import Losses, Model
+    lr = 1e-4                                   # train.py:53
+    bs = 2
+    x = np.random.default_rng(31).standard_normal((bs, 3, 300, 300), dtype=np.float32)
+    boxes, classes = synth_gt(np.random.default_rng(32), bs)
+    params = O.ssd300_random_params(5)
+    # CPU oracle loop
+    P = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    b_cpu, o_cpu = _sgd_groups(P.items())
+    opt_cpu = torch.optim.SGD([{"params": b_cpu, "lr": 2 * lr}, {"params": o_cpu}], lr=lr, momentum=0.9, weight_decay=5e-4)
+    ref = []
+    for _ in range(3):
+        opt_cpu.zero_grad()
+        loc, conf = O.ssd300_forward(torch.from_numpy(x), P)
+        l1, l2 = O.multibox_loss_torch(loc, conf, [torch.from_numpy(b) for b in boxes], [torch.from_numpy(c) for c in classes])
+        (l1 + l2).backward()
+        opt_cpu.step()
+        ref.append((l1.item(), l2.item()))
+    # GPU path, written like the reference's caller
+    cnn = Model.SSD_300()
+    _load_params(cnn, params)
+    cnn = cnn.to(DEV)
+    biases, not_biases = _sgd_groups(cnn.named_parameters())
+    assert len(biases) == 38
+    optimizer = torch.optim.SGD(params=[{"params": biases, "lr": 2 * lr}, {"params": not_biases}], lr=lr, momentum=0.9, weight_decay=5e-4)
+    inputs = _t(x)
+    cl = [_t(c) for c in classes]
+    bx = [_t(b) for b in boxes]
+    cnn.train()
+    got = []
+    for _ in range(3):
+        optimizer.zero_grad()
+        with torch.set_grad_enabled(True):
+            outputs = cnn(inputs)
+            loss1, loss2 = Losses.ssd(outputs, cl, bx)
+            loss = loss1 + loss2
+            got.append((loss1.item(), loss2.item()))
+            loss.backward()
+            optimizer.step()
+    for (a1, a2), (b1, b2) in zip(got, ref):
+        assert abs(a1 - b1) <= 2e-4 * max(1, abs(b1)), (got, ref)
+        assert abs(a2 - b2) <= 2e-4 * max(1, abs(b2)), (got, ref)
+    assert len(not_biases) == 39          # 77 named parameters - 38 biases (incl. the dead VGG classifier)
+    assert got[2][0] + got[2][1] < got[0][0] + got[0][1]            # it trains
+    # eval / no_grad path gives the same outputs as the autograd path
+    cnn.eval()
+    with torch.no_grad():
+        l_e, c_e = cnn(inputs)
+    cnn.train()
+    l_t, c_t = cnn(inputs)
+    assert torch.equal(l_e, l_t.detach()) and torch.equal(c_e, c_t.detach())
+
+
+def test_flat_sgd_data_parallel_step_equals_torch_sgd():
+    """ddp.FlatSGDDataParallel (un-normalised sums, flat buffers, fused SGD * 1/n_pos) == reference normalisation +
+    torch.optim.SGD with train.py's groups, for three steps at world size 1."""
+    from objectdetection_ssd_amd import Losses, Model
+    from objectdetection_ssd_amd.ddp import FlatSGDDataParallel
+    lr, bs = 1e-4, 2
+    x = _t(np.random.default_rng(41).standard_normal((bs, 3, 300, 300), dtype=np.float32))
+    boxes, classes = synth_gt(np.random.default_rng(42), bs)
+    cl = [_t(c) for c in classes]
+    bx = [_t(b) for b in boxes]
+    params = O.ssd300_random_params(6)
+    a = Model.SSD_300(); _load_params(a, params); a = a.to(DEV).train()
+    b = Model.SSD_300(); _load_params(b, params); b = b.to(DEV).train()
+    biases, others = _sgd_groups(a.named_parameters())
+    opt = torch.optim.SGD([{"params": biases, "lr": 2 * lr}, {"params": others}], lr=lr, momentum=0.9, weight_decay=5e-4)
+    dp = FlatSGDDataParallel(b, lr=lr, momentum=0.9, weight_decay=5e-4)
+    for _ in range(3):
+        opt.zero_grad()
+        l1, l2 = Losses.ssd(a(x), cl, bx)
+        (l1 + l2).backward()
+        opt.step()
+        dp.zero_grad()
+        m1, m2 = Losses.ssd(b(x), cl, bx, norm_mode=1)
+        (m1 + m2).backward()
+        dp.reduce_and_step(Losses.last_match["n_pos"])
+    na, nb = dict(a.named_parameters()), dict(b.named_parameters())
+    for k in a._engine.names:
+        ref = na[k].detach()
+        err = float((nb[k].detach() - ref).abs().max())
+        assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (k, err)
