@@ -309,6 +309,11 @@ def main():
         store["g_" + k] = names[k].grad.numpy().astype(np.float32)
     n_named = len(list(net.named_parameters()))
     store["ref_named_parameters"] = np.int64(n_named)
+    # checkpoint layout of the reference (train_function.py:114-120 saves cnn.state_dict()): key names + shapes
+    sd = net.state_dict()
+    store["state_dict_keys"] = np.asarray(list(sd.keys()))
+    store["state_dict_shapes"] = np.asarray([",".join(str(d) for d in v.shape) for v in sd.values()])
+    store["named_parameter_keys"] = np.asarray([n for n, _ in net.named_parameters()])
     np.savez_compressed(os.path.join(GOLD, "network.npz"), **store)
     print("golden fixtures written to", GOLD)
     for f in sorted(os.listdir(GOLD)):

@@ -119,3 +119,26 @@ def test_dropin_module_names():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_state_dict_layout_equals_reference_checkpoint_layout(gold_dir, tmp_path):
+    """(f)-2: `cnn.state_dict()` written by train_function.py:114-120 / read by :25-27 -- same 107 keys, same
+    shapes, same order as the reference model's; save/load round trip keeps the aliases tied."""
+    from objectdetection_ssd_amd import Model
+    z = np.load(os.path.join(gold_dir, "network.npz"))
+    ref_keys = [str(k) for k in z["state_dict_keys"]]
+    ref_shapes = [tuple(int(d) for d in s.split(",")) if s else () for s in z["state_dict_shapes"]]
+    net = Model.SSD_300()
+    sd = net.state_dict()
+    assert list(sd.keys()) == ref_keys and len(ref_keys) == 107
+    assert [tuple(v.shape) for v in sd.values()] == ref_shapes
+    assert [n for n, _ in net.named_parameters()] == [str(k) for k in z["named_parameter_keys"]]
+    path = tmp_path / "ckpt.pt"
+    torch.save({"epoch": 3, "cnn_state_dict": sd}, path)               # the reference's checkpoint dict shape
+    other = Model.SSD_300()
+    ck = torch.load(path, weights_only=True)
+    other.load_state_dict(ck["cnn_state_dict"])                         # strict: every key present
+    assert torch.equal(other.conv_4_3[0].weight, net.model.features[0].weight)
+    assert other.conv_4_3[0].weight is other.model.features[0].weight   # aliases still share storage
+    assert other.seq7[0].weight is other.conv_fc6.weight
+    assert torch.equal(other.c_11_cl.bias, net.c_11_cl.bias)
