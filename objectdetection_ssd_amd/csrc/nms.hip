@@ -7,11 +7,11 @@
 //                      prob, lower prior index first on ties (the CPU sort order)
 //   D3 rank_scatter    rank of every candidate = number of larger keys (keys are unique), so
 //                      the sort is a scatter; all classes and candidates in parallel
-//   D4 nms             block per class, greedy in sorted order: a kept box marks every later
-//                      box with IoU >= threshold; suppression flags live in LDS
-//   D5 offsets         class-major offsets of the kept boxes
-//   D6 emit            if more than top_k survive, rank by prob (stable on the class-major
-//                      position) and keep ranks < top_k; scale boxes by (w,h,w,h)
+//   D4 nms             block per class, greedy in sorted order, 64 rows at a time: suppression words by
+//                      wave ballot, in-chunk resolve by v_readlane, removed bitset in LDS
+//   D5 offsets/gather  class-major offsets and compact list of the kept boxes
+//   D6 topk_emit       if more than top_k survive: radix select of the top_k-th probability, ties in
+//                      class-major order, rank of the selected entries in LDS; scale boxes by (w,h,w,h)
 // IoU uses the same contraction-free f32 sequence as the matcher.
 #include "common.h"
 #pragma clang fp contract(off)
@@ -41,6 +41,8 @@ struct NmsWs {
     int32_t* kept_pos;   // [C-1][P] sorted positions of kept boxes, in order
     int32_t* kept_cnt;   // [C-1]
     int32_t* offsets;    // [C] class-major exclusive offsets, [C-1] = total
+    uint32_t* k_prob;    // [(C-1)*P] prob bits of the kept boxes, class-major
+    int32_t* k_src;      // [(C-1)*P] index into the sorted arrays (c*P + pos)
     size_t bytes;
 };
 
@@ -60,6 +62,8 @@ NmsWs carve(void* ws, int P, int C) {
     w.kept_pos = reinterpret_cast<int32_t*>(b + o); o += up(K * 4);
     w.kept_cnt = reinterpret_cast<int32_t*>(b + o); o += up((size_t)C * 4);
     w.offsets = reinterpret_cast<int32_t*>(b + o); o += up((size_t)(C + 1) * 4);
+    w.k_prob = reinterpret_cast<uint32_t*>(b + o); o += up(K * 4);
+    w.k_src = reinterpret_cast<int32_t*>(b + o); o += up(K * 4);
     w.bytes = o;
     return w;
 }
@@ -130,33 +134,86 @@ __global__ __launch_bounds__(256) void rank_scatter_kernel(const uint64_t* __res
     }
 }
 
+// Greedy NMS of one class (block per class, 16 waves), boxes already sorted by descending probability.
+// Rows are taken CR (64 or 32) at a time:
+//   A  every wave builds suppression words with one ballot each: word (r,w) = lanes j = 64w..64w+63 with
+//      IoU(box[base+r], box[j]) >= thr and j > base+r (rows already removed are skipped);
+//   B  wave 0 resolves the CR rows against each other serially from the diagonal words held one per lane
+//      (v_readlane), giving the chunk's keep mask;
+//   C  the kept rows' words are OR-ed into the removed bitset of all later columns.
+// All state (removed bitset, CR x n/64 words) lives in LDS; no n x n matrix ever reaches memory.
 __global__ __launch_bounds__(NB_T) void nms_kernel(const float* __restrict__ s_boxes, const int32_t* __restrict__ cand_cnt, int P,
-                                                   float thr, int32_t* __restrict__ kept_pos, int32_t* __restrict__ kept_cnt) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t sup[];     // P flags
+                                                   float thr, int CR, int32_t* __restrict__ kept_pos, int32_t* __restrict__ kept_cnt) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t sm64[];
     __shared__ int wave_tot[NB_T / 64];
     __shared__ int running;
+    __shared__ uint64_t s_keep;
     const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = cand_cnt[c];
+    const int nw = (n + 63) >> 6, nwcap = (P + 63) >> 6;
+    uint64_t* removed = sm64;                 // [nwcap]
+    uint64_t* chunk = sm64 + nwcap;           // [CR][nw]
     const float* bx = s_boxes + (size_t)c * P * 4;
-    for (int j = tid; j < n; j += NB_T) sup[j] = 0;
+    for (int w = tid; w < nw; w += NB_T) removed[w] = 0;
     __syncthreads();
-    for (int i = 0; i < n; ++i) {
-        if (sup[i]) continue;                                   // uniform: every thread reads the same flag
-        const f32x4 a = *reinterpret_cast<const f32x4*>(bx + (size_t)i * 4);
-        for (int j = i + 1 + tid; j < n; j += NB_T) {
-            if (!sup[j]) {
+    for (int base = 0; base < n; base += CR) {
+        const int R = base >> 6, bit0 = base & 63;
+        const int span = nw - R;
+        // ---- A ------------------------------------------------------------------------------------------
+        const uint64_t rem_start = removed[R];
+        for (int item = wave; item < CR * span; item += NB_T / 64) {
+            const int r = item / span, w = R + item - r * span;
+            const int i = base + r;
+            if (i >= n || ((rem_start >> (bit0 + r)) & 1ull)) continue;          // uniform per wave
+            const int j = (w << 6) + lane;
+            bool hit = false;
+            if (j < n && j > i) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(bx + (size_t)i * 4);
                 const f32x4 b = *reinterpret_cast<const f32x4*>(bx + (size_t)j * 4);
-                if (iou_boxes(a, b) >= thr) sup[j] = 1;         // Losses.py:51 (NaN >= thr is false)
+                hit = iou_boxes(a, b) >= thr;                                    // Losses.py:51 (NaN >= thr is false)
+            }
+            const uint64_t m = __ballot(hit);
+            if (lane == 0) chunk[r * nw + w] = m;
+        }
+        __syncthreads();
+        // ---- B ------------------------------------------------------------------------------------------
+        if (wave == 0) {
+            const int i = base + lane;
+            const bool live = lane < CR && i < n && !((rem_start >> (bit0 + lane)) & 1ull);
+            const uint64_t d = live ? chunk[lane * nw + R] : 0ull;
+            const unsigned dlo = (unsigned)d, dhi = (unsigned)(d >> 32);
+            uint64_t rem = rem_start, keep = 0;
+            for (int r = 0; r < CR; ++r) {
+                if (base + r >= n) break;
+                const uint64_t row = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)dhi, r) << 32) |
+                                     (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)dlo, r);
+                if (!((rem >> (bit0 + r)) & 1ull)) {
+                    keep |= 1ull << r;
+                    rem |= row;
+                }
+            }
+            if (lane == 0) {
+                removed[R] = rem;
+                s_keep = keep;
             }
         }
         __syncthreads();
+        // ---- C ------------------------------------------------------------------------------------------
+        const uint64_t keep = s_keep;
+        for (int w = R + 1 + tid; w < nw; w += NB_T) {
+            uint64_t acc = 0;
+            for (int r = 0; r < CR; ++r)
+                if ((keep >> r) & 1ull) acc |= chunk[r * nw + w];
+            removed[w] |= acc;
+        }
+        __syncthreads();
     }
-    // ordered compaction of the survivors
+    // ---- ordered compaction of the survivors ------------------------------------------------------------------
     if (tid == 0) running = 0;
     __syncthreads();
     for (int j0 = 0; j0 < n; j0 += NB_T) {
         const int j = j0 + tid;
-        const int keep = (j < n && !sup[j]) ? 1 : 0;
+        const int keep = (j < n && !((removed[j >> 6] >> (j & 63)) & 1ull)) ? 1 : 0;
         int incl = keep;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -187,48 +244,119 @@ __global__ void offsets_kernel(const int32_t* __restrict__ kept_cnt, int C1, int
     }
 }
 
-struct EmitArgs {
-    const float* s_boxes; const float* s_prob; const int32_t* s_idx; const int32_t* kept_pos; const int32_t* kept_cnt;
-    const int32_t* offsets; int P, C1, top_k; float w, h;
+// class-major compact list of the survivors: k_prob[offsets[c] + i], k_src = c*P + sorted position
+__global__ __launch_bounds__(256) void gather_kept_kernel(const float* __restrict__ s_prob, const int32_t* __restrict__ kept_pos,
+                                                          const int32_t* __restrict__ kept_cnt, const int32_t* __restrict__ offsets,
+                                                          int P, uint32_t* __restrict__ k_prob, int32_t* __restrict__ k_src) {
+    const int c = blockIdx.y;
+    const int n = kept_cnt[c];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int src = c * P + kept_pos[(size_t)c * P + i];
+    k_prob[offsets[c] + i] = __float_as_uint(s_prob[src]);
+    k_src[offsets[c] + i] = src;
+}
+
+struct TopkArgs {
+    const float* s_boxes; const int32_t* s_idx; const uint32_t* k_prob; const int32_t* k_src; const int32_t* offsets;
+    int P, C1, top_k; float w, h;
     float* boxes; int64_t* classes; float* probs; int32_t* prior_ids; int32_t* count;
 };
 
-// thread per (class, kept slot).  Output slot = class-major position when everything fits, else the
-// rank by (prob desc, class-major position asc); only ranks < top_k are written.
-__global__ __launch_bounds__(256) void emit_kernel(const EmitArgs a) {
-    const int c = blockIdx.y;
-    const int n = a.kept_cnt[c];
+// One block.  total <= top_k: everything is emitted in class-major order (Losses.py:71-73).  Otherwise
+// (Losses.py:77-81) the top_k-th largest probability is found by radix select on the float bits (probabilities
+// are positive), ties at the threshold are taken in class-major order, and the <= top_k selected entries are
+// ranked among themselves (prob descending, class-major position ascending) in LDS.
+__global__ __launch_bounds__(NB_T) void topk_emit_kernel(const TopkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* sel_prob = reinterpret_cast<uint32_t*>(smem);                 // [top_k]
+    int32_t* sel_pos = reinterpret_cast<int32_t*>(smem) + a.top_k;          // [top_k]
+    __shared__ int hist[256];
+    __shared__ int wsum_gt[NB_T / 64], wsum_eq[NB_T / 64];
+    __shared__ int bc[3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int total = a.offsets[a.C1];
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.count = total > a.top_k ? a.top_k : total;
-    if (blockIdx.x * 256 >= n) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int pos = a.kept_pos[(size_t)c * a.P + i];
-    const size_t src = (size_t)c * a.P + pos;
-    const float pr = a.s_prob[src];
-    const int gpos = a.offsets[c] + i;
-    int slot = gpos;
-    if (total > a.top_k) {
-        const uint32_t mine = __float_as_uint(pr);
-        int rank = 0;
-        for (int c2 = 0; c2 < a.C1; ++c2) {
-            const int n2 = a.kept_cnt[c2];
-            const int base = a.offsets[c2];
-            for (int j = 0; j < n2; ++j) {
-                const uint32_t o = __float_as_uint(a.s_prob[(size_t)c2 * a.P + a.kept_pos[(size_t)c2 * a.P + j]]);
-                rank += (o > mine) || (o == mine && base + j < gpos);
-            }
-        }
-        slot = rank;
-    }
-    if (slot < a.top_k) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(a.s_boxes + src * 4);
+    auto emit = [&](int gpos, int slot) {
+        const int src = a.k_src[gpos];
+        const f32x4 b = *reinterpret_cast<const f32x4*>(a.s_boxes + (size_t)src * 4);
         f32x4 o;
         o[0] = b[0] * a.w; o[1] = b[1] * a.h; o[2] = b[2] * a.w; o[3] = b[3] * a.h;    // Losses.py:89
         *reinterpret_cast<f32x4*>(a.boxes + (size_t)slot * 4) = o;
-        a.classes[slot] = c;
-        a.probs[slot] = pr;
+        a.classes[slot] = src / a.P;
+        a.probs[slot] = __uint_as_float(a.k_prob[gpos]);
         a.prior_ids[slot] = a.s_idx[src];
+    };
+    if (tid == 0) *a.count = total > a.top_k ? a.top_k : total;
+    if (total <= a.top_k) {
+        for (int g = tid; g < total; g += NB_T) emit(g, g);
+        return;
+    }
+    // ---- radix select of the top_k-th largest value --------------------------------------------------
+    uint32_t prefix = 0, mask = 0;
+    int remaining = a.top_k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int b = tid; b < 256; b += NB_T) hist[b] = 0;
+        __syncthreads();
+        for (int g = tid; g < total; g += NB_T) {
+            const uint32_t u = a.k_prob[g];
+            if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int rem = remaining, d = 255;
+            for (; d > 0; --d) {
+                if (hist[d] >= rem) break;
+                rem -= hist[d];
+            }
+            bc[0] = d;
+            bc[1] = rem;
+        }
+        __syncthreads();
+        prefix |= (uint32_t)bc[0] << shift;
+        mask |= 255u << shift;
+        remaining = bc[1];
+        __syncthreads();
+    }
+    const uint32_t T = prefix;            // take everything > T and the first `remaining` entries == T
+    // ---- ordered selection: thread t owns the contiguous slice [t*CH, (t+1)*CH) ----------------------------
+    const int CH = (total + NB_T - 1) / NB_T;
+    const int g0 = tid * CH, g1 = min(total, g0 + CH);
+    int n_gt = 0, n_eq = 0;
+    for (int g = g0; g < g1; ++g) {
+        const uint32_t u = a.k_prob[g];
+        n_gt += u > T;
+        n_eq += u == T;
+    }
+    int i_gt = n_gt, i_eq = n_eq;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t1 = __shfl_up(i_gt, o, 64), t2 = __shfl_up(i_eq, o, 64);
+        if (lane >= o) { i_gt += t1; i_eq += t2; }
+    }
+    if (lane == 63) { wsum_gt[wave] = i_gt; wsum_eq[wave] = i_eq; }
+    __syncthreads();
+    int off_gt = 0, off_eq = 0, all_gt = 0;
+    for (int w2 = 0; w2 < NB_T / 64; ++w2) {
+        if (w2 < wave) { off_gt += wsum_gt[w2]; off_eq += wsum_eq[w2]; }
+        all_gt += wsum_gt[w2];
+    }
+    int r_gt = off_gt + i_gt - n_gt;      // entries > T before this slice
+    int r_eq = off_eq + i_eq - n_eq;      // entries == T before this slice
+    for (int g = g0; g < g1; ++g) {
+        const uint32_t u = a.k_prob[g];
+        int idx = -1;
+        if (u > T) idx = r_gt++;
+        else if (u == T) { if (r_eq < remaining) idx = all_gt + r_eq; ++r_eq; }
+        if (idx >= 0) { sel_prob[idx] = u; sel_pos[idx] = g; }      // exactly top_k entries in all
+    }
+    __syncthreads();
+    // ---- rank inside the selection ------------------------------------------------------------------------
+    for (int e = tid; e < a.top_k; e += NB_T) {
+        const uint32_t u = sel_prob[e];
+        const int g = sel_pos[e];
+        int rank = 0;
+        for (int f = 0; f < a.top_k; ++f) rank += (sel_prob[f] > u) || (sel_prob[f] == u && sel_pos[f] < g);
+        emit(g, rank);
     }
 }
 
@@ -244,7 +372,7 @@ extern "C" int ssd_decode_nms(const float* l_, const float* c_, const float* pri
                               int64_t* classes, float* probs, int32_t* prior_ids, int32_t* count, void* workspace,
                               size_t workspace_bytes, void* stream) {
     if (!l_ || !c_ || !priors_cxcywh || !boxes || !classes || !probs || !prior_ids || !count || !workspace) return SSD_ERR_NULL;
-    if (P <= 0 || P > 100000 || n_classes < 2 || n_classes > 256 || top_k <= 0) return SSD_ERR_BAD_SHAPE;
+    if (P <= 0 || P > 100000 || n_classes < 2 || n_classes > 256 || top_k <= 0 || top_k > 4096) return SSD_ERR_BAD_SHAPE;
     if (!ssd_aligned16(l_) || !ssd_aligned16(priors_cxcywh) || !ssd_aligned16(boxes) || !ssd_aligned16(workspace)) return SSD_ERR_ALIGN;
     if (workspace_bytes < ssd_decode_nms_workspace(P, n_classes)) return SSD_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -256,7 +384,11 @@ extern "C" int ssd_decode_nms(const float* l_, const float* c_, const float* pri
     SSD_CHECK_LAUNCH();
     hipLaunchKernelGGL(rank_scatter_kernel, dim3(ssd_cdiv(P, 256), C1), dim3(256), 0, st, w.keys, w.cand_cnt, w.boxes, P, w.s_boxes, w.s_prob, w.s_idx);
     SSD_CHECK_LAUNCH();
-    const size_t lds = ((size_t)P + 15) / 16 * 16;
+    const int nwcap = (P + 63) / 64;
+    int CR = 64;
+    size_t lds = (size_t)(1 + CR) * nwcap * 8;
+    if (lds > 140 * 1024) { CR = 32; lds = (size_t)(1 + CR) * nwcap * 8; }
+    if (lds > 140 * 1024) return SSD_ERR_BAD_SHAPE;
     if (lds > 48 * 1024) {
         static bool raised = false;
         if (!raised) {
@@ -265,13 +397,15 @@ extern "C" int ssd_decode_nms(const float* l_, const float* c_, const float* pri
             raised = true;
         }
     }
-    hipLaunchKernelGGL(nms_kernel, dim3(C1), dim3(NB_T), lds, st, w.s_boxes, w.cand_cnt, P, iou_threshold, w.kept_pos, w.kept_cnt);
+    hipLaunchKernelGGL(nms_kernel, dim3(C1), dim3(NB_T), lds, st, w.s_boxes, w.cand_cnt, P, iou_threshold, CR, w.kept_pos, w.kept_cnt);
     SSD_CHECK_LAUNCH();
     hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(64), 0, st, w.kept_cnt, C1, w.offsets);
     SSD_CHECK_LAUNCH();
-    EmitArgs ea{w.s_boxes, w.s_prob, w.s_idx, w.kept_pos, w.kept_cnt, w.offsets, P, C1, top_k, img_w, img_h,
-                boxes, classes, probs, prior_ids, count};
-    hipLaunchKernelGGL(emit_kernel, dim3(ssd_cdiv(P, 256), C1), dim3(256), 0, st, ea);
+    hipLaunchKernelGGL(gather_kept_kernel, dim3(ssd_cdiv(P, 256), C1), dim3(256), 0, st, w.s_prob, w.kept_pos, w.kept_cnt, w.offsets, P,
+                       w.k_prob, w.k_src);
+    SSD_CHECK_LAUNCH();
+    TopkArgs ta{w.s_boxes, w.s_idx, w.k_prob, w.k_src, w.offsets, P, C1, top_k, img_w, img_h, boxes, classes, probs, prior_ids, count};
+    hipLaunchKernelGGL(topk_emit_kernel, dim3(1), dim3(NB_T), (size_t)top_k * 8, st, ta);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
 }

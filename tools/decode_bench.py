@@ -1,0 +1,26 @@
+"""decode + NMS latency (l_ ~ 0.5*randn, c_ ~ 3*randn, one image)"""
+import os, sys, time, torch, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from objectdetection_ssd_amd import Losses, ops
+dev = torch.device("cuda")
+pri, _ = Losses._priors_on(dev)
+for scale in (1.0, 2.0, 3.0, 4.0):
+    g = torch.Generator().manual_seed(1)
+    l_ = (torch.randn(8732, 4, generator=g) * 0.5).to(dev)
+    c_ = (torch.randn(8732, 21, generator=g) * scale).to(dev)
+    for _ in range(3):
+        out = ops.decode_nms(l_, c_, pri, 500, 375)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+    e0.record()
+    for _ in range(20):
+        out = ops.decode_nms(l_, c_, pri, 500, 375)
+    e1.record(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        b = Losses.inference(l_, c_, (500, 375), toDraw=False)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / 20
+    p = torch.softmax(c_, 1)[:, :20]
+    print(f"scale {scale}: candidates {(p >= 0.2).sum().item():6d}  kept {int(out[4].item()):4d}  gpu {e0.elapsed_time(e1) / 20 * 1e3:8.1f} us  inference() wall {wall * 1e6:8.1f} us", flush=True)
