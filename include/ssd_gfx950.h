@@ -141,6 +141,13 @@ int ssd_decode_nms(const float* l_, const float* c_, const float* priors_cxcywh,
                    float* boxes, int64_t* classes, float* probs, int32_t* prior_ids, int32_t* count,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* Batched form: l_ (B,P,4), c_ (B,P,n_classes), img_wh (B,2) DEVICE floats
+ * (img_w, img_h per image); outputs (B,top_k,...) and count (B).  One launch set for the whole batch. */
+size_t ssd_decode_nms_batch_workspace(int B, int P, int n_classes);
+int ssd_decode_nms_batch(const float* l_, const float* c_, const float* priors_cxcywh, const float* img_wh, int B, int P,
+                         int n_classes, float min_score, float iou_threshold, int top_k, float* boxes, int64_t* classes,
+                         float* probs, int32_t* prior_ids, int32_t* count, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- fused SGD (train.py:53-55: momentum .9, weight decay 5e-4; bias lr 2x) on a flat buffer;
  * grad_scale multiplies the gradient first (1/n_pos_global in data-parallel runs). */
 int ssd_sgd_momentum(float* param, const float* grad, float* momentum_buf, size_t n, float lr, float momentum,

@@ -51,6 +51,8 @@ SIGNATURES = {
     "ssd_multibox_loss": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _F, _I, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "ssd_decode_nms_workspace": (_Z, [_I, _I]),
     "ssd_decode_nms": (_I, [_P, _P, _P, _I, _I, _F, _F, _I, _F, _F, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "ssd_decode_nms_batch_workspace": (_Z, [_I, _I, _I]),
+    "ssd_decode_nms_batch": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "ssd_sgd_momentum": (_I, [_P, _P, _P, _Z, _F, _F, _F, _P, _I, _P]),
 }
 

@@ -46,22 +46,22 @@ struct NmsWs {
     size_t bytes;
 };
 
-NmsWs carve(void* ws, int P, int C) {
+NmsWs carve(void* ws, int P, int C, int B) {
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     char* b = reinterpret_cast<char*>(ws);
     size_t o = 0;
-    const size_t K = (size_t)(C - 1) * P;
+    const size_t K = (size_t)(C - 1) * P * B;
     NmsWs w;
-    w.boxes = reinterpret_cast<float*>(b + o); o += up((size_t)P * 16);
+    w.boxes = reinterpret_cast<float*>(b + o); o += up((size_t)P * 16 * B);
     w.probs_t = reinterpret_cast<float*>(b + o); o += up(K * 4);
     w.keys = reinterpret_cast<uint64_t*>(b + o); o += up(K * 8);
-    w.cand_cnt = reinterpret_cast<int32_t*>(b + o); o += up((size_t)C * 4);
+    w.cand_cnt = reinterpret_cast<int32_t*>(b + o); o += up((size_t)C * 4 * B);
     w.s_boxes = reinterpret_cast<float*>(b + o); o += up(K * 16);
     w.s_prob = reinterpret_cast<float*>(b + o); o += up(K * 4);
     w.s_idx = reinterpret_cast<int32_t*>(b + o); o += up(K * 4);
     w.kept_pos = reinterpret_cast<int32_t*>(b + o); o += up(K * 4);
-    w.kept_cnt = reinterpret_cast<int32_t*>(b + o); o += up((size_t)C * 4);
-    w.offsets = reinterpret_cast<int32_t*>(b + o); o += up((size_t)(C + 1) * 4);
+    w.kept_cnt = reinterpret_cast<int32_t*>(b + o); o += up((size_t)C * 4 * B);
+    w.offsets = reinterpret_cast<int32_t*>(b + o); o += up((size_t)(C + 1) * 4 * B);
     w.k_prob = reinterpret_cast<uint32_t*>(b + o); o += up(K * 4);
     w.k_src = reinterpret_cast<int32_t*>(b + o); o += up(K * 4);
     w.bytes = o;
@@ -72,6 +72,8 @@ __global__ void decode_softmax_kernel(const float* __restrict__ l_, const float*
                                       int P, int C, float* __restrict__ boxes, float* __restrict__ probs_t) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
+    const size_t img = blockIdx.z;                                  // one image per grid.z slice
+    l_ += img * P * 4; c_ += img * P * C; boxes += img * P * 4; probs_t += img * (size_t)(C - 1) * P;
     const f32x4 g = *reinterpret_cast<const f32x4*>(l_ + (size_t)p * 4);
     const f32x4 pr = *reinterpret_cast<const f32x4*>(pri + (size_t)p * 4);
     // Util.py:89-91: g_c * p_wh / 10 + p_c ; exp(g_wh / 5) * p_wh
@@ -93,6 +95,8 @@ __global__ __launch_bounds__(NB_T) void compact_kernel(const float* __restrict__
                                                        uint64_t* __restrict__ keys, int32_t* __restrict__ cand_cnt) {
     __shared__ int cnt;
     const int c = blockIdx.x;
+    const size_t img = blockIdx.z, C1 = gridDim.x;
+    probs_t += img * C1 * P; keys += img * C1 * P; cand_cnt += img * (C1 + 1);
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
     for (int p = threadIdx.x; p < P; p += NB_T) {
@@ -111,6 +115,9 @@ __global__ __launch_bounds__(256) void rank_scatter_kernel(const uint64_t* __res
                                                            float* __restrict__ s_prob, int32_t* __restrict__ s_idx) {
     __shared__ uint64_t tile[256];
     const int c = blockIdx.y;
+    const size_t img = blockIdx.z, C1 = gridDim.y;
+    keys += img * C1 * P; cand_cnt += img * (C1 + 1); boxes += img * P * 4;
+    s_boxes += img * C1 * P * 4; s_prob += img * C1 * P; s_idx += img * C1 * P;
     const int n = cand_cnt[c];
     if (blockIdx.x * 256 >= n) return;                          // uniform per block
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -136,8 +143,8 @@ __global__ __launch_bounds__(256) void rank_scatter_kernel(const uint64_t* __res
 
 // Greedy NMS of one class (block per class, 16 waves), boxes already sorted by descending probability.
 // Rows are taken CR (64 or 32) at a time:
-//   A  every wave builds suppression words with one ballot each: word (r,w) = lanes j = 64w..64w+63 with
-//      IoU(box[base+r], box[j]) >= thr and j > base+r (rows already removed are skipped);
+//   A  suppression words by wave ballot: word (r,w) = lanes j = 64w..64w+63 with IoU(box[base+r], box[j]) >= thr
+//      and j > base+r (rows already removed are skipped); column boxes are loaded once per (chunk, word);
 //   B  wave 0 resolves the CR rows against each other serially from the diagonal words held one per lane
 //      (v_readlane), giving the chunk's keep mask;
 //   C  the kept rows' words are OR-ed into the removed bitset of all later columns.
@@ -148,7 +155,10 @@ __global__ __launch_bounds__(NB_T) void nms_kernel(const float* __restrict__ s_b
     __shared__ int wave_tot[NB_T / 64];
     __shared__ int running;
     __shared__ uint64_t s_keep;
+    __shared__ __attribute__((aligned(16))) float rowbox[64 * 4];
     const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t img = blockIdx.z, C1 = gridDim.x;
+    s_boxes += img * C1 * P * 4; cand_cnt += img * (C1 + 1); kept_pos += img * C1 * P; kept_cnt += img * (C1 + 1);
     const int n = cand_cnt[c];
     const int nw = (n + 63) >> 6, nwcap = (P + 63) >> 6;
     uint64_t* removed = sm64;                 // [nwcap]
@@ -160,20 +170,30 @@ __global__ __launch_bounds__(NB_T) void nms_kernel(const float* __restrict__ s_b
         const int R = base >> 6, bit0 = base & 63;
         const int span = nw - R;
         // ---- A ------------------------------------------------------------------------------------------
+        // the chunk's row boxes go to LDS once; a wave item = (column word w, group of CR/4 rows): every lane
+        // loads its column box once and tests it against the rows (LDS broadcast), one ballot per row
         const uint64_t rem_start = removed[R];
-        for (int item = wave; item < CR * span; item += NB_T / 64) {
-            const int r = item / span, w = R + item - r * span;
-            const int i = base + r;
-            if (i >= n || ((rem_start >> (bit0 + r)) & 1ull)) continue;          // uniform per wave
+        if (tid < CR) {
+            const int i = base + tid;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i < n) v = *reinterpret_cast<const f32x4*>(bx + (size_t)i * 4);
+            *reinterpret_cast<f32x4*>(rowbox + tid * 4) = v;
+        }
+        __syncthreads();
+        const int RG = CR >> 2;
+        for (int item = wave; item < 4 * span; item += NB_T / 64) {
+            const int w = R + (item >> 2), r0 = (item & 3) * RG;
             const int j = (w << 6) + lane;
-            bool hit = false;
-            if (j < n && j > i) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(bx + (size_t)i * 4);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(bx + (size_t)j * 4);
-                hit = iou_boxes(a, b) >= thr;                                    // Losses.py:51 (NaN >= thr is false)
+            f32x4 b = {0.f, 0.f, 0.f, 0.f};
+            if (j < n) b = *reinterpret_cast<const f32x4*>(bx + (size_t)j * 4);
+            for (int r = r0; r < r0 + RG; ++r) {
+                const int i = base + r;
+                if (i >= n || ((rem_start >> (bit0 + r)) & 1ull)) continue;      // uniform per wave
+                const f32x4 a = *reinterpret_cast<const f32x4*>(rowbox + r * 4);
+                const bool hit = j < n && j > i && iou_boxes(a, b) >= thr;       // Losses.py:51 (NaN >= thr is false)
+                const uint64_t m = __ballot(hit);
+                if (lane == 0) chunk[r * nw + w] = m;
             }
-            const uint64_t m = __ballot(hit);
-            if (lane == 0) chunk[r * nw + w] = m;
         }
         __syncthreads();
         // ---- B ------------------------------------------------------------------------------------------
@@ -237,6 +257,8 @@ __global__ __launch_bounds__(NB_T) void nms_kernel(const float* __restrict__ s_b
 }
 
 __global__ void offsets_kernel(const int32_t* __restrict__ kept_cnt, int C1, int32_t* __restrict__ offsets) {
+    kept_cnt += (size_t)blockIdx.z * (C1 + 1);
+    offsets += (size_t)blockIdx.z * (C1 + 2);
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         int o = 0;
         for (int c = 0; c < C1; ++c) { offsets[c] = o; o += kept_cnt[c]; }
@@ -249,6 +271,9 @@ __global__ __launch_bounds__(256) void gather_kept_kernel(const float* __restric
                                                           const int32_t* __restrict__ kept_cnt, const int32_t* __restrict__ offsets,
                                                           int P, uint32_t* __restrict__ k_prob, int32_t* __restrict__ k_src) {
     const int c = blockIdx.y;
+    const size_t img = blockIdx.z, C1 = gridDim.y;
+    s_prob += img * C1 * P; kept_pos += img * C1 * P; kept_cnt += img * (C1 + 1); offsets += img * (C1 + 2);
+    k_prob += img * C1 * P; k_src += img * C1 * P;
     const int n = kept_cnt[c];
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -259,7 +284,7 @@ __global__ __launch_bounds__(256) void gather_kept_kernel(const float* __restric
 
 struct TopkArgs {
     const float* s_boxes; const int32_t* s_idx; const uint32_t* k_prob; const int32_t* k_src; const int32_t* offsets;
-    int P, C1, top_k; float w, h;
+    int P, C1, top_k; const float* wh;          // wh: (B,2) device array of (img_w, img_h)
     float* boxes; int64_t* classes; float* probs; int32_t* prior_ids; int32_t* count;
 };
 
@@ -267,7 +292,14 @@ struct TopkArgs {
 // (Losses.py:77-81) the top_k-th largest probability is found by radix select on the float bits (probabilities
 // are positive), ties at the threshold are taken in class-major order, and the <= top_k selected entries are
 // ranked among themselves (prob descending, class-major position ascending) in LDS.
-__global__ __launch_bounds__(NB_T) void topk_emit_kernel(const TopkArgs a) {
+__global__ __launch_bounds__(NB_T) void topk_emit_kernel(TopkArgs a) {
+    {
+        const size_t img = blockIdx.z, K = (size_t)a.C1 * a.P;
+        a.s_boxes += img * K * 4; a.s_idx += img * K; a.k_prob += img * K; a.k_src += img * K; a.offsets += img * (a.C1 + 2);
+        a.wh += img * 2;
+        a.boxes += img * a.top_k * 4; a.classes += img * a.top_k; a.probs += img * a.top_k; a.prior_ids += img * a.top_k; a.count += img;
+    }
+    const float img_w = a.wh[0], img_h = a.wh[1];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* sel_prob = reinterpret_cast<uint32_t*>(smem);                 // [top_k]
     int32_t* sel_pos = reinterpret_cast<int32_t*>(smem) + a.top_k;          // [top_k]
@@ -280,7 +312,7 @@ __global__ __launch_bounds__(NB_T) void topk_emit_kernel(const TopkArgs a) {
         const int src = a.k_src[gpos];
         const f32x4 b = *reinterpret_cast<const f32x4*>(a.s_boxes + (size_t)src * 4);
         f32x4 o;
-        o[0] = b[0] * a.w; o[1] = b[1] * a.h; o[2] = b[2] * a.w; o[3] = b[3] * a.h;    // Losses.py:89
+        o[0] = b[0] * img_w; o[1] = b[1] * img_h; o[2] = b[2] * img_w; o[3] = b[3] * img_h;    // Losses.py:89
         *reinterpret_cast<f32x4*>(a.boxes + (size_t)slot * 4) = o;
         a.classes[slot] = src / a.P;
         a.probs[slot] = __uint_as_float(a.k_prob[gpos]);
@@ -360,29 +392,31 @@ __global__ __launch_bounds__(NB_T) void topk_emit_kernel(const TopkArgs a) {
     }
 }
 
+__global__ void set_wh_kernel(float* wh, float w, float h) { wh[0] = w; wh[1] = h; }
+
 }  // namespace
 
-extern "C" size_t ssd_decode_nms_workspace(int P, int n_classes) {
-    if (P <= 0 || n_classes < 2) return 0;
-    return carve(nullptr, P, n_classes).bytes;
+extern "C" size_t ssd_decode_nms_batch_workspace(int B, int P, int n_classes) {
+    if (B <= 0 || P <= 0 || n_classes < 2) return 0;
+    return carve(nullptr, P, n_classes, B).bytes + 256;
 }
+extern "C" size_t ssd_decode_nms_workspace(int P, int n_classes) { return ssd_decode_nms_batch_workspace(1, P, n_classes); }
 
-extern "C" int ssd_decode_nms(const float* l_, const float* c_, const float* priors_cxcywh, int P, int n_classes,
-                              float min_score, float iou_threshold, int top_k, float img_w, float img_h, float* boxes,
-                              int64_t* classes, float* probs, int32_t* prior_ids, int32_t* count, void* workspace,
-                              size_t workspace_bytes, void* stream) {
-    if (!l_ || !c_ || !priors_cxcywh || !boxes || !classes || !probs || !prior_ids || !count || !workspace) return SSD_ERR_NULL;
-    if (P <= 0 || P > 100000 || n_classes < 2 || n_classes > 256 || top_k <= 0 || top_k > 4096) return SSD_ERR_BAD_SHAPE;
+extern "C" int ssd_decode_nms_batch(const float* l_, const float* c_, const float* priors_cxcywh, const float* img_wh, int B, int P,
+                                    int n_classes, float min_score, float iou_threshold, int top_k, float* boxes, int64_t* classes,
+                                    float* probs, int32_t* prior_ids, int32_t* count, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!l_ || !c_ || !priors_cxcywh || !img_wh || !boxes || !classes || !probs || !prior_ids || !count || !workspace) return SSD_ERR_NULL;
+    if (B <= 0 || B > 65535 || P <= 0 || P > 100000 || n_classes < 2 || n_classes > 256 || top_k <= 0 || top_k > 4096) return SSD_ERR_BAD_SHAPE;
     if (!ssd_aligned16(l_) || !ssd_aligned16(priors_cxcywh) || !ssd_aligned16(boxes) || !ssd_aligned16(workspace)) return SSD_ERR_ALIGN;
-    if (workspace_bytes < ssd_decode_nms_workspace(P, n_classes)) return SSD_ERR_WORKSPACE;
+    if (workspace_bytes < ssd_decode_nms_batch_workspace(B, P, n_classes)) return SSD_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const NmsWs w = carve(workspace, P, n_classes);
+    const NmsWs w = carve(workspace, P, n_classes, B);
     const int C1 = n_classes - 1;
-    hipLaunchKernelGGL(decode_softmax_kernel, dim3(ssd_cdiv(P, 256)), dim3(256), 0, st, l_, c_, priors_cxcywh, P, n_classes, w.boxes, w.probs_t);
+    hipLaunchKernelGGL(decode_softmax_kernel, dim3(ssd_cdiv(P, 256), 1, B), dim3(256), 0, st, l_, c_, priors_cxcywh, P, n_classes, w.boxes, w.probs_t);
     SSD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(compact_kernel, dim3(C1), dim3(NB_T), 0, st, w.probs_t, P, min_score, w.keys, w.cand_cnt);
+    hipLaunchKernelGGL(compact_kernel, dim3(C1, 1, B), dim3(NB_T), 0, st, w.probs_t, P, min_score, w.keys, w.cand_cnt);
     SSD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(rank_scatter_kernel, dim3(ssd_cdiv(P, 256), C1), dim3(256), 0, st, w.keys, w.cand_cnt, w.boxes, P, w.s_boxes, w.s_prob, w.s_idx);
+    hipLaunchKernelGGL(rank_scatter_kernel, dim3(ssd_cdiv(P, 256), C1, B), dim3(256), 0, st, w.keys, w.cand_cnt, w.boxes, P, w.s_boxes, w.s_prob, w.s_idx);
     SSD_CHECK_LAUNCH();
     const int nwcap = (P + 63) / 64;
     int CR = 64;
@@ -397,15 +431,31 @@ extern "C" int ssd_decode_nms(const float* l_, const float* c_, const float* pri
             raised = true;
         }
     }
-    hipLaunchKernelGGL(nms_kernel, dim3(C1), dim3(NB_T), lds, st, w.s_boxes, w.cand_cnt, P, iou_threshold, CR, w.kept_pos, w.kept_cnt);
+    hipLaunchKernelGGL(nms_kernel, dim3(C1, 1, B), dim3(NB_T), lds, st, w.s_boxes, w.cand_cnt, P, iou_threshold, CR, w.kept_pos, w.kept_cnt);
     SSD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(64), 0, st, w.kept_cnt, C1, w.offsets);
+    hipLaunchKernelGGL(offsets_kernel, dim3(1, 1, B), dim3(64), 0, st, w.kept_cnt, C1, w.offsets);
     SSD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gather_kept_kernel, dim3(ssd_cdiv(P, 256), C1), dim3(256), 0, st, w.s_prob, w.kept_pos, w.kept_cnt, w.offsets, P,
+    hipLaunchKernelGGL(gather_kept_kernel, dim3(ssd_cdiv(P, 256), C1, B), dim3(256), 0, st, w.s_prob, w.kept_pos, w.kept_cnt, w.offsets, P,
                        w.k_prob, w.k_src);
     SSD_CHECK_LAUNCH();
-    TopkArgs ta{w.s_boxes, w.s_idx, w.k_prob, w.k_src, w.offsets, P, C1, top_k, img_w, img_h, boxes, classes, probs, prior_ids, count};
-    hipLaunchKernelGGL(topk_emit_kernel, dim3(1), dim3(NB_T), (size_t)top_k * 8, st, ta);
+    TopkArgs ta{w.s_boxes, w.s_idx, w.k_prob, w.k_src, w.offsets, P, C1, top_k, img_wh, boxes, classes, probs, prior_ids, count};
+    hipLaunchKernelGGL(topk_emit_kernel, dim3(1, 1, B), dim3(NB_T), (size_t)top_k * 8, st, ta);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
+}
+
+// one image, image size passed by value (kept in the last 256 bytes of the workspace)
+extern "C" int ssd_decode_nms(const float* l_, const float* c_, const float* priors_cxcywh, int P, int n_classes,
+                              float min_score, float iou_threshold, int top_k, float img_w, float img_h, float* boxes,
+                              int64_t* classes, float* probs, int32_t* prior_ids, int32_t* count, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    if (!workspace) return SSD_ERR_NULL;
+    const size_t need = ssd_decode_nms_batch_workspace(1, P, n_classes);
+    if (need == 0) return SSD_ERR_BAD_SHAPE;
+    if (workspace_bytes < need) return SSD_ERR_WORKSPACE;
+    float* wh = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + need - 256);
+    hipLaunchKernelGGL(set_wh_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, wh, img_w, img_h);
+    SSD_CHECK_LAUNCH();
+    return ssd_decode_nms_batch(l_, c_, priors_cxcywh, wh, 1, P, n_classes, min_score, iou_threshold, top_k, boxes, classes, probs,
+                                prior_ids, count, workspace, workspace_bytes, stream);
 }

@@ -323,6 +323,28 @@ def decode_nms(l_, c_, priors_cxcywh, img_w, img_h, top_k=200, min_score=0.2, io
     return boxes, classes, probs, ids, count
 
 
+def decode_nms_batch(l, c, priors_cxcywh, img_wh, top_k=200, min_score=0.2, iou_threshold=0.45):
+    """l (B,P,4), c (B,P,C), img_wh (B,2) device floats -> (boxes (B,top_k,4), classes (B,top_k) i64, probs (B,top_k),
+    prior_ids (B,top_k) i32, count (B,) i32), all on the device, one launch set, no host sync."""
+    _req(l, "l"); _req(c, "c"); _req(priors_cxcywh, "priors"); _req(img_wh, "img_wh")
+    b, p, ncls = c.shape
+    if tuple(l.shape) != (b, p, 4) or tuple(priors_cxcywh.shape) != (p, 4) or tuple(img_wh.shape) != (b, 2):
+        raise ValueError("decode_nms_batch shapes")
+    lib = _lib.load()
+    ws = workspace(lib.ssd_decode_nms_batch_workspace(b, p, ncls), l.device, "nms")
+    dev = l.device
+    boxes = torch.zeros((b, top_k, 4), device=dev, dtype=torch.float32)
+    classes = torch.zeros((b, top_k), device=dev, dtype=torch.int64)
+    probs = torch.zeros((b, top_k), device=dev, dtype=torch.float32)
+    ids = torch.zeros((b, top_k), device=dev, dtype=torch.int32)
+    count = torch.zeros((b,), device=dev, dtype=torch.int32)
+    check(lib.ssd_decode_nms_batch(l.data_ptr(), c.data_ptr(), priors_cxcywh.data_ptr(), img_wh.data_ptr(), b, p, ncls,
+                                   float(min_score), float(iou_threshold), int(top_k), boxes.data_ptr(), classes.data_ptr(),
+                                   probs.data_ptr(), ids.data_ptr(), count.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+          "decode_nms_batch")
+    return boxes, classes, probs, ids, count
+
+
 def sgd_momentum_(param, grad, buf, lr, momentum, weight_decay, grad_scale=None, first_step=False):
     _req(param, "param"); _req(grad, "grad"); _req(buf, "buf")
     if grad.numel() != param.numel() or buf.numel() != param.numel():

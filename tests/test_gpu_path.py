@@ -372,3 +372,25 @@ def test_flat_sgd_data_parallel_step_equals_torch_sgd():
         ref = na[k].detach()
         err = float((nb[k].detach() - ref).abs().max())
         assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (k, err)
+
+
+def test_inference_batch_equals_single_image_calls(gold_dir):
+    """(f)-4: the batched decode gives, image by image, exactly what `inference` gives (incl. an empty image)"""
+    from objectdetection_ssd_amd import Losses
+    z = np.load(os.path.join(gold_dir, "nms.npz"))
+    ls, cs = [], []
+    for ni in (0, 3, 5, 2):                      # case 5 has no detections
+        l_, c_, _, _ = nms_case(z, ni)
+        ls.append(l_); cs.append(c_)
+    sizes = [(500, 375), (300, 300), (640, 480), (123, 77)]
+    L, C = _t(np.stack(ls)), _t(np.stack(cs))
+    outs = Losses.inference_batch(L, C, sizes, top_k=100)
+    assert len(outs) == 4
+    for i, (sz, o) in enumerate(zip(sizes, outs)):
+        single = Losses.inference(L[i], C[i], sz, top_k=100, toDraw=False)
+        if single == ([], [], []):
+            assert o == ([], [], [])
+            continue
+        for a, b in zip(o, single):
+            assert torch.equal(a, b)
+        assert torch.equal(Losses.inference_batch.last_prior_ids[i], Losses.inference.last_prior_ids)

@@ -24,3 +24,17 @@ for scale in (1.0, 2.0, 3.0, 4.0):
     wall = (time.perf_counter() - t0) / 20
     p = torch.softmax(c_, 1)[:, :20]
     print(f"scale {scale}: candidates {(p >= 0.2).sum().item():6d}  kept {int(out[4].item()):4d}  gpu {e0.elapsed_time(e1) / 20 * 1e3:8.1f} us  inference() wall {wall * 1e6:8.1f} us", flush=True)
+# batched
+for B in (1, 8, 32):
+    g = torch.Generator().manual_seed(2)
+    L = (torch.randn(B, 8732, 4, generator=g) * 0.5).to(dev)
+    C = (torch.randn(B, 8732, 21, generator=g) * 3.0).to(dev)
+    wh = torch.tensor([[500., 375.]] * B, device=dev)
+    for _ in range(2): ops.decode_nms_batch(L, C, pri, wh)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+    e0.record()
+    for _ in range(10): ops.decode_nms_batch(L, C, pri, wh)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    print(f"batch {B:3d}: {ms * 1e3:8.1f} us per call = {ms * 1e3 / B:7.1f} us per image = {B / ms * 1e3:8.0f} images/s", flush=True)
