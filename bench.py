@@ -147,6 +147,13 @@ def main():
         elapsed = float(t.item())
     ms = elapsed / args.steps * 1e3
     ips = bs * world * args.steps / elapsed
+    # host-side enqueue time per step (diagnostic: the step is GPU-bound while this stays below ms_per_step)
+    fence()
+    h0 = time.perf_counter()
+    for _ in range(3):
+        step()
+    host_ms = (time.perf_counter() - h0) / 3 * 1e3
+    fence()
     n_pos = float(trainer.flat_grad[trainer.n].item())
     loss = (float(l1.item()) + float(l2.item())) / max(float(Losses.last_match["n_pos"].item()), 1.0)
 
@@ -159,7 +166,8 @@ def main():
                       "train_gflop_per_image": TRAIN_GFLOP_PER_IMAGE,
                       "step_tflops_per_gpu": round(TRAIN_GFLOP_PER_IMAGE * ips / world / 1e3, 2),
                       "step_frac_of_f32_mfma_peak": round(TRAIN_GFLOP_PER_IMAGE * ips / world / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
-                      "last_loss_per_rank": round(loss, 5), "n_pos_global_last": n_pos}}
+                      "last_loss_per_rank": round(loss, 5), "n_pos_global_last": n_pos,
+                      "host_enqueue_ms_per_step": round(host_ms, 2)}}
 
     # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream -----------------
     if not args.no_roofline and rank != 0:
