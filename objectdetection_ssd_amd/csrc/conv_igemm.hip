@@ -17,8 +17,6 @@
 // (lane half h takes k = 8q+4h+e): A and B use the same permutation, so the sum is
 // the same set of products.
 #include "common.h"
-#include <cstdlib>
-#include <cstring>
 
 namespace {
 
