@@ -13,7 +13,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 from . import ops
-from .Util import all_images, class_to_label, create_priors_ssd300, device, xywh_to_xyxy  # noqa: F401  (re-exported)
+from .Util import all_images, class_to_label, create_priors_ssd300, create_priors_ssd512, device, xywh_to_xyxy  # noqa: F401
 
 # module-level priors, as reference Losses.py:6-7 (immutable after import)
 ancs_xywh = create_priors_ssd300()
@@ -28,17 +28,26 @@ _dev_priors: Dict[str, tuple] = {}
 last_match: Optional[dict] = None
 
 
-def _priors_on(dev: torch.device):
-    key = str(dev)
+def _priors_on(dev: torch.device, n_priors: int = 8732):
+    """device copies of the prior set with `n_priors` boxes: 8732 = the reference's SSD300 set (module globals
+    above), 24564 = the build-defined SSD512 set"""
+    key = (str(dev), n_priors)
     if key not in _dev_priors:
-        _dev_priors[key] = (ancs_xywh.to(dev).contiguous(), ancs_xyxy.to(dev).contiguous())
+        if n_priors == ancs_xywh.shape[0]:
+            cx, xy = ancs_xywh, ancs_xyxy
+        else:
+            cx = create_priors_ssd512()
+            if n_priors != cx.shape[0]:
+                raise ValueError(f"no prior set with {n_priors} boxes (8732 = SSD300, {cx.shape[0]} = SSD512)")
+            xy = xywh_to_xyxy(cx)
+        _dev_priors[key] = (cx.to(dev).contiguous(), xy.to(dev).contiguous())
     return _dev_priors[key]
 
 
 class _MultiBoxLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, loc, conf, gt, gt_cls, img_start, norm_mode):
-        pri, pri_xyxy = _priors_on(loc.device)
+        pri, pri_xyxy = _priors_on(loc.device, loc.shape[1])
         want = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         out = ops.multibox_loss(loc.detach().contiguous(), conf.detach().contiguous(), gt, gt_cls, img_start, pri, pri_xyxy,
                                 IOU_THRESHOLD, NEG_POS_RATIO, norm_mode, want_grads=want)
@@ -75,7 +84,7 @@ def ssd(outputs, tr_classes, tr_bboxs, norm_mode: int = 0):
     0..19; tr_bboxs: list of (n_i,4) xyxy fractional boxes.  Returns (loc_loss, conf_loss) as 0-dim tensors
     that support `+`, `.item()` and `.backward()` (train_function.py:82-94)."""
     loc, conf = outputs
-    if loc.dim() != 3 or conf.dim() != 3 or loc.shape[0] != len(tr_bboxs) or loc.shape[1] != ancs_xywh.shape[0]:
+    if loc.dim() != 3 or conf.dim() != 3 or loc.shape[0] != len(tr_bboxs) or loc.shape[1] not in (ancs_xywh.shape[0], 24564):
         raise ValueError(f"ssd(): outputs {tuple(loc.shape)}, {tuple(conf.shape)} do not match {len(tr_bboxs)} images "
                          f"x {ancs_xywh.shape[0]} priors")
     gt, cls, img_start = _pack_targets(tr_classes, tr_bboxs, loc.device)
@@ -106,7 +115,7 @@ def inference(l_, c_, index, top_k=200, phase='train', toDraw=True, min_score=0.
     if not l_.is_cuda:
         raise RuntimeError("inference() runs on the gfx950 HIP kernels only (no CPU fallback)")
     w, h = _image_size(index, phase)
-    pri, _ = _priors_on(l_.device)
+    pri, _ = _priors_on(l_.device, l_.shape[0])
     boxes, classes, probs, ids, count = ops.decode_nms(l_.detach().float().contiguous(), c_.detach().float().contiguous(), pri,
                                                       w, h, top_k, min_score, iou_threshold)
     k = int(count.item())
@@ -128,7 +137,7 @@ def inference_batch(l, c, sizes, top_k=200, min_score=0.2, iou_threshold=0.45):
     if not l.is_cuda:
         raise RuntimeError("inference_batch() runs on the gfx950 HIP kernels only (no CPU fallback)")
     wh = torch.as_tensor(sizes, dtype=torch.float32).reshape(-1, 2).to(l.device).contiguous()
-    pri, _ = _priors_on(l.device)
+    pri, _ = _priors_on(l.device, l.shape[1])
     boxes, classes, probs, ids, count = ops.decode_nms_batch(l.detach().float().contiguous(), c.detach().float().contiguous(),
                                                             pri, wh, top_k, min_score, iou_threshold)
     out = []

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .Util import ANCHORS_PER_CELL, subsampling
+from .Util import ANCHORS_PER_CELL, ANCHORS_PER_CELL_512, subsampling
 
 N_CLASSES = 21
 _VGG_CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M")
@@ -64,14 +64,23 @@ def _pool(x, y, k=2, s=2, pad=0, ceil=False):
     return dict(op="pool", x=x, y=y, k=k, s=s, pad=pad, ceil=ceil)
 
 
-def _head(p, x, scale, ci):
-    return dict(op="head", p=p, x=x, scale=scale, ci=ci, a=ANCHORS_PER_CELL[scale])
+def _head(p, x, scale, ci, anchors=ANCHORS_PER_CELL):
+    return dict(op="head", p=p, x=x, scale=scale, ci=ci, a=anchors[scale])
 
 
-def build_ops() -> List[dict]:
+# aux blocks (name, cin, mid, cout, stride, pad) after fc7
+_AUX_300 = (("seq8", 1024, 256, 512, 2, 1), ("seq9", 512, 128, 256, 2, 1), ("seq10", 256, 128, 256, 1, 0), ("seq11", 256, 128, 256, 1, 0))
+_AUX_512 = (("seq8", 1024, 256, 512, 2, 1), ("seq9", 512, 128, 256, 2, 1), ("seq10", 256, 128, 256, 2, 1), ("seq11", 256, 128, 256, 2, 1),
+            ("seq12", 256, 128, 256, 2, 1))
+
+
+def build_ops(variant: int = 300) -> List[dict]:
     """SSD300 as a flat op list (reference Model.py:203-235).  Order matters only where a
     tensor has two consumers: in reverse order the consumer that cannot accumulate
     (L2-norm backward) must deliver its gradient first."""
+    if variant not in (300, 512):
+        raise ValueError("variant must be 300 or 512")
+    anchors = ANCHORS_PER_CELL if variant == 300 else ANCHORS_PER_CELL_512
     f = "model.features."
     o = [dict(op="conv_first", p=f + "0", x="x", y="a1_1"),
          _conv(f + "2", "a1_1", "a1_2", 64, 64), _pool("a1_2", "p1"),
@@ -82,19 +91,18 @@ def build_ops() -> List[dict]:
          _conv(f + "21", "a4_2", "a4_3", 512, 512),
          _pool("a4_3", "p4"),
          dict(op="l2norm", p="rescaling_conv_4_3", x="a4_3", y="n4_3"),                         # Model.py:206-209
-         _head("c_4", "n4_3", 0, 512),
+         _head("c_4", "n4_3", 0, 512, anchors),
          _conv(f + "24", "p4", "a5_1", 512, 512), _conv(f + "26", "a5_1", "a5_2", 512, 512),
          _conv(f + "28", "a5_2", "a5_3", 512, 512), _pool("a5_3", "p5", k=3, s=1, pad=1, ceil=True),   # Model.py:142
          _conv("conv_fc6", "p5", "a6", 512, 1024, k=3, pad=4, dil=4),                            # Model.py:149
          _conv("conv_fc7", "a6", "a7", 1024, 1024, k=1, pad=0),
-         _head("c_7", "a7", 1, 1024)]
+         _head("c_7", "a7", 1, 1024, anchors)]
     prev = "a7"
-    for i, (name, cin, mid, cout, s, pad) in enumerate((("seq8", 1024, 256, 512, 2, 1), ("seq9", 512, 128, 256, 2, 1),
-                                                        ("seq10", 256, 128, 256, 1, 0), ("seq11", 256, 128, 256, 1, 0))):
+    for i, (name, cin, mid, cout, s, pad) in enumerate(_AUX_300 if variant == 300 else _AUX_512):
         n = 8 + i
         o.append(_conv(f"{name}.0", prev, f"a{n}a", cin, mid, k=1, pad=0))
         o.append(_conv(f"{name}.2", f"a{n}a", f"a{n}", mid, cout, k=3, s=s, pad=pad))
-        o.append(_head(f"c_{n}", f"a{n}", 2 + i, cout))
+        o.append(_head(f"c_{n}", f"a{n}", 2 + i, cout, anchors))
         prev = f"a{n}"
     return o
 
@@ -114,8 +122,8 @@ def param_names(op_list: List[dict]) -> List[str]:
 class _Engine:
     """Runs the op list on the current HIP stream.  Holds only caches (re-laid-out weights)."""
 
-    def __init__(self):
-        self.ops = build_ops()
+    def __init__(self, variant: int = 300):
+        self.ops = build_ops(variant)
         self.names = param_names(self.ops)
         self._wcache: Dict[str, tuple] = {}
         self.consumers: Dict[str, int] = {}
@@ -316,6 +324,7 @@ class _SSD300Function(torch.autograd.Function):
 
 class SSD_300(nn.Module):
     """Drop-in for reference Model.py:128-235 (same no-argument constructor, same parameter names)."""
+    _VARIANT = 300
 
     def __init__(self):
         super().__init__()
@@ -339,25 +348,28 @@ class SSD_300(nn.Module):
         self.seq7 = nn.Sequential(self.conv_fc6, nn.ReLU(), self.conv_fc7, nn.ReLU())
         self.seq8 = nn.Sequential(nn.Conv2d(1024, 256, 1), nn.ReLU(), nn.Conv2d(256, 512, 3, 2, padding=1), nn.ReLU())
         self.seq9 = nn.Sequential(nn.Conv2d(512, 128, 1), nn.ReLU(), nn.Conv2d(128, 256, 3, 2, padding=1), nn.ReLU())
-        self.seq10 = nn.Sequential(nn.Conv2d(256, 128, 1), nn.ReLU(), nn.Conv2d(128, 256, 3, 1), nn.ReLU())
-        self.seq11 = nn.Sequential(nn.Conv2d(256, 128, 1), nn.ReLU(), nn.Conv2d(128, 256, 3, 1), nn.ReLU())
-        for name, cin, a in (("c_4", 512, 4), ("c_7", 1024, 6), ("c_8", 512, 6), ("c_9", 256, 6), ("c_10", 256, 4),
-                             ("c_11", 256, 4)):
+        aux = _AUX_300 if self._VARIANT == 300 else _AUX_512
+        for name, cin, mid, cout, stride, pad in aux[2:]:
+            setattr(self, name, nn.Sequential(nn.Conv2d(cin, mid, 1), nn.ReLU(), nn.Conv2d(mid, cout, 3, stride, padding=pad), nn.ReLU()))
+        anchors = ANCHORS_PER_CELL if self._VARIANT == 300 else ANCHORS_PER_CELL_512
+        self._aux_names = tuple(a[0] for a in aux)
+        self._head_names = ("c_4", "c_7") + tuple(f"c_{8 + i}" for i in range(len(aux)))
+        for name, cin, a in zip(self._head_names, (512, 1024, 512) + (256,) * (len(aux) - 1), anchors):
             setattr(self, name + "_bb", nn.Conv2d(cin, 4 * a, 3, padding=1))
             setattr(self, name + "_cl", nn.Conv2d(cin, N_CLASSES * a, 3, padding=1))
         self.initialization()
-        self._engine = _Engine()
+        self._engine = _Engine(self._VARIANT)
 
     def get_norm(self):
         return torch.norm(self.fc6) + torch.norm(self.fc6_b) + torch.norm(self.fc7) + torch.norm(self.fc7_b)
 
     def initialization(self):
         """Xavier-uniform weights / zero biases for the aux and head convolutions (Model.py:190-200)."""
-        for name in ("seq8", "seq9", "seq10", "seq11"):
+        for name in self._aux_names:
             seq = getattr(self, name)
             self.initialize(seq[0])
             self.initialize(seq[2])
-        for name in ("c_4", "c_7", "c_8", "c_9", "c_10", "c_11"):
+        for name in self._head_names:
             self.initialize(getattr(self, name + "_bb"))
             self.initialize(getattr(self, name + "_cl"))
 
@@ -376,3 +388,11 @@ class SSD_300(nn.Module):
             return _SSD300Function.apply(x, eng, *[P[n] for n in eng.names])
         loc, conf, _ = eng.forward(x, P, save=False)
         return loc, conf
+
+
+class SSD_512(SSD_300):
+    """Build-defined SSD512 (NOT in the reference): 512x512 input, seven maps
+    64/32/16/8/4/2/1 (every aux block 1x1 -> 3x3 stride 2 pad 1, plus `seq12` / `c_12_*`), 24564 priors
+    (`Util.create_priors_ssd512`).  Same kernels, same parameter naming scheme; parity is against the oracle's own
+    restatement only -- there is no reference implementation to compare with."""
+    _VARIANT = 512

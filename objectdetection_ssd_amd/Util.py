@@ -49,6 +49,31 @@ def create_priors_ssd300() -> torch.Tensor:
     return torch.tensor(out, dtype=torch.float64).to(torch.float32).clamp_(0, 1)
 
 
+# SSD512 is NOT in the reference: build-defined extension in the reference's
+# style -- seven maps 64..1, the standard SSD512 scales, the reference's per-cell ratio lists and rounding.
+_GRID512 = (64, 32, 16, 8, 4, 2, 1)
+_SCALE512 = (0.07, 0.15, 0.30, 0.45, 0.60, 0.75, 0.90)
+_RATIO512 = ((1., 2., .5),) + ((1., 2., 3., .5, .333),) * 4 + ((1., 2., .5),) * 2
+ANCHORS_PER_CELL_512 = (4, 6, 6, 6, 6, 4, 4)
+
+
+def create_priors_ssd512() -> torch.Tensor:
+    """(24564,4) f32 cx,cy,w,h: create_priors_ssd300's construction on the SSD512 grids (build-defined)."""
+    out = []
+    for k, g in enumerate(_GRID512):
+        s = _SCALE512[k]
+        extra = sqrt(s * _SCALE512[k + 1]) if k + 1 < len(_SCALE512) else 1.
+        for row in range(g):
+            cy = (row + 0.5) / float(g)
+            for col in range(g):
+                cx = (col + 0.5) / float(g)
+                for a in _RATIO512[k]:
+                    out.append([cx, cy, s * sqrt(a), s / sqrt(a)])
+                    if a == 1.:
+                        out.append([cx, cy, extra, extra])
+    return torch.tensor(out, dtype=torch.float64).to(torch.float32).clamp_(0, 1)
+
+
 def xywh_to_xyxy(box: torch.Tensor) -> torch.Tensor:
     """reference Util.py:93-96"""
     return torch.cat((box[:, :2] - box[:, 2:] / 2., box[:, :2] + box[:, 2:] / 2.), dim=1)

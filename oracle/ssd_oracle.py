@@ -67,6 +67,32 @@ def create_priors_ssd300() -> np.ndarray:
     return pri
 
 
+# ---- SSD512: NOT in the reference.  Build-defined geometry, restated here only so
+# that the kernels can be checked at this size too; nothing below is pinned by the reference.
+_GRIDS_512 = (64, 32, 16, 8, 4, 2, 1)
+_SCALES_512 = (0.07, 0.15, 0.30, 0.45, 0.60, 0.75, 0.90)
+_RATIOS_512 = ((1., 2., .5),) + ((1., 2., 3., .5, .333),) * 4 + ((1., 2., .5),) * 2
+P_SSD512 = 24564
+
+
+def create_priors_ssd512() -> np.ndarray:
+    rows = []
+    for k, g in enumerate(_GRIDS_512):
+        s = _SCALES_512[k]
+        s_next = math.sqrt(s * _SCALES_512[k + 1]) if k + 1 < len(_SCALES_512) else 1.0
+        for i in range(g):
+            for j in range(g):
+                cx, cy = (j + 0.5) / float(g), (i + 0.5) / float(g)
+                for a in _RATIOS_512[k]:
+                    rows.append((cx, cy, s * math.sqrt(a), s / math.sqrt(a)))
+                    if a == 1.:
+                        rows.append((cx, cy, s_next, s_next))
+    pri = np.asarray(rows, dtype=np.float64).astype(np.float32)
+    np.clip(pri, 0.0, 1.0, out=pri)
+    assert pri.shape == (P_SSD512, 4)
+    return pri
+
+
 def xywh_to_xyxy(b: np.ndarray) -> np.ndarray:
     """Util.py:93-96 (f32: c - wh/2, c + wh/2)."""
     b = np.asarray(b, dtype=np.float32)
@@ -293,9 +319,14 @@ HEADS = (("c_4", 512, 4), ("c_7", 1024, 6), ("c_8", 512, 6),
          ("c_9", 256, 6), ("c_10", 256, 4), ("c_11", 256, 4))
 AUX = (("seq8", 1024, 256, 512, 2, 1), ("seq9", 512, 128, 256, 2, 1),
        ("seq10", 256, 128, 256, 1, 0), ("seq11", 256, 128, 256, 1, 0))
+# build-defined SSD512 (not in the reference): every aux block is 1x1 -> 3x3 stride 2 pad 1, one more block
+HEADS_512 = (("c_4", 512, 4), ("c_7", 1024, 6), ("c_8", 512, 6), ("c_9", 256, 6), ("c_10", 256, 6), ("c_11", 256, 4),
+             ("c_12", 256, 4))
+AUX_512 = (("seq8", 1024, 256, 512, 2, 1), ("seq9", 512, 128, 256, 2, 1), ("seq10", 256, 128, 256, 2, 1),
+           ("seq11", 256, 128, 256, 2, 1), ("seq12", 256, 128, 256, 2, 1))
 
 
-def ssd300_param_shapes() -> Dict[str, Tuple[int, ...]]:
+def ssd300_param_shapes(variant: int = 300) -> Dict[str, Tuple[int, ...]]:
     """Names follow the reference's named_parameters() for the tensors the
     forward actually uses."""
     sh: Dict[str, Tuple[int, ...]] = {"rescaling_conv_4_3": (1, 512, 1, 1)}
@@ -304,16 +335,16 @@ def ssd300_param_shapes() -> Dict[str, Tuple[int, ...]]:
         sh[f"model.features.{idx}.bias"] = (VGG_CH[li + 1],)
     sh["conv_fc6.weight"] = (1024, 512, 3, 3); sh["conv_fc6.bias"] = (1024,)
     sh["conv_fc7.weight"] = (1024, 1024, 1, 1); sh["conv_fc7.bias"] = (1024,)
-    for name, cin, mid, cout, _, _ in AUX:
+    for name, cin, mid, cout, _, _ in (AUX if variant == 300 else AUX_512):
         sh[f"{name}.0.weight"] = (mid, cin, 1, 1); sh[f"{name}.0.bias"] = (mid,)
         sh[f"{name}.2.weight"] = (cout, mid, 3, 3); sh[f"{name}.2.bias"] = (cout,)
-    for name, cin, a in HEADS:
+    for name, cin, a in (HEADS if variant == 300 else HEADS_512):
         sh[f"{name}_bb.weight"] = (4 * a, cin, 3, 3); sh[f"{name}_bb.bias"] = (4 * a,)
         sh[f"{name}_cl.weight"] = (21 * a, cin, 3, 3); sh[f"{name}_cl.bias"] = (21 * a,)
     return sh
 
 
-def ssd300_random_params(seed: int = 0):
+def ssd300_random_params(seed: int = 0, variant: int = 300):
     """Seeded parameters with O(1) activations (He-normal fan-in for the ReLU
     stack, Xavier-uniform + zero bias for aux/head convs as Model.py:190-200,
     rescale 20 as Model.py:133).  Pretrained VGG weights are not available
@@ -321,7 +352,7 @@ def ssd300_random_params(seed: int = 0):
     import torch
     g = torch.Generator().manual_seed(seed)
     out = {}
-    for name, shape in ssd300_param_shapes().items():
+    for name, shape in ssd300_param_shapes(variant).items():
         if name == "rescaling_conv_4_3":
             t = torch.full(shape, 20.0)
         elif name.endswith(".bias"):
@@ -339,7 +370,7 @@ def ssd300_random_params(seed: int = 0):
     return out
 
 
-def ssd300_forward(x, params, return_features: bool = False):
+def ssd300_forward(x, params, return_features: bool = False, variant: int = 300):
     """x (bs,3,300,300) f32 NCHW torch tensor -> loc (bs,8732,4), conf (bs,8732,21).
 
     Model.py:203-235: conv1_1..conv4_3 with 2x2/s2 pools (third one
@@ -369,13 +400,13 @@ def ssd300_forward(x, params, return_features: bool = False):
     h = F.relu(F.conv2d(h, params["conv_fc6.weight"], params["conv_fc6.bias"], padding=4, dilation=4))
     h = F.relu(F.conv2d(h, params["conv_fc7.weight"], params["conv_fc7.bias"]))
     srcs = [c43n, h]
-    for name, _, _, _, stride, pad in AUX:
+    for name, _, _, _, stride, pad in (AUX if variant == 300 else AUX_512):
         h = F.relu(F.conv2d(h, params[f"{name}.0.weight"], params[f"{name}.0.bias"]))
         h = F.relu(F.conv2d(h, params[f"{name}.2.weight"], params[f"{name}.2.bias"], stride=stride, padding=pad))
         srcs.append(h)
     bs = x.shape[0]
     locs, confs = [], []
-    for (name, _, _), s in zip(HEADS, srcs):
+    for (name, _, _), s in zip(HEADS if variant == 300 else HEADS_512, srcs):
         bb = F.conv2d(s, params[f"{name}_bb.weight"], params[f"{name}_bb.bias"], padding=1)
         cl = F.conv2d(s, params[f"{name}_cl.weight"], params[f"{name}_cl.bias"], padding=1)
         locs.append(bb.permute(0, 2, 3, 1).reshape(bs, -1, 4))

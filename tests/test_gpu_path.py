@@ -394,3 +394,74 @@ def test_inference_batch_equals_single_image_calls(gold_dir):
         for a, b in zip(o, single):
             assert torch.equal(a, b)
         assert torch.equal(Losses.inference_batch.last_prior_ids[i], Losses.inference.last_prior_ids)
+
+
+def test_ssd512_build_defined_extension_vs_oracle():
+    """SSD512 does not exist in the reference; this checks the same kernels at the larger
+    geometry (64x64 ... 1x1 maps, 24564 priors) against the oracle's own restatement: forward, loss, matching
+    (bit-exact), backward, and decode."""
+    from objectdetection_ssd_amd import Losses, Model
+    params = O.ssd300_random_params(8, variant=512)
+    net = Model.SSD_512()
+    assert set(net._engine.names) == set(params)
+    _load_params(net, params)
+    net = net.to(DEV).train()
+    bs = 1
+    x = np.random.default_rng(61).standard_normal((bs, 3, 512, 512), dtype=np.float32)
+    boxes = [np.array([[.05, .05, .95, .95], [.1, .3, .475, .675], [.40, .40, .47, .48], [.6, .2, .8, .45]], np.float32)]
+    classes = [np.array([1., 5., 12., 7.], np.float32)]
+    pri = O.create_priors_ssd512()
+    assert np.array_equal(Losses._priors_on(torch.device(DEV), 24564)[0].cpu().numpy(), pri)
+    P64 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    lo, co = O.ssd300_forward(torch.from_numpy(x), P64, variant=512)
+    assert lo.shape == (bs, 24564, 4) and co.shape == (bs, 24564, 21)
+    ref = O.multibox_loss(lo.detach().numpy(), co.detach().numpy(), boxes, classes, pri_cxcywh=pri, want_grads=False)
+    a1, a2 = O.multibox_loss_torch(lo, co, [torch.from_numpy(b) for b in boxes], [torch.from_numpy(c) for c in classes], pri_cxcywh=pri)
+    (a1 + a2).backward()
+    loc, conf = net(_t(x))
+    l1, l2 = Losses.ssd((loc, conf), [_t(c) for c in classes], [_t(b) for b in boxes])
+    (l1 + l2).backward()
+    assert float((loc.detach().cpu() - lo.detach()).abs().max()) <= 1e-4 * max(1, float(lo.abs().max()))
+    assert float((conf.detach().cpu() - co.detach()).abs().max()) <= 1e-4 * max(1, float(co.abs().max()))
+    assert np.array_equal(Losses.last_match["cls"].cpu().numpy(), ref["cls"])
+    assert abs(l1.item() - a1.item()) <= 1e-4 * max(1, a1.item()) and abs(l2.item() - a2.item()) <= 1e-4 * max(1, a2.item())
+    named = dict(net.named_parameters())
+    for k, p64 in P64.items():
+        g = p64.grad
+        if float(g.norm()) == 0:
+            continue
+        rel = float((named[k].grad.cpu() - g).norm() / g.norm())
+        assert rel <= (2e-2 if k.startswith("model.features") else 5e-3), (k, rel)
+
+
+def test_decode_at_ssd512_prior_count():
+    """decode + NMS with 24564 priors (the NMS kernel then works in 32-row chunks: 64-row suppression words for that
+    many columns do not fit the LDS); inputs are drawn until every decision has a margin, as for the golden cases"""
+    from objectdetection_ssd_amd import Losses
+    pri = O.create_priors_ssd512()
+    seed = 700
+    while True:
+        r = np.random.default_rng(seed)
+        seed += 1
+        l_ = r.standard_normal((24564, 4), dtype=np.float32) * np.float32(0.5)
+        c_ = r.standard_normal((24564, 21), dtype=np.float32) * np.float32(1.0)
+        pr = torch.softmax(torch.from_numpy(c_).double(), 1).numpy()
+        if np.min(np.abs(pr[:, :20] - 0.2)) < 2e-6:
+            continue
+        bx = O.xywh_to_xyxy(O.decode_offsets(l_, pri))
+        ok = True
+        for c in range(20):
+            idx = np.nonzero(pr[:, c] >= 0.2)[0]
+            if idx.size < 2:
+                continue
+            if np.min(np.diff(np.sort(pr[idx, c]))) < 1e-7 or np.min(np.abs(O.iou_matrix(bx[idx], bx[idx]).astype(np.float64) - 0.45)) < 2e-6:
+                ok = False
+                break
+        if ok:
+            break
+    out = Losses.inference(_t(l_), _t(c_), (512, 512), top_k=200, toDraw=False)
+    ob, oc, op_, oi = O.decode_nms(l_, c_, 512, 512, top_k=200, pri_cxcywh=pri)
+    assert ob.shape[0] > 0
+    assert np.array_equal(Losses.inference.last_prior_ids.cpu().numpy(), oi)
+    assert np.array_equal(out[1].cpu().numpy(), oc)
+    np.testing.assert_allclose(out[0].cpu().numpy(), ob, rtol=1e-5, atol=1e-3)
