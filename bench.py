@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-launch table to stderr")
+    ap.add_argument("--variant", type=int, default=300, choices=(300, 512), help="512 = build-defined SSD512 (not a bench line)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
@@ -114,11 +115,13 @@ def main():
     from objectdetection_ssd_amd.ddp import FlatSGDDataParallel
 
     torch.manual_seed(0)                                   # same initial weights on every rank
-    net = Model.SSD_300().to(dev).train()
+    net = (Model.SSD_300() if args.variant == 300 else Model.SSD_512()).to(dev).train()
     trainer = FlatSGDDataParallel(net, lr=1e-4, momentum=0.9, weight_decay=5e-4)
     trainer.broadcast_parameters(0)
     bs = args.batch
     x, classes, boxes = synth_batch(bs, 1234 + rank, dev)
+    if args.variant == 512:
+        x = torch.randn(bs, 3, 512, 512, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
 
     def step():
         trainer.zero_grad()
@@ -160,7 +163,8 @@ def main():
     out = {"metric": "images/sec SSD300-VGG16 train step", "value": round(ips, 2), "unit": "images/sec",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"SSD300-VGG16 train step (fwd + MultiBox loss + bwd + all-reduce + SGD), "
+           "config": {"workload": ("" if args.variant == 300 else "[build-defined SSD512, FLOP figures below are the SSD300 ones] ") +
+                                  f"SSD300-VGG16 train step (fwd + MultiBox loss + bwd + all-reduce + SGD), "
                                   f"batch {bs}/GPU, 300x300x3, 21 classes, 8732 priors (BASELINE configs[1])",
                       "global_batch": bs * world, "per_gpu_batch": bs, "parallelism": f"dp{world}",
                       "train_gflop_per_image": TRAIN_GFLOP_PER_IMAGE,
