@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-launch table to stderr")
+    ap.add_argument("--conv-dtype", default="f32", choices=("f32", "bf16"),
+                    help="bf16 = BASELINE configs[2] (bf16-operand fwd/dgrad convs, f32 accumulate); not the headline bench line")
     ap.add_argument("--variant", type=int, default=300, choices=(300, 512), help="512 = build-defined SSD512 (not a bench line)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
@@ -116,6 +118,7 @@ def main():
 
     torch.manual_seed(0)                                   # same initial weights on every rank
     net = (Model.SSD_300() if args.variant == 300 else Model.SSD_512()).to(dev).train()
+    net.conv_dtype = args.conv_dtype
     trainer = FlatSGDDataParallel(net, lr=1e-4, momentum=0.9, weight_decay=5e-4)
     trainer.broadcast_parameters(0)
     bs = args.batch
@@ -162,7 +165,8 @@ def main():
 
     out = {"metric": "images/sec SSD300-VGG16 train step", "value": round(ips, 2), "unit": "images/sec",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32" if args.conv_dtype == "f32" else "bf16 operands (fwd+dgrad convs), f32 accumulate / wgrad / loss", "data": "synthetic",
            "config": {"workload": ("" if args.variant == 300 else "[build-defined SSD512, FLOP figures below are the SSD300 ones] ") +
                                   f"SSD300-VGG16 train step (fwd + MultiBox loss + bwd + all-reduce + SGD), "
                                   f"batch {bs}/GPU, 300x300x3, 21 classes, 8732 priors (BASELINE configs[1])",
@@ -200,8 +204,9 @@ def main():
                 traffic = tj["bytes_per_launch"]
         except Exception:
             pass
+        peak = 2500.0 if "bf16" in tag else PEAK_F32_MFMA_TFLOPS        # dense peak of the dtype the kernel multiplies in
         out["roofline"] = {"bound": "mfma", "kernel": tag + ", ...>", "achieved": round(ach, 2),
-                           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                           "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                            "traffic": traffic, "traffic_unit": "bytes per launch (profiles/r01_traffic.json)", "launches_timed": n, "avg_launch_ms": round(tsum / n * 1e3, 4),
                            "avg_launch_gflop": round(fsum / n / 1e9, 3),
                            "all_conv_kernels_tflops": round(sum(a[1] for a in agg.values()) / sum(a[0] for a in agg.values()) / 1e12, 2),

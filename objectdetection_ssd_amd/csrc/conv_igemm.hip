@@ -258,6 +258,192 @@ int dispatch_igemm(IgemmParams& p, hipStream_t st) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16-operand variant (BASELINE.json configs[2]: "bf16 convs"): same implicit GEMM, same f32 global
+// tensors, f32 accumulation and epilogue; the A and B tiles are rounded to bf16 on their way into LDS
+// (v_cvt_pk_bf16_f32) and multiplied on v_mfma_f32_32x32x16_bf16 (16x the f32 MFMA rate).  LDS rows are
+// [row][32 bf16] with an 80-byte stride (conflict-free ds_read_b128 of the 8 k values a lane needs).
+// At this MFMA rate the kernel is bound by the L2 -> LDS stream, so the tile is 128 x 128 / 256 x 128
+// (twice / 2.7x the FLOPs per loaded byte of the 64 x 64 tile the f32 kernel prefers).
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int LDH = 40;       // LDS row stride in bf16 elements (32 + 8 pad)
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmParams p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;
+    static_assert(WM * WN == 4, "4 waves");
+    __shared__ __attribute__((aligned(16))) __bf16 lds[(BM + BN) * LDH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int lid = xcd_swizzle(blockIdx.x, nblk);
+    const int tile_m = lid / p.tiles_n, tile_n = lid % p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int chunk = tid & 7, row0 = tid >> 3;
+
+    const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+
+    int a_h[A_ROWS], a_w[A_ROWS];
+    unsigned a_base[A_ROWS], voff_a[A_ROWS];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int j = 0; j < A_ROWS; ++j) {
+        const int m = m0 + row0 + 32 * j;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int n = mm / HoWo, rem = mm - n * HoWo;
+        const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+        a_h[j] = ok ? oh * p.sm + p.off : -(1 << 24);
+        a_w[j] = ow * p.sm + p.off;
+        a_base[j] = (unsigned)n * (unsigned)(p.Ha * p.Wa * p.Ca) * 4u + chunk * 16u;
+    }
+    const int T = p.R * p.S;
+    unsigned voff_b[B_ROWS];
+#pragma unroll
+    for (int j = 0; j < B_ROWS; ++j) {
+        const int n = n0 + row0 + 32 * j;
+        voff_b[j] = n < p.Nrows ? ((unsigned)n * (unsigned)(T * p.Ca)) * 4u + chunk * 16u : OOB;
+    }
+    auto tap_offsets = [&](int r, int s) {
+        const int dh = r * p.dstep, dw = s * p.dstep;
+#pragma unroll
+        for (int j = 0; j < A_ROWS; ++j) {
+            int th = a_h[j] + dh, tw = a_w[j] + dw;
+            bool ok = th >= 0 && tw >= 0;
+            if (p.sd > 1) {
+                ok = ok && (th % p.sd == 0) && (tw % p.sd == 0);
+                th /= p.sd;
+                tw /= p.sd;
+            }
+            ok = ok && th < p.Ha && tw < p.Wa;
+            voff_a[j] = ok ? a_base[j] + (unsigned)((th * p.Wa + tw) * p.Ca) * 4u : OOB;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int kc = p.Ca / BK;
+    const int KT = T * kc;
+    f32x4 ra[A_ROWS], rb[B_ROWS];
+    int c_nxt = 0, r_nxt = 0, s_nxt = 0;
+    unsigned soff_a = 0, soff_b = 0;
+    tap_offsets(0, 0);
+    auto issue_loads = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_ROWS; ++j) ra[j] = buf_load16(srd_a, voff_a[j], soff_a);
+#pragma unroll
+        for (int j = 0; j < B_ROWS; ++j) rb[j] = buf_load16(srd_w, voff_b[j], soff_b);
+        soff_a += BK * 4;
+        soff_b += BK * 4;
+        if (++c_nxt == kc) {
+            c_nxt = 0;
+            soff_a = 0;
+            if (++s_nxt == p.S) { s_nxt = 0; ++r_nxt; }
+            tap_offsets(r_nxt, s_nxt);
+        }
+    };
+    auto to_bf16 = [](const f32x4 v) { return bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]}; };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_ROWS; ++j)
+            *reinterpret_cast<bf16x4*>(&lds[(row0 + 32 * j) * LDH + chunk * 4]) = to_bf16(ra[j]);
+#pragma unroll
+        for (int j = 0; j < B_ROWS; ++j)
+            *reinterpret_cast<bf16x4*>(&lds[(BM + row0 + 32 * j) * LDH + chunk * 4]) = to_bf16(rb[j]);
+    };
+
+    const int lr = lane & 31, lh = lane >> 5;
+    // A operand of 32x32x16: lane (row lr, half lh) holds k = 8*lh .. 8*lh+7 of the 16-deep sub-step
+    const __bf16* a_rd = lds + (wm * TM * 32 + lr) * LDH + lh * 8;
+    const __bf16* b_rd = lds + (BM + wn * TN * 32 + lr) * LDH + lh * 8;
+
+    issue_loads();
+    store_tile();
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const bool more = kt + 1 < KT;
+        if (more) issue_loads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a_rd + i * 32 * LDH + ks * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(b_rd + j * 32 * LDH + ks * 16);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + lr;
+            const bool n_ok = n < p.Nout;
+            const float bv = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (n_ok && m < p.M) {
+                    const size_t idx = (size_t)m * p.ldo + n;
+                    float v = acc[i][j][r] + bv;
+                    if (p.accumulate) v += p.out[idx];
+                    if (p.relu) v = v < 0.f ? 0.f : v;
+                    if (p.mask != nullptr) v = p.mask[idx] > 0.f ? v : 0.f;
+                    p.out[idx] = v;
+                }
+            }
+        }
+    }
+}
+
+int g_bf16_tile = -1;        // tuning aid: 0 = 256x128, 1 = 128x128, 2 = 128x64, 3 = 64x64; -1 = automatic
+
+template <int BM, int BN, int WM, int WN>
+int launch_igemm_bf16(IgemmParams& p, hipStream_t st) {
+    p.tiles_m = ssd_cdiv(p.M, BM);
+    p.tiles_n = ssd_cdiv(p.Nout, BN);
+    hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
+int dispatch_igemm_bf16(IgemmParams& p, hipStream_t st) {
+    int t = g_bf16_tile;
+    if (t < 0) {
+        // measured (tools/conv_bench.py bf16): 128x128 wins once it yields >= ~300 blocks (300-620 TFLOP/s),
+        // 128x64 for the 64-channel outputs, 64x64 for the small maps
+        const long b128 = (long)ssd_cdiv(p.M, 128) * ssd_cdiv(p.Nout, 128);
+        t = p.Nout <= 64 ? 2 : (b128 >= 300 ? 1 : 3);
+    }
+    switch (t) {
+        case 0: return launch_igemm_bf16<256, 128, 4, 1>(p, st);
+        case 1: return launch_igemm_bf16<128, 128, 2, 2>(p, st);
+        case 2: return launch_igemm_bf16<128, 64, 4, 1>(p, st);
+        default: return launch_igemm_bf16<64, 64, 2, 2>(p, st);
+    }
+}
+
 int check_geom(const ssd_conv_geom* g) {
     if (g == nullptr) return SSD_ERR_NULL;
     if (g->N <= 0 || g->H <= 0 || g->W <= 0 || g->Ci <= 0 || g->Co <= 0 || g->R <= 0 || g->S <= 0 ||
@@ -272,8 +458,8 @@ int check_geom(const ssd_conv_geom* g) {
 
 }  // namespace
 
-extern "C" int ssd_conv2d_fwd(const float* x, const float* w_ohwi, const float* bias, float* y, int ldy,
-                              const ssd_conv_geom* g, int relu, void* stream) {
+static int conv2d_fwd_impl(const float* x, const float* w_ohwi, const float* bias, float* y, int ldy,
+                           const ssd_conv_geom* g, int relu, void* stream, bool bf16) {
     if (int e = check_geom(g)) return e;
     if (!x || !w_ohwi || !y) return SSD_ERR_NULL;
     if (g->Ci % 32 != 0 || ldy < g->Co) return SSD_ERR_BAD_SHAPE;
@@ -289,11 +475,20 @@ extern "C" int ssd_conv2d_fwd(const float* x, const float* w_ohwi, const float* 
     p.Nout = g->Co; p.Nrows = g->Co; p.ldo = ldy; p.R = g->R; p.S = g->S;
     p.sm = g->stride; p.sd = 1; p.off = -g->pad; p.dstep = g->dil;
     p.M = g->N * g->Ho * g->Wo; p.relu = relu; p.accumulate = 0;
-    return dispatch_igemm(p, (hipStream_t)stream);
+    return bf16 ? dispatch_igemm_bf16(p, (hipStream_t)stream) : dispatch_igemm(p, (hipStream_t)stream);
 }
 
-extern "C" int ssd_conv2d_dgrad(const float* dy, int ldy, const float* w_ihwo, int Co_pad, float* dx,
-                                const float* relu_mask, int accumulate, const ssd_conv_geom* g, void* stream) {
+extern "C" int ssd_conv2d_fwd(const float* x, const float* w_ohwi, const float* bias, float* y, int ldy,
+                              const ssd_conv_geom* g, int relu, void* stream) {
+    return conv2d_fwd_impl(x, w_ohwi, bias, y, ldy, g, relu, stream, false);
+}
+extern "C" int ssd_conv2d_fwd_bf16(const float* x, const float* w_ohwi, const float* bias, float* y, int ldy,
+                                   const ssd_conv_geom* g, int relu, void* stream) {
+    return conv2d_fwd_impl(x, w_ohwi, bias, y, ldy, g, relu, stream, true);
+}
+
+static int conv2d_dgrad_impl(const float* dy, int ldy, const float* w_ihwo, int Co_pad, float* dx,
+                             const float* relu_mask, int accumulate, const ssd_conv_geom* g, void* stream, bool bf16) {
     if (int e = check_geom(g)) return e;
     if (!dy || !w_ihwo || !dx) return SSD_ERR_NULL;
     if (Co_pad % 32 != 0 || Co_pad < g->Co || ldy != Co_pad || g->Ci % 4 != 0) return SSD_ERR_BAD_SHAPE;
@@ -309,7 +504,21 @@ extern "C" int ssd_conv2d_dgrad(const float* dy, int ldy, const float* w_ihwo, i
     p.Nout = g->Ci; p.Nrows = g->Ci; p.ldo = g->Ci; p.R = g->R; p.S = g->S;
     p.sm = 1; p.sd = g->stride; p.off = g->pad; p.dstep = -g->dil;
     p.M = g->N * g->H * g->W; p.relu = 0; p.accumulate = accumulate;
-    return dispatch_igemm(p, (hipStream_t)stream);
+    return bf16 ? dispatch_igemm_bf16(p, (hipStream_t)stream) : dispatch_igemm(p, (hipStream_t)stream);
+}
+
+extern "C" int ssd_conv2d_dgrad(const float* dy, int ldy, const float* w_ihwo, int Co_pad, float* dx,
+                                const float* relu_mask, int accumulate, const ssd_conv_geom* g, void* stream) {
+    return conv2d_dgrad_impl(dy, ldy, w_ihwo, Co_pad, dx, relu_mask, accumulate, g, stream, false);
+}
+extern "C" int ssd_conv2d_dgrad_bf16(const float* dy, int ldy, const float* w_ihwo, int Co_pad, float* dx,
+                                     const float* relu_mask, int accumulate, const ssd_conv_geom* g, void* stream) {
+    return conv2d_dgrad_impl(dy, ldy, w_ihwo, Co_pad, dx, relu_mask, accumulate, g, stream, true);
+}
+extern "C" int ssd_tune_set_igemm_bf16(int tile) {
+    if (tile < -1 || tile > 3) return SSD_ERR_BAD_SHAPE;
+    g_bf16_tile = tile;
+    return SSD_OK;
 }
 
 extern "C" int ssd_conv2d_igemm_tile(const ssd_conv_geom* g, int direction, int* bm, int* bn) {

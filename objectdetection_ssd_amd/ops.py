@@ -47,7 +47,9 @@ def pad32(c: int) -> int:
     return (c + 31) // 32 * 32
 
 
-def igemm_tile(g: ConvGeom, direction: int) -> str:
+def igemm_tile(g: ConvGeom, direction: int, bf16: bool = False) -> str:
+    if bf16:
+        return "igemm_bf16_kernel"
     bm, bn = C.c_int(0), C.c_int(0)
     check(_lib.load().ssd_conv2d_igemm_tile(C.byref(g), direction, C.byref(bm), C.byref(bn)), "igemm_tile")
     return f"igemm_kernel<{bm.value}, {bn.value}"
@@ -85,7 +87,7 @@ def weight_ihwo(w_oihw: torch.Tensor, co_pad: Optional[int] = None) -> torch.Ten
 
 # ---- convolution -----------------------------------------------------------------------
 def conv2d_fwd(x: torch.Tensor, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], g: ConvGeom, relu: bool,
-               ld: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+               ld: Optional[int] = None, out: Optional[torch.Tensor] = None, bf16: bool = False) -> torch.Tensor:
     """x (N,H,W,Ci) -> (N,Ho,Wo,ld) (ld defaults to Co; columns Co..ld-1 are left untouched)."""
     _req(x, "x"); _req(w_ohwi, "w_ohwi")
     if tuple(x.shape) != (g.N, g.H, g.W, g.Ci):
@@ -104,13 +106,13 @@ def conv2d_fwd(x: torch.Tensor, w_ohwi: torch.Tensor, bias: Optional[torch.Tenso
         _req(out, "out")
         if out.numel() != g.N * g.Ho * g.Wo * ld:
             raise ValueError("out size")
-    check(_lib.load().ssd_conv2d_fwd(x.data_ptr(), w_ohwi.data_ptr(), _ptr(bias), out.data_ptr(), ld, C.byref(g),
-                                     int(relu), _stream()), "conv2d_fwd")
+    fn = _lib.load().ssd_conv2d_fwd_bf16 if bf16 else _lib.load().ssd_conv2d_fwd
+    check(fn(x.data_ptr(), w_ohwi.data_ptr(), _ptr(bias), out.data_ptr(), ld, C.byref(g), int(relu), _stream()), "conv2d_fwd")
     return out
 
 
 def conv2d_dgrad(dy: torch.Tensor, w_ihwo: torch.Tensor, g: ConvGeom, dx: Optional[torch.Tensor] = None,
-                 relu_mask: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+                 relu_mask: Optional[torch.Tensor] = None, accumulate: bool = False, bf16: bool = False) -> torch.Tensor:
     _req(dy, "dy"); _req(w_ihwo, "w_ihwo")
     co_pad = w_ihwo.shape[2]
     if dy.numel() != g.N * g.Ho * g.Wo * co_pad:
@@ -128,8 +130,9 @@ def conv2d_dgrad(dy: torch.Tensor, w_ihwo: torch.Tensor, g: ConvGeom, dx: Option
         _req(relu_mask, "relu_mask")
         if relu_mask.numel() != dx.numel():
             raise ValueError("relu_mask size")
-    check(_lib.load().ssd_conv2d_dgrad(dy.data_ptr(), co_pad, w_ihwo.data_ptr(), co_pad, dx.data_ptr(), _ptr(relu_mask),
-                                       int(accumulate), C.byref(g), _stream()), "conv2d_dgrad")
+    fn = _lib.load().ssd_conv2d_dgrad_bf16 if bf16 else _lib.load().ssd_conv2d_dgrad
+    check(fn(dy.data_ptr(), co_pad, w_ihwo.data_ptr(), co_pad, dx.data_ptr(), _ptr(relu_mask), int(accumulate), C.byref(g),
+             _stream()), "conv2d_dgrad")
     return dx
 
 

@@ -272,3 +272,35 @@ def test_every_kernel_variant(case):
     finally:
         lib.ssd_tune_set_igemm(-1, -1)
         lib.ssd_tune_set_wgrad(-1, -1, -1)
+
+
+@pytest.mark.parametrize("case", [CONV_CASES[i] for i in (0, 1, 2, 4, 5, 6, 10, 11)])
+def test_conv_bf16_operand_variant(case):
+    """bf16-operand kernels (configs[2]): against an f32 torch conv of the SAME bf16-rounded operands the result must
+    agree to f32 accuracy (bf16 x bf16 products are exact in f32); against the unrounded conv it is bf16-accurate."""
+    from objectdetection_ssd_amd import _lib, ops
+    lib = _lib.load()
+    n, h, w, ci, co, k, s, p, d = case
+    dev = _dev()
+    x, wt, b = _conv_data(case, seed=31)
+    xr, wr = x.bfloat16().float().requires_grad_(True), wt.bfloat16().float()
+    y = F.conv2d(xr, wr, b, stride=s, padding=p, dilation=d)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(32)).bfloat16().float()
+    y.backward(dy)
+    g = ops.make_geom(n, h, w, ci, co, k, s, p, d)
+    ld = ops.pad32(co)
+    wf, wb = ops.weight_ohwi(wt.to(dev), ld), ops.weight_ihwo(wt.to(dev), ld)
+    dy_p = torch.zeros(n, g.Ho, g.Wo, ld)
+    dy_p[..., :co] = _nhwc(dy)
+    try:
+        for tile in (-1, 0, 1, 2, 3):
+            assert lib.ssd_tune_set_igemm_bf16(tile) == 0
+            yd = ops.conv2d_fwd(_nhwc(x).to(dev), wf, b.to(dev), g, False, ld=ld, bf16=True)
+            _close(yd[..., :co], _nhwc(y), tol=2e-5, what=f"bf16 fwd tile {tile} {case}")
+            dx = ops.conv2d_dgrad(dy_p.to(dev), wb, g, bf16=True)
+            _close(dx, _nhwc(xr.grad), tol=2e-5, what=f"bf16 dgrad tile {tile} {case}")
+    finally:
+        lib.ssd_tune_set_igemm_bf16(-1)
+    full = F.conv2d(x, wt, b, stride=s, padding=p, dilation=d)
+    rel = float((yd[..., :co].cpu() - _nhwc(full)).norm() / _nhwc(full).norm())
+    assert 1e-4 < rel < 2e-2, rel             # it really is bf16 arithmetic, and no worse than bf16

@@ -465,3 +465,38 @@ def test_decode_at_ssd512_prior_count():
     assert np.array_equal(Losses.inference.last_prior_ids.cpu().numpy(), oi)
     assert np.array_equal(out[1].cpu().numpy(), oc)
     np.testing.assert_allclose(out[0].cpu().numpy(), ob, rtol=1e-5, atol=1e-3)
+
+
+def test_bf16_conv_mode_config3(golden_net):
+    """BASELINE configs[2] ("bf16 convs"): forward / dgrad convolutions on bf16-rounded operands with f32 accumulation.
+    Tolerance for this mode: loc/conf within 3e-2 of max|ref| and both losses within 2e-2 relative of the f32 path
+    (bf16 has 8 significant bits; 20 layers deep); matching is computed from GT and priors only, so the per-prior
+    classes stay bit-exact; gradients keep their direction (cosine > 0.99)."""
+    from objectdetection_ssd_amd import Losses
+    net, params, z = golden_net
+    bs = int(z["bs"])
+    x = _t(np.random.default_rng(int(z["x_seed"])).standard_normal((bs, 3, 300, 300), dtype=np.float32))
+    boxes, classes = synth_gt(np.random.default_rng(int(z["gt_seed"])), bs)
+    cl = [_t(c) for c in classes]; bx = [_t(b) for b in boxes]
+    net.train()
+    out = {}
+    try:
+        for mode in ("f32", "bf16"):
+            net.conv_dtype = mode
+            assert net.conv_dtype == mode
+            net.zero_grad()
+            loc, conf = net(x)
+            l1, l2 = Losses.ssd((loc, conf), cl, bx)
+            (l1 + l2).backward()
+            g = torch.cat([p.grad.flatten() for n, p in net.named_parameters() if p.grad is not None])
+            out[mode] = (loc.detach(), conf.detach(), l1.item(), l2.item(), Losses.last_match["cls"].clone(), g)
+    finally:
+        net.conv_dtype = "f32"
+    a, b = out["f32"], out["bf16"]
+    assert float((a[0] - b[0]).abs().max()) <= 3e-2 * float(a[0].abs().max())
+    assert float((a[1] - b[1]).abs().max()) <= 3e-2 * float(a[1].abs().max())
+    assert float((a[0] - b[0]).abs().max()) > 1e-5                    # the mode really changes the arithmetic
+    assert abs(a[2] - b[2]) <= 2e-2 * a[2] and abs(a[3] - b[3]) <= 2e-2 * a[3]
+    assert torch.equal(a[4], b[4])
+    cos = float(torch.dot(a[5], b[5]) / (a[5].norm() * b[5].norm()))
+    assert cos > 0.99, cos

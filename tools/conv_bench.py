@@ -60,6 +60,18 @@ def main():
                 row.append(f"{lab}:{fl / ms / 1e9:6.1f}")
             print(f"dgrad {name:8s} " + "  ".join(row), flush=True)
         lib.ssd_tune_set_igemm(-1, -1)
+        if which in ("bf16", "all"):
+            for dirn in ("fwd", "dgrad"):
+                row = []
+                for t, lab in ((-1, "auto"), (0, "256x128"), (1, "128x128"), (2, "128x64"), (3, "64x64")):
+                    lib.ssd_tune_set_igemm_bf16(t)
+                    if dirn == "fwd":
+                        ms = timeit(lambda: ops.conv2d_fwd(x, wf, b, g, True, ld=ld, out=dy, bf16=True))
+                    else:
+                        ms = timeit(lambda: ops.conv2d_dgrad(dy, wb, g, dx, x, False, bf16=True))
+                    row.append(f"{lab}:{fl / ms / 1e9:6.1f}")
+                print(f"bf16 {dirn:5s} {name:8s} " + "  ".join(row), flush=True)
+            lib.ssd_tune_set_igemm_bf16(-1)
         if which in ("wgrad", "all"):
             row = []
             for bt, nb, bpc, lab in wg_var:
