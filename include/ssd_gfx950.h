@@ -72,11 +72,14 @@ int ssd_conv2d_dgrad(const float* dy, int ldy, const float* w_ihwo, int Co_pad, 
 
 /* bf16-operand variants (BASELINE.json configs[2] "bf16 convs"): identical signatures and f32 tensors; the
  * operand tiles are rounded to bf16 on their way into LDS and multiplied on v_mfma_f32_32x32x16_bf16 with f32
- * accumulation.  Opt-in (Model.SSD_300.conv_dtype = "bf16"); the weight gradient stays f32. */
+ * accumulation.  Opt-in (Model.SSD_300.conv_dtype = "bf16").  The weight gradient has a bf16 kernel for the 3x3 / stride 1
+ * layers on maps >= 30 px (same workspace query as the f32 entry); other layers fall through to the f32 kernels. */
 int ssd_conv2d_fwd_bf16(const float* x, const float* w_ohwi, const float* bias, float* y, int ldy,
                         const ssd_conv_geom* g, int relu, void* stream);
 int ssd_conv2d_dgrad_bf16(const float* dy, int ldy, const float* w_ihwo, int Co_pad, float* dx,
                           const float* relu_mask, int accumulate, const ssd_conv_geom* g, void* stream);
+int ssd_conv2d_wgrad_bf16(const float* x, const float* dy, int ldy, float* dw_oihw, float* dbias,
+                          const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream);
 int ssd_tune_set_igemm_bf16(int tile);   /* 0 = 256x128, 1 = 128x128, 2 = 128x64, 3 = 64x64, -1 = automatic */
 
 /* dw_oihw[n][c][r][s] = sum_m dy[m][n] * x[pix(m,tap)][c];  dbias[n] = sum_m dy[m][n]

@@ -254,7 +254,7 @@ class _Engine:
                 a4 = 4 * op["a"]
                 if any(need[pre + s] for s in ("_bb.weight", "_bb.bias", "_cl.weight", "_cl.bias")):
                     dw, db = self._timed("wgrad " + pre, ops.wgrad_tile(g) if self.prof is not None else "", ops.conv_flops(g),
-                                         lambda: ops.conv2d_wgrad(xin, dy, g, co_pad, True))
+                                         lambda: ops.conv2d_wgrad(xin, dy, g, co_pad, True, bf16=self.bf16))
                     grads[pre + "_bb.weight"], grads[pre + "_cl.weight"] = dw[:a4], dw[a4:]
                     grads[pre + "_bb.bias"], grads[pre + "_cl.bias"] = db[:a4], db[a4:]
                 _, wb = self._layouts(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]), co_pad, True)
@@ -267,7 +267,7 @@ class _Engine:
                 xin = T[op["x"]]
                 if need[op["p"] + ".weight"] or need[op["p"] + ".bias"]:
                     dw, db = self._timed("wgrad " + op["p"], ops.wgrad_tile(g) if self.prof is not None else "", ops.conv_flops(g),
-                                         lambda: ops.conv2d_wgrad(xin, dy, g, g.Co, True))
+                                         lambda: ops.conv2d_wgrad(xin, dy, g, g.Co, True, bf16=self.bf16))
                     grads[op["p"] + ".weight"], grads[op["p"] + ".bias"] = dw, db
                 _, wb = self._layouts(op["p"], (P[op["p"] + ".weight"],), op["co"], True)
                 deliver(op["x"], lambda dx, acc, mask: self._timed(

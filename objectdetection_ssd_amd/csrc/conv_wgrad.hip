@@ -370,6 +370,160 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const WgradParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16-operand version of the fused nine-tap kernel (BASELINE.json configs[2]).  Same patches, same halo, f32 tensors in
+// HBM and f32 accumulators / slabs; the dy and x tiles are rounded to bf16 on their way into LDS ([pixel][channel], 192-byte
+// rows: conflict-free for the transposed read) and the MFMA operands -- 8 consecutive PIXELS of one channel per lane --
+// are fetched with ds_read_b64_tr_b16, the gfx950 transposing LDS read (4 pixel rows x 16 channels per 16-lane group).
+// K step = one 4x8 patch = two 32x32x16 MFMAs per tap (sub-step ks covers patch rows 2ks, 2ks+1; lane half h = the row).
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+constexpr int LDT = 96;        // LDS row stride in bf16 elements (64 channels + 32 pad = 192 bytes)
+
+// fragment of a 32x32x16 operand: rows row0..row0+7 of `tile` (k), columns col0 + (lane & 31) (the M / N index)
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int row0, int col0, int lane) {
+    const int q = (lane & 15) >> 2, p4 = (lane & 3) * 4, g16 = ((lane >> 4) & 1) * 16;
+    const __bf16* a0 = tile + (row0 + q) * LDT + col0 + g16 + p4;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * LDT));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const WgradParams p) {
+    constexpr int BT = 64, CHUNKS = 16, RPP = 16;
+    __shared__ __attribute__((aligned(16))) __bf16 Ys[PH * PW * LDT];
+    __shared__ __attribute__((aligned(16))) __bf16 Xs[HPIX * LDT];
+    __shared__ float bias_red[256 * 4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int per_split = p.tiles_co * p.tiles_ci;
+    const int nblk = per_split * p.nsplit;
+    int lid = xcd_swizzle(blockIdx.x, nblk);
+    const int split = lid / per_split;
+    lid -= split * per_split;
+    const int tile_ci = lid % p.tiles_ci, tile_co = lid / p.tiles_ci;
+    const int co0 = tile_co * BT, ci0 = tile_ci * BT;
+    const int npw = (p.Wo + PW - 1) / PW, nph = (p.Ho + PH - 1) / PH;
+    const int per_img = npw * nph;
+    const int npatch = per_img * (p.M / (p.Ho * p.Wo));
+    const int pb = split * p.m_per_split;
+    const int pe = min(npatch, pb + p.m_per_split);
+
+    const int chunk = tid % CHUNKS, prow = tid / CHUNKS;
+    const bool y_col_ok = co0 + chunk * 4 < p.ldy;
+    const bool x_col_ok = ci0 + chunk * 4 < p.Ci;
+    const bool do_bias = p.bias_slab != nullptr && tile_ci == 0;
+    const unsigned y_col = (unsigned)(co0 + chunk * 4) * 4u, x_col = (unsigned)(ci0 + chunk * 4) * 4u;
+    const unsigned ldy4 = (unsigned)p.ldy * 4u, ci4 = (unsigned)p.Ci * 4u;
+
+    const __amdgpu_buffer_rsrc_t srd_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
+
+    int ypy[2], ypx[2], xhy[4], xhx[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int q = prow + RPP * j; ypy[j] = q / PW; ypx[j] = q % PW; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int q = prow + RPP * j; xhy[j] = q / HW; xhx[j] = q % HW; }
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ry[2], rx[4];
+
+    auto issue_loads = [&](int patch) {
+        const int n = patch / per_img, rem = patch - n * per_img;
+        const int oh0 = (rem / npw) * PH, ow0 = (rem % npw) * PW;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int oh = oh0 + ypy[j], ow = ow0 + ypx[j];
+            const bool ok = y_col_ok && oh < p.Ho && ow < p.Wo;
+            const unsigned v = ok ? (unsigned)((n * p.Ho + oh) * p.Wo + ow) * ldy4 + y_col : OOB;
+            ry[j] = buf_load16(srd_y, v, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ih = oh0 + xhy[j] - 1, iw = ow0 + xhx[j] - 1;
+            const bool ok = x_col_ok && (prow + RPP * j) < HPIX && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            const unsigned v = ok ? (unsigned)((n * p.H + ih) * p.W + iw) * ci4 + x_col : OOB;
+            rx[j] = buf_load16(srd_x, v, 0);
+        }
+    };
+    auto to_bf16 = [](const f32x4 v) { return bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]}; };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            *reinterpret_cast<bf16x4*>(&Ys[(prow + RPP * j) * LDT + chunk * 4]) = to_bf16(ry[j]);
+            if (do_bias) bsum += ry[j];                       // bias gradient from the unrounded values
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (prow + RPP * j < HPIX) *reinterpret_cast<bf16x4*>(&Xs[(prow + RPP * j) * LDT + chunk * 4]) = to_bf16(rx[j]);
+    };
+
+    if (pb < pe) {
+        issue_loads(pb);
+        store_tile();
+        __syncthreads();
+        for (int patch = pb; patch < pe; ++patch) {
+            const bool more = patch + 1 < pe;
+            if (more) issue_loads(patch + 1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                // k = 8*lh + j  <->  patch pixel (py = 2ks + lh, px = j)
+                const bf16x8 a = tr_frag(Ys, (2 * ks + lh) * PW, wm * 32, lane);
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int s2 = 0; s2 < 3; ++s2) {
+                        const bf16x8 b = tr_frag(Xs, (2 * ks + lh + r) * HW + s2, wn * 32, lane);
+                        acc[r * 3 + s2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[r * 3 + s2], 0, 0, 0);
+                    }
+            }
+            __syncthreads();
+            if (more) {
+                store_tile();
+                __syncthreads();
+            }
+        }
+    }
+
+    float* slab = p.slab + (size_t)split * p.Co * 9 * p.Ci;
+    const int ci = ci0 + wn * 32 + lr;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int co = co0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+            if (co < p.Co && ci < p.Ci) slab[((size_t)co * 9 + t) * p.Ci + ci] = acc[t][q];
+        }
+    if (do_bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bias_red[tid * 4 + e] = bsum[e];
+        __syncthreads();
+        if (tid < CHUNKS) {
+            f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < RPP; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tot[e] += bias_red[(q * CHUNKS + tid) * 4 + e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = co0 + tid * 4 + e;
+                if (co < p.Co) p.bias_slab[(size_t)split * p.Co + co] = tot[e];
+            }
+        }
+    }
+}
+
 // out_oihw[co][ci][t] = sum_split slab[split][co][t][ci].  The split loop is unrolled into eight independent
 // partial sums (loads in flight instead of one dependent load per ~1 us); the association order is fixed, so
 // the result stays bitwise reproducible.
@@ -410,7 +564,7 @@ struct WgradPlan {
 
 int g_force_fused = -1;          // tuning aid: 0 = never use the fused 3x3 kernel, 1 = whenever applicable
 
-WgradPlan plan_wgrad(const ssd_conv_geom* g) {
+WgradPlan plan_wgrad(const ssd_conv_geom* g, bool bf16 = false) {
     WgradPlan pl;
     const int T = g->R * g->S;
     const int M = g->N * g->Ho * g->Wo;
@@ -418,7 +572,7 @@ WgradPlan plan_wgrad(const ssd_conv_geom* g) {
     // below ~30 pixels per side the 4x8 patch grid wastes >= 25 % of the MFMAs (19x19 -> 5x3 patches) and the
     // 128-wide kernel is as fast, so small maps keep the old path unless forced.
     pl.fused = g->R == 3 && g->S == 3 && g->stride == 1 && g->dil == 1 && g->pad == 1 && g_force_fused != 0 &&
-               (g_force_fused == 1 || (g->Ho >= 30 && g->Wo >= 30));
+               (g_force_fused == 1 || bf16 || (g->Ho >= 30 && g->Wo >= 30));   // bf16: the fused kernel is 6x the f32 rate, patch waste is irrelevant
     if (pl.fused) {
         pl.bt = 64; pl.nbuf = 1;
         pl.tiles_co = ssd_cdiv(g->Co, 64);
@@ -471,17 +625,18 @@ WgradPlan plan_wgrad(const ssd_conv_geom* g) {
 
 extern "C" size_t ssd_conv2d_wgrad_workspace(const ssd_conv_geom* g) {
     if (g == nullptr) return 0;
-    const WgradPlan pl = plan_wgrad(g);
-    return (pl.slab_floats + pl.bias_floats) * sizeof(float) + 256;
+    const WgradPlan a = plan_wgrad(g, false), b = plan_wgrad(g, true);       // covers both entry points
+    const size_t fa = a.slab_floats + a.bias_floats, fb = b.slab_floats + b.bias_floats;
+    return (fa > fb ? fa : fb) * sizeof(float) + 256;
 }
 
-extern "C" int ssd_conv2d_wgrad(const float* x, const float* dy, int ldy, float* dw_oihw, float* dbias,
-                                const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream) {
+static int conv2d_wgrad_impl(const float* x, const float* dy, int ldy, float* dw_oihw, float* dbias,
+                             const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream, bool bf16) {
     if (!g || !x || !dy || !dw_oihw || !workspace) return SSD_ERR_NULL;
     if (g->Ci % 4 != 0 || ldy % 4 != 0 || ldy < g->Co) return SSD_ERR_BAD_SHAPE;
     if (!ssd_aligned16(x) || !ssd_aligned16(dy) || !ssd_aligned16(workspace)) return SSD_ERR_ALIGN;
-    if (workspace_bytes < ssd_conv2d_wgrad_workspace(g)) return SSD_ERR_WORKSPACE;
-    const WgradPlan pl = plan_wgrad(g);
+    const WgradPlan pl = plan_wgrad(g, bf16);
+    if (workspace_bytes < (pl.slab_floats + pl.bias_floats) * sizeof(float) + 256) return SSD_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     WgradParams p{};
     p.x = x; p.dy = dy;
@@ -498,7 +653,9 @@ extern "C" int ssd_conv2d_wgrad(const float* x, const float* dy, int ldy, float*
     p.tiles_co = pl.tiles_co; p.tiles_ci = pl.tiles_ci;
     const int T = g->R * g->S;
     const int nblk = T * pl.tiles_co * pl.tiles_ci * pl.nsplit;
-    if (pl.fused) {
+    if (pl.fused && bf16) {
+        hipLaunchKernelGGL(wgrad3x3_bf16_kernel, dim3(pl.tiles_co * pl.tiles_ci * pl.nsplit), dim3(256), 0, st, p);
+    } else if (pl.fused) {
         hipLaunchKernelGGL(wgrad3x3_kernel, dim3(pl.tiles_co * pl.tiles_ci * pl.nsplit), dim3(256), 0, st, p);
     } else if (pl.bt == 128) {
         if (pl.nbuf == 2) hipLaunchKernelGGL((wgrad_kernel<128, 2>), dim3(nblk), dim3(256), 0, st, p);
@@ -535,4 +692,15 @@ extern "C" int ssd_tune_set_wgrad(int bt, int nbuf, int blocks_per_cu) {
     g_force_wnbuf = nbuf;
     g_force_blocks_per_cu = blocks_per_cu;
     return SSD_OK;
+}
+
+extern "C" int ssd_conv2d_wgrad(const float* x, const float* dy, int ldy, float* dw_oihw, float* dbias,
+                                const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream) {
+    return conv2d_wgrad_impl(x, dy, ldy, dw_oihw, dbias, g, workspace, workspace_bytes, stream, false);
+}
+// bf16-operand weight gradient: the fused nine-tap kernel multiplies bf16-rounded tiles (f32 accumulate);
+// layers the fused kernel does not take (small maps, 1x1, dilated, strided) still run the f32 kernels.
+extern "C" int ssd_conv2d_wgrad_bf16(const float* x, const float* dy, int ldy, float* dw_oihw, float* dbias,
+                                     const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream) {
+    return conv2d_wgrad_impl(x, dy, ldy, dw_oihw, dbias, g, workspace, workspace_bytes, stream, true);
 }

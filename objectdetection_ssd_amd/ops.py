@@ -149,7 +149,7 @@ def workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:
     return buf
 
 
-def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, g: ConvGeom, ldy: int, want_bias: bool = True):
+def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, g: ConvGeom, ldy: int, want_bias: bool = True, bf16: bool = False):
     """-> (dw (Co,Ci,R,S) OIHW, dbias (Co,) or None)."""
     _req(x, "x"); _req(dy, "dy")
     if tuple(x.shape) != (g.N, g.H, g.W, g.Ci):
@@ -161,8 +161,9 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, g: ConvGeom, ldy: int, want_
     ws = workspace(nbytes, x.device)
     dw = torch.empty((g.Co, g.Ci, g.R, g.S), device=x.device, dtype=torch.float32)
     db = torch.empty((g.Co,), device=x.device, dtype=torch.float32) if want_bias else None
-    check(lib.ssd_conv2d_wgrad(x.data_ptr(), dy.data_ptr(), ldy, dw.data_ptr(), _ptr(db), C.byref(g), ws.data_ptr(),
-                               ws.numel(), _stream()), "conv2d_wgrad")
+    fn = lib.ssd_conv2d_wgrad_bf16 if bf16 else lib.ssd_conv2d_wgrad
+    check(fn(x.data_ptr(), dy.data_ptr(), ldy, dw.data_ptr(), _ptr(db), C.byref(g), ws.data_ptr(), ws.numel(), _stream()),
+          "conv2d_wgrad")
     return dw, db
 
 

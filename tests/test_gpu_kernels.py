@@ -283,7 +283,7 @@ def test_conv_bf16_operand_variant(case):
     n, h, w, ci, co, k, s, p, d = case
     dev = _dev()
     x, wt, b = _conv_data(case, seed=31)
-    xr, wr = x.bfloat16().float().requires_grad_(True), wt.bfloat16().float()
+    xr, wr = x.bfloat16().float().requires_grad_(True), wt.bfloat16().float().requires_grad_(True)
     y = F.conv2d(xr, wr, b, stride=s, padding=p, dilation=d)
     dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(32)).bfloat16().float()
     y.backward(dy)
@@ -301,6 +301,17 @@ def test_conv_bf16_operand_variant(case):
             _close(dx, _nhwc(xr.grad), tol=2e-5, what=f"bf16 dgrad tile {tile} {case}")
     finally:
         lib.ssd_tune_set_igemm_bf16(-1)
+    # weight gradient: bf16 fused nine-tap kernel where it applies (every 3x3 s1 p1 layer), f32 kernels elsewhere
+    dw, db = ops.conv2d_wgrad(_nhwc(x).to(dev), dy_p.to(dev), g, ld, True, bf16=True)
+    fused = k == 3 and s == 1 and p == 1 and d == 1          # in bf16 mode every such layer takes the fused kernel
+    ref_dw = wr.grad if fused else None
+    if ref_dw is None:                                    # f32 path: unrounded x
+        x2 = x.clone().requires_grad_(False)
+        w2 = wt.clone().requires_grad_(True)
+        F.conv2d(x2, w2, b, stride=s, padding=p, dilation=d).backward(dy)
+        ref_dw = w2.grad
+    _close(dw, ref_dw, tol=1e-4, what=f"bf16-mode wgrad {case}")
+    _close(db, dy.sum(dim=(0, 2, 3)), tol=1e-4, what=f"bf16-mode bias grad {case}")
     full = F.conv2d(x, wt, b, stride=s, padding=p, dilation=d)
     rel = float((yd[..., :co].cpu() - _nhwc(full)).norm() / _nhwc(full).norm())
     assert 1e-4 < rel < 2e-2, rel             # it really is bf16 arithmetic, and no worse than bf16
