@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-launch table to stderr")
-    ap.add_argument("--conv-dtype", default="f32", choices=("f32", "bf16"),
+    ap.add_argument("--conv-dtype", default="f32", choices=("f32", "f32x3", "bf16"),
                     help="bf16 = BASELINE configs[2] (bf16-operand fwd/dgrad convs, f32 accumulate); not the headline bench line")
     ap.add_argument("--variant", type=int, default=300, choices=(300, 512), help="512 = build-defined SSD512 (not a bench line)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -166,7 +166,8 @@ def main():
     out = {"metric": "images/sec SSD300-VGG16 train step", "value": round(ips, 2), "unit": "images/sec",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32" if args.conv_dtype == "f32" else "bf16 operands (fwd+dgrad convs), f32 accumulate / wgrad / loss", "data": "synthetic",
+           "dtype": {"f32": "f32", "f32x3": "f32 (fwd/dgrad products from three bf16 limbs per operand, f32 accumulate)",
+                     "bf16": "bf16 operands (convs), f32 accumulate / loss"}[args.conv_dtype], "data": "synthetic",
            "config": {"workload": ("" if args.variant == 300 else "[build-defined SSD512, FLOP figures below are the SSD300 ones] ") +
                                   f"SSD300-VGG16 train step (fwd + MultiBox loss + bwd + all-reduce + SGD), "
                                   f"batch {bs}/GPU, 300x300x3, 21 classes, 8732 priors (BASELINE configs[1])",

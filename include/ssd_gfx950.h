@@ -82,6 +82,18 @@ int ssd_conv2d_wgrad_bf16(const float* x, const float* dy, int ldy, float* dw_oi
                           const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream);
 int ssd_tune_set_igemm_bf16(int tile);   /* 0 = 256x128, 1 = 128x128, 2 = 128x64, 3 = 64x64, -1 = automatic */
 
+/* "f32 from three bf16 limbs" variants (opt-in: Model.SSD_300.conv_dtype = "f32x3"): every operand is split exactly
+ * into hi + mid + lo bf16 limbs (8+8+8 significant bits); a product block is the six limb products of weight >= 2^-16
+ * on the bf16 MFMA with f32 accumulation (dropped terms <= 2^-24 relative).  Weights are passed pre-split:
+ * ssd_weight_split_bf16x3 writes three bf16 planes [3][n] from an f32 array of n elements (the OHWI / IHWO layouts
+ * above); w_rows = rows of the OHWI layout (>= Co). */
+int ssd_weight_split_bf16x3(const float* w, void* planes_bf16, size_t n, void* stream);
+int ssd_conv2d_fwd_x3(const float* x, const void* w3_ohwi, int w_rows, const float* bias, float* y, int ldy,
+                      const ssd_conv_geom* g, int relu, void* stream);
+int ssd_conv2d_dgrad_x3(const float* dy, int ldy, const void* w3_ihwo, int Co_pad, float* dx,
+                        const float* relu_mask, int accumulate, const ssd_conv_geom* g, void* stream);
+int ssd_tune_set_igemm_x3(int tile);     /* 1 = 128x128, 2 = 128x64, 3 = 64x64, -1 = automatic */
+
 /* dw_oihw[n][c][r][s] = sum_m dy[m][n] * x[pix(m,tap)][c];  dbias[n] = sum_m dy[m][n]
  * (dbias may be NULL).  Deterministic: split-K partial slabs in `workspace`, then a
  * fixed-order reduction. */

@@ -131,7 +131,8 @@ class _Engine:
             self.consumers[op["x"]] = self.consumers.get(op["x"], 0) + 1
         self.relu_out = {op["y"] for op in self.ops if op["op"] == "conv_first" or (op["op"] == "conv" and op["relu"])}
         self.prof = None          # bench.py: list collecting (label, kernel tag, flops, start event, end event)
-        self.bf16 = False         # True: forward / dgrad convolutions multiply bf16-rounded operands (f32 accumulate)
+        self.bf16 = False         # True: forward / dgrad / fused-wgrad convolutions multiply bf16-rounded operands (f32 accumulate)
+        self.x3 = False           # True: forward / dgrad convolutions form f32 products from three bf16 limbs per operand
 
     def _timed(self, label, tag, flops, fn):
         """Run fn(); when profiling, bracket it with HIP events on the current stream."""
@@ -156,6 +157,14 @@ class _Engine:
             self._wcache[key] = ent
         if need_bwd and ent[3] is None:
             ent[3] = ops.weight_ihwo(ent[1], co_pad)
+        if self.x3:                                   # pre-split limb planes of the layouts in use
+            if len(ent) == 4:
+                ent += [None, None]
+            if ent[4] is None:
+                ent[4] = ops.weight_split3(ent[2])
+            if need_bwd and ent[5] is None:
+                ent[5] = ops.weight_split3(ent[3])
+            return ent[4], ent[5]
         return ent[2], ent[3]
 
     # -- forward ----------------------------------------------------------------------------
@@ -185,7 +194,7 @@ class _Engine:
                     ent = [sig, None, ops.first_weight_rows(wkey), None]
                     self._wcache[op["p"]] = ent
                 bias = P[op["p"] + ".bias"].detach()
-                T[op["y"]] = self._timed("fwd " + op["p"], ops.igemm_tile(g, 0, self.bf16) if self.prof is not None else "", 2.0 * bs * g.Ho * g.Wo * 64 * 27,
+                T[op["y"]] = self._timed("fwd " + op["p"], ops.igemm_tile(g, 0, self.bf16, self.x3) if self.prof is not None else "", 2.0 * bs * g.Ho * g.Wo * 64 * 27,
                                          lambda: ops.conv2d_fwd(col, ent[2], bias, g, True, bf16=self.bf16))
                 T["x_col"] = col
                 aux[op["y"]] = g
@@ -194,8 +203,9 @@ class _Engine:
                 g = ops.make_geom(bs, xin.shape[1], xin.shape[2], op["ci"], op["co"], op["k"], op["s"], op["pad"], op["dil"])
                 wf, _ = self._layouts(op["p"], (P[op["p"] + ".weight"],), op["co"], False)
                 bias = P[op["p"] + ".bias"].detach()
-                T[op["y"]] = self._timed("fwd " + op["p"], ops.igemm_tile(g, 0, self.bf16) if self.prof is not None else "", ops.conv_flops(g),
-                                         lambda: ops.conv2d_fwd(xin, wf, bias, g, op["relu"], bf16=self.bf16))
+                T[op["y"]] = self._timed("fwd " + op["p"], ops.igemm_tile(g, 0, self.bf16, self.x3) if self.prof is not None else "", ops.conv_flops(g),
+                                         lambda: ops.conv2d_fwd_x3(xin, wf, bias, g, op["relu"]) if self.x3 else
+                                         ops.conv2d_fwd(xin, wf, bias, g, op["relu"], bf16=self.bf16))
                 aux[op["y"]] = g
             elif kind == "pool":
                 y, am = ops.maxpool_fwd(T[op["x"]], op["k"], op["s"], op["pad"], op["ceil"], want_argmax=save)
@@ -211,8 +221,9 @@ class _Engine:
                 pre = op["p"]
                 wf, _ = self._layouts(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]), ops.pad32(co), False)
                 bias = torch.cat((P[pre + "_bb.bias"].detach(), P[pre + "_cl.bias"].detach()))
-                packed = self._timed("fwd " + pre, ops.igemm_tile(g, 0, self.bf16) if self.prof is not None else "", ops.conv_flops(g),
-                                     lambda: ops.conv2d_fwd(xin, wf, bias, g, False, ld=ops.pad32(co), bf16=self.bf16))
+                packed = self._timed("fwd " + pre, ops.igemm_tile(g, 0, self.bf16, self.x3) if self.prof is not None else "", ops.conv_flops(g),
+                                     lambda: ops.conv2d_fwd_x3(xin, wf, bias, g, False, ld=ops.pad32(co)) if self.x3 else
+                                     ops.conv2d_fwd(xin, wf, bias, g, False, ld=ops.pad32(co), bf16=self.bf16))
                 heads.append((op, packed, g))
         P_total = sum(g.Ho * g.Wo * op["a"] for op, _, g in heads)
         loc = torch.empty((bs, P_total, 4), device=x.device, dtype=torch.float32)
@@ -259,8 +270,9 @@ class _Engine:
                     grads[pre + "_bb.bias"], grads[pre + "_cl.bias"] = db[:a4], db[a4:]
                 _, wb = self._layouts(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]), co_pad, True)
                 deliver(op["x"], lambda dx, acc, mask: self._timed(
-                    "dgrad " + pre, ops.igemm_tile(g, 1, self.bf16) if self.prof is not None else "", ops.conv_flops(g),
-                    lambda: ops.conv2d_dgrad(dy, wb, g, dx, mask, acc, bf16=self.bf16)))
+                    "dgrad " + pre, ops.igemm_tile(g, 1, self.bf16, self.x3) if self.prof is not None else "", ops.conv_flops(g),
+                    lambda: ops.conv2d_dgrad_x3(dy, wb, g, dx, mask, acc) if self.x3 else
+                    ops.conv2d_dgrad(dy, wb, g, dx, mask, acc, bf16=self.bf16)))
             elif kind == "conv":
                 dy = G.pop(op["y"])
                 g = aux[op["y"]]
@@ -271,8 +283,9 @@ class _Engine:
                     grads[op["p"] + ".weight"], grads[op["p"] + ".bias"] = dw, db
                 _, wb = self._layouts(op["p"], (P[op["p"] + ".weight"],), op["co"], True)
                 deliver(op["x"], lambda dx, acc, mask: self._timed(
-                    "dgrad " + op["p"], ops.igemm_tile(g, 1, self.bf16) if self.prof is not None else "", ops.conv_flops(g),
-                    lambda: ops.conv2d_dgrad(dy, wb, g, dx, mask, acc, bf16=self.bf16)))
+                    "dgrad " + op["p"], ops.igemm_tile(g, 1, self.bf16, self.x3) if self.prof is not None else "", ops.conv_flops(g),
+                    lambda: ops.conv2d_dgrad_x3(dy, wb, g, dx, mask, acc) if self.x3 else
+                    ops.conv2d_dgrad(dy, wb, g, dx, mask, acc, bf16=self.bf16)))
             elif kind == "pool":
                 dy = G.pop(op["y"])
                 xin = T[op["x"]]
@@ -366,13 +379,17 @@ class SSD_300(nn.Module):
         """"f32" (default: exact-f32 MFMA, the reference's precision) or "bf16" (BASELINE configs[2]: forward and
         data-gradient convolutions on the bf16 MFMA with f32 accumulation; weight gradients, loss and everything
         else stay f32)."""
-        return "bf16" if self._engine.bf16 else "f32"
+        return "bf16" if self._engine.bf16 else ("f32x3" if self._engine.x3 else "f32")
 
     @conv_dtype.setter
     def conv_dtype(self, value: str) -> None:
-        if value not in ("f32", "bf16"):
-            raise ValueError("conv_dtype must be 'f32' or 'bf16'")
+        """"f32x3": forward / dgrad products formed from three exact bf16 limbs per f32 operand (six bf16 MFMAs per
+        block, f32 accumulate): f32-accurate (measured against f64: not worse than the exact-f32 MFMA kernels)."""
+        if value not in ("f32", "bf16", "f32x3"):
+            raise ValueError("conv_dtype must be 'f32', 'f32x3' or 'bf16'")
         self._engine.bf16 = value == "bf16"
+        self._engine.x3 = value == "f32x3"
+        self._engine._wcache.clear()
 
     def get_norm(self):
         return torch.norm(self.fc6) + torch.norm(self.fc6_b) + torch.norm(self.fc7) + torch.norm(self.fc7_b)

@@ -417,6 +417,239 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// "f32 from bf16 limbs" variant (opt-in, conv_dtype = "f32x3"): every f32 operand is split EXACTLY into three bf16
+// limbs x = hi + mid + lo (8 + 8 + 8 significant bits) and a product block is formed from the six limb products
+// whose weight is >= 2^-16 (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid) on v_mfma_f32_32x32x16_bf16 with f32
+// accumulation; the dropped terms (mid*lo, lo*mid, lo*lo) are <= 2^-24 relative, i.e. at f32 rounding level.
+// Six bf16 MFMAs cost 6/16 of one f32 MFMA block.  The activation tile is split on its way into LDS (VALU),
+// the weights arrive pre-split (three bf16 planes, ssd_weight_split_bf16x3).
+// ---------------------------------------------------------------------------------------------
+struct X3Params {
+    IgemmParams g;
+    const __bf16* __restrict__ w3;      // [3][Nrows_alloc][T][Ca] bf16 limb planes of the weights
+    unsigned plane_bytes;               // bytes of one plane
+};
+
+__device__ __forceinline__ void split3(const f32x4 v, bf16x4& hi, bf16x4& mid, bf16x4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 h = (__bf16)v[e];
+        const float r1 = v[e] - (float)h;          // exact: the difference fits in 16 significant bits
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;            // exact, <= 8 significant bits
+        hi[e] = h; mid[e] = m; lo[e] = (__bf16)r2;
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_x3_kernel(const X3Params q) {
+    const IgemmParams& p = q.g;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;
+    constexpr int PLANE_A = BM * LDH, PLANE_B = BN * LDH;
+    static_assert(WM * WN == 4, "4 waves");
+    __shared__ __attribute__((aligned(16))) __bf16 lds[3 * (PLANE_A + PLANE_B)];
+    __bf16* const As = lds;                         // [3][BM][LDH]
+    __bf16* const Bs = lds + 3 * PLANE_A;           // [3][BN][LDH]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int lid = xcd_swizzle(blockIdx.x, nblk);
+    const int tile_m = lid / p.tiles_n, tile_n = lid % p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int chunk = tid & 7, row0 = tid >> 3;
+
+    const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(q.w3), 0, (int)(3u * q.plane_bytes), 0x00020000);
+
+    int a_h[A_ROWS], a_w[A_ROWS];
+    unsigned a_base[A_ROWS], voff_a[A_ROWS];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int j = 0; j < A_ROWS; ++j) {
+        const int m = m0 + row0 + 32 * j;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int n = mm / HoWo, rem = mm - n * HoWo;
+        const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+        a_h[j] = ok ? oh * p.sm + p.off : -(1 << 24);
+        a_w[j] = ow * p.sm + p.off;
+        a_base[j] = (unsigned)n * (unsigned)(p.Ha * p.Wa * p.Ca) * 4u + chunk * 16u;
+    }
+    const int T = p.R * p.S;
+    unsigned voff_b[B_ROWS];
+#pragma unroll
+    for (int j = 0; j < B_ROWS; ++j) {
+        const int n = n0 + row0 + 32 * j;
+        voff_b[j] = n < p.Nrows ? ((unsigned)n * (unsigned)(T * p.Ca)) * 2u + chunk * 8u : OOB;      // bf16 planes: 2 bytes / element
+    }
+    auto tap_offsets = [&](int r, int s) {
+        const int dh = r * p.dstep, dw = s * p.dstep;
+#pragma unroll
+        for (int j = 0; j < A_ROWS; ++j) {
+            int th = a_h[j] + dh, tw = a_w[j] + dw;
+            bool ok = th >= 0 && tw >= 0;
+            if (p.sd > 1) {
+                ok = ok && (th % p.sd == 0) && (tw % p.sd == 0);
+                th /= p.sd;
+                tw /= p.sd;
+            }
+            ok = ok && th < p.Ha && tw < p.Wa;
+            voff_a[j] = ok ? a_base[j] + (unsigned)((th * p.Wa + tw) * p.Ca) * 4u : OOB;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int kc = p.Ca / BK;
+    const int KT = T * kc;
+    f32x4 ra[A_ROWS];
+    bf16x4 rb[3][B_ROWS];
+    int c_nxt = 0, r_nxt = 0, s_nxt = 0;
+    unsigned soff_a = 0, soff_b = 0;
+    tap_offsets(0, 0);
+    auto issue_loads = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_ROWS; ++j) ra[j] = buf_load16(srd_a, voff_a[j], soff_a);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int j = 0; j < B_ROWS; ++j)
+                rb[pl][j] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(srd_w, (int)voff_b[j], (int)(soff_b + pl * q.plane_bytes), 0));
+        soff_a += BK * 4;
+        soff_b += BK * 2;
+        if (++c_nxt == kc) {
+            c_nxt = 0;
+            soff_a = 0;
+            if (++s_nxt == p.S) { s_nxt = 0; ++r_nxt; }
+            tap_offsets(r_nxt, s_nxt);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_ROWS; ++j) {
+            bf16x4 hi, mid, lo;
+            split3(ra[j], hi, mid, lo);
+            const int o = (row0 + 32 * j) * LDH + chunk * 4;
+            *reinterpret_cast<bf16x4*>(&As[o]) = hi;
+            *reinterpret_cast<bf16x4*>(&As[PLANE_A + o]) = mid;
+            *reinterpret_cast<bf16x4*>(&As[2 * PLANE_A + o]) = lo;
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int j = 0; j < B_ROWS; ++j)
+                *reinterpret_cast<bf16x4*>(&Bs[pl * PLANE_B + (row0 + 32 * j) * LDH + chunk * 4]) = rb[pl][j];
+    };
+
+    const int lr = lane & 31, lh = lane >> 5;
+    const __bf16* a_rd = As + (wm * TM * 32 + lr) * LDH + lh * 8;
+    const __bf16* b_rd = Bs + (wn * TN * 32 + lr) * LDH + lh * 8;
+
+    issue_loads();
+    store_tile();
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const bool more = kt + 1 < KT;
+        if (more) issue_loads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[3][TM], bf[3][TN];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[pl][i] = *reinterpret_cast<const bf16x8*>(a_rd + pl * PLANE_A + i * 32 * LDH + ks * 16);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8*>(b_rd + pl * PLANE_B + j * 32 * LDH + ks * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    // smallest terms first; limb index sum <= 2
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (more) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + lr;
+            const bool n_ok = n < p.Nout;
+            const float bv = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (n_ok && m < p.M) {
+                    const size_t idx = (size_t)m * p.ldo + n;
+                    float v = acc[i][j][r] + bv;
+                    if (p.accumulate) v += p.out[idx];
+                    if (p.relu) v = v < 0.f ? 0.f : v;
+                    if (p.mask != nullptr) v = p.mask[idx] > 0.f ? v : 0.f;
+                    p.out[idx] = v;
+                }
+            }
+        }
+    }
+}
+
+int g_x3_tile = -1;          // tuning aid: 1 = 128x128, 2 = 128x64, 3 = 64x64; -1 = automatic
+
+template <int BM, int BN, int WM, int WN>
+int launch_igemm_x3(X3Params& q, hipStream_t st) {
+    q.g.tiles_m = ssd_cdiv(q.g.M, BM);
+    q.g.tiles_n = ssd_cdiv(q.g.Nout, BN);
+    hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN>), dim3(q.g.tiles_m * q.g.tiles_n), dim3(256), 0, st, q);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
+int dispatch_igemm_x3(X3Params& q, hipStream_t st) {
+    int t = g_x3_tile;
+    if (t < 0) {
+        // measured (tools/conv_bench.py x3): 128x128 for the 256/512-channel layers on large maps, 128x64 elsewhere
+        const long b128 = (long)ssd_cdiv(q.g.M, 128) * ssd_cdiv(q.g.Nout, 128);
+        t = (q.g.Nout >= 256 && b128 >= 1000) ? 1 : (q.g.M >= 4096 ? 2 : 3);
+    }
+    switch (t) {
+        case 1: return launch_igemm_x3<128, 128, 2, 2>(q, st);
+        case 2: return launch_igemm_x3<128, 64, 4, 1>(q, st);
+        default: return launch_igemm_x3<64, 64, 2, 2>(q, st);
+    }
+}
+
+__global__ void split_bf16x3_kernel(const float* __restrict__ w, __bf16* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = w[i];
+        const __bf16 h = (__bf16)v;
+        const float r1 = v - (float)h;
+        const __bf16 m = (__bf16)r1;
+        out[i] = h;
+        out[n + i] = m;
+        out[2 * n + i] = (__bf16)(r1 - (float)m);
+    }
+}
+
 int g_bf16_tile = -1;        // tuning aid: 0 = 256x128, 1 = 128x128, 2 = 128x64, 3 = 64x64; -1 = automatic
 
 template <int BM, int BN, int WM, int WN>
@@ -540,5 +773,60 @@ extern "C" int ssd_tune_set_igemm(int tile, int nbuf) {
     if (tile < -1 || tile > 3 || nbuf < -1 || nbuf > 2 || nbuf == 0) return SSD_ERR_BAD_SHAPE;
     g_force_tile = tile;
     g_force_nbuf = nbuf;
+    return SSD_OK;
+}
+
+// ---- "f32 from three bf16 limbs" entry points (opt-in; see igemm_x3_kernel) -----------------------------------
+extern "C" int ssd_weight_split_bf16x3(const float* w, void* planes, size_t n, void* stream) {
+    if (!w || !planes) return SSD_ERR_NULL;
+    if (n == 0) return SSD_OK;
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, w,
+                       reinterpret_cast<__bf16*>(planes), n);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
+extern "C" int ssd_conv2d_fwd_x3(const float* x, const void* w3_ohwi, int w_rows, const float* bias, float* y, int ldy,
+                                 const ssd_conv_geom* g, int relu, void* stream) {
+    if (int e = check_geom(g)) return e;
+    if (!x || !w3_ohwi || !y) return SSD_ERR_NULL;
+    if (g->Ci % 32 != 0 || ldy < g->Co || w_rows < g->Co) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(x) || !ssd_aligned16(w3_ohwi)) return SSD_ERR_ALIGN;
+    X3Params q{};
+    IgemmParams& p = q.g;
+    p.a = x; p.w = nullptr; p.bias = bias; p.out = y; p.mask = nullptr;
+    const size_t ab = (size_t)g->N * g->H * g->W * g->Ci * 4, pb = (size_t)w_rows * g->R * g->S * g->Ci * 2;
+    if (ab >= 0xF0000000ull || 3 * pb >= 0xF0000000ull) return SSD_ERR_BAD_SHAPE;
+    p.a_bytes = (unsigned)ab; q.plane_bytes = (unsigned)pb; q.w3 = reinterpret_cast<const __bf16*>(w3_ohwi);
+    p.Ha = g->H; p.Wa = g->W; p.Ca = g->Ci; p.Ho = g->Ho; p.Wo = g->Wo;
+    p.Nout = g->Co; p.Nrows = g->Co; p.ldo = ldy; p.R = g->R; p.S = g->S;
+    p.sm = g->stride; p.sd = 1; p.off = -g->pad; p.dstep = g->dil;
+    p.M = g->N * g->Ho * g->Wo; p.relu = relu; p.accumulate = 0;
+    return dispatch_igemm_x3(q, (hipStream_t)stream);
+}
+
+extern "C" int ssd_conv2d_dgrad_x3(const float* dy, int ldy, const void* w3_ihwo, int Co_pad, float* dx,
+                                   const float* relu_mask, int accumulate, const ssd_conv_geom* g, void* stream) {
+    if (int e = check_geom(g)) return e;
+    if (!dy || !w3_ihwo || !dx) return SSD_ERR_NULL;
+    if (Co_pad % 32 != 0 || Co_pad < g->Co || ldy != Co_pad || g->Ci % 4 != 0) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(dy) || !ssd_aligned16(w3_ihwo)) return SSD_ERR_ALIGN;
+    X3Params q{};
+    IgemmParams& p = q.g;
+    p.a = dy; p.w = nullptr; p.bias = nullptr; p.out = dx; p.mask = relu_mask;
+    const size_t ab = (size_t)g->N * g->Ho * g->Wo * Co_pad * 4, pb = (size_t)g->Ci * g->R * g->S * Co_pad * 2;
+    if (ab >= 0xF0000000ull || 3 * pb >= 0xF0000000ull) return SSD_ERR_BAD_SHAPE;
+    p.a_bytes = (unsigned)ab; q.plane_bytes = (unsigned)pb; q.w3 = reinterpret_cast<const __bf16*>(w3_ihwo);
+    p.Ha = g->Ho; p.Wa = g->Wo; p.Ca = Co_pad; p.Ho = g->H; p.Wo = g->W;
+    p.Nout = g->Ci; p.Nrows = g->Ci; p.ldo = g->Ci; p.R = g->R; p.S = g->S;
+    p.sm = 1; p.sd = g->stride; p.off = g->pad; p.dstep = -g->dil;
+    p.M = g->N * g->H * g->W; p.relu = 0; p.accumulate = accumulate;
+    return dispatch_igemm_x3(q, (hipStream_t)stream);
+}
+
+extern "C" int ssd_tune_set_igemm_x3(int tile) {
+    if (tile < -1 || tile > 3 || tile == 0) return SSD_ERR_BAD_SHAPE;
+    g_x3_tile = tile;
     return SSD_OK;
 }

@@ -47,7 +47,9 @@ def pad32(c: int) -> int:
     return (c + 31) // 32 * 32
 
 
-def igemm_tile(g: ConvGeom, direction: int, bf16: bool = False) -> str:
+def igemm_tile(g: ConvGeom, direction: int, bf16: bool = False, x3: bool = False) -> str:
+    if x3:
+        return "igemm_x3_kernel"
     if bf16:
         return "igemm_bf16_kernel"
     bm, bn = C.c_int(0), C.c_int(0)
@@ -83,6 +85,54 @@ def weight_ihwo(w_oihw: torch.Tensor, co_pad: Optional[int] = None) -> torch.Ten
     out = torch.empty((ci, r * s, co_pad), device=w_oihw.device, dtype=torch.float32)
     check(_lib.load().ssd_weight_oihw_to_ihwo(w_oihw.data_ptr(), out.data_ptr(), co, ci, r, s, co_pad, _stream()), "weight_ihwo")
     return out
+
+
+def weight_split3(w_layout: torch.Tensor) -> torch.Tensor:
+    """f32 weights in a kernel layout (OHWI / IHWO) -> (3, *shape) bf16 limb planes hi, mid, lo with hi+mid+lo == w exactly"""
+    _req(w_layout, "w_layout")
+    out = torch.empty((3,) + tuple(w_layout.shape), device=w_layout.device, dtype=torch.bfloat16)
+    check(_lib.load().ssd_weight_split_bf16x3(w_layout.data_ptr(), out.data_ptr(), w_layout.numel(), _stream()), "weight_split3")
+    return out
+
+
+def conv2d_fwd_x3(x: torch.Tensor, w3_ohwi: torch.Tensor, bias: Optional[torch.Tensor], g: ConvGeom, relu: bool,
+                  ld: Optional[int] = None) -> torch.Tensor:
+    _req(x, "x"); _req(w3_ohwi, "w3_ohwi", torch.bfloat16)
+    if tuple(x.shape) != (g.N, g.H, g.W, g.Ci):
+        raise ValueError("x shape does not match geometry")
+    if w3_ohwi.dim() != 4 or w3_ohwi.shape[0] != 3 or w3_ohwi.shape[1] < g.Co or w3_ohwi.shape[2] != g.R * g.S or w3_ohwi.shape[3] != g.Ci:
+        raise ValueError("w3_ohwi shape does not match geometry")
+    if bias is not None:
+        _req(bias, "bias")
+    ld = g.Co if ld is None else ld
+    out = torch.empty((g.N, g.Ho, g.Wo, ld), device=x.device, dtype=torch.float32) if ld == g.Co else \
+        torch.zeros((g.N, g.Ho, g.Wo, ld), device=x.device, dtype=torch.float32)
+    check(_lib.load().ssd_conv2d_fwd_x3(x.data_ptr(), w3_ohwi.data_ptr(), int(w3_ohwi.shape[1]), _ptr(bias), out.data_ptr(), ld,
+                                        C.byref(g), int(relu), _stream()), "conv2d_fwd_x3")
+    return out
+
+
+def conv2d_dgrad_x3(dy: torch.Tensor, w3_ihwo: torch.Tensor, g: ConvGeom, dx: Optional[torch.Tensor] = None,
+                    relu_mask: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    _req(dy, "dy"); _req(w3_ihwo, "w3_ihwo", torch.bfloat16)
+    co_pad = w3_ihwo.shape[3]
+    if dy.numel() != g.N * g.Ho * g.Wo * co_pad or w3_ihwo.shape[0] != 3 or w3_ihwo.shape[1] != g.Ci or w3_ihwo.shape[2] != g.R * g.S \
+            or co_pad % 32 != 0:
+        raise ValueError("dgrad_x3 shapes do not match geometry")
+    if dx is None:
+        if accumulate:
+            raise ValueError("accumulate needs an existing dx")
+        dx = torch.empty((g.N, g.H, g.W, g.Ci), device=dy.device, dtype=torch.float32)
+    _req(dx, "dx")
+    if dx.numel() != g.N * g.H * g.W * g.Ci:
+        raise ValueError("dx size")
+    if relu_mask is not None:
+        _req(relu_mask, "relu_mask")
+        if relu_mask.numel() != dx.numel():
+            raise ValueError("relu_mask size")
+    check(_lib.load().ssd_conv2d_dgrad_x3(dy.data_ptr(), co_pad, w3_ihwo.data_ptr(), co_pad, dx.data_ptr(), _ptr(relu_mask),
+                                          int(accumulate), C.byref(g), _stream()), "conv2d_dgrad_x3")
+    return dx
 
 
 # ---- convolution -----------------------------------------------------------------------

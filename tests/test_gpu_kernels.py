@@ -315,3 +315,45 @@ def test_conv_bf16_operand_variant(case):
     full = F.conv2d(x, wt, b, stride=s, padding=p, dilation=d)
     rel = float((yd[..., :co].cpu() - _nhwc(full)).norm() / _nhwc(full).norm())
     assert 1e-4 < rel < 2e-2, rel             # it really is bf16 arithmetic, and no worse than bf16
+
+
+@pytest.mark.parametrize("case", [CONV_CASES[i] for i in (0, 1, 2, 4, 5, 6, 8, 10, 11)])
+def test_conv_f32_from_three_bf16_limbs(case):
+    """"f32x3" kernels: operands split exactly into three bf16 limbs, six limb products per block.  Judged against an f64
+    convolution: the error must be at f32 level -- no worse than 2x the exact-f32 MFMA kernel's own error (+1e-7)."""
+    from objectdetection_ssd_amd import _lib, ops
+    lib = _lib.load()
+    n, h, w, ci, co, k, s, p, d = case
+    dev = _dev()
+    x, wt, b = _conv_data(case, seed=41)
+    x64 = x.double().requires_grad_(True)
+    y64 = F.conv2d(x64, wt.double(), b.double(), stride=s, padding=p, dilation=d)
+    dy = torch.randn(y64.shape, generator=torch.Generator().manual_seed(42))
+    y64.backward(dy.double())
+    g = ops.make_geom(n, h, w, ci, co, k, s, p, d)
+    ld = ops.pad32(co)
+    wf, wb = ops.weight_ohwi(wt.to(dev), ld), ops.weight_ihwo(wt.to(dev), ld)
+    wf3, wb3 = ops.weight_split3(wf), ops.weight_split3(wb)
+    assert torch.equal(wf3.float().sum(0), wf)                     # hi + mid + lo == w exactly
+    dy_p = torch.zeros(n, g.Ho, g.Wo, ld)
+    dy_p[..., :co] = _nhwc(dy)
+    xd, dyd = _nhwc(x).to(dev), dy_p.to(dev)
+    y_f32 = ops.conv2d_fwd(xd, wf, b.to(dev), g, False, ld=ld)[..., :co].cpu().double()
+    dx_f32 = ops.conv2d_dgrad(dyd, wb, g).cpu().double()
+    ref_y, ref_dx = _nhwc(y64.detach()), _nhwc(x64.grad)
+    e_y32 = float((y_f32 - ref_y).norm() / ref_y.norm())
+    e_dx32 = float((dx_f32 - ref_dx).norm() / ref_dx.norm())
+    try:
+        for tile in (-1, 1, 2, 3):
+            assert lib.ssd_tune_set_igemm_x3(tile) == 0
+            y3 = ops.conv2d_fwd_x3(xd, wf3, b.to(dev), g, False, ld=ld)[..., :co].cpu().double()
+            dx3 = ops.conv2d_dgrad_x3(dyd, wb3, g).cpu().double()
+            e_y3 = float((y3 - ref_y).norm() / ref_y.norm())
+            e_dx3 = float((dx3 - ref_dx).norm() / ref_dx.norm())
+            assert e_y3 <= 2 * e_y32 + 1e-7, (tile, e_y3, e_y32)
+            assert e_dx3 <= 2 * e_dx32 + 1e-7, (tile, e_dx3, e_dx32)
+            _close(y3, ref_y, tol=1e-5, what=f"x3 fwd {case}")
+            _close(dx3, ref_dx, tol=1e-5, what=f"x3 dgrad {case}")
+    finally:
+        lib.ssd_tune_set_igemm_x3(-1)
+    print(f"{case}: fwd rel err f32 {e_y32:.2e} x3 {e_y3:.2e}; dgrad f32 {e_dx32:.2e} x3 {e_dx3:.2e}")

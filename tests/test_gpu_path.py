@@ -500,3 +500,33 @@ def test_bf16_conv_mode_config3(golden_net):
     assert torch.equal(a[4], b[4])
     cos = float(torch.dot(a[5], b[5]) / (a[5].norm() * b[5].norm()))
     assert cos > 0.99, cos
+
+
+def test_f32x3_mode_is_f32_accurate(golden_net):
+    """conv_dtype = "f32x3" (three exact bf16 limbs per operand, six bf16 MFMAs per product block, f32 accumulate):
+    the full train step must meet the SAME bars as the exact-f32 path -- golden loc/conf/losses within 1e-4, gradients
+    against the golden f32 reference within 5e-3 relative L2."""
+    from objectdetection_ssd_amd import Losses
+    net, params, z = golden_net
+    bs = int(z["bs"])
+    x = _t(np.random.default_rng(int(z["x_seed"])).standard_normal((bs, 3, 300, 300), dtype=np.float32))
+    boxes, classes = synth_gt(np.random.default_rng(int(z["gt_seed"])), bs)
+    net.train()
+    try:
+        net.conv_dtype = "f32x3"
+        net.zero_grad()
+        loc, conf = net(x)
+        l1, l2 = Losses.ssd((loc, conf), [_t(c) for c in classes], [_t(b) for b in boxes])
+        (l1 + l2).backward()
+    finally:
+        net.conv_dtype = "f32"
+    idx = z["prior_idx"]
+    for got, ref in ((loc.detach().cpu().numpy()[:, idx], z["loc_s"]), (conf.detach().cpu().numpy()[:, idx], z["conf_s"])):
+        assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    assert abs(l1.item() - float(z["loc_loss"])) <= 1e-4 * max(1, float(z["loc_loss"]))
+    assert abs(l2.item() - float(z["conf_loss"])) <= 1e-4 * max(1, float(z["conf_loss"]))
+    named = dict(net.named_parameters())
+    for k in ("model.features.0.weight", "model.features.21.bias", "c_11_cl.weight", "seq10.2.weight", "rescaling_conv_4_3", "c_4_bb.bias"):
+        ref = z["g_" + k].astype(np.float64)
+        got = named[k].grad.cpu().numpy().astype(np.float64)
+        assert np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-12) <= 5e-3, k

@@ -72,6 +72,19 @@ def main():
                     row.append(f"{lab}:{fl / ms / 1e9:6.1f}")
                 print(f"bf16 {dirn:5s} {name:8s} " + "  ".join(row), flush=True)
             lib.ssd_tune_set_igemm_bf16(-1)
+        if which in ("x3", "all"):
+            wf3, wb3 = ops.weight_split3(wf), ops.weight_split3(wb)
+            for dirn in ("fwd", "dgrad"):
+                row = []
+                for t, lab in ((-1, "auto"), (1, "128x128"), (2, "128x64"), (3, "64x64")):
+                    lib.ssd_tune_set_igemm_x3(t)
+                    if dirn == "fwd":
+                        ms = timeit(lambda: ops.conv2d_fwd_x3(x, wf3, b, g, True, ld=ld))
+                    else:
+                        ms = timeit(lambda: ops.conv2d_dgrad_x3(dy, wb3, g, dx, x, False))
+                    row.append(f"{lab}:{fl / ms / 1e9:6.1f}")
+                print(f"x3   {dirn:5s} {name:8s} " + "  ".join(row), flush=True)
+            lib.ssd_tune_set_igemm_x3(-1)
         if which in ("wgrad", "all"):
             row = []
             for bt, nb, bpc, lab in wg_var:
