@@ -205,9 +205,17 @@ def main():
                 traffic = tj["bytes_per_launch"]
         except Exception:
             pass
-        peak = 2500.0 if "bf16" in tag else PEAK_F32_MFMA_TFLOPS        # dense peak of the dtype the kernel multiplies in
+        # dense peak of the dtype the kernel multiplies in; an f32x3 product costs six bf16 MFMAs, so its ceiling in
+        # algorithmic f32 FLOPs is a sixth of the bf16 peak
+        mfma_f32 = tag.startswith("igemm_kernel") or tag.startswith("wgrad")
+        if args.conv_dtype == "f32" or (mfma_f32 and "bf16" not in tag and not (args.conv_dtype == "bf16" and tag.startswith("wgrad3x3"))):
+            peak, peak_note = PEAK_F32_MFMA_TFLOPS, "f32 MFMA dense"
+        elif args.conv_dtype == "bf16":
+            peak, peak_note = 2500.0, "bf16 MFMA dense"
+        else:
+            peak, peak_note = round(2500.0 / 6, 1), "bf16 MFMA dense / 6 limb products per f32 product"
         out["roofline"] = {"bound": "mfma", "kernel": tag + ", ...>", "achieved": round(ach, 2),
-                           "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                           "peak": peak, "peak_note": peak_note, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                            "traffic": traffic, "traffic_unit": "bytes per launch (profiles/r01_traffic.json)", "launches_timed": n, "avg_launch_ms": round(tsum / n * 1e3, 4),
                            "avg_launch_gflop": round(fsum / n / 1e9, 3),
                            "all_conv_kernels_tflops": round(sum(a[1] for a in agg.values()) / sum(a[0] for a in agg.values()) / 1e12, 2),

@@ -93,6 +93,13 @@ int ssd_conv2d_fwd_x3(const float* x, const void* w3_ohwi, int w_rows, const flo
 int ssd_conv2d_dgrad_x3(const float* dy, int ldy, const void* w3_ihwo, int Co_pad, float* dx,
                         const float* relu_mask, int accumulate, const ssd_conv_geom* g, void* stream);
 int ssd_tune_set_igemm_x3(int tile);     /* 1 = 128x128, 2 = 128x64, 3 = 64x64, -1 = automatic */
+/* bf16-operand halo-tile kernels for 3x3/s1/p1 layers (plane 0 of the split weights); return 1 (not an error) when the
+ * geometry is not a halo case and the caller should use the generic bf16 entry. */
+int ssd_conv3x3_halo_fwd_bf16(const float* x, const void* w3_ohwi, int w_rows, const float* bias, float* y, int ldy,
+                              const ssd_conv_geom* g, int relu, void* stream);
+int ssd_conv3x3_halo_dgrad_bf16(const float* dy, int ldy, const void* w3_ihwo, int Co_pad, float* dx,
+                                const float* relu_mask, int accumulate, const ssd_conv_geom* g, void* stream);
+int ssd_tune_set_halo(int mode);         /* 3x3/s1 halo-tile kernel: 0 = off, 1 = 8x8 patches, 2 = 8x16 patches, -1 = automatic */
 
 /* dw_oihw[n][c][r][s] = sum_m dy[m][n] * x[pix(m,tap)][c];  dbias[n] = sum_m dy[m][n]
  * (dbias may be NULL).  Deterministic: split-K partial slabs in `workspace`, then a

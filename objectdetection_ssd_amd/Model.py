@@ -157,15 +157,23 @@ class _Engine:
             self._wcache[key] = ent
         if need_bwd and ent[3] is None:
             ent[3] = ops.weight_ihwo(ent[1], co_pad)
-        if self.x3:                                   # pre-split limb planes of the layouts in use
+        if self.x3 or self.bf16:                      # pre-split limb planes of the layouts in use
             if len(ent) == 4:
                 ent += [None, None]
             if ent[4] is None:
                 ent[4] = ops.weight_split3(ent[2])
             if need_bwd and ent[5] is None:
                 ent[5] = ops.weight_split3(ent[3])
-            return ent[4], ent[5]
+            if self.x3:
+                return ent[4], ent[5]
         return ent[2], ent[3]
+
+    def _planes(self, key: str, bwd: bool):
+        """bf16 mode: the limb planes of a cached layout (plane 0 feeds the halo-tile kernel); None otherwise."""
+        if not self.bf16:
+            return None
+        ent = self._wcache.get(key)
+        return None if ent is None or len(ent) < 6 else ent[5 if bwd else 4]
 
     # -- forward ----------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, P: Dict[str, torch.Tensor], save: bool):
@@ -205,7 +213,7 @@ class _Engine:
                 bias = P[op["p"] + ".bias"].detach()
                 T[op["y"]] = self._timed("fwd " + op["p"], ops.igemm_tile(g, 0, self.bf16, self.x3) if self.prof is not None else "", ops.conv_flops(g),
                                          lambda: ops.conv2d_fwd_x3(xin, wf, bias, g, op["relu"]) if self.x3 else
-                                         ops.conv2d_fwd(xin, wf, bias, g, op["relu"], bf16=self.bf16))
+                                         ops.conv2d_fwd(xin, wf, bias, g, op["relu"], bf16=self.bf16, w3=self._planes(op["p"], False)))
                 aux[op["y"]] = g
             elif kind == "pool":
                 y, am = ops.maxpool_fwd(T[op["x"]], op["k"], op["s"], op["pad"], op["ceil"], want_argmax=save)
@@ -223,7 +231,7 @@ class _Engine:
                 bias = torch.cat((P[pre + "_bb.bias"].detach(), P[pre + "_cl.bias"].detach()))
                 packed = self._timed("fwd " + pre, ops.igemm_tile(g, 0, self.bf16, self.x3) if self.prof is not None else "", ops.conv_flops(g),
                                      lambda: ops.conv2d_fwd_x3(xin, wf, bias, g, False, ld=ops.pad32(co)) if self.x3 else
-                                     ops.conv2d_fwd(xin, wf, bias, g, False, ld=ops.pad32(co), bf16=self.bf16))
+                                     ops.conv2d_fwd(xin, wf, bias, g, False, ld=ops.pad32(co), bf16=self.bf16, w3=self._planes(pre, False)))
                 heads.append((op, packed, g))
         P_total = sum(g.Ho * g.Wo * op["a"] for op, _, g in heads)
         loc = torch.empty((bs, P_total, 4), device=x.device, dtype=torch.float32)
@@ -272,7 +280,7 @@ class _Engine:
                 deliver(op["x"], lambda dx, acc, mask: self._timed(
                     "dgrad " + pre, ops.igemm_tile(g, 1, self.bf16, self.x3) if self.prof is not None else "", ops.conv_flops(g),
                     lambda: ops.conv2d_dgrad_x3(dy, wb, g, dx, mask, acc) if self.x3 else
-                    ops.conv2d_dgrad(dy, wb, g, dx, mask, acc, bf16=self.bf16)))
+                    ops.conv2d_dgrad(dy, wb, g, dx, mask, acc, bf16=self.bf16, w3=self._planes(pre, True))))
             elif kind == "conv":
                 dy = G.pop(op["y"])
                 g = aux[op["y"]]
@@ -285,7 +293,7 @@ class _Engine:
                 deliver(op["x"], lambda dx, acc, mask: self._timed(
                     "dgrad " + op["p"], ops.igemm_tile(g, 1, self.bf16, self.x3) if self.prof is not None else "", ops.conv_flops(g),
                     lambda: ops.conv2d_dgrad_x3(dy, wb, g, dx, mask, acc) if self.x3 else
-                    ops.conv2d_dgrad(dy, wb, g, dx, mask, acc, bf16=self.bf16)))
+                    ops.conv2d_dgrad(dy, wb, g, dx, mask, acc, bf16=self.bf16, w3=self._planes(op["p"], True))))
             elif kind == "pool":
                 dy = G.pop(op["y"])
                 xin = T[op["x"]]

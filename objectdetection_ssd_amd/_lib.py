@@ -41,6 +41,9 @@ SIGNATURES = {
     "ssd_conv2d_fwd_x3": (_I, [_P, _P, _I, _P, _P, _I, _G, _I, _P]),
     "ssd_conv2d_dgrad_x3": (_I, [_P, _I, _P, _I, _P, _P, _I, _G, _P]),
     "ssd_tune_set_igemm_x3": (_I, [_I]),
+    "ssd_tune_set_halo": (_I, [_I]),
+    "ssd_conv3x3_halo_fwd_bf16": (_I, [_P, _P, _I, _P, _P, _I, _G, _I, _P]),
+    "ssd_conv3x3_halo_dgrad_bf16": (_I, [_P, _I, _P, _I, _P, _P, _I, _G, _P]),
     "ssd_conv2d_wgrad_workspace": (_Z, [_G]),
     "ssd_conv2d_wgrad": (_I, [_P, _P, _I, _P, _P, _G, _P, _Z, _P]),
     "ssd_conv2d_igemm_tile": (_I, [_G, _I, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -613,6 +613,196 @@ __global__ __launch_bounds__(256) void igemm_x3_kernel(const X3Params q) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Halo-tile kernel for the 3x3 / stride 1 / dilation 1 / padding 1 layers (forward AND data gradient: the latter is the
+// same convolution with the taps mirrored).  M tile = a PH x PW patch of output pixels, N tile = BN channels.  Per
+// 32-channel chunk the (PH+2) x (PW+2) input HALO is loaded and split into limb planes ONCE and serves all nine taps
+// (tap = an LDS row offset), so the global A traffic and the limb-splitting VALU work drop 9x against the generic
+// kernel, where they -- not the MFMA -- bound the "f32x3" and bf16 variants.  Only the weight tile (pre-split bf16
+// planes, L2-resident) is re-staged per tap, double-buffered: one barrier per tap, one more per channel chunk.
+// PLANES = 3: "f32x3" (six limb products per block); PLANES = 1: plain bf16 operands (plane 0 = RNE bf16 of the weight).
+// ---------------------------------------------------------------------------------------------
+template <int PH_, int PW_, int BN, int PLANES>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const X3Params q) {
+    const IgemmParams& p = q.g;
+    constexpr int HH_ = PH_ + 2, HW_ = PW_ + 2, HPIX_ = HH_ * HW_, MPIX = PH_ * PW_;
+    constexpr int WM = MPIX / 32, WN = 4 / WM, TN = BN / WN / 32;
+    constexpr int A_LOADS = (HPIX_ + 31) / 32;                  // float4 loads per thread per chunk (8 lanes per halo pixel)
+    constexpr int PLANE_A = HPIX_ * LDH, PLANE_B = BN * LDH;
+    static_assert(WM * WN == 4 && TN >= 1 && BN * 4 == 256, "4 waves; one 16-byte weight load per thread and plane");
+    __shared__ __attribute__((aligned(16))) __bf16 lds[PLANES * PLANE_A + 2 * PLANES * PLANE_B];
+    __bf16* const As = lds;                                      // [PLANES][HPIX][LDH]
+    __bf16* const Bs = lds + PLANES * PLANE_A;                   // [2][PLANES][BN][LDH]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int npw = (p.Wo + PW_ - 1) / PW_, nph = (p.Ho + PH_ - 1) / PH_;
+    const int per_img = npw * nph;
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int lid = xcd_swizzle(blockIdx.x, nblk);
+    const int patch = lid / p.tiles_n, tile_n = lid % p.tiles_n;            // n fastest: neighbours share the halo in L2
+    const int n0 = tile_n * BN;
+    const int img = patch / per_img, prem = patch - img * per_img;
+    const int oh0 = (prem / npw) * PH_, ow0 = (prem % npw) * PW_;
+
+    const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(q.w3), 0, (int)(3u * q.plane_bytes), 0x00020000);
+
+    // ---- A halo: pixel hp = (tid>>3) + 32 j, 16-byte chunk tid&7; offsets are fixed for the whole kernel -------------
+    const int chunk = tid & 7;
+    unsigned voff_a[A_LOADS];
+#pragma unroll
+    for (int j = 0; j < A_LOADS; ++j) {
+        const int hp = (tid >> 3) + 32 * j;
+        const int ih = oh0 - 1 + hp / HW_, iw = ow0 - 1 + hp % HW_;
+        const bool ok = hp < HPIX_ && (unsigned)ih < (unsigned)p.Ha && (unsigned)iw < (unsigned)p.Wa;
+        voff_a[j] = ok ? (unsigned)((img * p.Ha + ih) * p.Wa + iw) * (unsigned)p.Ca * 4u + chunk * 16u : OOB;
+    }
+    // ---- B tile: row n0 + (tid>>2), 8 k values (16 bytes) at chunk tid&3 -------------------------------------------------
+    const int brow = tid >> 2, bchunk = tid & 3;
+    const unsigned voff_b = (n0 + brow) < p.Nrows ? ((unsigned)(n0 + brow) * (unsigned)(9 * p.Ca)) * 2u + bchunk * 16u : OOB;
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    f32x4 ra[A_LOADS];
+    f32x4 rb[PLANES];                                            // 8 bf16 each
+    const int KC = p.Ca / BK, NS = KC * 9;
+    auto issue_a = [&](int kc) {
+#pragma unroll
+        for (int j = 0; j < A_LOADS; ++j) ra[j] = buf_load16(srd_a, voff_a[j], (unsigned)kc * BK * 4);
+    };
+    auto issue_b = [&](int st) {
+        const int kc = st / 9, t = st - kc * 9;
+        const unsigned so = (unsigned)(t * p.Ca + kc * BK) * 2u;
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl) rb[pl] = buf_load16(srd_w, voff_b, so + pl * q.plane_bytes);
+    };
+    auto store_a = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_LOADS; ++j) {
+            const int hp = (tid >> 3) + 32 * j;
+            if (hp < HPIX_) {
+                const int o = hp * LDH + chunk * 4;
+                if constexpr (PLANES == 3) {
+                    bf16x4 hi, mid, lo;
+                    split3(ra[j], hi, mid, lo);
+                    *reinterpret_cast<bf16x4*>(&As[o]) = hi;
+                    *reinterpret_cast<bf16x4*>(&As[PLANE_A + o]) = mid;
+                    *reinterpret_cast<bf16x4*>(&As[2 * PLANE_A + o]) = lo;
+                } else {
+                    *reinterpret_cast<bf16x4*>(&As[o]) = bf16x4{(__bf16)ra[j][0], (__bf16)ra[j][1], (__bf16)ra[j][2], (__bf16)ra[j][3]};
+                }
+            }
+        }
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl)
+            *reinterpret_cast<f32x4*>(&Bs[(buf * PLANES + pl) * PLANE_B + brow * LDH + bchunk * 8]) = rb[pl];
+    };
+
+    // this lane's output pixel inside the patch and its halo row for tap (0,0)
+    const int pix = wm * 32 + lr, py = pix / PW_, px = pix % PW_;
+    const __bf16* a_rd = As + (py * HW_ + px) * LDH + lh * 8;
+    const __bf16* b_rd = Bs + (wn * TN * 32 + lr) * LDH + lh * 8;
+
+    issue_a(0);
+    issue_b(0);
+    store_a();
+    store_b(0);
+    __syncthreads();
+    for (int st = 0; st < NS; ++st) {
+        const int kc = st / 9, t = st - kc * 9;
+        const bool more = st + 1 < NS, new_chunk = t == 8 && kc + 1 < KC;
+        if (more) issue_b(st + 1);
+        if (new_chunk) issue_a(kc + 1);
+        // tap (r,s) reads input (oh + off + r*dstep, ow + off + s*dstep); the halo origin is (oh0-1, ow0-1)
+        const int r = t / 3, s2 = t - r * 3;
+        const int hoff = ((1 + p.off + r * p.dstep) * HW_ + (1 + p.off + s2 * p.dstep)) * LDH;
+        const __bf16* bb = b_rd + (st & 1) * PLANES * PLANE_B;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[PLANES], bf[PLANES][TN];
+#pragma unroll
+            for (int pl = 0; pl < PLANES; ++pl) {
+                af[pl] = *reinterpret_cast<const bf16x8*>(a_rd + pl * PLANE_A + hoff + ks * 16);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8*>(bb + pl * PLANE_B + j * 32 * LDH + ks * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (PLANES == 3) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0][j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2][j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1][j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0][j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1][j], acc[j], 0, 0, 0);
+                }
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0][j], acc[j], 0, 0, 0);
+            }
+        }
+        if (more) store_b((st + 1) & 1);               // other buffer: last read one step ago
+        __syncthreads();
+        if (new_chunk) {
+            store_a();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: this lane's accumulator rows are patch pixels (wm*32 + row) -------------------------------------------
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + lr;
+        const bool n_ok = n < p.Nout;
+        const float bv = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pq = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int oh = oh0 + pq / PW_, ow = ow0 + pq % PW_;
+            if (n_ok && oh < p.Ho && ow < p.Wo) {
+                const size_t idx = ((size_t)(img * p.Ho + oh) * p.Wo + ow) * p.ldo + n;
+                float v = acc[j][r] + bv;
+                if (p.accumulate) v += p.out[idx];
+                if (p.relu) v = v < 0.f ? 0.f : v;
+                if (p.mask != nullptr) v = p.mask[idx] > 0.f ? v : 0.f;
+                p.out[idx] = v;
+            }
+        }
+    }
+}
+
+int g_halo = -1;             // tuning aid: 0 = never use the halo kernel, 1 = 8x8 patches, 2 = 8x16 patches; -1 = automatic
+
+// returns SSD_OK when launched, 1 when the geometry is not a halo case
+template <int PLANES>
+int try_halo(X3Params& q, const ssd_conv_geom* g, hipStream_t st) {
+    if (g_halo == 0 || g->R != 3 || g->S != 3 || g->stride != 1 || g->dil != 1 || g->pad != 1) return 1;
+    IgemmParams& p = q.g;
+    const int images = p.M / (p.Ho * p.Wo);
+    int shape = g_halo;
+    if (shape < 0) {
+        // measured (tools/conv_bench.py x3 / halobf16): with three limbs the halo tile only wins on the 150^2 and 300^2 maps;
+        // with one bf16 plane it wins down to 38^2.  8x16 patches beat 8x8 everywhere.
+        if (p.Ho < 30 || p.Wo < (PLANES == 3 ? 64 : 30)) return 1;
+        shape = 2;
+    }
+    p.tiles_n = ssd_cdiv(p.Nout, 64);
+    if (shape == 2) {
+        p.tiles_m = images * ssd_cdiv(p.Ho, 8) * ssd_cdiv(p.Wo, 16);
+        hipLaunchKernelGGL((conv3x3_halo_kernel<8, 16, 64, PLANES>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, q);
+    } else {
+        p.tiles_m = images * ssd_cdiv(p.Ho, 8) * ssd_cdiv(p.Wo, 8);
+        hipLaunchKernelGGL((conv3x3_halo_kernel<8, 8, 64, PLANES>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, q);
+    }
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
 int g_x3_tile = -1;          // tuning aid: 1 = 128x128, 2 = 128x64, 3 = 64x64; -1 = automatic
 
 template <int BM, int BN, int WM, int WN>
@@ -803,6 +993,7 @@ extern "C" int ssd_conv2d_fwd_x3(const float* x, const void* w3_ohwi, int w_rows
     p.Nout = g->Co; p.Nrows = g->Co; p.ldo = ldy; p.R = g->R; p.S = g->S;
     p.sm = g->stride; p.sd = 1; p.off = -g->pad; p.dstep = g->dil;
     p.M = g->N * g->Ho * g->Wo; p.relu = relu; p.accumulate = 0;
+    { const int h = try_halo<3>(q, g, (hipStream_t)stream); if (h <= 0) return h; }
     return dispatch_igemm_x3(q, (hipStream_t)stream);
 }
 
@@ -822,6 +1013,7 @@ extern "C" int ssd_conv2d_dgrad_x3(const float* dy, int ldy, const void* w3_ihwo
     p.Nout = g->Ci; p.Nrows = g->Ci; p.ldo = g->Ci; p.R = g->R; p.S = g->S;
     p.sm = 1; p.sd = g->stride; p.off = g->pad; p.dstep = -g->dil;
     p.M = g->N * g->H * g->W; p.relu = 0; p.accumulate = accumulate;
+    { const int h = try_halo<3>(q, g, (hipStream_t)stream); if (h <= 0) return h; }
     return dispatch_igemm_x3(q, (hipStream_t)stream);
 }
 
@@ -829,4 +1021,46 @@ extern "C" int ssd_tune_set_igemm_x3(int tile) {
     if (tile < -1 || tile > 3 || tile == 0) return SSD_ERR_BAD_SHAPE;
     g_x3_tile = tile;
     return SSD_OK;
+}
+extern "C" int ssd_tune_set_halo(int mode) {
+    if (mode < -1 || mode > 2) return SSD_ERR_BAD_SHAPE;
+    g_halo = mode;
+    return SSD_OK;
+}
+
+// bf16-operand halo entry points (configs[2]): same pre-split weight planes as f32x3 (plane 0 = RNE bf16 of the weight);
+// geometries the halo kernel does not take return 1 so that the caller uses ssd_conv2d_fwd_bf16 / _dgrad_bf16 instead.
+extern "C" int ssd_conv3x3_halo_fwd_bf16(const float* x, const void* w3_ohwi, int w_rows, const float* bias, float* y, int ldy,
+                                         const ssd_conv_geom* g, int relu, void* stream) {
+    if (int e = check_geom(g)) return e;
+    if (!x || !w3_ohwi || !y) return SSD_ERR_NULL;
+    if (g->Ci % 32 != 0 || ldy < g->Co || w_rows < g->Co) return SSD_ERR_BAD_SHAPE;
+    X3Params q{};
+    IgemmParams& p = q.g;
+    p.a = x; p.bias = bias; p.out = y; p.mask = nullptr;
+    const size_t ab = (size_t)g->N * g->H * g->W * g->Ci * 4, pb = (size_t)w_rows * g->R * g->S * g->Ci * 2;
+    if (ab >= 0xF0000000ull || 3 * pb >= 0xF0000000ull) return SSD_ERR_BAD_SHAPE;
+    p.a_bytes = (unsigned)ab; q.plane_bytes = (unsigned)pb; q.w3 = reinterpret_cast<const __bf16*>(w3_ohwi);
+    p.Ha = g->H; p.Wa = g->W; p.Ca = g->Ci; p.Ho = g->Ho; p.Wo = g->Wo;
+    p.Nout = g->Co; p.Nrows = g->Co; p.ldo = ldy; p.R = 3; p.S = 3;
+    p.sm = 1; p.sd = 1; p.off = -g->pad; p.dstep = g->dil;
+    p.M = g->N * g->Ho * g->Wo; p.relu = relu; p.accumulate = 0;
+    return try_halo<1>(q, g, (hipStream_t)stream);
+}
+extern "C" int ssd_conv3x3_halo_dgrad_bf16(const float* dy, int ldy, const void* w3_ihwo, int Co_pad, float* dx,
+                                           const float* relu_mask, int accumulate, const ssd_conv_geom* g, void* stream) {
+    if (int e = check_geom(g)) return e;
+    if (!dy || !w3_ihwo || !dx) return SSD_ERR_NULL;
+    if (Co_pad % 32 != 0 || Co_pad < g->Co || ldy != Co_pad || g->Ci % 4 != 0) return SSD_ERR_BAD_SHAPE;
+    X3Params q{};
+    IgemmParams& p = q.g;
+    p.a = dy; p.bias = nullptr; p.out = dx; p.mask = relu_mask;
+    const size_t ab = (size_t)g->N * g->Ho * g->Wo * Co_pad * 4, pb = (size_t)g->Ci * g->R * g->S * Co_pad * 2;
+    if (ab >= 0xF0000000ull || 3 * pb >= 0xF0000000ull) return SSD_ERR_BAD_SHAPE;
+    p.a_bytes = (unsigned)ab; q.plane_bytes = (unsigned)pb; q.w3 = reinterpret_cast<const __bf16*>(w3_ihwo);
+    p.Ha = g->Ho; p.Wa = g->Wo; p.Ca = Co_pad; p.Ho = g->H; p.Wo = g->W;
+    p.Nout = g->Ci; p.Nrows = g->Ci; p.ldo = g->Ci; p.R = 3; p.S = 3;
+    p.sm = 1; p.sd = g->stride; p.off = g->pad; p.dstep = -g->dil;
+    p.M = g->N * g->H * g->W; p.relu = 0; p.accumulate = accumulate;
+    return try_halo<1>(q, g, (hipStream_t)stream);
 }

@@ -48,6 +48,11 @@ def pad32(c: int) -> int:
 
 
 def igemm_tile(g: ConvGeom, direction: int, bf16: bool = False, x3: bool = False) -> str:
+    """Name prefix of the kernel the library picks for this geometry (bench.py groups per-launch timings by it)."""
+    if (x3 or bf16) and g.R == 3 and g.S == 3 and g.stride == 1 and g.dil == 1 and g.pad == 1 and (direction == 1 or g.Ci % 32 == 0):
+        ho, wo = (g.Ho, g.Wo) if direction == 0 else (g.H, g.W)
+        if ho >= 30 and wo >= (64 if x3 else 30):
+            return "conv3x3_halo_kernel"
     if x3:
         return "igemm_x3_kernel"
     if bf16:
@@ -137,8 +142,10 @@ def conv2d_dgrad_x3(dy: torch.Tensor, w3_ihwo: torch.Tensor, g: ConvGeom, dx: Op
 
 # ---- convolution -----------------------------------------------------------------------
 def conv2d_fwd(x: torch.Tensor, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], g: ConvGeom, relu: bool,
-               ld: Optional[int] = None, out: Optional[torch.Tensor] = None, bf16: bool = False) -> torch.Tensor:
-    """x (N,H,W,Ci) -> (N,Ho,Wo,ld) (ld defaults to Co; columns Co..ld-1 are left untouched)."""
+               ld: Optional[int] = None, out: Optional[torch.Tensor] = None, bf16: bool = False,
+               w3: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x (N,H,W,Ci) -> (N,Ho,Wo,ld) (ld defaults to Co; columns Co..ld-1 are left untouched).
+    bf16 with `w3` (weight_split3 of w_ohwi): 3x3/s1/p1 layers on large maps take the halo-tile kernel."""
     _req(x, "x"); _req(w_ohwi, "w_ohwi")
     if tuple(x.shape) != (g.N, g.H, g.W, g.Ci):
         raise ValueError(f"x shape {tuple(x.shape)} != geometry {(g.N, g.H, g.W, g.Ci)}")
@@ -156,13 +163,23 @@ def conv2d_fwd(x: torch.Tensor, w_ohwi: torch.Tensor, bias: Optional[torch.Tenso
         _req(out, "out")
         if out.numel() != g.N * g.Ho * g.Wo * ld:
             raise ValueError("out size")
+    if bf16 and w3 is not None and g.Ci % 32 == 0:
+        _req(w3, "w3", torch.bfloat16)
+        if tuple(w3.shape) != (3,) + tuple(w_ohwi.shape):
+            raise ValueError("w3 must be weight_split3(w_ohwi)")
+        rc = _lib.load().ssd_conv3x3_halo_fwd_bf16(x.data_ptr(), w3.data_ptr(), int(w3.shape[1]), _ptr(bias), out.data_ptr(), ld,
+                                                   C.byref(g), int(relu), _stream())
+        if rc <= 0:
+            check(rc, "conv3x3_halo_fwd_bf16")
+            return out
     fn = _lib.load().ssd_conv2d_fwd_bf16 if bf16 else _lib.load().ssd_conv2d_fwd
     check(fn(x.data_ptr(), w_ohwi.data_ptr(), _ptr(bias), out.data_ptr(), ld, C.byref(g), int(relu), _stream()), "conv2d_fwd")
     return out
 
 
 def conv2d_dgrad(dy: torch.Tensor, w_ihwo: torch.Tensor, g: ConvGeom, dx: Optional[torch.Tensor] = None,
-                 relu_mask: Optional[torch.Tensor] = None, accumulate: bool = False, bf16: bool = False) -> torch.Tensor:
+                 relu_mask: Optional[torch.Tensor] = None, accumulate: bool = False, bf16: bool = False,
+                 w3: Optional[torch.Tensor] = None) -> torch.Tensor:
     _req(dy, "dy"); _req(w_ihwo, "w_ihwo")
     co_pad = w_ihwo.shape[2]
     if dy.numel() != g.N * g.Ho * g.Wo * co_pad:
@@ -180,6 +197,15 @@ def conv2d_dgrad(dy: torch.Tensor, w_ihwo: torch.Tensor, g: ConvGeom, dx: Option
         _req(relu_mask, "relu_mask")
         if relu_mask.numel() != dx.numel():
             raise ValueError("relu_mask size")
+    if bf16 and w3 is not None and g.Ci % 4 == 0:
+        _req(w3, "w3", torch.bfloat16)
+        if tuple(w3.shape) != (3,) + tuple(w_ihwo.shape):
+            raise ValueError("w3 must be weight_split3(w_ihwo)")
+        rc = _lib.load().ssd_conv3x3_halo_dgrad_bf16(dy.data_ptr(), co_pad, w3.data_ptr(), co_pad, dx.data_ptr(), _ptr(relu_mask),
+                                                     int(accumulate), C.byref(g), _stream())
+        if rc <= 0:
+            check(rc, "conv3x3_halo_dgrad_bf16")
+            return dx
     fn = _lib.load().ssd_conv2d_dgrad_bf16 if bf16 else _lib.load().ssd_conv2d_dgrad
     check(fn(dy.data_ptr(), co_pad, w_ihwo.data_ptr(), co_pad, dx.data_ptr(), _ptr(relu_mask), int(accumulate), C.byref(g),
              _stream()), "conv2d_dgrad")

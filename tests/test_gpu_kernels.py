@@ -299,8 +299,21 @@ def test_conv_bf16_operand_variant(case):
             _close(yd[..., :co], _nhwc(y), tol=2e-5, what=f"bf16 fwd tile {tile} {case}")
             dx = ops.conv2d_dgrad(dy_p.to(dev), wb, g, bf16=True)
             _close(dx, _nhwc(xr.grad), tol=2e-5, what=f"bf16 dgrad tile {tile} {case}")
+        if (k, s, p, d) == (3, 1, 1, 1) and ci % 32 == 0:       # halo-tile kernel on plane 0 of the split weights
+            wf3, wb3 = ops.weight_split3(wf), ops.weight_split3(wb)
+            for halo in (1, 2):
+                assert lib.ssd_tune_set_halo(halo) == 0
+                yh = torch.zeros_like(yd)
+                yh = ops.conv2d_fwd(_nhwc(x).to(dev), wf, b.to(dev), g, False, ld=ld, out=yh, bf16=True, w3=wf3)
+                _close(yh[..., :co], _nhwc(y), tol=2e-5, what=f"bf16 halo fwd {halo} {case}")
+                dxh = ops.conv2d_dgrad(dy_p.to(dev), wb, g, bf16=True, w3=wb3)
+                _close(dxh, _nhwc(xr.grad), tol=2e-5, what=f"bf16 halo dgrad {halo} {case}")
+                mask = (torch.rand(dxh.shape, generator=torch.Generator().manual_seed(5)) > .5).float().to(dev)
+                dxa = ops.conv2d_dgrad(dy_p.to(dev), wb, g, dx=dxh.clone(), relu_mask=mask, accumulate=True, bf16=True, w3=wb3)
+                _close(dxa, 2 * dxh * mask, tol=2e-5, what=f"bf16 halo dgrad accumulate+mask {halo} {case}")
     finally:
         lib.ssd_tune_set_igemm_bf16(-1)
+        lib.ssd_tune_set_halo(-1)
     # weight gradient: bf16 fused nine-tap kernel where it applies (every 3x3 s1 p1 layer), f32 kernels elsewhere
     dw, db = ops.conv2d_wgrad(_nhwc(x).to(dev), dy_p.to(dev), g, ld, True, bf16=True)
     fused = k == 3 and s == 1 and p == 1 and d == 1          # in bf16 mode every such layer takes the fused kernel
@@ -344,16 +357,19 @@ def test_conv_f32_from_three_bf16_limbs(case):
     e_y32 = float((y_f32 - ref_y).norm() / ref_y.norm())
     e_dx32 = float((dx_f32 - ref_dx).norm() / ref_dx.norm())
     try:
-        for tile in (-1, 1, 2, 3):
-            assert lib.ssd_tune_set_igemm_x3(tile) == 0
+        # (tile, halo): generic x3 kernel in every tile; for the 3x3/s1 layers also the halo-tile kernel in both patch shapes
+        combos = [(-1, 0), (1, 0), (2, 0), (3, 0), (-1, -1)] + ([(-1, 1), (-1, 2)] if (k, s, p, d) == (3, 1, 1, 1) else [])
+        for tile, halo in combos:
+            assert lib.ssd_tune_set_igemm_x3(tile) == 0 and lib.ssd_tune_set_halo(halo) == 0
             y3 = ops.conv2d_fwd_x3(xd, wf3, b.to(dev), g, False, ld=ld)[..., :co].cpu().double()
             dx3 = ops.conv2d_dgrad_x3(dyd, wb3, g).cpu().double()
             e_y3 = float((y3 - ref_y).norm() / ref_y.norm())
             e_dx3 = float((dx3 - ref_dx).norm() / ref_dx.norm())
-            assert e_y3 <= 2 * e_y32 + 1e-7, (tile, e_y3, e_y32)
-            assert e_dx3 <= 2 * e_dx32 + 1e-7, (tile, e_dx3, e_dx32)
+            assert e_y3 <= 2 * e_y32 + 1e-7, (tile, halo, e_y3, e_y32)
+            assert e_dx3 <= 2 * e_dx32 + 1e-7, (tile, halo, e_dx3, e_dx32)
             _close(y3, ref_y, tol=1e-5, what=f"x3 fwd {case}")
             _close(dx3, ref_dx, tol=1e-5, what=f"x3 dgrad {case}")
     finally:
         lib.ssd_tune_set_igemm_x3(-1)
+        lib.ssd_tune_set_halo(-1)
     print(f"{case}: fwd rel err f32 {e_y32:.2e} x3 {e_y3:.2e}; dgrad f32 {e_dx32:.2e} x3 {e_dx3:.2e}")

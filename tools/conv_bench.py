@@ -72,12 +72,26 @@ def main():
                     row.append(f"{lab}:{fl / ms / 1e9:6.1f}")
                 print(f"bf16 {dirn:5s} {name:8s} " + "  ".join(row), flush=True)
             lib.ssd_tune_set_igemm_bf16(-1)
+        if which in ("halobf16",):
+            wf3, wb3 = ops.weight_split3(wf), ops.weight_split3(wb)
+            import ctypes as CC
+            for hm, lab in ((1, "halo8x8"), (2, "halo8x16")):
+                lib.ssd_tune_set_halo(hm)
+                st = torch.cuda.current_stream().cuda_stream
+                r1 = lib.ssd_conv3x3_halo_fwd_bf16(x.data_ptr(), wf3.data_ptr(), int(wf3.shape[1]), b.data_ptr(), dy.data_ptr(), ld, CC.byref(g), 1, st)
+                if r1 != 0:
+                    continue
+                ms = timeit(lambda: lib.ssd_conv3x3_halo_fwd_bf16(x.data_ptr(), wf3.data_ptr(), int(wf3.shape[1]), b.data_ptr(), dy.data_ptr(), ld, CC.byref(g), 1, st))
+                ms2 = timeit(lambda: lib.ssd_conv3x3_halo_dgrad_bf16(dy.data_ptr(), ld, wb3.data_ptr(), ld, dx.data_ptr(), x.data_ptr(), 0, CC.byref(g), st))
+                print(f"halobf16 {name:8s} {lab}: fwd {fl / ms / 1e9:6.1f}  dgrad {fl / ms2 / 1e9:6.1f}", flush=True)
+            lib.ssd_tune_set_halo(-1)
         if which in ("x3", "all"):
             wf3, wb3 = ops.weight_split3(wf), ops.weight_split3(wb)
             for dirn in ("fwd", "dgrad"):
                 row = []
-                for t, lab in ((-1, "auto"), (1, "128x128"), (2, "128x64"), (3, "64x64")):
+                for t, hm, lab in ((-1, -1, "auto"), (1, 0, "128x128"), (2, 0, "128x64"), (3, 0, "64x64"), (-1, 1, "halo8x8"), (-1, 2, "halo8x16")):
                     lib.ssd_tune_set_igemm_x3(t)
+                    lib.ssd_tune_set_halo(hm)
                     if dirn == "fwd":
                         ms = timeit(lambda: ops.conv2d_fwd_x3(x, wf3, b, g, True, ld=ld))
                     else:
@@ -85,6 +99,7 @@ def main():
                     row.append(f"{lab}:{fl / ms / 1e9:6.1f}")
                 print(f"x3   {dirn:5s} {name:8s} " + "  ".join(row), flush=True)
             lib.ssd_tune_set_igemm_x3(-1)
+            lib.ssd_tune_set_halo(-1)
         if which in ("wgrad", "all"):
             row = []
             for bt, nb, bpc, lab in wg_var:
