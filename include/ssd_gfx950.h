@@ -124,6 +124,23 @@ int ssd_tune_set_wgrad(int bt, int nbuf, int blocks_per_cu);
  * zero); forward / wgrad are then the 1x1 cases of ssd_conv2d_fwd / ssd_conv2d_wgrad with Ci = 32. */
 int ssd_im2col_first(const float* x_nchw, float* out, int N, int H, int W, void* stream);
 
+/* ---- SSD_resnet34 (Model.py:12-126, BASELINE configs[4]) eval-mode forward pieces ----
+ * Stem Conv2d(3,64,7,stride 2,pad 3) (Model.py:26 seq1[0]): general 3-channel NCHW im2col into [N*Ho*Wo][Kpad]
+ * rows (k = (r*S+s)*3 + c, zero from R*S*3 to Kpad; Kpad % 32 == 0 for the 1x1 case of ssd_conv2d_fwd). */
+int ssd_im2col_nchw3(const float* x_nchw, float* out, int N, int H, int W, int R, int S, int stride, int pad,
+                     int Ho, int Wo, int Kpad, void* stream);
+/* BasicBlock tail `relu(bn2(conv2(o)) + identity)` (torchvision layer list sliced at Model.py:27-30): the
+ * convolution (BatchNorm folded into w / bias by the host) is ADDED to y_inout, which holds the identity /
+ * downsample branch on entry, then ReLU'd in place. */
+int ssd_conv2d_fwd_accum(const float* x, const float* w_ohwi, const float* bias, float* y_inout, int ldy,
+                         const ssd_conv_geom* g, int relu, void* stream);
+int ssd_conv2d_fwd_accum_bf16(const float* x, const float* w_ohwi, const float* bias, float* y_inout, int ldy,
+                              const ssd_conv_geom* g, int relu, void* stream);
+/* eval-mode BatchNorm2d after a ReLU (Model.py:56-62 Conv -> ReLU -> BN -> Dropout2d): y = x*scale[c] + shift[c]
+ * over [M][C] NHWC rows, C % 4 == 0, optional ReLU; x may alias y. */
+int ssd_channel_affine(const float* x, const float* scale, const float* shift, float* y, size_t M, int C, int relu,
+                       void* stream);
+
 /* ---- max pooling (Model.py:137,142 nn.MaxPool2d incl. ceil_mode; features[4,9,23]) ----
  * argmax: uint8 window-relative index (r*k+s) of the first maximum, for backward. */
 int ssd_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int N, int H, int W, int C,

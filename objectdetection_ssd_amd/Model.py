@@ -435,3 +435,6 @@ class SSD_512(SSD_300):
     (`Util.create_priors_ssd512`).  Same kernels, same parameter naming scheme; parity is against the oracle's own
     restatement only -- there is no reference implementation to compare with."""
     _VARIANT = 512
+
+
+from .ModelResnet import SSD_resnet34  # noqa: E402,F401  (reference Model.py:12-126 lives in the same module)

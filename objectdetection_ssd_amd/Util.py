@@ -105,3 +105,15 @@ def subsampling(x: torch.Tensor, step) -> torch.Tensor:
         if s is not None:
             x = x.index_select(d, torch.arange(0, x.shape[d], s, device=x.device))
     return x
+
+
+def create_ancs_xywh_zoom_ratio() -> torch.Tensor:
+    """(189,4) f32 anchors of the SSD_resnet34 variant (reference Util.py:142-164): grids 4/2/1, nine zoom x ratio
+    shapes per cell, centres at linspace(1/(2g), 1-1/(2g), g); the first returned coordinate varies fastest."""
+    import numpy as np
+    shapes = [(z * i, z * j) for z in (0.75, 1., 1.3) for (i, j) in ((1., 1.), (1., 0.5), (0.5, 1.))]
+    rows = []
+    for g in (4, 2, 1):
+        ctr = np.linspace(1 / (g * 2), 1 - 1 / (g * 2), g)
+        rows += [[fast, slow, o / g, p / g] for slow in ctr for fast in ctr for o, p in shapes]
+    return torch.tensor(np.asarray(rows, np.float64), dtype=torch.float32)

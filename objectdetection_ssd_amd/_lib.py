@@ -42,6 +42,10 @@ SIGNATURES = {
     "ssd_conv2d_dgrad_x3": (_I, [_P, _I, _P, _I, _P, _P, _I, _G, _P]),
     "ssd_tune_set_igemm_x3": (_I, [_I]),
     "ssd_tune_set_halo": (_I, [_I]),
+    "ssd_im2col_nchw3": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ssd_conv2d_fwd_accum": (_I, [_P, _P, _P, _P, _I, _G, _I, _P]),
+    "ssd_conv2d_fwd_accum_bf16": (_I, [_P, _P, _P, _P, _I, _G, _I, _P]),
+    "ssd_channel_affine": (_I, [_P, _P, _P, _P, C.c_size_t, _I, _I, _P]),
     "ssd_conv3x3_halo_fwd_bf16": (_I, [_P, _P, _I, _P, _P, _I, _G, _I, _P]),
     "ssd_conv3x3_halo_dgrad_bf16": (_I, [_P, _I, _P, _I, _P, _P, _I, _G, _P]),
     "ssd_conv2d_wgrad_workspace": (_Z, [_G]),

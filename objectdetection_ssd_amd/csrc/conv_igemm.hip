@@ -882,7 +882,7 @@ int check_geom(const ssd_conv_geom* g) {
 }  // namespace
 
 static int conv2d_fwd_impl(const float* x, const float* w_ohwi, const float* bias, float* y, int ldy,
-                           const ssd_conv_geom* g, int relu, void* stream, bool bf16) {
+                           const ssd_conv_geom* g, int relu, void* stream, bool bf16, int accumulate = 0) {
     if (int e = check_geom(g)) return e;
     if (!x || !w_ohwi || !y) return SSD_ERR_NULL;
     if (g->Ci % 32 != 0 || ldy < g->Co) return SSD_ERR_BAD_SHAPE;
@@ -897,8 +897,17 @@ static int conv2d_fwd_impl(const float* x, const float* w_ohwi, const float* bia
     p.Ha = g->H; p.Wa = g->W; p.Ca = g->Ci; p.Ho = g->Ho; p.Wo = g->Wo;
     p.Nout = g->Co; p.Nrows = g->Co; p.ldo = ldy; p.R = g->R; p.S = g->S;
     p.sm = g->stride; p.sd = 1; p.off = -g->pad; p.dstep = g->dil;
-    p.M = g->N * g->Ho * g->Wo; p.relu = relu; p.accumulate = 0;
+    p.M = g->N * g->Ho * g->Wo; p.relu = relu; p.accumulate = accumulate;
     return bf16 ? dispatch_igemm_bf16(p, (hipStream_t)stream) : dispatch_igemm(p, (hipStream_t)stream);
+}
+
+extern "C" int ssd_conv2d_fwd_accum(const float* x, const float* w_ohwi, const float* bias, float* y_inout, int ldy,
+                                    const ssd_conv_geom* g, int relu, void* stream) {
+    return conv2d_fwd_impl(x, w_ohwi, bias, y_inout, ldy, g, relu, stream, false, 1);
+}
+extern "C" int ssd_conv2d_fwd_accum_bf16(const float* x, const float* w_ohwi, const float* bias, float* y_inout, int ldy,
+                                         const ssd_conv_geom* g, int relu, void* stream) {
+    return conv2d_fwd_impl(x, w_ohwi, bias, y_inout, ldy, g, relu, stream, true, 1);
 }
 
 extern "C" int ssd_conv2d_fwd(const float* x, const float* w_ohwi, const float* bias, float* y, int ldy,

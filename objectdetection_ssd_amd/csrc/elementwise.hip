@@ -59,6 +59,52 @@ __global__ __launch_bounds__(256) void im2col_first_kernel(const float* __restri
     }
 }
 
+// General im2col of a 3-channel NCHW batch (ResNet-34 stem, Model.py:26 seq1[0]: Conv2d(3,64,7,stride 2,pad 3)):
+// out[pix][k], k = (r*S+s)*3 + c for k < R*S*3, zero up to Kpad.  Kpad/4 threads per output pixel, 16 bytes each.
+__global__ __launch_bounds__(256) void im2col_nchw3_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int H, int W,
+                                                           int R, int S, int stride, int pad, int Ho, int Wo, int Kpad) {
+    const int q_per = Kpad >> 2, K = R * S * 3;
+    const size_t HW = (size_t)H * W;
+    const size_t total = (size_t)N * Ho * Wo * q_per;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
+        const size_t pix = g / q_per;
+        const int q = (int)(g - pix * q_per);
+        const int n = (int)(pix / ((size_t)Ho * Wo));
+        const int rem = (int)(pix - (size_t)n * Ho * Wo);
+        const int oh = rem / Wo, ow = rem - oh * Wo;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = q * 4 + e;
+            if (k < K) {
+                const int c = k % 3, t = k / 3;
+                const int ih = oh * stride + t / S - pad, iw = ow * stride + t % S - pad;
+                if (ih >= 0 && ih < H && iw >= 0 && iw < W) v[e] = x[((size_t)n * 3 + c) * HW + (size_t)ih * W + iw];
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + g * 4) = v;
+    }
+}
+
+// y = x * scale[c] + shift[c] (optionally ReLU) over [M][C] rows: eval-mode BatchNorm that follows a ReLU
+// (Model.py:56-62 Conv -> ReLU -> BN) and so cannot be folded into the convolution before it.
+__global__ __launch_bounds__(256) void channel_affine_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, float* __restrict__ y, size_t total4,
+                                                             int C4, int relu) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        const f32x4 a = reinterpret_cast<const f32x4*>(scale)[c], b = reinterpret_cast<const f32x4*>(shift)[c];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = v[e] * a[e] + b[e];
+            if (relu) o[e] = o[e] < 0.f ? 0.f : o[e];
+        }
+        reinterpret_cast<f32x4*>(y)[i] = o;
+    }
+}
+
 __global__ void slab_sum_kernel(const float* __restrict__ slab, float* __restrict__ out, int n, int nslab) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -323,6 +369,32 @@ extern "C" int ssd_im2col_first(const float* x_nchw, float* out, int N, int H, i
     if (!ssd_aligned16(out)) return SSD_ERR_ALIGN;
     const size_t total = (size_t)N * H * W * 8;
     hipLaunchKernelGGL(im2col_first_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x_nchw, out, N, H, W);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
+extern "C" int ssd_im2col_nchw3(const float* x_nchw, float* out, int N, int H, int W, int R, int S, int stride, int pad,
+                                int Ho, int Wo, int Kpad, void* stream) {
+    if (!x_nchw || !out) return SSD_ERR_NULL;
+    if (N <= 0 || H <= 0 || W <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0 || Kpad % 4 != 0 || Kpad < R * S * 3)
+        return SSD_ERR_BAD_SHAPE;
+    if (Ho != (H + 2 * pad - R) / stride + 1 || Wo != (W + 2 * pad - S) / stride + 1 || Ho <= 0 || Wo <= 0) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(out)) return SSD_ERR_ALIGN;
+    const size_t total = (size_t)N * Ho * Wo * (Kpad / 4);
+    hipLaunchKernelGGL(im2col_nchw3_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x_nchw, out, N, H, W,
+                       R, S, stride, pad, Ho, Wo, Kpad);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
+extern "C" int ssd_channel_affine(const float* x, const float* scale, const float* shift, float* y, size_t M, int C, int relu,
+                                  void* stream) {
+    if (!x || !scale || !shift || !y) return SSD_ERR_NULL;
+    if (M == 0 || C <= 0 || C % 4 != 0) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(x) || !ssd_aligned16(y) || !ssd_aligned16(scale) || !ssd_aligned16(shift)) return SSD_ERR_ALIGN;
+    const size_t total4 = M * (size_t)(C / 4);
+    hipLaunchKernelGGL(channel_affine_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y, total4,
+                       C / 4, relu);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
 }

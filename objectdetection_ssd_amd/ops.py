@@ -143,7 +143,7 @@ def conv2d_dgrad_x3(dy: torch.Tensor, w3_ihwo: torch.Tensor, g: ConvGeom, dx: Op
 # ---- convolution -----------------------------------------------------------------------
 def conv2d_fwd(x: torch.Tensor, w_ohwi: torch.Tensor, bias: Optional[torch.Tensor], g: ConvGeom, relu: bool,
                ld: Optional[int] = None, out: Optional[torch.Tensor] = None, bf16: bool = False,
-               w3: Optional[torch.Tensor] = None) -> torch.Tensor:
+               w3: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
     """x (N,H,W,Ci) -> (N,Ho,Wo,ld) (ld defaults to Co; columns Co..ld-1 are left untouched).
     bf16 with `w3` (weight_split3 of w_ohwi): 3x3/s1/p1 layers on large maps take the halo-tile kernel."""
     _req(x, "x"); _req(w_ohwi, "w_ohwi")
@@ -163,6 +163,12 @@ def conv2d_fwd(x: torch.Tensor, w_ohwi: torch.Tensor, bias: Optional[torch.Tenso
         _req(out, "out")
         if out.numel() != g.N * g.Ho * g.Wo * ld:
             raise ValueError("out size")
+    if accumulate:                         # out += conv (+ bias), then ReLU: the residual tail of a ResNet BasicBlock
+        if out is None:
+            raise ValueError("accumulate needs an existing out")
+        fn = _lib.load().ssd_conv2d_fwd_accum_bf16 if bf16 else _lib.load().ssd_conv2d_fwd_accum
+        check(fn(x.data_ptr(), w_ohwi.data_ptr(), _ptr(bias), out.data_ptr(), ld, C.byref(g), int(relu), _stream()), "conv2d_fwd_accum")
+        return out
     if bf16 and w3 is not None and g.Ci % 32 == 0:
         _req(w3, "w3", torch.bfloat16)
         if tuple(w3.shape) != (3,) + tuple(w_ohwi.shape):
@@ -251,6 +257,42 @@ def im2col_first(x_nchw: torch.Tensor) -> torch.Tensor:
         raise ValueError("im2col_first expects 3 input channels")
     out = torch.empty((n, h, w, 32), device=x_nchw.device, dtype=torch.float32)
     check(_lib.load().ssd_im2col_first(x_nchw.data_ptr(), out.data_ptr(), n, h, w, _stream()), "im2col_first")
+    return out
+
+
+def im2col_nchw3(x_nchw: torch.Tensor, k: int, stride: int, pad: int, kpad: Optional[int] = None) -> torch.Tensor:
+    """(N,3,H,W) -> (N,Ho,Wo,Kpad) rows with k = (r*k+s)*3 + c, zero-padded to a multiple of 32 (ResNet-34 stem)."""
+    _req(x_nchw, "x")
+    if x_nchw.dim() != 4 or x_nchw.shape[1] != 3:
+        raise ValueError("im2col_nchw3 expects (N,3,H,W)")
+    n, _, h, w = x_nchw.shape
+    ho, wo = conv_out_hw(h, w, k, stride, pad, 1)
+    kpad = pad32(k * k * 3) if kpad is None else kpad
+    out = torch.empty((n, ho, wo, kpad), device=x_nchw.device, dtype=torch.float32)
+    check(_lib.load().ssd_im2col_nchw3(x_nchw.data_ptr(), out.data_ptr(), n, h, w, k, k, stride, pad, ho, wo, kpad, _stream()),
+          "im2col_nchw3")
+    return out
+
+
+def stem_weight_rows(w_oihw: torch.Tensor, kpad: Optional[int] = None) -> torch.Tensor:
+    """(Co,3,R,S) -> (Co,1,Kpad) rows in im2col_nchw3's column order (the 1x1 OHWI layout)."""
+    co, ci, r, s_ = w_oihw.shape
+    kpad = pad32(r * s_ * ci) if kpad is None else kpad
+    rows = torch.zeros((co, 1, kpad), device=w_oihw.device, dtype=torch.float32)
+    rows[:, 0, :r * s_ * ci] = w_oihw.detach().permute(0, 2, 3, 1).reshape(co, -1)
+    return rows
+
+
+def channel_affine(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, relu: bool = False,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y[..., c] = x[..., c] * scale[c] + shift[c] over NHWC rows (eval-mode BatchNorm after a ReLU)."""
+    _req(x, "x"); _req(scale, "scale"); _req(shift, "shift")
+    c = x.shape[-1]
+    if scale.numel() != c or shift.numel() != c or c % 4 != 0:
+        raise ValueError("scale / shift must have one entry per channel, C % 4 == 0")
+    out = torch.empty_like(x) if out is None else out
+    check(_lib.load().ssd_channel_affine(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(), x.numel() // c, c,
+                                         int(relu), _stream()), "channel_affine")
     return out
 
 

@@ -74,6 +74,43 @@ def _install_stand_ins():
                                      nn.Linear(4096, 1000))
         return m
     md.vgg16 = vgg16
+
+    def resnet34(pretrained=False, **kw):
+        """The standard ResNet-34 layer list built from torch.nn (torchvision is not installed): only the module tree /
+        children() order matters to the reference (Model.py:21-30); weights are overwritten with the seeded state."""
+        class BasicBlock(nn.Module):
+            def __init__(self, cin, c, stride):
+                super().__init__()
+                self.conv1 = nn.Conv2d(cin, c, 3, stride, 1, bias=False)
+                self.bn1 = nn.BatchNorm2d(c)
+                self.relu = nn.ReLU(inplace=True)
+                self.conv2 = nn.Conv2d(c, c, 3, 1, 1, bias=False)
+                self.bn2 = nn.BatchNorm2d(c)
+                self.downsample = None
+                if stride != 1 or cin != c:
+                    self.downsample = nn.Sequential(nn.Conv2d(cin, c, 1, stride, bias=False), nn.BatchNorm2d(c))
+
+            def forward(self, x):
+                idt = x if self.downsample is None else self.downsample(x)
+                out = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
+                return self.relu(out + idt)
+
+        m = nn.Module()
+        m.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        m.bn1 = nn.BatchNorm2d(64)
+        m.relu = nn.ReLU(inplace=True)
+        m.maxpool = nn.MaxPool2d(3, 2, 1)
+        cin = 64
+        for li, (c, nblk, stride) in enumerate(((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)), start=1):
+            blocks = []
+            for b in range(nblk):
+                blocks.append(BasicBlock(cin, c, stride if b == 0 else 1))
+                cin = c
+            setattr(m, f"layer{li}", nn.Sequential(*blocks))
+        m.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        m.fc = nn.Linear(512, 1000)
+        return m
+    md.resnet34 = resnet34
     tr.functional = ft
     tv.transforms = tr
     tv.models = md
@@ -140,8 +177,43 @@ def edge_cases(pri_xyxy):
     return cases
 
 
+def write_resnet34(RM, RU):
+    """SSD_resnet34 (Model.py:12-126) in eval mode on the seeded state, plus the zoom/ratio anchors (Util.py:142-164)."""
+    with quiet():
+        net = RM.SSD_resnet34(20)
+    state = O.ssd_resnet34_random_state(seed=0)
+    sd = net.state_dict()
+    full = dict(state)
+    for alias, trunk in O.ssd_resnet34_aliases().items():
+        for k in list(state):
+            if k.startswith(trunk):
+                full[alias + k[len(trunk):]] = state[k]
+    assert set(full) == set(sd), (sorted(set(full) ^ set(sd))[:8])
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(full[k].shape), (k, v.shape, full[k].shape)
+    net.load_state_dict(full)
+    net.eval()
+    x = np.random.default_rng(5151).standard_normal((2, 3, 224, 224), dtype=np.float32)
+    with torch.no_grad():
+        loc, conf = net(torch.from_numpy(x))
+    np.savez_compressed(os.path.join(GOLD, "resnet34.npz"), x_seed=np.int64(5151), state_seed=np.int64(0),
+                        loc=loc.numpy(), conf=conf.numpy(),
+                        state_dict_keys=np.asarray(list(sd.keys())),
+                        state_dict_shapes=np.asarray([",".join(str(d) for d in v.shape) for v in sd.values()]),
+                        named_parameter_keys=np.asarray([n for n, _ in net.named_parameters()]),
+                        ancs_zoom_ratio=RU.create_ancs_xywh_zoom_ratio().numpy().astype(np.float32))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if sys.argv[1:] == ["resnet34"]:                # add this one fixture without rewriting the others
+        _install_stand_ins()
+        with quiet():
+            import Util as RU
+            import Model as RM
+        torch.manual_seed(0)
+        write_resnet34(RM, RU)
+        return
     _install_stand_ins()
     with quiet():
         import Util as RU          # noqa: F401  (reference)
@@ -315,6 +387,7 @@ def main():
     store["state_dict_shapes"] = np.asarray([",".join(str(d) for d in v.shape) for v in sd.values()])
     store["named_parameter_keys"] = np.asarray([n for n, _ in net.named_parameters()])
     np.savez_compressed(os.path.join(GOLD, "network.npz"), **store)
+    write_resnet34(RM, RU)
     print("golden fixtures written to", GOLD)
     for f in sorted(os.listdir(GOLD)):
         print(f"  {f}: {os.path.getsize(os.path.join(GOLD, f))} bytes")

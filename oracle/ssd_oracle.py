@@ -442,3 +442,157 @@ def multibox_loss_torch(loc, conf, boxes, classes, pri_cxcywh=None):
     hn = torch.arange(P)[None, :] < k
     conf_loss = (neg_sorted[hn].sum() + cce[pos].sum()) / pos.sum().float()
     return loc_loss, conf_loss
+
+
+# ---------------------------------------------------------------------------
+# SSD_resnet34 (Model.py:12-126) -- eval-mode forward only (train mode draws
+# dropout masks from the global RNG stream and cannot be matched).
+# ---------------------------------------------------------------------------
+RESNET34_LAYERS = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))      # (channels, blocks, first stride)
+BN_EPS = 1e-5
+_BN_FIELDS = (("weight", None), ("bias", None), ("running_mean", None), ("running_var", None), ("num_batches_tracked", ()))
+
+
+def _bn_shapes(prefix: str, c: int, sh: Dict[str, Tuple[int, ...]]):
+    for f, shape in _BN_FIELDS:
+        sh[f"{prefix}.{f}"] = (c,) if shape is None else shape
+
+
+def resnet34_trunk_shapes(prefix: str = "resnet.") -> Dict[str, Tuple[int, ...]]:
+    """state_dict entries of the torchvision ResNet-34 layer list the reference slices (Model.py:21-30):
+    conv1 7x7/s2/p3 (no bias), bn1, four stages of BasicBlocks (conv3x3 -> bn -> relu -> conv3x3 -> bn, identity or
+    1x1-stride conv + bn shortcut, relu), fc 512 -> 1000 (dead in the reference's forward)."""
+    sh: Dict[str, Tuple[int, ...]] = {prefix + "conv1.weight": (64, 3, 7, 7)}
+    _bn_shapes(prefix + "bn1", 64, sh)
+    cin = 64
+    for li, (c, nblk, stride) in enumerate(RESNET34_LAYERS, start=1):
+        for b in range(nblk):
+            p = f"{prefix}layer{li}.{b}."
+            sh[p + "conv1.weight"] = (c, cin, 3, 3)
+            _bn_shapes(p + "bn1", c, sh)
+            sh[p + "conv2.weight"] = (c, c, 3, 3)
+            _bn_shapes(p + "bn2", c, sh)
+            if b == 0 and (stride != 1 or cin != c):
+                sh[p + "downsample.0.weight"] = (c, cin, 1, 1)
+                _bn_shapes(p + "downsample.1", c, sh)
+            cin = c
+    sh[prefix + "fc.weight"] = (1000, 512)
+    sh[prefix + "fc.bias"] = (1000,)
+    return sh
+
+
+def ssd_resnet34_state_shapes(k: int = 3, n_classes: int = 20) -> Dict[str, Tuple[int, ...]]:
+    """The reference module's state_dict layout minus the seq1..seq5 aliases of the trunk (Model.py:26-54)."""
+    sh = resnet34_trunk_shapes("resnet.")
+    for name, cin in (("conv2d_0", 512), ("conv2d_01", 256), ("conv2d_02", 256), ("conv2d_03", 256)):
+        sh[f"{name}.0.weight"] = (256, cin, 3, 3); sh[f"{name}.0.bias"] = (256,)
+        _bn_shapes(f"{name}.2", 256, sh)
+    for s in ("4", "2", "1"):
+        sh[f"conv2d_02_bb{s}.0.weight"] = (4 * k, 256, 3, 3); sh[f"conv2d_02_bb{s}.0.bias"] = (4 * k,)
+        _bn_shapes(f"conv2d_02_bb{s}.1", 4 * k, sh)
+        sh[f"conv2d_02_c{s}.weight"] = ((n_classes + 1) * k, 256, 3, 3); sh[f"conv2d_02_c{s}.bias"] = ((n_classes + 1) * k,)
+    for s in ("4", "2", "1"):
+        _bn_shapes(f"bn{s}", (n_classes + 1) * k, sh)
+    return sh
+
+
+def ssd_resnet34_aliases() -> Dict[str, str]:
+    """alias prefix -> trunk prefix for the seq1..seq5 views (Model.py:26-30): children() order is conv1, bn1, relu,
+    maxpool, layer1..4, avgpool, fc, so seq1 = [conv1, bn1, relu], seq2 = [maxpool, layer1], seq3/4/5 = the blocks of
+    layer2/3/4 unpacked."""
+    al = {"seq1.0.": "resnet.conv1.", "seq1.1.": "resnet.bn1.", "seq2.1.": "resnet.layer1."}
+    for s, li in ((3, 2), (4, 3), (5, 4)):
+        al[f"seq{s}."] = f"resnet.layer{li}."
+    return al
+
+
+def ssd_resnet34_random_state(seed: int = 0, k: int = 3):
+    """Seeded state (pretrained weights are not available offline): He-normal convs (second conv of a block scaled down
+    so the residual sum stays O(1)), BN gamma in [.5,1.5], beta/mean ~ N(0,.1), var in [.5,1.5], conf-head bias -2
+    (Model.py:39,43,47)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    shapes = ssd_resnet34_state_shapes(k)
+    bn_prefixes = {n[:-len("running_mean")] for n in shapes if n.endswith(".running_mean")}
+    for name, shape in shapes.items():
+        prefix, leaf = name.rsplit(".", 1)
+        is_bn = prefix + "." in bn_prefixes
+        if leaf == "num_batches_tracked":
+            t = torch.zeros((), dtype=torch.int64)
+        elif leaf == "running_mean":
+            t = torch.randn(shape, generator=g) * 0.1
+        elif leaf == "running_var":
+            t = torch.rand(shape, generator=g) + 0.5
+        elif is_bn and leaf == "weight":
+            t = torch.rand(shape, generator=g) + 0.5
+        elif is_bn and leaf == "bias":
+            t = torch.randn(shape, generator=g) * 0.1
+        elif leaf == "bias":
+            t = torch.full(shape, -2.0) if "_c" in name else torch.randn(shape, generator=g) * 0.05
+        elif len(shape) == 2:
+            t = torch.randn(shape, generator=g) * 0.01
+        else:
+            fan_in = shape[1] * shape[2] * shape[3]
+            t = torch.randn(shape, generator=g) * math.sqrt(2.0 / fan_in) * (0.25 if name.endswith("conv2.weight") else 1.0)
+        out[name] = t if t.dtype == torch.int64 else t.float()
+    return out
+
+
+def ssd_resnet34_forward(x, st, k: int = 3):
+    """Eval-mode forward of Model.py:72-126.  x (bs,3,224,224) -> (bs, 21k, 4), (bs, 21k, 21).
+    Quirks kept: conv2d_01 is applied twice (:91,:96) and conv2d_03 / bn4 / bn2 / bn1 are never used; blocks are
+    Conv -> ReLU -> BN (:56-62); loc heads Conv -> BN (:64-70); conf heads plain convs (:38)."""
+    import torch.nn.functional as F
+
+    def bn(h, p):
+        return F.batch_norm(h, st[p + ".running_mean"], st[p + ".running_var"], st[p + ".weight"], st[p + ".bias"], False, 0.0, BN_EPS)
+
+    h = F.relu(bn(F.conv2d(x, st["resnet.conv1.weight"], None, stride=2, padding=3), "resnet.bn1"))
+    h = F.max_pool2d(h, 3, 2, padding=1)
+    for li, (c, nblk, stride) in enumerate(RESNET34_LAYERS, start=1):
+        for b in range(nblk):
+            p = f"resnet.layer{li}.{b}."
+            s = stride if b == 0 else 1
+            idt = h
+            o = F.relu(bn(F.conv2d(h, st[p + "conv1.weight"], None, stride=s, padding=1), p + "bn1"))
+            o = bn(F.conv2d(o, st[p + "conv2.weight"], None, padding=1), p + "bn2")
+            if p + "downsample.0.weight" in st:
+                idt = bn(F.conv2d(h, st[p + "downsample.0.weight"], None, stride=s), p + "downsample.1")
+            h = F.relu(o + idt)
+
+    def block(h, name, stride):
+        return bn(F.relu(F.conv2d(h, st[name + ".0.weight"], st[name + ".0.bias"], stride=stride, padding=1)), name + ".2")
+
+    h = F.relu(h)                                 # :88 (dropout is the identity in eval)
+    x6 = block(h, "conv2d_0", 1)
+    x7 = block(x6, "conv2d_01", 2)
+    x8 = block(x7, "conv2d_01", 2)
+    x9 = block(x8, "conv2d_02", 2)
+    bs = x.shape[0]
+    locs, confs = [], []
+    for s, f in (("4", x7), ("2", x8), ("1", x9)):
+        bb = bn(F.conv2d(f, st[f"conv2d_02_bb{s}.0.weight"], st[f"conv2d_02_bb{s}.0.bias"], padding=1), f"conv2d_02_bb{s}.1")
+        cl = F.conv2d(f, st[f"conv2d_02_c{s}.weight"], st[f"conv2d_02_c{s}.bias"], padding=1)
+        locs.append(bb.permute(0, 2, 3, 1).reshape(bs, -1, 4))
+        confs.append(cl.permute(0, 2, 3, 1).reshape(bs, -1, 21))
+    import torch
+    return torch.cat(locs, 1), torch.cat(confs, 1)
+
+
+def create_ancs_xywh_zoom_ratio() -> np.ndarray:
+    """(189,4) f32 cx,cy,w,h  (Util.py:142-164): grids 4/2/1, nine (zoom x ratio) shapes per cell, centres at
+    linspace(1/(2g), 1-1/(2g), g); the x column repeats and the y column tiles, and the function returns (y, x, w, h)
+    order -- i.e. the first returned coordinate varies fastest."""
+    grids = (4, 2, 1)
+    zooms = (0.75, 1., 1.3)
+    ratios = ((1., 1.), (1., 0.5), (0.5, 1.))
+    shapes = [(z * i, z * j) for z in zooms for (i, j) in ratios]
+    rows = []
+    for gsz in grids:
+        ctr = np.linspace(1 / (gsz * 2), 1 - 1 / (gsz * 2), gsz)
+        for slow in ctr:
+            for fast in ctr:
+                for o, p in shapes:
+                    rows.append([fast, slow, o / gsz, p / gsz])
+    return np.asarray(rows, np.float64).astype(np.float32)

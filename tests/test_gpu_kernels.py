@@ -373,3 +373,62 @@ def test_conv_f32_from_three_bf16_limbs(case):
         lib.ssd_tune_set_igemm_x3(-1)
         lib.ssd_tune_set_halo(-1)
     print(f"{case}: fwd rel err f32 {e_y32:.2e} x3 {e_y3:.2e}; dgrad f32 {e_dx32:.2e} x3 {e_dx3:.2e}")
+
+
+# ---- SSD_resnet34 pieces (Model.py:12-126) ---------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 224, 224, 7, 2, 3), (1, 37, 53, 7, 2, 3), (2, 30, 30, 3, 1, 1), (1, 16, 20, 5, 3, 0)])
+def test_stem_im2col_and_conv(shape):
+    """3-channel NCHW im2col + the 1x1 MFMA convolution == F.conv2d (the ResNet-34 stem is 7x7/s2/p3)."""
+    from objectdetection_ssd_amd import ops
+    n, h, w, k, s, p = shape
+    dev = _dev()
+    g0 = torch.Generator().manual_seed(3)
+    x = torch.randn(n, 3, h, w, generator=g0)
+    wt = torch.randn(64, 3, k, k, generator=g0) * (2.0 / (3 * k * k)) ** 0.5
+    b = torch.randn(64, generator=g0) * 0.1
+    col = ops.im2col_nchw3(x.to(dev), k, s, p)
+    ref_col = F.unfold(x, k, padding=p, stride=s)                         # (n, 3*k*k, L) with row index c*k*k + t
+    L = ref_col.shape[2]
+    ref_col = ref_col.view(n, 3, k * k, L).permute(0, 3, 2, 1).reshape(n, L, k * k * 3)
+    got = col.view(n, L, -1).cpu()
+    assert torch.equal(got[..., :k * k * 3], ref_col) and float(got[..., k * k * 3:].abs().max()) == 0.0
+    g = ops.make_geom(n, col.shape[1], col.shape[2], col.shape[3], 64, 1, 1, 0, 1)
+    y = ops.conv2d_fwd(col, ops.stem_weight_rows(wt.to(dev)), b.to(dev), g, True)
+    _close(y, _nhwc(F.relu(F.conv2d(x, wt, b, stride=s, padding=p))), what=f"stem {shape}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [CONV_CASES[i] for i in (0, 1, 5, 6)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_conv2d_fwd_accumulate_residual(case, bf16):
+    """relu(conv(x) + bias + identity) accumulated in place into the identity buffer (BasicBlock tail)."""
+    from objectdetection_ssd_amd import ops
+    n, h, w, ci, co, k, s, p, d = case
+    dev = _dev()
+    x, wt, b = _conv_data(case, seed=51)
+    if bf16:
+        x, wt = x.bfloat16().float(), wt.bfloat16().float()
+    y0 = F.conv2d(x, wt, b, stride=s, padding=p, dilation=d)
+    idt = torch.randn(y0.shape, generator=torch.Generator().manual_seed(52))
+    g = ops.make_geom(n, h, w, ci, co, k, s, p, d)
+    buf = _nhwc(idt).to(dev)
+    out = ops.conv2d_fwd(_nhwc(x).to(dev), ops.weight_ohwi(wt.to(dev)), b.to(dev), g, True, out=buf, bf16=bf16, accumulate=True)
+    assert out.data_ptr() == buf.data_ptr()
+    _close(out, _nhwc(F.relu(y0 + idt)), tol=2e-5 if bf16 else 1e-4, what=f"fwd accumulate {case}")
+
+
+@pytest.mark.gpu
+def test_channel_affine():
+    from objectdetection_ssd_amd import ops
+    dev = _dev()
+    g0 = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 7, 7, 256, generator=g0)
+    sc, sh = torch.rand(256, generator=g0) + .5, torch.randn(256, generator=g0)
+    y = ops.channel_affine(x.to(dev), sc.to(dev), sh.to(dev))
+    assert torch.equal(y.cpu(), x * sc + sh) or float((y.cpu() - (x * sc + sh)).abs().max()) < 1e-6
+    xin = x.to(dev)
+    y2 = ops.channel_affine(xin, sc.to(dev), sh.to(dev), relu=True, out=xin)          # in place
+    assert float((y2.cpu() - F.relu(x * sc + sh)).abs().max()) < 1e-6
+    with pytest.raises(ValueError):
+        ops.channel_affine(torch.zeros(2, 6, device=dev), torch.zeros(6, device=dev), torch.zeros(6, device=dev))

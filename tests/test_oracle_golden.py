@@ -114,3 +114,30 @@ def test_network_forward_and_step_vs_reference(gold_dir):
         g = params[k].grad.numpy()
         ref = z["g_" + k]
         np.testing.assert_allclose(g, ref, rtol=1e-3, atol=1e-5 * max(1.0, float(np.abs(ref).max())))
+
+
+def test_resnet34_variant_vs_reference(gold_dir):
+    """SSD_resnet34 eval forward (Model.py:72-126) and the zoom/ratio anchors (Util.py:142-164)."""
+    z = np.load(os.path.join(gold_dir, "resnet34.npz"))
+    st = O.ssd_resnet34_random_state(int(z["state_seed"]))
+    x = np.random.default_rng(int(z["x_seed"])).standard_normal((2, 3, 224, 224), dtype=np.float32)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        loc, conf = O.ssd_resnet34_forward(torch.from_numpy(x), st)
+    assert tuple(loc.shape) == (2, 63, 4) and tuple(conf.shape) == (2, 63, 21)
+    np.testing.assert_allclose(loc.numpy(), z["loc"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(conf.numpy(), z["conf"], rtol=1e-4, atol=1e-4)
+    # state_dict layout: our shape table + the seq1..seq5 aliases == the reference's keys, in shapes too
+    ref = dict(zip(z["state_dict_keys"].tolist(), z["state_dict_shapes"].tolist()))
+    shapes = O.ssd_resnet34_state_shapes()
+    full = dict(shapes)
+    for alias, trunk in O.ssd_resnet34_aliases().items():
+        for k, v in shapes.items():
+            if k.startswith(trunk):
+                full[alias + k[len(trunk):]] = v
+    assert set(full) == set(ref)
+    for k, v in full.items():
+        assert ",".join(str(d) for d in v) == ref[k], k
+    anc = O.create_ancs_xywh_zoom_ratio()
+    assert anc.shape == (189, 4)
+    np.testing.assert_allclose(anc, z["ancs_zoom_ratio"], rtol=0, atol=1e-7)
