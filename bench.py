@@ -79,6 +79,55 @@ def cpu_baseline(bs: int = 4, iters: int = 2, max_threads: int = 16):
             "sample": f"oracle torch-CPU train step (fwd+loss+bwd+SGD), bs={bs}, median of {iters} after 1 warm-up"}
 
 
+def aux_workload(args, world, rank, dev):
+    """configs[4]: no exchange step in either half, so N ranks are N independent replicas."""
+    from objectdetection_ssd_amd import Losses, Model
+    bs = args.batch
+    g = torch.Generator().manual_seed(1234 + rank)
+    if args.workload == "resnet34":
+        torch.manual_seed(0)
+        net = Model.SSD_resnet34(20).to(dev).eval()
+        if args.conv_dtype == "f32x3":
+            raise SystemExit("SSD_resnet34 supports --conv-dtype f32 or bf16")
+        net.conv_dtype = args.conv_dtype
+        x = torch.randn(bs, 3, 224, 224, generator=g).to(dev)
+        step = lambda: net(x)                                              # noqa: E731
+        metric = "images/sec SSD_resnet34 eval forward (224x224, 63 priors)"
+        dtype = args.conv_dtype
+    else:
+        l = (torch.randn(bs, 8732, 4, generator=g)).to(dev)
+        c = (3 * torch.randn(bs, 8732, 21, generator=g)).to(dev)
+        wh = torch.tensor([[500, 375]] * bs, dtype=torch.float32)
+        step = lambda: Losses.inference_batch(l, c, wh)                    # noqa: E731
+        metric = "images/sec batched decode + per-class NMS + top-200 (8732 priors, conf ~ 3*randn)"
+        dtype = "f32"
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": metric, "value": round(bs * world * args.steps / elapsed, 2), "unit": "images/sec", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+                          "config": {"workload": f"BASELINE configs[4] half: {args.workload}, batch {bs}/GPU", "global_batch": bs * world,
+                                     "parallelism": f"replicas x{world}"}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,6 +140,9 @@ def main():
     ap.add_argument("--conv-dtype", default="f32", choices=("f32", "f32x3", "bf16"),
                     help="bf16 = BASELINE configs[2] (bf16-operand fwd/dgrad convs, f32 accumulate); not the headline bench line")
     ap.add_argument("--variant", type=int, default=300, choices=(300, 512), help="512 = build-defined SSD512 (not a bench line)")
+    ap.add_argument("--workload", default="train", choices=("train", "resnet34", "decode"),
+                    help="train = the headline line (BASELINE configs[1]); resnet34 / decode = the two halves of configs[4] "
+                         "(SSD_resnet34 eval forward at 224x224; batched per-class NMS decode of SSD300-shaped outputs): replicas only")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
@@ -115,6 +167,9 @@ def main():
 
     from objectdetection_ssd_amd import Losses, Model
     from objectdetection_ssd_amd.ddp import FlatSGDDataParallel
+
+    if args.workload != "train":
+        return aux_workload(args, world, rank, dev)
 
     torch.manual_seed(0)                                   # same initial weights on every rank
     net = (Model.SSD_300() if args.variant == 300 else Model.SSD_512()).to(dev).train()
