@@ -196,6 +196,19 @@ int ssd_decode_nms_batch(const float* l_, const float* c_, const float* priors_c
                          int n_classes, float min_score, float iou_threshold, int top_k, float* boxes, int64_t* classes,
                          float* probs, int32_t* prior_ids, int32_t* count, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- mAP evaluator (Util.py:783-885 get_map: per-class 11-point interpolated AP, IoU > 0.5, one claim per
+ * ground-truth box, no 'difficult' handling) over B images given as concatenated arrays:
+ * det_* (D rows; det_start[B+1] = first row of each image), gt_* (G rows; gt_start[B+1]); classes are int32 in
+ * [0, n_classes) (others are ignored, as the reference's `range(20)` loop does).  recall_levels is a HOST array
+ * (the reference's torch.arange(0, 1.1, 0.1) as doubles), n_levels <= 16.  Outputs: tp (D bytes, must be zeroed by
+ * the caller; 1 = true positive), table (n_classes x n_levels doubles: max precision at recall >= level, 0 where none;
+ * AP[c] = mean of row c), counts (2*n_classes int32: detections per class, then ground truth per class). */
+size_t ssd_map_eval_workspace(int D, int G);
+int ssd_map_eval(const float* det_boxes, const int32_t* det_classes, const float* det_scores, const int32_t* det_start,
+                 int D, const float* gt_boxes, const int32_t* gt_classes, const int32_t* gt_start, int G, int B,
+                 int n_classes, const double* recall_levels_host, int n_levels, uint8_t* tp, double* table,
+                 int32_t* counts, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- fused SGD (train.py:53-55: momentum .9, weight decay 5e-4; bias lr 2x) on a flat buffer;
  * grad_scale multiplies the gradient first (1/n_pos_global in data-parallel runs). */
 int ssd_sgd_momentum(float* param, const float* grad, float* momentum_buf, size_t n, float lr, float momentum,

@@ -117,3 +117,33 @@ def create_ancs_xywh_zoom_ratio() -> torch.Tensor:
         ctr = np.linspace(1 / (g * 2), 1 - 1 / (g * 2), g)
         rows += [[fast, slow, o / g, p / g] for slow in ctr for fast in ctr for o, p in shapes]
     return torch.tensor(np.asarray(rows, np.float64), dtype=torch.float32)
+
+
+def get_map(det_boxes, det_classes, det_scores, gt_boxes, gt_classes):
+    """Per-class 11-point interpolated AP (reference Util.py:783-885; same arguments: per-image lists of (n,4) boxes,
+    (n,) classes, (n,) scores and the ground-truth boxes / classes).  Matching, the per-class sort and the
+    precision/recall scan run on the GPU (csrc/map_eval.hip); returns {class: numpy.float64 AP} like the reference
+    (which also prints each value).  Score ties are ordered lower flat index first."""
+    import numpy as np
+    from . import ops
+    if not torch.cuda.is_available():
+        raise RuntimeError("get_map() runs on the gfx950 HIP kernels only (no CPU fallback)")
+    n_img = len(det_boxes)
+    if not (n_img == len(det_classes) == len(det_scores) == len(gt_boxes) == len(gt_classes)) or n_img == 0:
+        raise ValueError("get_map expects five lists with one entry per image")
+    dev = next((t.device for t in list(det_boxes) + list(gt_boxes) if torch.is_tensor(t) and t.is_cuda), device)
+
+    def flat(items, dtype, width):
+        parts = [torch.as_tensor(t).reshape((-1, width) if width else (-1,)).to(device=dev, dtype=dtype) for t in items]
+        start = torch.tensor([0] + [int(p.shape[0]) for p in parts], dtype=torch.int64).cumsum(0).to(device=dev, dtype=torch.int32)
+        return torch.cat(parts).contiguous(), start
+
+    db, d_start = flat(det_boxes, torch.float32, 4)
+    dc, _ = flat(det_classes, torch.int32, 0)
+    ds, _ = flat(det_scores, torch.float32, 0)
+    gb, g_start = flat(gt_boxes, torch.float32, 4)
+    gc, _ = flat(gt_classes, torch.int32, 0)
+    levels = torch.arange(0, 1.1, 0.1).double().numpy()                # Util.py:874, float32 levels compared in float64
+    table, _, _ = ops.map_eval(db, dc, ds, d_start, gb, gc, g_start, levels, 20)
+    t = table.cpu().numpy()
+    return {cls: np.float64(np.mean(t[cls])) for cls in range(20)}

@@ -42,6 +42,8 @@ SIGNATURES = {
     "ssd_conv2d_dgrad_x3": (_I, [_P, _I, _P, _I, _P, _P, _I, _G, _P]),
     "ssd_tune_set_igemm_x3": (_I, [_I]),
     "ssd_tune_set_halo": (_I, [_I]),
+    "ssd_map_eval_workspace": (_Z, [_I, _I]),
+    "ssd_map_eval": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _Z, _P]),
     "ssd_im2col_nchw3": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ssd_conv2d_fwd_accum": (_I, [_P, _P, _P, _P, _I, _G, _I, _P]),
     "ssd_conv2d_fwd_accum_bf16": (_I, [_P, _P, _P, _P, _I, _G, _I, _P]),

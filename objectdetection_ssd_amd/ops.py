@@ -475,3 +475,26 @@ def sgd_momentum_(param, grad, buf, lr, momentum, weight_decay, grad_scale=None,
         _req(grad_scale, "grad_scale")
     check(_lib.load().ssd_sgd_momentum(param.data_ptr(), grad.data_ptr(), buf.data_ptr(), param.numel(), float(lr), float(momentum),
                                        float(weight_decay), _ptr(grad_scale), int(first_step), _stream()), "sgd_momentum")
+
+
+def map_eval(det_boxes, det_classes, det_scores, det_start, gt_boxes, gt_classes, gt_start, recall_levels, n_classes=20):
+    """Concatenated detections / ground truth (see include/ssd_gfx950.h ssd_map_eval) -> (table (n_classes, n_levels)
+    float64, tp (D,) uint8, counts (2, n_classes) int32).  recall_levels: host sequence of floats."""
+    import numpy as np
+    dev = det_start.device
+    D, G, B = int(det_boxes.shape[0]), int(gt_boxes.shape[0]), int(det_start.numel()) - 1
+    _req(det_boxes, "det_boxes"); _req(det_scores, "det_scores"); _req(gt_boxes, "gt_boxes")
+    _req(det_classes, "det_classes", torch.int32); _req(gt_classes, "gt_classes", torch.int32)
+    _req(det_start, "det_start", torch.int32); _req(gt_start, "gt_start", torch.int32)
+    if det_classes.numel() != D or det_scores.numel() != D or gt_classes.numel() != G or gt_start.numel() != B + 1 or B < 1:
+        raise ValueError("map_eval: inconsistent array lengths")
+    lv = np.ascontiguousarray(np.asarray(recall_levels, np.float64))
+    tp = torch.zeros(max(D, 1), device=dev, dtype=torch.uint8)
+    table = torch.empty((n_classes, lv.size), device=dev, dtype=torch.float64)
+    counts = torch.empty((2, n_classes), device=dev, dtype=torch.int32)
+    lib = _lib.load()
+    ws = workspace(lib.ssd_map_eval_workspace(D, G), dev, "map")
+    check(lib.ssd_map_eval(_ptr(det_boxes), _ptr(det_classes), _ptr(det_scores), det_start.data_ptr(), D, _ptr(gt_boxes),
+                           _ptr(gt_classes), gt_start.data_ptr(), G, B, n_classes, lv.ctypes.data, int(lv.size), tp.data_ptr(),
+                           table.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "map_eval")
+    return table, tp[:D], counts

@@ -177,6 +177,92 @@ def edge_cases(pri_xyxy):
     return cases
 
 
+def map_cases():
+    """Detections / ground truth for the mAP fixture: jittered copies of the GT (true positives at varying IoU),
+    duplicates of the same GT (the second is a false positive), random boxes, classes without detections and classes
+    without ground truth; scores are distinct so the reference's unstable sort has one answer."""
+    cases = []
+    for seed, n_img, p_det, n_fp in ((11, 6, .8, 3), (12, 24, .6, 6), (13, 3, 1., 0), (14, 40, .7, 10)):
+        rng = np.random.default_rng(seed)
+        gtb, gtc = synth_gt(rng, n_img)
+        gtc = [c.astype(np.int64) % (20 if seed != 13 else 4) for c in gtc]
+        dets_b, dets_c, dets_s = [], [], []
+        for b, c in zip(gtb, gtc):
+            bb, cc = [], []
+            for k in range(len(b)):
+                if rng.uniform() < p_det:
+                    jit = rng.normal(0, rng.choice([.01, .05, .12]), 4).astype(np.float32)
+                    bb.append(np.clip(b[k] + jit, 0, 1)); cc.append(c[k])
+                    if rng.uniform() < .3:                       # duplicate detection of the same object
+                        bb.append(np.clip(b[k] + rng.normal(0, .01, 4).astype(np.float32), 0, 1)); cc.append(c[k])
+                    if rng.uniform() < .2:                       # right box, wrong class
+                        bb.append(b[k].copy()); cc.append((c[k] + 1) % 20)
+            for _ in range(int(rng.integers(0, n_fp + 1))):
+                x1, y1 = rng.uniform(0, .7, 2)
+                bb.append(np.asarray([x1, y1, x1 + rng.uniform(.05, .3), y1 + rng.uniform(.05, .3)], np.float32))
+                cc.append(int(rng.integers(0, 20)))
+            bb = np.asarray(bb, np.float32).reshape(-1, 4)
+            bb = np.stack([np.minimum(bb[:, 0], bb[:, 2]), np.minimum(bb[:, 1], bb[:, 3]),
+                           np.maximum(bb[:, 0], bb[:, 2]) + np.float32(1e-3), np.maximum(bb[:, 1], bb[:, 3]) + np.float32(1e-3)], 1) \
+                if len(bb) else bb
+            dets_b.append(bb.astype(np.float32)); dets_c.append(np.asarray(cc, np.int64))
+            dets_s.append(np.zeros(len(cc), np.float32))
+        total = sum(len(c) for c in dets_c)
+        scores = rng.permutation(total).astype(np.float32) / np.float32(total + 1) + np.float32(.01)   # distinct
+        o = 0
+        for i in range(n_img):
+            dets_s[i] = scores[o:o + len(dets_c[i])]; o += len(dets_c[i])
+        if seed == 12:                                            # pixel coordinates, as `inference` returns them
+            dets_b = [b * np.float32([500, 375, 500, 375]) for b in dets_b]
+            gtb = [b * np.float32([500, 375, 500, 375]) for b in gtb]
+        cases.append((dets_b, dets_c, dets_s, gtb, gtc))
+    return cases
+
+
+class _MaskArray(np.ndarray):
+    """ndarray whose indexing accepts a torch bool mask as the boolean mask it is (see write_map)."""
+
+    def __getitem__(self, idx):
+        if isinstance(idx, torch.Tensor):
+            idx = idx.numpy()
+        return super().__getitem__(idx)
+
+
+def write_map(RU):
+    """Util.get_map (Util.py:783-885) on the cases above.
+
+    As shipped the function does not run under this image's numpy 2.2 / torch 2.10: `cum_precision[recalls_mask]`
+    (Util.py:879) indexes a numpy array with a torch bool tensor, which numpy 2 takes as the integer indices 0/1
+    (IndexError for a class with one detection, silently wrong values otherwise); under the numpy 1.x the code was
+    written for it is a boolean mask -- and the `recalls_mask.sum() != 0` guard one line above shows that intent.
+    The fixture is therefore generated with `Util.np.array` wrapped (not replaced) so that the arrays it returns
+    accept a torch mask as a boolean mask; nothing else of the function is touched."""
+    store = {}
+    cases = map_cases()
+    real_np = RU.np
+    proxy = types.ModuleType("numpy_proxy")
+    proxy.__dict__.update(real_np.__dict__)
+    proxy.array = lambda *a, **k: real_np.array(*a, **k).view(_MaskArray)
+    RU.np = proxy
+    for ci, (db, dc, ds, gb, gc) in enumerate(cases):
+        with quiet():
+            aps = RU.get_map([torch.from_numpy(b) for b in db], [torch.from_numpy(c) for c in dc],
+                             [torch.from_numpy(s) for s in ds], [torch.from_numpy(b) for b in gb],
+                             [torch.from_numpy(c) for c in gc])
+        p = f"c{ci}_"
+        store[p + "ap"] = np.asarray([float(aps[c]) for c in range(20)], np.float64)
+        store[p + "n_img"] = np.int64(len(db))
+        store[p + "det_count"] = np.asarray([len(c) for c in dc], np.int64)
+        store[p + "gt_count"] = np.asarray([len(c) for c in gc], np.int64)
+        store[p + "det_boxes"] = np.concatenate(db); store[p + "det_classes"] = np.concatenate(dc)
+        store[p + "det_scores"] = np.concatenate(ds)
+        store[p + "gt_boxes"] = np.concatenate(gb); store[p + "gt_classes"] = np.concatenate(gc)
+    RU.np = real_np
+    store["n_cases"] = np.int64(len(cases))
+    store["recall_levels"] = torch.arange(0, 1.1, 0.1).double().numpy()
+    np.savez_compressed(os.path.join(GOLD, "map.npz"), **store)
+
+
 def write_resnet34(RM, RU):
     """SSD_resnet34 (Model.py:12-126) in eval mode on the seeded state, plus the zoom/ratio anchors (Util.py:142-164)."""
     with quiet():
@@ -206,13 +292,16 @@ def write_resnet34(RM, RU):
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    if sys.argv[1:] == ["resnet34"]:                # add this one fixture without rewriting the others
+    if sys.argv[1:] in (["resnet34"], ["map"]):     # add one fixture without rewriting the others
         _install_stand_ins()
         with quiet():
             import Util as RU
             import Model as RM
         torch.manual_seed(0)
-        write_resnet34(RM, RU)
+        if sys.argv[1] == "map":
+            write_map(RU)
+        else:
+            write_resnet34(RM, RU)
         return
     _install_stand_ins()
     with quiet():
@@ -388,6 +477,7 @@ def main():
     store["named_parameter_keys"] = np.asarray([n for n, _ in net.named_parameters()])
     np.savez_compressed(os.path.join(GOLD, "network.npz"), **store)
     write_resnet34(RM, RU)
+    write_map(RU)
     print("golden fixtures written to", GOLD)
     for f in sorted(os.listdir(GOLD)):
         print(f"  {f}: {os.path.getsize(os.path.join(GOLD, f))} bytes")

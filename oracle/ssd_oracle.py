@@ -596,3 +596,73 @@ def create_ancs_xywh_zoom_ratio() -> np.ndarray:
                 for o, p in shapes:
                     rows.append([fast, slow, o / gsz, p / gsz])
     return np.asarray(rows, np.float64).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------
+# mAP  (Util.py:783-885 get_map) -- SURVEY.md section 8(f) row 4
+# ---------------------------------------------------------------------------
+def ap_recall_thresholds() -> np.ndarray:
+    """The eleven recall levels `torch.arange(0, 1.1, 0.1)` (Util.py:874) as float64 values of its float32 entries."""
+    import torch
+    return torch.arange(0, 1.1, 0.1).double().numpy()
+
+
+def get_map(det_boxes, det_classes, det_scores, gt_boxes, gt_classes, return_details: bool = False):
+    """Per-class 11-point interpolated AP over a list of images (Util.py:783-885).
+
+    Per class: that class's detections of all images in descending score order (ties: lower flat index first --
+    the reference's torch.sort is unstable, fixtures avoid ties); a detection is a true positive when its best-IoU
+    ground truth of the same class in the same image (first index on ties, `:854`) has IoU > 0.5 (strict, `:855`)
+    and is still unclaimed (`:856-859`); every other detection is a false positive, including those in images with
+    no GT of that class (`:845-848`).  No 'difficult' handling.  precision = cumTP/(cumTP+cumFP) in float64, recall =
+    float64(float32(1/n_gt)) * cumTP (see the note in the body); AP = mean over the eleven levels of max precision at recall >= level, 0 where no
+    position reaches it (`:869-881`); a class without detections or without ground truth scores 0."""
+    n_img = len(det_boxes)
+    db = np.concatenate([np.asarray(b, np.float32).reshape(-1, 4) for b in det_boxes]) if n_img else np.zeros((0, 4), np.float32)
+    dc = np.concatenate([np.asarray(c).reshape(-1).astype(np.int64) for c in det_classes]) if n_img else np.zeros(0, np.int64)
+    ds = np.concatenate([np.asarray(s, np.float32).reshape(-1) for s in det_scores]) if n_img else np.zeros(0, np.float32)
+    di = np.concatenate([np.full(len(np.asarray(b).reshape(-1, 4)), i, np.int64) for i, b in enumerate(det_boxes)]) if n_img else np.zeros(0, np.int64)
+    gb = np.concatenate([np.asarray(b, np.float32).reshape(-1, 4) for b in gt_boxes]) if n_img else np.zeros((0, 4), np.float32)
+    gc = np.concatenate([np.asarray(c).reshape(-1).astype(np.int64) for c in gt_classes]) if n_img else np.zeros(0, np.int64)
+    gi = np.concatenate([np.full(len(np.asarray(b).reshape(-1, 4)), i, np.int64) for i, b in enumerate(gt_boxes)]) if n_img else np.zeros(0, np.int64)
+    avail = np.ones(gb.shape[0], bool)
+    tp_flag = np.zeros(db.shape[0], np.uint8)
+    thr = ap_recall_thresholds()
+    table = np.zeros((20, 11), np.float64)
+    for cls in range(20):
+        sel = np.nonzero(dc == cls)[0]
+        if sel.size == 0:
+            continue
+        order = sel[np.lexsort((sel, -ds[sel].astype(np.float64)))]        # score descending, flat index ascending
+        n_gt = int((gc == cls).sum())
+        tps = []
+        for d in order:
+            cand = np.nonzero((gi == di[d]) & (gc == cls))[0]
+            hit = False
+            if cand.size:
+                iou = iou_matrix(db[d:d + 1], gb[cand])[0]
+                if np.isnan(iou).any():
+                    best = -1                                           # torch.max propagates NaN; NaN > .5 is False
+                else:
+                    best = int(np.argmax(iou))                          # first index on ties
+                if best >= 0 and iou[best] > np.float32(0.5) and avail[cand[best]]:
+                    hit = True
+                    avail[cand[best]] = False
+            tps.append(1.0 if hit else 0.0)
+            tp_flag[d] = 1 if hit else 0
+        tps = np.asarray(tps, np.float64)
+        cum_tp, cum_fp = tps.cumsum(), (1.0 - tps).cumsum()
+        prec = cum_tp / (cum_tp + cum_fp)
+        # `cum_TP / Objs[cls]` (Util.py:872) divides a numpy array by a 0-dim LONG tensor: torch answers through
+        # Tensor.__rtruediv__ = reciprocal() * other, and the reciprocal of an integer tensor is float32 -- so the
+        # recall is float64(float32(1/n_gt)) * cumTP, not cumTP/n_gt (n_gt = 0: inf * 0 = NaN, never >= a level)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            rec = np.float64(np.float32(1.0) / np.float32(n_gt)) * cum_tp
+        for t in range(11):
+            m = rec >= thr[t]
+            if m.any():
+                table[cls, t] = prec[m].max()
+    aps = {cls: np.float64(table[cls].mean()) for cls in range(20)}
+    if return_details:
+        return aps, tp_flag, table
+    return aps

@@ -166,3 +166,11 @@ def test_resnet34_variant_surface_and_checkpoint_layout(gold_dir):
     anc = Util.create_ancs_xywh_zoom_ratio()
     assert anc.dtype == torch.float32 and tuple(anc.shape) == (189, 4)
     np.testing.assert_allclose(anc.numpy(), z["ancs_zoom_ratio"], rtol=0, atol=1e-7)
+
+
+def test_get_map_needs_the_gpu():
+    from objectdetection_ssd_amd import Util
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Util.get_map([torch.zeros(1, 4)], [torch.zeros(1)], [torch.zeros(1)], [torch.zeros(1, 4)], [torch.zeros(1)])

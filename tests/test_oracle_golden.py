@@ -141,3 +141,24 @@ def test_resnet34_variant_vs_reference(gold_dir):
     anc = O.create_ancs_xywh_zoom_ratio()
     assert anc.shape == (189, 4)
     np.testing.assert_allclose(anc, z["ancs_zoom_ratio"], rtol=0, atol=1e-7)
+
+
+def _map_case(z, ci):
+    p = f"c{ci}_"
+    def split(a, cnt):
+        o = np.cumsum(np.r_[0, cnt])
+        return [a[o[i]:o[i + 1]] for i in range(len(cnt))]
+    dc, gc = z[p + "det_count"], z[p + "gt_count"]
+    return (split(z[p + "det_boxes"], dc), split(z[p + "det_classes"], dc), split(z[p + "det_scores"], dc),
+            split(z[p + "gt_boxes"], gc), split(z[p + "gt_classes"], gc)), z[p + "ap"]
+
+
+@pytest.mark.parametrize("ci", range(4))
+def test_map_vs_reference(gold_dir, ci):
+    """get_map (Util.py:783-885): the APs are sums/ratios of small integers in float64 -> bit-exact."""
+    z = np.load(os.path.join(gold_dir, "map.npz"))
+    assert int(z["n_cases"]) == 4
+    args, ref = _map_case(z, ci)
+    aps = O.get_map(*args)
+    assert np.array_equal(np.asarray([aps[c] for c in range(20)]), ref)
+    assert np.array_equal(O.ap_recall_thresholds(), z["recall_levels"])
