@@ -209,6 +209,25 @@ int ssd_map_eval(const float* det_boxes, const int32_t* det_classes, const float
                  int n_classes, const double* recall_levels_host, int n_levels, uint8_t* tp, double* table,
                  int32_t* counts, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- input pipeline (Dataset.py:10-13,24-39 Resize((300,300)) + ToTensor + Normalize; Util.py:610-749 expand /
+ * random_crop / flip as geometry) on 8-bit HWC RGB images packed in one device arena.  The resize reproduces
+ * Pillow's Image.resize(BILINEAR) on 8-bit images bit for bit.  Geometry per image, in this order: the source is
+ * placed at (place_top, place_left) on a canvas_h x canvas_w canvas of `filler` (no expand: canvas = source, place
+ * 0,0); the window (crop_top, crop_left, crop_h, crop_w) of the canvas is taken (no crop: the whole canvas); its
+ * columns are mirrored when flip != 0; the result is resized to out_h x out_w and normalised into out_nchw
+ * (B,3,out_h,out_w) float32.  descs_dev / descs_host are the same B descriptors in device / host memory. */
+typedef struct ssd_image_desc {
+    int64_t src_offset;            /* byte offset of the image's first pixel in the arena */
+    int32_t src_h, src_w;
+    int32_t canvas_h, canvas_w, place_top, place_left;
+    int32_t crop_top, crop_left, crop_h, crop_w;
+    int32_t flip, reserved;
+} ssd_image_desc;
+size_t ssd_preprocess_workspace(const ssd_image_desc* descs_host, int B, int out_h, int out_w);
+int ssd_preprocess_u8(const uint8_t* arena, const ssd_image_desc* descs_dev, const ssd_image_desc* descs_host, int B,
+                      int out_h, int out_w, const float* mean3_host, const float* std3_host, const uint8_t* filler3_host,
+                      float* out_nchw, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- fused SGD (train.py:53-55: momentum .9, weight decay 5e-4; bias lr 2x) on a flat buffer;
  * grad_scale multiplies the gradient first (1/n_pos_global in data-parallel runs). */
 int ssd_sgd_momentum(float* param, const float* grad, float* momentum_buf, size_t n, float lr, float momentum,

@@ -19,6 +19,13 @@ class ConvGeom(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("N", "H", "W", "Ci", "Ho", "Wo", "Co", "R", "S", "stride", "pad", "dil")]
 
 
+class ImageDesc(C.Structure):
+    """struct ssd_image_desc"""
+    _fields_ = [("src_offset", C.c_int64)] + [(n, C.c_int32) for n in (
+        "src_h", "src_w", "canvas_h", "canvas_w", "place_top", "place_left", "crop_top", "crop_left", "crop_h", "crop_w",
+        "flip", "reserved")]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _F = C.c_float
@@ -42,6 +49,8 @@ SIGNATURES = {
     "ssd_conv2d_dgrad_x3": (_I, [_P, _I, _P, _I, _P, _P, _I, _G, _P]),
     "ssd_tune_set_igemm_x3": (_I, [_I]),
     "ssd_tune_set_halo": (_I, [_I]),
+    "ssd_preprocess_workspace": (_Z, [_P, _I, _I, _I]),
+    "ssd_preprocess_u8": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "ssd_map_eval_workspace": (_Z, [_I, _I]),
     "ssd_map_eval": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _Z, _P]),
     "ssd_im2col_nchw3": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

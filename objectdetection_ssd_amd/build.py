@@ -19,7 +19,8 @@ ARCH = "gfx950"
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fhip-fp32-correctly-rounded-divide-sqrt",
           "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 # bit-exact box arithmetic: no fused multiply-add may be formed in these files
-PER_FILE = {"loss.hip": ["-ffp-contract=off"], "nms.hip": ["-ffp-contract=off"], "map_eval.hip": ["-ffp-contract=off"]}
+PER_FILE = {"loss.hip": ["-ffp-contract=off"], "nms.hip": ["-ffp-contract=off"], "map_eval.hip": ["-ffp-contract=off"],
+            "preprocess.hip": ["-ffp-contract=off"]}
 
 
 def _hipcc() -> str:

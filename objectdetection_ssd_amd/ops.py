@@ -498,3 +498,28 @@ def map_eval(det_boxes, det_classes, det_scores, det_start, gt_boxes, gt_classes
                            _ptr(gt_classes), gt_start.data_ptr(), G, B, n_classes, lv.ctypes.data, int(lv.size), tp.data_ptr(),
                            table.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "map_eval")
     return table, tp[:D], counts
+
+
+def preprocess_u8(arena: torch.Tensor, descs, out_hw=(300, 300), mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225),
+                  filler=(123, 116, 103)) -> torch.Tensor:
+    """arena: uint8 device tensor holding the HWC RGB images; descs: ctypes array of _lib.ImageDesc (host).
+    -> (B,3,out_h,out_w) float32: expand / crop / flip geometry, Pillow-exact bilinear resize, /255, (x-mean)/std."""
+    import numpy as np
+    _req(arena, "arena", torch.uint8)
+    B = len(descs)
+    oh, ow = out_hw
+    for d in descs:
+        if d.src_offset < 0 or d.src_offset + d.src_h * d.src_w * 3 > arena.numel():
+            raise ValueError("image descriptor points outside the arena")
+    lib = _lib.load()
+    nbytes = lib.ssd_preprocess_workspace(C.byref(descs), B, oh, ow)
+    if nbytes == 0:
+        raise ValueError("preprocess_u8: bad geometry (window outside the canvas, empty image, or a down-scale factor above 31)")
+    ws = workspace(nbytes, arena.device, "pre")
+    raw = np.frombuffer(bytes(descs), dtype=np.uint8)          # bytes() copies: safe to hand to torch
+    descs_dev = torch.from_numpy(raw.copy()).to(arena.device, non_blocking=False)
+    out = torch.empty((B, 3, oh, ow), device=arena.device, dtype=torch.float32)
+    m = (C.c_float * 3)(*mean); s_ = (C.c_float * 3)(*std); f = (C.c_uint8 * 3)(*filler)
+    check(lib.ssd_preprocess_u8(arena.data_ptr(), descs_dev.data_ptr(), C.byref(descs), B, oh, ow, C.addressof(m), C.addressof(s_),
+                                C.addressof(f), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "preprocess_u8")
+    return out

@@ -74,6 +74,7 @@ def _install_stand_ins():
                                      nn.Linear(4096, 1000))
         return m
     md.vgg16 = vgg16
+    ft.hflip = lambda im: im          # Util.flip (Util.py:732-749) is called for its BOX arithmetic only; see write_augment
 
     def resnet34(pretrained=False, **kw):
         """The standard ResNet-34 layer list built from torch.nn (torchvision is not installed): only the module tree /
@@ -219,6 +220,55 @@ def map_cases():
     return cases
 
 
+def write_augment(RU):
+    """The geometric half of Util.transform (Util.py:566-607): `expand`, `random_crop`, `flip` of the reference, run on
+    seeded `random` streams in transform's own order.  photometric_distort and the PIL<->tensor conversions are
+    torchvision functions (absent): the script restates to_tensor as /255 and to_pil_image as mul(255).byte(), mirrors
+    the pixels itself for the flip, and calls the reference's `flip` with a width-only stand-in image for the boxes."""
+    import hashlib
+    import random
+
+    class _W:
+        def __init__(self, w):
+            self.width = w
+    store = {}
+    mean = [0.485, 0.456, 0.406]
+    n = 40
+    for ci in range(n):
+        r = np.random.default_rng(700 + ci)
+        h, w = int(r.integers(18, 60)), int(r.integers(18, 60))
+        img = r.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        nb = int(r.integers(1, 5))
+        x1 = r.uniform(0, w * .6, nb); y1 = r.uniform(0, h * .6, nb)
+        bx = np.stack([x1, y1, np.minimum(x1 + r.uniform(3, w * .6, nb), w - 1), np.minimum(y1 + r.uniform(3, h * .6, nb), h - 1)], 1)
+        boxes = torch.from_numpy(bx.astype(np.float32))
+        labels = torch.from_numpy(r.integers(0, 20, nb).astype(np.float32))
+        random.seed(9000 + ci)
+        t = torch.from_numpy(img).permute(2, 0, 1).float().div(255)
+        new_image, new_boxes, new_labels = t, boxes, labels
+        if random.random() < .5:
+            new_image, new_boxes = RU.expand(t, boxes, filler=mean)
+        new_image, new_boxes, new_labels = RU.random_crop(new_image, new_boxes, new_labels)
+        u8 = new_image.mul(255).byte().permute(1, 2, 0).contiguous().numpy()
+        flipped = False
+        if random.random() < .5:
+            _, new_boxes = RU.flip(_W(u8.shape[1]), new_boxes)
+            u8 = np.ascontiguousarray(u8[:, ::-1])
+            flipped = True
+        p = f"c{ci}_"
+        store[p + "img"] = img; store[p + "boxes"] = bx.astype(np.float32); store[p + "labels"] = labels.numpy()
+        store[p + "seed"] = np.int64(9000 + ci)
+        store[p + "out_shape"] = np.asarray(u8.shape[:2], np.int64)
+        store[p + "out_sha256"] = np.asarray(hashlib.sha256(u8.tobytes()).hexdigest())
+        store[p + "out_boxes"] = new_boxes.numpy().astype(np.float32)
+        store[p + "out_labels"] = new_labels.numpy().astype(np.float32)
+        store[p + "flipped"] = np.bool_(flipped)
+        if ci < 4:
+            store[p + "out_img"] = u8
+    store["n_cases"] = np.int64(n)
+    np.savez_compressed(os.path.join(GOLD, "augment.npz"), **store)
+
+
 class _MaskArray(np.ndarray):
     """ndarray whose indexing accepts a torch bool mask as the boolean mask it is (see write_map)."""
 
@@ -292,7 +342,7 @@ def write_resnet34(RM, RU):
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    if sys.argv[1:] in (["resnet34"], ["map"]):     # add one fixture without rewriting the others
+    if sys.argv[1:] in (["resnet34"], ["map"], ["augment"]):     # add one fixture without rewriting the others
         _install_stand_ins()
         with quiet():
             import Util as RU
@@ -300,6 +350,8 @@ def main():
         torch.manual_seed(0)
         if sys.argv[1] == "map":
             write_map(RU)
+        elif sys.argv[1] == "augment":
+            write_augment(RU)
         else:
             write_resnet34(RM, RU)
         return
@@ -478,6 +530,7 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "network.npz"), **store)
     write_resnet34(RM, RU)
     write_map(RU)
+    write_augment(RU)
     print("golden fixtures written to", GOLD)
     for f in sorted(os.listdir(GOLD)):
         print(f"  {f}: {os.path.getsize(os.path.join(GOLD, f))} bytes")

@@ -666,3 +666,112 @@ def get_map(det_boxes, det_classes, det_scores, gt_boxes, gt_classes, return_det
     if return_details:
         return aps, tp_flag, table
     return aps
+
+
+# ---------------------------------------------------------------------------
+# input pipeline, deterministic part  (Dataset.py:10-13,24-39; Util.py:610-750) -- SURVEY.md section 8(f) row 3
+#
+# Third-party arithmetic restated here (neither ships inside the reference):
+#   * Pillow (12.2.0 in this image; unpinned by the reference)  Image.resize(size, BILINEAR) on 8-bit images =
+#     ImagingResample: per axis, scale = in/out, support = max(scale, 1), window [int(c - s + .5), int(c + s + .5))
+#     around c = (o + .5) * scale, triangle weights in double normalised by their running sum, converted to 22-bit
+#     fixed point (round half up), accumulated from 1 << 21, shifted and clamped to 0..255; horizontal pass first,
+#     the vertical pass reads its 8-bit result.  Pinned against Pillow itself in tests (it is installed here and on
+#     the GPU box).
+#   * torchvision (absent; version unpinned) transforms.Resize -> the call above; ToTensor -> CHW float32 / 255;
+#     Normalize -> (x - mean) / std in float32.  Restated from their documented behaviour: "parity unpinned" for
+#     these two one-line formulas, Pillow-pinned for the resize.
+# ---------------------------------------------------------------------------
+PRECISION_BITS = 32 - 8 - 2
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def resample_coefficients(in_size: int, out_size: int):
+    """-> (xmin (out,), count (out,), fixed-point weights (out, ksize) int32) of Pillow's bilinear precompute_coeffs."""
+    scale = float(in_size) / float(out_size)
+    filterscale = scale if scale > 1.0 else 1.0
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    xmin = np.zeros(out_size, np.int32)
+    cnt = np.zeros(out_size, np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for o in range(out_size):
+        center = (o + 0.5) * scale
+        lo = int(center - support + 0.5)
+        lo = max(lo, 0)
+        hi = int(center + support + 0.5)
+        hi = min(hi, in_size)
+        n = hi - lo
+        w = np.zeros(ksize, np.float64)
+        ww = 0.0
+        for x in range(n):
+            v = (x + lo - center + 0.5) * ss
+            v = -v if v < 0 else v
+            wx = 1.0 - v if v < 1.0 else 0.0
+            w[x] = wx
+            ww += wx
+        for x in range(n):
+            if ww != 0.0:
+                w[x] /= ww
+        for x in range(ksize):
+            kk[o, x] = int(w[x] * (1 << PRECISION_BITS) - 0.5) if w[x] < 0 else int(w[x] * (1 << PRECISION_BITS) + 0.5)
+        xmin[o], cnt[o] = lo, n
+    return xmin, cnt, kk
+
+
+def _resample_axis0(img: np.ndarray, out_size: int) -> np.ndarray:
+    """8-bit pass along axis 0 of an (L, ..., C) uint8 array."""
+    xmin, cnt, kk = resample_coefficients(img.shape[0], out_size)
+    out = np.empty((out_size,) + img.shape[1:], np.uint8)
+    src = img.astype(np.int64)
+    for o in range(out_size):
+        acc = np.full(img.shape[1:], 1 << (PRECISION_BITS - 1), np.int64)
+        for x in range(int(cnt[o])):
+            acc += src[xmin[o] + x] * int(kk[o, x])
+        out[o] = np.clip(acc >> PRECISION_BITS, 0, 255).astype(np.uint8)
+    return out
+
+
+def resize_bilinear_u8(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """(H, W, C) uint8 -> (out_h, out_w, C) uint8, Pillow's two-pass order (a pass is skipped when the size is kept)."""
+    h, w = img.shape[:2]
+    tmp = img if w == out_w else _resample_axis0(img.transpose(1, 0, 2), out_w).transpose(1, 0, 2)
+    return tmp if h == out_h else _resample_axis0(tmp, out_h)
+
+
+def compose_input(img: np.ndarray, canvas=None, crop=None, flip: bool = False, filler=None) -> np.ndarray:
+    """The image the reference hands to Resize after its geometric augmentations, on 8-bit pixels:
+    expand (Util.py:610-645): canvas = (canvas_h, canvas_w, top, left), filled with `filler` (the ImageNet mean after
+    to_pil_image's `mul(255).byte()` truncation: 123, 116, 103); random_crop (:648-729): crop = (top, left, h, w) of the
+    canvas; flip (:732-749): mirrored columns.  to_tensor -> to_pil_image is the identity on 8-bit values."""
+    out = img
+    if canvas is not None:
+        ch, cw, top, left = canvas
+        f = np.asarray(filler if filler is not None else mean_filler_u8(), np.uint8)
+        big = np.empty((ch, cw, 3), np.uint8)
+        big[:] = f
+        big[top:top + img.shape[0], left:left + img.shape[1]] = img
+        out = big
+    if crop is not None:
+        t, l, h, w = crop
+        out = out[t:t + h, l:l + w]
+    if flip:
+        out = out[:, ::-1]
+    return np.ascontiguousarray(out)
+
+
+def mean_filler_u8() -> np.ndarray:
+    import torch
+    return torch.tensor(IMAGENET_MEAN, dtype=torch.float32).mul(255).byte().numpy()
+
+
+def preprocess_image(img: np.ndarray, out_h: int = 300, out_w: int = 300, canvas=None, crop=None, flip: bool = False) -> np.ndarray:
+    """(H, W, 3) uint8 -> (3, out_h, out_w) float32: compose_input, Resize, ToTensor, Normalize (Dataset.py:10-13,37)."""
+    import torch
+    u8 = resize_bilinear_u8(compose_input(img, canvas, crop, flip), out_h, out_w)
+    t = torch.from_numpy(u8).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+    mean = torch.tensor(IMAGENET_MEAN, dtype=torch.float32).view(3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, dtype=torch.float32).view(3, 1, 1)
+    return t.sub_(mean).div_(std).numpy()

@@ -643,3 +643,46 @@ def test_get_map_large_with_ties_vs_oracle():
     assert counts[0].tolist() == [int((dcat == c).sum()) for c in range(20)]
     assert counts[1].tolist() == [int((gcat == c).sum()) for c in range(20)]
     assert 0.05 < float(np.mean([aps[c] for c in range(20)])) < 0.95
+
+
+# ---- (f)-3: input pipeline (Dataset.py:10-13,24-39; Util.py:610-749) ---------------------------------------------------------
+def test_preprocess_batch_equals_pillow_resize_and_normalize():
+    """Ragged batch of VOC-like sizes (down-scale, up-scale, unchanged axis): the device batch equals
+    Pillow resize -> /255 -> (x-mean)/std bit for bit."""
+    from PIL import Image
+    from objectdetection_ssd_amd import Dataset
+    rng = np.random.default_rng(21)
+    shapes = [(375, 500), (500, 333), (120, 90), (300, 300), (300, 451), (900, 1300), (37, 53), (301, 299), (500, 500)]
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in shapes]
+    out = Dataset.preprocess_batch(imgs)
+    assert tuple(out.shape) == (len(imgs), 3, 300, 300) and out.dtype == torch.float32 and out.is_cuda
+    mean = torch.tensor(Dataset.MEAN).view(3, 1, 1)
+    std = torch.tensor(Dataset.STD).view(3, 1, 1)
+    for i, a in enumerate(imgs):
+        u8 = np.asarray(Image.fromarray(a).resize((300, 300), Image.BILINEAR))
+        ref = torch.from_numpy(u8.copy()).permute(2, 0, 1).contiguous().float().div(255).sub_(mean).div_(std)
+        assert torch.equal(out[i].cpu(), ref), (shapes[i], float((out[i].cpu() - ref).abs().max()))
+        assert np.array_equal(O.preprocess_image(a), ref.numpy())
+    small = Dataset.preprocess_batch(imgs[:3], size=(64, 48))
+    assert np.array_equal(small[1].cpu().numpy(), O.preprocess_image(imgs[1], 64, 48))
+
+
+def test_preprocess_batch_with_reference_geometry(gold_dir):
+    """expand / crop / flip plans drawn like the reference (tests/golden/augment.npz seeds), pixels on the device:
+    equal to the oracle's composition + Pillow-exact resize of the same plan."""
+    import random
+    from objectdetection_ssd_amd import Dataset
+    z = np.load(os.path.join(gold_dir, "augment.npz"))
+    imgs, plans = [], []
+    for ci in range(int(z["n_cases"])):
+        p = f"c{ci}_"
+        img = z[p + "img"]
+        random.seed(int(z[p + "seed"]))
+        plan, _, _ = Dataset.plan_transform(img.shape[1], img.shape[0], torch.from_numpy(z[p + "boxes"]), torch.from_numpy(z[p + "labels"]))
+        imgs.append(img); plans.append(plan)
+    out = Dataset.preprocess_batch(imgs, plans).cpu().numpy()
+    for i, (img, plan) in enumerate(zip(imgs, plans)):
+        ref = O.preprocess_image(img, 300, 300, canvas=plan.canvas, crop=plan.crop, flip=plan.flip)
+        assert np.array_equal(out[i], ref), i
+    with pytest.raises(ValueError):
+        Dataset.preprocess_batch([imgs[0]], [plans[1]])

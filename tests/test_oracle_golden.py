@@ -162,3 +162,24 @@ def test_map_vs_reference(gold_dir, ci):
     aps = O.get_map(*args)
     assert np.array_equal(np.asarray([aps[c] for c in range(20)]), ref)
     assert np.array_equal(O.ap_recall_thresholds(), z["recall_levels"])
+
+
+@pytest.mark.parametrize("shape", [(375, 500, 300, 300), (500, 333, 300, 300), (120, 90, 300, 300), (300, 300, 300, 300),
+                                   (300, 451, 300, 300), (900, 1300, 300, 300), (37, 53, 64, 48), (301, 299, 300, 300)])
+def test_resize_restatement_equals_pillow(shape):
+    """The oracle's ImagingResample restatement against Pillow itself (the library Dataset.py:10 calls through
+    torchvision's Resize): bit-exact on 8-bit RGB, down-scaling (antialiased), up-scaling and size-preserving axes."""
+    from PIL import Image
+    h, w, oh, ow = shape
+    a = np.random.default_rng(h * 1000 + w).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    ref = np.asarray(Image.fromarray(a).resize((ow, oh), Image.BILINEAR))
+    assert np.array_equal(O.resize_bilinear_u8(a, oh, ow), ref)
+
+
+def test_preprocess_restatement_layout():
+    a = np.random.default_rng(3).integers(0, 256, (40, 50, 3), dtype=np.uint8)
+    out = O.preprocess_image(a, 30, 20)
+    assert out.shape == (3, 30, 20) and out.dtype == np.float32
+    u8 = O.resize_bilinear_u8(a, 30, 20)
+    np.testing.assert_allclose(out[1], (u8[..., 1] / 255.0 - 0.456) / 0.224, rtol=0, atol=1e-5)
+    assert tuple(O.mean_filler_u8()) == (123, 116, 103)
