@@ -94,6 +94,50 @@ def aux_workload(args, world, rank, dev):
         step = lambda: net(x)                                              # noqa: E731
         metric = "images/sec SSD_resnet34 eval forward (224x224, 63 priors)"
         dtype = args.conv_dtype
+    elif args.workload == "preprocess":
+        # (f)-3: VOC-sized 8-bit images (375x500 / 500x375 / 333x500) already in HBM -> normalised (bs,3,300,300)
+        from objectdetection_ssd_amd import Dataset, _lib, ops
+        rng = np.random.default_rng(1234 + rank)
+        shapes = [((375, 500), (500, 375), (333, 500), (500, 333))[i % 4] for i in range(bs)]
+        imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in shapes]
+        descs = (_lib.ImageDesc * bs)()
+        parts, off = [], 0
+        for i, a in enumerate(imgs):
+            d = descs[i]
+            d.src_offset, d.src_h, d.src_w = off, a.shape[0], a.shape[1]
+            d.canvas_h, d.canvas_w, d.place_top, d.place_left = a.shape[0], a.shape[1], 0, 0
+            d.crop_top, d.crop_left, d.crop_h, d.crop_w = 0, 0, a.shape[0], a.shape[1]
+            parts.append(a.reshape(-1)); off += a.size
+        arena = torch.from_numpy(np.concatenate(parts)).to(dev)
+        step = lambda: ops.preprocess_u8(arena, descs)                      # noqa: E731
+        metric = "images/sec device input pipeline (PIL-exact resize to 300x300 + normalize, VOC-sized sources)"
+        dtype = "u8 -> f32"
+        extra = {"algorithmic_bytes_per_image": int(off / bs + 3 * 300 * 300 * 4)}
+    elif args.workload == "map":
+        # (f)-4: 4952 images (VOC07 test size) x 200 detections, ~2.4 GT per image, resident in HBM
+        from objectdetection_ssd_amd import ops
+        rng = np.random.default_rng(1234 + rank)
+        n_img, per = 4952, 200
+        D = n_img * per
+        gcnt = 1 + np.minimum(rng.poisson(1.4, n_img), 7)
+        G = int(gcnt.sum())
+        gx = rng.uniform(0, .6, (G, 2)); gwh = rng.uniform(.08, .4, (G, 2))
+        gb = np.concatenate([gx, gx + gwh], 1).astype(np.float32)
+        gimg = np.repeat(np.arange(n_img), gcnt)
+        gstart = np.concatenate([[0], np.cumsum(gcnt)])
+        pick = (gstart[:-1, None] + rng.integers(0, 1 << 30, (n_img, per)) % gcnt[:, None]).reshape(-1)
+        db = (gb[pick] + rng.normal(0, .05, (D, 4))).astype(np.float32)
+        gc = rng.integers(0, 20, G)
+        dc = np.where(rng.uniform(size=D) < .7, gc[pick], rng.integers(0, 20, D))
+        t32 = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt)     # noqa: E731
+        a_ = (t32(db, torch.float32), t32(dc, torch.int32), t32(rng.uniform(0, 1, D), torch.float32),
+              t32(np.arange(n_img + 1) * per, torch.int32), t32(gb, torch.float32), t32(gc, torch.int32), t32(gstart, torch.int32))
+        levels = torch.arange(0, 1.1, 0.1).double().numpy()
+        step = lambda: ops.map_eval(*a_, levels, 20)                        # noqa: E731
+        metric = "evaluated images/sec, 20-class 11-point mAP (4952 images x 200 detections per pass)"
+        dtype = "f32 IoU / f64 precision-recall"
+        bs = n_img
+        extra = {"detections": D, "ground_truth": G}
     else:
         l = (torch.randn(bs, 8732, 4, generator=g)).to(dev)
         c = (3 * torch.randn(bs, 8732, 21, generator=g)).to(dev)
@@ -101,6 +145,8 @@ def aux_workload(args, world, rank, dev):
         step = lambda: Losses.inference_batch(l, c, wh)                    # noqa: E731
         metric = "images/sec batched decode + per-class NMS + top-200 (8732 priors, conf ~ 3*randn)"
         dtype = "f32"
+    if args.workload in ("resnet34", "decode"):
+        extra = {}
 
     def fence():
         if world > 1:
@@ -122,8 +168,8 @@ def aux_workload(args, world, rank, dev):
         print(json.dumps({"metric": metric, "value": round(bs * world * args.steps / elapsed, 2), "unit": "images/sec", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-                          "config": {"workload": f"BASELINE configs[4] half: {args.workload}, batch {bs}/GPU", "global_batch": bs * world,
-                                     "parallelism": f"replicas x{world}"}}))
+                          "config": dict({"workload": f"{args.workload} (see --help), {bs} images per pass per GPU", "global_batch": bs * world,
+                                          "parallelism": f"replicas x{world}"}, **extra)}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -140,7 +186,7 @@ def main():
     ap.add_argument("--conv-dtype", default="f32", choices=("f32", "f32x3", "bf16"),
                     help="bf16 = BASELINE configs[2] (bf16-operand fwd/dgrad convs, f32 accumulate); not the headline bench line")
     ap.add_argument("--variant", type=int, default=300, choices=(300, 512), help="512 = build-defined SSD512 (not a bench line)")
-    ap.add_argument("--workload", default="train", choices=("train", "resnet34", "decode"),
+    ap.add_argument("--workload", default="train", choices=("train", "resnet34", "decode", "preprocess", "map"),
                     help="train = the headline line (BASELINE configs[1]); resnet34 / decode = the two halves of configs[4] "
                          "(SSD_resnet34 eval forward at 224x224; batched per-class NMS decode of SSD300-shaped outputs): replicas only")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
