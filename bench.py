@@ -322,12 +322,13 @@ def main():
                            "all_conv_kernels_tflops": round(sum(a[1] for a in agg.values()) / sum(a[0] for a in agg.values()) / 1e12, 2),
                            "by_kernel": {k: {"ms_per_step": round(a[0] / 3 * 1e3, 3), "tflops": round(a[1] / a[0] / 1e12, 2),
                                              "launches_per_step": a[2] // 3} for k, a in sorted(agg.items())}}
-        if args.layers:
-            seen = set()
+        if args.layers:                       # per-layer table: mean over the three profiled steps
+            per = {}
             for label, tag, flops, dt in rows:
-                if label in seen:
-                    continue
-                seen.add(label)
+                e = per.setdefault(label, [tag, flops, 0.0, 0])
+                e[2] += dt; e[3] += 1
+            for label, (tag, flops, tsum_l, cnt) in per.items():
+                dt = tsum_l / cnt
                 print(f"{label:32s} {tag:28s} {flops / 1e9:9.2f} GF {dt * 1e3:8.3f} ms {flops / dt / 1e12:7.2f} TF/s", file=sys.stderr)
     if world > 1:
         dist.barrier()

@@ -16,7 +16,8 @@ __version__ = "0.1.0"
 
 
 def install_dropin() -> None:
-    from . import Losses, Model, Util
+    from . import Dataset, Losses, Model, Util
     _sys.modules["Model"] = Model
     _sys.modules["Losses"] = Losses
     _sys.modules["Util"] = Util
+    _sys.modules["Dataset"] = Dataset

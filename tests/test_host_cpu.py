@@ -107,12 +107,13 @@ def test_product_path_refuses_cpu_tensors():
 def test_dropin_module_names():
     import sys
     import objectdetection_ssd_amd as pkg
-    saved = {k: sys.modules.get(k) for k in ("Model", "Losses", "Util")}
+    saved = {k: sys.modules.get(k) for k in ("Model", "Losses", "Util", "Dataset")}
     try:
         pkg.install_dropin()
         from Losses import ancs_xywh, ancs_xyxy, device, inference, ssd  # noqa: F401
-        from Model import SSD_300  # noqa: F401
-        from Util import class_to_label  # noqa: F401
+        from Model import SSD_300, SSD_resnet34  # noqa: F401
+        from Util import class_to_label, get_map, create_ancs_xywh_zoom_ratio  # noqa: F401
+        from Dataset import MultiImageMultiBBoxDataset, collate_fn  # noqa: F401
     finally:
         for k, v in saved.items():
             if v is None:
