@@ -189,6 +189,7 @@ def main():
     ap.add_argument("--workload", default="train", choices=("train", "resnet34", "decode", "preprocess", "map"),
                     help="train = the headline line (BASELINE configs[1]); resnet34 / decode = the two halves of configs[4] "
                          "(SSD_resnet34 eval forward at 224x224; batched per-class NMS decode of SSD300-shaped outputs): replicas only")
+    ap.add_argument("--igemm-lds-pad", type=int, default=-1, help="tuning aid: extra dynamic LDS bytes per igemm block (-1 = library default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
@@ -217,6 +218,9 @@ def main():
     if args.workload != "train":
         return aux_workload(args, world, rank, dev)
 
+    if args.igemm_lds_pad >= 0:
+        from objectdetection_ssd_amd import _lib
+        _lib.check(_lib.load().ssd_tune_set_igemm_lds_pad(args.igemm_lds_pad), "tune")
     torch.manual_seed(0)                                   # same initial weights on every rank
     net = (Model.SSD_300() if args.variant == 300 else Model.SSD_512()).to(dev).train()
     net.conv_dtype = args.conv_dtype

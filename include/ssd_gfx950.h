@@ -117,6 +117,7 @@ int ssd_conv2d_wgrad_tile(const ssd_conv_geom* g, int* bt, int* nsplit);
  * (0 = 256x64, 1 = 128x128, 2 = 128x64, 3 = 64x64) / LDS stage count (1|2), and the wgrad tile edge
  * (64|128) / stage count / split-K target in blocks per CU.  -1 = automatic. */
 int ssd_tune_set_igemm(int tile, int nbuf);
+int ssd_tune_set_igemm_lds_pad(int bytes);   /* extra dynamic LDS per block: caps resident blocks per CU (experiments) */
 int ssd_tune_set_wgrad(int bt, int nbuf, int blocks_per_cu);
 
 /* conv1_1 (Model.py:136 features[0]: Conv2d(3,64,3,padding=1)+ReLU, Ci = 3): im2col of the caller's

@@ -64,6 +64,7 @@ SIGNATURES = {
     "ssd_conv2d_igemm_tile": (_I, [_G, _I, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ssd_conv2d_wgrad_tile": (_I, [_G, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ssd_tune_set_igemm": (_I, [_I, _I]),
+    "ssd_tune_set_igemm_lds_pad": (_I, [_I]),
     "ssd_tune_set_wgrad": (_I, [_I, _I, _I]),
     "ssd_im2col_first": (_I, [_P, _P, _I, _I, _I, _P]),
     "ssd_maxpool_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -218,11 +218,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
 }
 
+int g_lds_pad = 0;            // tuning aid: extra dynamic LDS per block (caps the blocks resident per CU)
+
 template <int BM, int BN, int WM, int WN, int NBUF>
 int launch_igemm(IgemmParams& p, hipStream_t st) {
     p.tiles_m = ssd_cdiv(p.M, BM);
     p.tiles_n = ssd_cdiv(p.Nout, BN);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, NBUF>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, NBUF>), dim3(p.tiles_m * p.tiles_n), dim3(256), g_lds_pad, st, p);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
 }
@@ -972,6 +974,13 @@ extern "C" int ssd_tune_set_igemm(int tile, int nbuf) {
     if (tile < -1 || tile > 3 || nbuf < -1 || nbuf > 2 || nbuf == 0) return SSD_ERR_BAD_SHAPE;
     g_force_tile = tile;
     g_force_nbuf = nbuf;
+    return SSD_OK;
+}
+
+// Tuning aid: extra dynamic LDS bytes per igemm block (occupancy cap experiments); 0 = none.
+extern "C" int ssd_tune_set_igemm_lds_pad(int bytes) {
+    if (bytes < 0 || bytes > 120 * 1024) return SSD_ERR_BAD_SHAPE;
+    g_lds_pad = bytes;
     return SSD_OK;
 }
 

@@ -52,6 +52,15 @@ def main():
                 ms = timeit(lambda: ops.conv2d_fwd(x, wf, b, g, True, ld=ld, out=dy))
                 row.append(f"{lab}:{fl / ms / 1e9:6.1f}")
             print(f"fwd   {name:8s} " + "  ".join(row), flush=True)
+        if which == "occ":                      # blocks per CU capped through extra dynamic LDS (64x64 tile, 18 KB static)
+            row = []
+            for pad_kb, lab in ((0, "7/CU"), (8, "6"), (14, "5"), (22, "4"), (35, "3"), (62, "2")):
+                lib.ssd_tune_set_igemm_lds_pad(pad_kb * 1024)
+                ms = timeit(lambda: ops.conv2d_fwd(x, wf, b, g, True, ld=ld, out=dy))
+                ms2 = timeit(lambda: ops.conv2d_dgrad(dy, wb, g, dx, x, False))
+                row.append(f"{lab}:{fl / ms / 1e9:6.1f}/{fl / ms2 / 1e9:6.1f}")
+            lib.ssd_tune_set_igemm_lds_pad(0)
+            print(f"occ fwd/dgrad {name:8s} " + "  ".join(row), flush=True)
         if which in ("dgrad", "all"):
             row = []
             for t, nb, lab in ig_var:
