@@ -116,6 +116,16 @@ int ssd_conv2d_wgrad_tile(const ssd_conv_geom* g, int* bt, int* nsplit);
 /* Tuning aids (process-global, not thread-safe, results unchanged): force the igemm tile
  * (0 = 256x64, 1 = 128x128, 2 = 128x64, 3 = 64x64) / LDS stage count (1|2), and the wgrad tile edge
  * (64|128) / stage count / split-K target in blocks per CU.  -1 = automatic. */
+/* Same convolutions with an optional scratch buffer: launches whose 64x64-tile grid would leave most of the chip idle
+ * while each block walks a long K loop (the 19x19 and smaller maps: c_7 ... c_11, seq8 ... seq11) are split along K
+ * into partial tiles in the workspace and finished (bias / accumulate / ReLU / mask) by a fixed-order reduction.
+ * workspace may be NULL or smaller than ssd_conv2d_igemm_workspace(g, direction) asks: the launch is then not split. */
+size_t ssd_conv2d_igemm_workspace(const ssd_conv_geom* g, int direction /* 0 forward, 1 dgrad */);
+int ssd_conv2d_fwd_ws(const float* x, const float* w_ohwi, const float* bias, float* y, int ldy, const ssd_conv_geom* g,
+                      int relu, void* workspace, size_t workspace_bytes, void* stream);
+int ssd_conv2d_dgrad_ws(const float* dy, int ldy, const float* w_ihwo, int Co_pad, float* dx, const float* relu_mask,
+                        int accumulate, const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream);
+int ssd_tune_set_igemm_splitk(int k);       /* -1 automatic, 1 never split, k > 1 force k slices */
 int ssd_tune_set_igemm(int tile, int nbuf);
 int ssd_tune_set_igemm_lds_pad(int bytes);   /* extra dynamic LDS per block: caps resident blocks per CU (experiments) */
 int ssd_tune_set_wgrad(int bt, int nbuf, int blocks_per_cu);

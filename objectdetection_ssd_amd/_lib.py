@@ -63,6 +63,10 @@ SIGNATURES = {
     "ssd_conv2d_wgrad": (_I, [_P, _P, _I, _P, _P, _G, _P, _Z, _P]),
     "ssd_conv2d_igemm_tile": (_I, [_G, _I, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ssd_conv2d_wgrad_tile": (_I, [_G, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ssd_conv2d_igemm_workspace": (_Z, [_G, _I]),
+    "ssd_conv2d_fwd_ws": (_I, [_P, _P, _P, _P, _I, _G, _I, _P, _Z, _P]),
+    "ssd_conv2d_dgrad_ws": (_I, [_P, _I, _P, _I, _P, _P, _I, _G, _P, _Z, _P]),
+    "ssd_tune_set_igemm_splitk": (_I, [_I]),
     "ssd_tune_set_igemm": (_I, [_I, _I]),
     "ssd_tune_set_igemm_lds_pad": (_I, [_I]),
     "ssd_tune_set_wgrad": (_I, [_I, _I, _I]),

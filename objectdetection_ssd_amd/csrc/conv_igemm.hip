@@ -38,6 +38,8 @@ struct IgemmParams {
     int M;                   // N*Ho*Wo
     int tiles_m, tiles_n;
     int relu, accumulate;
+    int ksplit, kt_per_split;   // split-K (small grids, deep K): blockIdx.y = split; partial tiles go to `slab`
+    float* slab;                // [ksplit][M][Nout] raw partial sums, reduced by splitk_reduce_kernel
 };
 
 constexpr int BK = 32;
@@ -122,11 +124,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int kc = p.Ca / BK;          // K steps per tap
-    const int KT = T * kc;
+    // this block's K steps: all of them, or the blockIdx.y-th slice when the launch is split-K
+    const int kt_begin = p.ksplit > 1 ? (int)blockIdx.y * p.kt_per_split : 0;
+    const int KT = p.ksplit > 1 ? min(T * kc - kt_begin, p.kt_per_split) : T * kc;
     f32x4 ra[A_ROWS], rb[B_ROWS];
-    int c_nxt = 0, r_nxt = 0, s_nxt = 0;
-    unsigned soff_a = 0, soff_b = 0;
-    tap_offsets(0, 0);
+    int c_nxt = kt_begin % kc, r_nxt = (kt_begin / kc) / p.S, s_nxt = (kt_begin / kc) % p.S;
+    unsigned soff_a = (unsigned)c_nxt * BK * 4, soff_b = (unsigned)kt_begin * BK * 4;
+    tap_offsets(r_nxt, s_nxt);
 
     auto issue_loads = [&]() {
 #pragma unroll
@@ -195,6 +199,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
 
     // ---- epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) --------
+    if (p.ksplit > 1) {                                   // uniform: raw partial tile, finished by splitk_reduce_kernel
+        float* slab = p.slab + (size_t)blockIdx.y * p.M * p.Nout;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + (wn * TN + j) * 32 + lr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (n < p.Nout && m < p.M) slab[(size_t)m * p.Nout + n] = acc[i][j][r];
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -219,12 +238,48 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 }
 
 int g_lds_pad = 0;            // tuning aid: extra dynamic LDS per block (caps the blocks resident per CU)
+int g_force_ksplit = -1;      // tuning aid: 1 = never split K, k > 1 = always k slices (when a workspace is given); -1 = automatic
+
+// out = [accumulate: out +] sum_split slab[split] (+ bias) -> ReLU -> ReLU mask; splits added in index order (reproducible)
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, int ksplit, int M, int N, int ldo, const float* __restrict__ bias,
+                                     float* __restrict__ out, const float* __restrict__ mask, int relu, int accumulate) {
+    const size_t total = (size_t)M * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i % N);
+        const size_t m = i / N;
+        float v = slab[i];
+        for (int k = 1; k < ksplit; ++k) v += slab[(size_t)k * total + i];
+        if (bias != nullptr) v += bias[n];
+        const size_t idx = m * ldo + n;
+        if (accumulate) v += out[idx];
+        if (relu) v = v < 0.f ? 0.f : v;
+        if (mask != nullptr) v = mask[idx] > 0.f ? v : 0.f;
+        out[idx] = v;
+    }
+}
+
+// K slices for a launch of `blocks` 64x64 tiles with `kt` K steps each: only when the grid leaves most of the 256 CUs'
+// ~1800 resident-block slots empty and every slice keeps at least 4 K steps; the slab is capped at 64 MB.
+int pick_ksplit(int blocks, int kt, size_t tile_elems_total) {
+    if (g_force_ksplit == 1) return 1;
+    int k;
+    if (g_force_ksplit > 1) k = g_force_ksplit;
+    else {
+        if (blocks >= 1024 || kt < 16) return 1;
+        k = 1792 / blocks;
+        if (k > 16) k = 16;
+    }
+    if (k > kt / 4) k = kt / 4;
+    while (k > 1 && (size_t)k * tile_elems_total * 4 > ((size_t)64 << 20)) --k;
+    return k < 2 ? 1 : k;
+}
 
 template <int BM, int BN, int WM, int WN, int NBUF>
 int launch_igemm(IgemmParams& p, hipStream_t st) {
     p.tiles_m = ssd_cdiv(p.M, BM);
     p.tiles_n = ssd_cdiv(p.Nout, BN);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, NBUF>), dim3(p.tiles_m * p.tiles_n), dim3(256), g_lds_pad, st, p);
+    const int ks = p.ksplit > 1 ? p.ksplit : 1;
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, NBUF>), dim3(p.tiles_m * p.tiles_n, ks), dim3(256), g_lds_pad, st, p);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
 }
@@ -250,14 +305,38 @@ TileChoice pick_tile(int M, int Nout) {
     return c;
 }
 
-int dispatch_igemm(IgemmParams& p, hipStream_t st) {
+// K slices this launch would use (1 = none) for M x Nout outputs with Ca-channel taps
+int plan_ksplit(int M, int Nout, int Ca, int taps) {
+    const int blocks = ssd_cdiv(M, 64) * ssd_cdiv(Nout, 64), kt = taps * (Ca / BK);
+    const int k = pick_ksplit(blocks, kt, (size_t)M * Nout);
+    return k > 1 ? ssd_cdiv(kt, ssd_cdiv(kt, k)) : 1;            // no empty slice
+}
+
+int dispatch_igemm(IgemmParams& p, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0) {
     const TileChoice c = pick_tile(p.M, p.Nout);
-    switch (c.tile) {
-        case T256x64: return c.nbuf == 2 ? launch_igemm<256, 64, 4, 1, 2>(p, st) : launch_igemm<256, 64, 4, 1, 1>(p, st);
-        case T128x128: return c.nbuf == 2 ? launch_igemm<128, 128, 2, 2, 2>(p, st) : launch_igemm<128, 128, 2, 2, 1>(p, st);
-        case T128x64: return c.nbuf == 2 ? launch_igemm<128, 64, 4, 1, 2>(p, st) : launch_igemm<128, 64, 4, 1, 1>(p, st);
-        default: return c.nbuf == 2 ? launch_igemm<64, 64, 2, 2, 2>(p, st) : launch_igemm<64, 64, 2, 2, 1>(p, st);
+    p.ksplit = 1;
+    if (ws != nullptr && c.tile == T64x64) {
+        const int k = plan_ksplit(p.M, p.Nout, p.Ca, p.R * p.S);
+        if (k > 1 && (size_t)k * p.M * p.Nout * sizeof(float) <= ws_bytes) {
+            p.ksplit = k;
+            p.kt_per_split = ssd_cdiv(p.R * p.S * (p.Ca / BK), k);
+            p.slab = static_cast<float*>(ws);
+        }
     }
+    int e;
+    switch (c.tile) {
+        case T256x64: e = c.nbuf == 2 ? launch_igemm<256, 64, 4, 1, 2>(p, st) : launch_igemm<256, 64, 4, 1, 1>(p, st); break;
+        case T128x128: e = c.nbuf == 2 ? launch_igemm<128, 128, 2, 2, 2>(p, st) : launch_igemm<128, 128, 2, 2, 1>(p, st); break;
+        case T128x64: e = c.nbuf == 2 ? launch_igemm<128, 64, 4, 1, 2>(p, st) : launch_igemm<128, 64, 4, 1, 1>(p, st); break;
+        default: e = c.nbuf == 2 ? launch_igemm<64, 64, 2, 2, 2>(p, st) : launch_igemm<64, 64, 2, 2, 1>(p, st); break;
+    }
+    if (e != SSD_OK || p.ksplit <= 1) return e;
+    const size_t total = (size_t)p.M * p.Nout;
+    const int rb = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, st, p.slab, p.ksplit, p.M, p.Nout, p.ldo, p.bias, p.out, p.mask,
+                       p.relu, p.accumulate);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -884,7 +963,8 @@ int check_geom(const ssd_conv_geom* g) {
 }  // namespace
 
 static int conv2d_fwd_impl(const float* x, const float* w_ohwi, const float* bias, float* y, int ldy,
-                           const ssd_conv_geom* g, int relu, void* stream, bool bf16, int accumulate = 0) {
+                           const ssd_conv_geom* g, int relu, void* stream, bool bf16, int accumulate = 0,
+                           void* ws = nullptr, size_t ws_bytes = 0) {
     if (int e = check_geom(g)) return e;
     if (!x || !w_ohwi || !y) return SSD_ERR_NULL;
     if (g->Ci % 32 != 0 || ldy < g->Co) return SSD_ERR_BAD_SHAPE;
@@ -900,7 +980,28 @@ static int conv2d_fwd_impl(const float* x, const float* w_ohwi, const float* bia
     p.Nout = g->Co; p.Nrows = g->Co; p.ldo = ldy; p.R = g->R; p.S = g->S;
     p.sm = g->stride; p.sd = 1; p.off = -g->pad; p.dstep = g->dil;
     p.M = g->N * g->Ho * g->Wo; p.relu = relu; p.accumulate = accumulate;
-    return bf16 ? dispatch_igemm_bf16(p, (hipStream_t)stream) : dispatch_igemm(p, (hipStream_t)stream);
+    return bf16 ? dispatch_igemm_bf16(p, (hipStream_t)stream) : dispatch_igemm(p, (hipStream_t)stream, ws, ws_bytes);
+}
+
+// Workspace the split-K path of ssd_conv2d_fwd_ws (direction 0) / ssd_conv2d_dgrad_ws (direction 1) wants for this
+// geometry; 0 = the launch is not split (large grids), and the _ws entry points accept workspace == NULL.
+extern "C" size_t ssd_conv2d_igemm_workspace(const ssd_conv_geom* g, int direction) {
+    if (check_geom(g) != SSD_OK) return 0;
+    const int taps = g->R * g->S;
+    if (direction == 0) {
+        if (g->Ci % 32 != 0) return 0;
+        const int M = g->N * g->Ho * g->Wo;
+        const int k = plan_ksplit(M, g->Co, g->Ci, taps);
+        return k > 1 ? (size_t)k * M * g->Co * sizeof(float) : 0;
+    }
+    const int M = g->N * g->H * g->W, co_pad = (g->Co + 31) / 32 * 32;
+    const int k = plan_ksplit(M, g->Ci, co_pad, taps);
+    return k > 1 ? (size_t)k * M * g->Ci * sizeof(float) : 0;
+}
+extern "C" int ssd_conv2d_fwd_ws(const float* x, const float* w_ohwi, const float* bias, float* y, int ldy, const ssd_conv_geom* g,
+                                 int relu, void* workspace, size_t workspace_bytes, void* stream) {
+    if (workspace != nullptr && !ssd_aligned16(workspace)) return SSD_ERR_ALIGN;
+    return conv2d_fwd_impl(x, w_ohwi, bias, y, ldy, g, relu, stream, false, 0, workspace, workspace_bytes);
 }
 
 extern "C" int ssd_conv2d_fwd_accum(const float* x, const float* w_ohwi, const float* bias, float* y_inout, int ldy,
@@ -922,7 +1023,8 @@ extern "C" int ssd_conv2d_fwd_bf16(const float* x, const float* w_ohwi, const fl
 }
 
 static int conv2d_dgrad_impl(const float* dy, int ldy, const float* w_ihwo, int Co_pad, float* dx,
-                             const float* relu_mask, int accumulate, const ssd_conv_geom* g, void* stream, bool bf16) {
+                             const float* relu_mask, int accumulate, const ssd_conv_geom* g, void* stream, bool bf16,
+                             void* ws = nullptr, size_t ws_bytes = 0) {
     if (int e = check_geom(g)) return e;
     if (!dy || !w_ihwo || !dx) return SSD_ERR_NULL;
     if (Co_pad % 32 != 0 || Co_pad < g->Co || ldy != Co_pad || g->Ci % 4 != 0) return SSD_ERR_BAD_SHAPE;
@@ -938,7 +1040,13 @@ static int conv2d_dgrad_impl(const float* dy, int ldy, const float* w_ihwo, int 
     p.Nout = g->Ci; p.Nrows = g->Ci; p.ldo = g->Ci; p.R = g->R; p.S = g->S;
     p.sm = 1; p.sd = g->stride; p.off = g->pad; p.dstep = -g->dil;
     p.M = g->N * g->H * g->W; p.relu = 0; p.accumulate = accumulate;
-    return bf16 ? dispatch_igemm_bf16(p, (hipStream_t)stream) : dispatch_igemm(p, (hipStream_t)stream);
+    return bf16 ? dispatch_igemm_bf16(p, (hipStream_t)stream) : dispatch_igemm(p, (hipStream_t)stream, ws, ws_bytes);
+}
+
+extern "C" int ssd_conv2d_dgrad_ws(const float* dy, int ldy, const float* w_ihwo, int Co_pad, float* dx, const float* relu_mask,
+                                   int accumulate, const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream) {
+    if (workspace != nullptr && !ssd_aligned16(workspace)) return SSD_ERR_ALIGN;
+    return conv2d_dgrad_impl(dy, ldy, w_ihwo, Co_pad, dx, relu_mask, accumulate, g, stream, false, workspace, workspace_bytes);
 }
 
 extern "C" int ssd_conv2d_dgrad(const float* dy, int ldy, const float* w_ihwo, int Co_pad, float* dx,
@@ -974,6 +1082,13 @@ extern "C" int ssd_tune_set_igemm(int tile, int nbuf) {
     if (tile < -1 || tile > 3 || nbuf < -1 || nbuf > 2 || nbuf == 0) return SSD_ERR_BAD_SHAPE;
     g_force_tile = tile;
     g_force_nbuf = nbuf;
+    return SSD_OK;
+}
+
+// Tuning aid: K slices of the _ws entry points: -1 automatic, 1 never, k > 1 always k (bounded by K/4 steps and the workspace).
+extern "C" int ssd_tune_set_igemm_splitk(int k) {
+    if (k < -1 || k == 0 || k > 64) return SSD_ERR_BAD_SHAPE;
+    g_force_ksplit = k;
     return SSD_OK;
 }
 

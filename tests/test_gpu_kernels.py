@@ -351,8 +351,10 @@ def test_conv_f32_from_three_bf16_limbs(case):
     dy_p = torch.zeros(n, g.Ho, g.Wo, ld)
     dy_p[..., :co] = _nhwc(dy)
     xd, dyd = _nhwc(x).to(dev), dy_p.to(dev)
+    lib.ssd_tune_set_igemm_splitk(1)                  # baseline: the plain f32 kernel, one accumulation chain over all of K
     y_f32 = ops.conv2d_fwd(xd, wf, b.to(dev), g, False, ld=ld)[..., :co].cpu().double()
     dx_f32 = ops.conv2d_dgrad(dyd, wb, g).cpu().double()
+    lib.ssd_tune_set_igemm_splitk(-1)
     ref_y, ref_dx = _nhwc(y64.detach()), _nhwc(x64.grad)
     e_y32 = float((y_f32 - ref_y).norm() / ref_y.norm())
     e_dx32 = float((dx_f32 - ref_dx).norm() / ref_dx.norm())
@@ -432,3 +434,42 @@ def test_channel_affine():
     assert float((y2.cpu() - F.relu(x * sc + sh)).abs().max()) < 1e-6
     with pytest.raises(ValueError):
         ops.channel_affine(torch.zeros(2, 6, device=dev), torch.zeros(6, device=dev), torch.zeros(6, device=dev))
+
+
+@pytest.mark.parametrize("case", [CONV_CASES[i] for i in (0, 4, 5, 6, 8, 9, 10)])
+@pytest.mark.parametrize("ksplit", [1, 2, 3, 7])
+def test_conv_split_k(case, ksplit):
+    """Split-K path of the forward / dgrad igemm (small grids, deep K): forced slice counts incl. ones that do not divide
+    the K steps; bias + ReLU + padded leading dimension (fwd), accumulate + mask + stride 2 (dgrad); bitwise reproducible."""
+    from objectdetection_ssd_amd import _lib, ops
+    lib = _lib.load()
+    n, h, w, ci, co, k, s, p, d = case
+    dev = _dev()
+    x, wt, b = _conv_data(case, seed=61)
+    x.requires_grad_(True)
+    y = F.conv2d(x, wt, b, stride=s, padding=p, dilation=d)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(62))
+    y.backward(dy)
+    g = ops.make_geom(n, h, w, ci, co, k, s, p, d)
+    ld = ops.pad32(co)
+    wf, wb = ops.weight_ohwi(wt.to(dev), ld), ops.weight_ihwo(wt.to(dev), ld)
+    dy_p = torch.zeros(n, g.Ho, g.Wo, ld)
+    dy_p[..., :co] = _nhwc(dy)
+    try:
+        assert lib.ssd_tune_set_igemm_splitk(ksplit) == 0
+        if ksplit > 1:
+            assert lib.ssd_conv2d_igemm_workspace(g, 0) > 0 and lib.ssd_conv2d_igemm_workspace(g, 1) > 0
+        else:
+            assert lib.ssd_conv2d_igemm_workspace(g, 0) == 0
+        yd = ops.conv2d_fwd(_nhwc(x.detach()).to(dev), wf, b.to(dev), g, True, ld=ld)
+        yd2 = ops.conv2d_fwd(_nhwc(x.detach()).to(dev), wf, b.to(dev), g, True, ld=ld)
+        _close(yd[..., :co], _nhwc(F.relu(y.detach())), what=f"split-K {ksplit} fwd {case}")
+        assert torch.equal(yd, yd2)
+        if ld != co:
+            assert float(yd[..., co:].abs().max()) == 0.0
+        prev = torch.randn(n, h, w, ci, generator=torch.Generator().manual_seed(63)).to(dev)
+        mask = torch.randn(n, h, w, ci, generator=torch.Generator().manual_seed(64)).clamp_min(0).to(dev)
+        dx = ops.conv2d_dgrad(dy_p.to(dev), wb, g, dx=prev.clone(), relu_mask=mask, accumulate=True)
+        _close(dx, (_nhwc(x.grad) + prev.cpu()) * (mask.cpu() > 0), what=f"split-K {ksplit} dgrad {case}")
+    finally:
+        lib.ssd_tune_set_igemm_splitk(-1)
