@@ -94,6 +94,22 @@ def aux_workload(args, world, rank, dev):
         step = lambda: net(x)                                              # noqa: E731
         metric = "images/sec SSD_resnet34 eval forward (224x224, 63 priors)"
         dtype = args.conv_dtype
+    elif args.workload in ("infer", "infer-graph"):
+        # SSD300 inference forward (no decode) at --batch images: eager launches vs one HIP-graph replay
+        torch.manual_seed(0)
+        net = Model.SSD_300().to(dev).eval()
+        net.conv_dtype = args.conv_dtype
+        x = torch.randn(bs, 3, 300, 300, generator=g).to(dev)
+        if args.workload == "infer-graph":
+            gf = net.graphed_forward(x)
+            step = lambda: gf(x)                                            # noqa: E731
+        else:
+            def step():
+                with torch.no_grad():
+                    return net(x)
+        metric = f"images/sec SSD300-VGG16 inference forward ({'HIP graph replay' if args.workload == 'infer-graph' else 'eager launches'})"
+        dtype = args.conv_dtype
+        extra = {}
     elif args.workload == "preprocess":
         # (f)-3: VOC-sized 8-bit images (375x500 / 500x375 / 333x500) already in HBM -> normalised (bs,3,300,300)
         from objectdetection_ssd_amd import Dataset, _lib, ops
@@ -186,7 +202,7 @@ def main():
     ap.add_argument("--conv-dtype", default="f32", choices=("f32", "f32x3", "bf16"),
                     help="bf16 = BASELINE configs[2] (bf16-operand fwd/dgrad convs, f32 accumulate); not the headline bench line")
     ap.add_argument("--variant", type=int, default=300, choices=(300, 512), help="512 = build-defined SSD512 (not a bench line)")
-    ap.add_argument("--workload", default="train", choices=("train", "resnet34", "decode", "preprocess", "map"),
+    ap.add_argument("--workload", default="train", choices=("train", "resnet34", "decode", "preprocess", "map", "infer", "infer-graph"),
                     help="train = the headline line (BASELINE configs[1]); resnet34 / decode = the two halves of configs[4] "
                          "(SSD_resnet34 eval forward at 224x224; batched per-class NMS decode of SSD300-shaped outputs): replicas only")
     ap.add_argument("--igemm-lds-pad", type=int, default=-1, help="tuning aid: extra dynamic LDS bytes per igemm block (-1 = library default)")

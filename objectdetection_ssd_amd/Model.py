@@ -416,6 +416,10 @@ class SSD_300(nn.Module):
         nn.init.xavier_uniform_(c.weight)
         nn.init.constant_(c.bias, 0.)
 
+    def graphed_forward(self, example_input: torch.Tensor) -> "GraphedForward":
+        """Capture the inference forward for this input shape into a HIP graph (see GraphedForward)."""
+        return GraphedForward(self, example_input)
+
     def _forward_params(self) -> Dict[str, torch.Tensor]:
         named = dict(self.named_parameters())
         return {n: named[n] for n in self._engine.names}
@@ -427,6 +431,37 @@ class SSD_300(nn.Module):
             return _SSD300Function.apply(x, eng, *[P[n] for n in eng.names])
         loc, conf, _ = eng.forward(x, P, save=False)
         return loc, conf
+
+
+class GraphedForward:
+    """Inference forward of a fixed input shape captured once into a HIP graph and replayed: at small batches the
+    ~80 kernel launches of a forward cost more host time than GPU time, the replay is one launch.  Every kernel of the
+    path only enqueues on the stream it is given (no allocation, no synchronisation inside the library), so the capture
+    needs nothing special.  The graph bakes in the weight layouts of the moment of capture: capture again after the
+    parameters change.  `__call__(x)` copies x into the static input and returns the static (loc, conf) tensors, which
+    the next call overwrites."""
+
+    def __init__(self, net: "SSD_300", example: torch.Tensor):
+        if net.training and any(p.requires_grad for p in net.parameters()) and torch.is_grad_enabled():
+            pass                                               # captured under no_grad below either way
+        self.net = net
+        self.x = example.detach().clone().contiguous()
+        side = torch.cuda.Stream(device=self.x.device)
+        side.wait_stream(torch.cuda.current_stream(self.x.device))
+        with torch.no_grad(), torch.cuda.stream(side):        # warm-up: weight layouts, workspaces, allocator pools
+            for _ in range(2):
+                net(self.x)
+        torch.cuda.current_stream(self.x.device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.loc, self.conf = net(self.x)
+
+    def __call__(self, x: torch.Tensor):
+        if tuple(x.shape) != tuple(self.x.shape) or x.dtype != self.x.dtype:
+            raise ValueError(f"graph captured for {tuple(self.x.shape)} {self.x.dtype}, got {tuple(x.shape)} {x.dtype}")
+        self.x.copy_(x, non_blocking=True)
+        self.graph.replay()
+        return self.loc, self.conf
 
 
 class SSD_512(SSD_300):

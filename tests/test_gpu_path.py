@@ -686,3 +686,25 @@ def test_preprocess_batch_with_reference_geometry(gold_dir):
         assert np.array_equal(out[i], ref), i
     with pytest.raises(ValueError):
         Dataset.preprocess_batch([imgs[0]], [plans[1]])
+
+
+def test_graphed_inference_forward_replays_bitwise():
+    """HIP-graph capture of the inference forward: replay equals the eager forward bit for bit, follows new inputs, and the
+    library calls are capture-safe (enqueue only)."""
+    from objectdetection_ssd_amd import Model
+    torch.manual_seed(3)
+    net = Model.SSD_300().to(DEV).eval()
+    x1 = torch.randn(2, 3, 300, 300, device=DEV)
+    x2 = torch.randn(2, 3, 300, 300, device=DEV)
+    with torch.no_grad():
+        l1, c1 = net(x1)
+        l2, c2 = net(x2)
+    g = net.graphed_forward(x1)
+    a, b = g(x1)
+    assert torch.equal(a, l1) and torch.equal(b, c1)
+    a, b = g(x2)
+    assert torch.equal(a, l2) and torch.equal(b, c2)
+    a, b = g(x1)
+    assert torch.equal(a, l1) and torch.equal(b, c1)
+    with pytest.raises(ValueError):
+        g(torch.zeros(1, 3, 300, 300, device=DEV))
