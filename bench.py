@@ -274,12 +274,14 @@ def main():
         elapsed = float(t.item())
     ms = elapsed / args.steps * 1e3
     ips = bs * world * args.steps / elapsed
-    # host-side enqueue time per step (diagnostic: the step is GPU-bound while this stays below ms_per_step)
-    fence()
-    h0 = time.perf_counter()
+    # host-side enqueue time of ONE step into an empty queue (diagnostic: the step is GPU-bound while this stays below
+    # ms_per_step; several steps back to back would measure the queue's back-pressure instead)
+    host_ms = 0.0
     for _ in range(3):
+        fence()
+        h0 = time.perf_counter()
         step()
-    host_ms = (time.perf_counter() - h0) / 3 * 1e3
+        host_ms += (time.perf_counter() - h0) / 3 * 1e3
     fence()
     n_pos = float(trainer.flat_grad[trainer.n].item())
     loss = (float(l1.item()) + float(l2.item())) / max(float(Losses.last_match["n_pos"].item()), 1.0)
