@@ -260,14 +260,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from objectdetection_ssd_amd import ops as _ops
     for _ in range(args.warmup):
         step()
     fence()
     t0 = time.perf_counter()
+    probe_a = _ops.clock_probe(dev)              # two tiny launches bracket the timed steps: average shader clock held
     for _ in range(args.steps):
         l1, l2 = step()
+    probe_b = _ops.clock_probe(dev)
     fence()
     elapsed = time.perf_counter() - t0
+    mhz = _ops.shader_mhz(probe_a, probe_b)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -299,7 +303,9 @@ def main():
                       "step_tflops_per_gpu": round(TRAIN_GFLOP_PER_IMAGE * ips / world / 1e3, 2),
                       "step_frac_of_f32_mfma_peak": round(TRAIN_GFLOP_PER_IMAGE * ips / world / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
                       "last_loss_per_rank": round(loss, 5), "n_pos_global_last": n_pos,
-                      "host_enqueue_ms_per_step": round(host_ms, 2)}}
+                      "host_enqueue_ms_per_step": round(host_ms, 2),
+                      "shader_clock_mhz_during_timed_steps": round(mhz, 0),
+                      "f32_mfma_peak_at_that_clock_tflops": round(PEAK_F32_MFMA_TFLOPS * mhz / 2400.0, 1)}}
 
     # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream -----------------
     if not args.no_roofline and rank != 0:

@@ -127,6 +127,7 @@ int ssd_conv2d_dgrad_ws(const float* dy, int ldy, const float* w_ihwo, int Co_pa
                         int accumulate, const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream);
 int ssd_tune_set_igemm_splitk(int k);       /* -1 automatic, 1 never split, k > 1 force k slices */
 int ssd_tune_set_igemm(int tile, int nbuf);
+int ssd_tune_set_igemm_stamps(uint64_t* device_buffer);   /* diagnostic: per-block shader-clock stamps (see conv_igemm.hip) */
 int ssd_tune_set_igemm_lds_pad(int bytes);   /* extra dynamic LDS per block: caps resident blocks per CU (experiments) */
 int ssd_tune_set_wgrad(int bt, int nbuf, int blocks_per_cu);
 
@@ -238,6 +239,11 @@ size_t ssd_preprocess_workspace(const ssd_image_desc* descs_host, int B, int out
 int ssd_preprocess_u8(const uint8_t* arena, const ssd_image_desc* descs_dev, const ssd_image_desc* descs_host, int B,
                       int out_h, int out_w, const float* mean3_host, const float* std3_host, const uint8_t* filler3_host,
                       float* out_nchw, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- diagnostic: out32[2*xcc] = shader-clock counter, out32[2*xcc+1] = 100 MHz wall clock, for each of the (up to 16)
+ * XCCs a block landed on; slots must be zeroed by the caller.  Two probes bracket a region: average shader MHz =
+ * 100 * d(counter) / d(wall clock) per XCC. */
+int ssd_clock_probe(uint64_t* out32, void* stream);
 
 /* ---- fused SGD (train.py:53-55: momentum .9, weight decay 5e-4; bias lr 2x) on a flat buffer;
  * grad_scale multiplies the gradient first (1/n_pos_global in data-parallel runs). */

@@ -49,6 +49,7 @@ SIGNATURES = {
     "ssd_conv2d_dgrad_x3": (_I, [_P, _I, _P, _I, _P, _P, _I, _G, _P]),
     "ssd_tune_set_igemm_x3": (_I, [_I]),
     "ssd_tune_set_halo": (_I, [_I]),
+    "ssd_clock_probe": (_I, [_P, _P]),
     "ssd_preprocess_workspace": (_Z, [_P, _I, _I, _I]),
     "ssd_preprocess_u8": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "ssd_map_eval_workspace": (_Z, [_I, _I]),
@@ -69,6 +70,7 @@ SIGNATURES = {
     "ssd_tune_set_igemm_splitk": (_I, [_I]),
     "ssd_tune_set_igemm": (_I, [_I, _I]),
     "ssd_tune_set_igemm_lds_pad": (_I, [_I]),
+    "ssd_tune_set_igemm_stamps": (_I, [_P]),
     "ssd_tune_set_wgrad": (_I, [_I, _I, _I]),
     "ssd_im2col_first": (_I, [_P, _P, _I, _I, _I, _P]),
     "ssd_maxpool_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -46,7 +46,8 @@ def _compile(src: str, force: bool, verbose: bool) -> str:
     deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"),
             os.path.join(os.path.dirname(PKG), "include", "ssd_gfx950.h"), os.path.abspath(__file__)]
     if force or _stale(obj, deps):
-        cmd = [_hipcc(), *COMMON, *PER_FILE.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+        extra = os.environ.get("SSD_HIPCC_FLAGS", "").split()          # experiments only (e.g. -DSSD_IGEMM_SETPRIO=1)
+        cmd = [_hipcc(), *COMMON, *PER_FILE.get(src, []), *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         r = subprocess.run(cmd, capture_output=True, text=True)

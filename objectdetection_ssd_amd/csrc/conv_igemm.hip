@@ -40,6 +40,7 @@ struct IgemmParams {
     int relu, accumulate;
     int ksplit, kt_per_split;   // split-K (small grids, deep K): blockIdx.y = split; partial tiles go to `slab`
     float* slab;                // [ksplit][M][Nout] raw partial sums, reduced by splitk_reduce_kernel
+    unsigned long long* stamps; // diagnostic (ssd_tune_set_igemm_stamps): shader-clock stamps of every 64th block, else NULL
 };
 
 constexpr int BK = 32;
@@ -57,6 +58,11 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t srd, unsigned
 // the buffer range check then returns zeros, no branch); inside a tap only a scalar offset moves.
 // NBUF = 2: the next tile is written into the other LDS stage while this one is multiplied
 // (one barrier per K step); NBUF = 1 keeps a single stage (two barriers) where LDS is scarce.
+#ifndef SSD_IGEMM_SETPRIO
+#define SSD_IGEMM_SETPRIO 0
+#endif
+constexpr int SETPRIO = SSD_IGEMM_SETPRIO;
+
 template <int BM, int BN, int WM, int WN, int NBUF>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -66,6 +72,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     __shared__ __attribute__((aligned(16))) float lds[NBUF * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool stamp = p.stamps != nullptr && (blockIdx.x & 63) == 0 && tid == 0;
+    unsigned long long t_start = 0, t_loop = 0, t_epi = 0;
+    if (stamp) t_start = __builtin_readcyclecounter();
+    if (SETPRIO) __builtin_amdgcn_s_setprio(3);      // prologue / epilogue instructions go ahead of the resident waves' MFMA loops
     const int wm = wave / WN, wn = wave % WN;
     const int nblk = p.tiles_m * p.tiles_n;
     const int lid = xcd_swizzle(blockIdx.x, nblk);
@@ -164,6 +174,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     issue_loads();
     store_tile(lds);
     __syncthreads();
+    if (stamp) t_loop = __builtin_readcyclecounter();
+    if (SETPRIO) __builtin_amdgcn_s_setprio(0);
 
     int cur = 0;
     for (int kt = 0; kt < KT; ++kt) {
@@ -198,6 +210,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         }
     }
 
+    if (stamp) t_epi = __builtin_readcyclecounter();
+    if (SETPRIO) __builtin_amdgcn_s_setprio(3);
     // ---- epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) --------
     if (p.ksplit > 1) {                                   // uniform: raw partial tile, finished by splitk_reduce_kernel
         float* slab = p.slab + (size_t)blockIdx.y * p.M * p.Nout;
@@ -230,14 +244,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                     if (p.accumulate) v += p.out[idx];
                     if (p.relu) v = v < 0.f ? 0.f : v;            // NaN stays NaN, like torch.relu
                     if (p.mask != nullptr) v = p.mask[idx] > 0.f ? v : 0.f;
+#ifdef SSD_IGEMM_NOSTORE
+                    if (v == 12345.678f)          // timing experiment only: results are NOT written
+#endif
                     p.out[idx] = v;
                 }
             }
         }
     }
+    if (stamp) {
+        unsigned long long* o = p.stamps + (size_t)(blockIdx.x >> 6) * 4;
+        o[0] = t_start; o[1] = t_loop; o[2] = t_epi; o[3] = __builtin_readcyclecounter();
+    }
 }
 
 int g_lds_pad = 0;            // tuning aid: extra dynamic LDS per block (caps the blocks resident per CU)
+unsigned long long* g_stamps = nullptr;   // diagnostic buffer (ssd_tune_set_igemm_stamps)
 int g_force_ksplit = -1;      // tuning aid: 1 = never split K, k > 1 = always k slices (when a workspace is given); -1 = automatic
 
 // out = [accumulate: out +] sum_split slab[split] (+ bias) -> ReLU -> ReLU mask; splits added in index order (reproducible)
@@ -315,6 +337,7 @@ int plan_ksplit(int M, int Nout, int Ca, int taps) {
 int dispatch_igemm(IgemmParams& p, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0) {
     const TileChoice c = pick_tile(p.M, p.Nout);
     p.ksplit = 1;
+    p.stamps = g_stamps;
     if (ws != nullptr && c.tile == T64x64) {
         const int k = plan_ksplit(p.M, p.Nout, p.Ca, p.R * p.S);
         if (k > 1 && (size_t)k * p.M * p.Nout * sizeof(float) <= ws_bytes) {
@@ -1089,6 +1112,13 @@ extern "C" int ssd_tune_set_igemm(int tile, int nbuf) {
 extern "C" int ssd_tune_set_igemm_splitk(int k) {
     if (k < -1 || k == 0 || k > 64) return SSD_ERR_BAD_SHAPE;
     g_force_ksplit = k;
+    return SSD_OK;
+}
+
+// Diagnostic: device buffer of 4 x uint64 per 64 blocks (block start, main loop start, epilogue start, end; shader-clock
+// counter) filled by every 64th block of the f32 igemm launches that follow; NULL switches it off.
+extern "C" int ssd_tune_set_igemm_stamps(uint64_t* device_buffer) {
+    g_stamps = reinterpret_cast<unsigned long long*>(device_buffer);
     return SSD_OK;
 }
 

@@ -105,6 +105,17 @@ __global__ __launch_bounds__(256) void channel_affine_kernel(const float* __rest
     }
 }
 
+// Diagnostic: shader-clock counter and the constant 100 MHz wall clock, one slot per XCC (each XCD has its own counter).
+// Two probes around a region give the average shader clock the chip held there (bench.py reports it next to the roofline:
+// under sustained f32-MFMA load on non-constant data this chip lowers its clock well below 2.4 GHz).
+__global__ void clock_probe_kernel(unsigned long long* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;       // HW_REG_XCC_ID[3:0]
+        out[xcc * 2 + 0] = __builtin_readcyclecounter();
+        out[xcc * 2 + 1] = wall_clock64();
+    }
+}
+
 __global__ void slab_sum_kernel(const float* __restrict__ slab, float* __restrict__ out, int n, int nslab) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -369,6 +380,13 @@ extern "C" int ssd_im2col_first(const float* x_nchw, float* out, int N, int H, i
     if (!ssd_aligned16(out)) return SSD_ERR_ALIGN;
     const size_t total = (size_t)N * H * W * 8;
     hipLaunchKernelGGL(im2col_first_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x_nchw, out, N, H, W);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
+extern "C" int ssd_clock_probe(uint64_t* out32, void* stream) {
+    if (!out32) return SSD_ERR_NULL;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(256), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long*>(out32));
     SSD_CHECK_LAUNCH();
     return SSD_OK;
 }

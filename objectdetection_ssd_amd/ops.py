@@ -536,3 +536,19 @@ def preprocess_u8(arena: torch.Tensor, descs, out_hw=(300, 300), mean=(0.485, 0.
     check(lib.ssd_preprocess_u8(arena.data_ptr(), descs_dev.data_ptr(), C.byref(descs), B, oh, ow, C.addressof(m), C.addressof(s_),
                                 C.addressof(f), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "preprocess_u8")
     return out
+
+
+def clock_probe(device) -> torch.Tensor:
+    """Enqueue a clock probe on the current stream; returns the (16, 2) int64 tensor it fills (counter, 100 MHz ticks per XCC)."""
+    out = torch.zeros((16, 2), device=device, dtype=torch.int64)
+    check(_lib.load().ssd_clock_probe(out.data_ptr(), _stream()), "clock_probe")
+    return out
+
+
+def shader_mhz(probe_a: torch.Tensor, probe_b: torch.Tensor) -> float:
+    """Average shader clock between two probes (mean over the XCCs both probes landed on)."""
+    a, b = probe_a.cpu(), probe_b.cpu()
+    ok = (a[:, 1] > 0) & (b[:, 1] > a[:, 1])
+    if not bool(ok.any()):
+        return float("nan")
+    return float((100.0 * (b[ok, 0] - a[ok, 0]).double() / (b[ok, 1] - a[ok, 1]).double()).mean())

@@ -52,6 +52,27 @@ def main():
                 ms = timeit(lambda: ops.conv2d_fwd(x, wf, b, g, True, ld=ld, out=dy))
                 row.append(f"{lab}:{fl / ms / 1e9:6.1f}")
             print(f"fwd   {name:8s} " + "  ".join(row), flush=True)
+        if which == "stamps":                   # in-kernel phase times of every 64th block (shader-clock cycles)
+            nblk = ((BS * g.Ho * g.Wo + 63) // 64) * ((co + 63) // 64)
+            buf = torch.zeros((nblk // 64 + 2, 4), device=dev, dtype=torch.int64)
+            lib.ssd_tune_set_igemm_splitk(1)
+            ops.conv2d_fwd(x, wf, b, g, True, ld=ld, out=dy)
+            torch.cuda.synchronize()
+            lib.ssd_tune_set_igemm_stamps(buf.data_ptr())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); ops.conv2d_fwd(x, wf, b, g, True, ld=ld, out=dy); e1.record()
+            torch.cuda.synchronize()
+            lib.ssd_tune_set_igemm_stamps(None)
+            lib.ssd_tune_set_igemm_splitk(-1)
+            t = buf[: (nblk + 63) // 64].cpu().double()
+            t = t[t[:, 3] > 0]
+            life, pro, loop, epi = t[:, 3] - t[:, 0], t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
+            kt = k * k * (ci // 32)
+            ms = e0.elapsed_time(e1)
+            print(f"stamps {name:8s} blocks {nblk} K-steps {kt}: kernel {ms:.3f} ms = {fl / ms / 1e9:.1f} TF/s | per sampled block (cycles): "
+                  f"life {life.mean():.0f} (min {life.min():.0f} max {life.max():.0f})  prologue {pro.mean():.0f}  loop {loop.mean():.0f} "
+                  f"= {loop.mean() / kt:.0f}/K-step  epilogue {epi.mean():.0f} | sum of block lives x64 / (256 CUs x 7) = "
+                  f"{life.sum() * 64 / 1792 / 2.4e6:.3f} ms at 2.4 GHz", flush=True)
         if which == "occ":                      # blocks per CU capped through extra dynamic LDS (64x64 tile, 18 KB static)
             row = []
             for pad_kb, lab in ((0, "7/CU"), (8, "6"), (14, "5"), (22, "4"), (35, "3"), (62, "2")):
