@@ -40,6 +40,7 @@ struct IgemmParams {
     int relu, accumulate;
     int ksplit, kt_per_split;   // split-K (small grids, deep K): blockIdx.y = split; partial tiles go to `slab`
     float* slab;                // [ksplit][M][Nout] raw partial sums, reduced by splitk_reduce_kernel
+    float rcp_howo, rcp_wo;     // 1 / (Ho*Wo), 1 / Wo for div_small_q (set by launch_igemm)
     unsigned long long* stamps; // diagnostic (ssd_tune_set_igemm_stamps): shader-clock stamps of every 64th block, else NULL
 };
 
@@ -58,13 +59,32 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t srd, unsigned
 // the buffer range check then returns zeros, no branch); inside a tap only a scalar offset moves.
 // NBUF = 2: the next tile is written into the other LDS stage while this one is multiplied
 // (one barrier per K step); NBUF = 1 keeps a single stage (two barriers) where LDS is scarce.
+// q = m / d for 0 <= m < 2^31 when the quotient is below 2^21 (image index, output row): float estimate, one correction.
+// Vector instructions are scarce while the resident waves' MFMA loops hold the SIMD (in-kernel stamps: ~200 cycles per
+// instruction), so the prologue avoids the ~35-instruction integer division sequence.
+__device__ __forceinline__ int div_small_q(int m, int d, float rcp) {
+    int q = (int)((float)m * rcp);
+    const int r = m - q * d;
+    q += r < 0 ? -1 : (r >= d ? 1 : 0);
+    return q;
+}
+
 #ifndef SSD_IGEMM_SETPRIO
 #define SSD_IGEMM_SETPRIO 0
 #endif
 constexpr int SETPRIO = SSD_IGEMM_SETPRIO;
 
+#ifndef SSD_IGEMM_WAVES
+#define SSD_IGEMM_WAVES 0
+#endif
+#if SSD_IGEMM_WAVES
+#define IGEMM_OCC __attribute__((amdgpu_waves_per_eu(SSD_IGEMM_WAVES)))
+#else
+#define IGEMM_OCC
+#endif
+
 template <int BM, int BN, int WM, int WN, int NBUF>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(256) IGEMM_OCC void igemm_kernel(const IgemmParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;
     constexpr int STAGE = (BM + BN) * LDS_LD;
@@ -95,8 +115,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         const int m = m0 + row0 + 32 * j;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
-        const int n = mm / HoWo, rem = mm - n * HoWo;
-        const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+        const int n = div_small_q(mm, HoWo, p.rcp_howo), rem = mm - n * HoWo;
+        const int oh = div_small_q(rem, p.Wo, p.rcp_wo), ow = rem - oh * p.Wo;
         a_h[j] = ok ? oh * p.sm + p.off : -(1 << 24);       // never in range for a row past M
         a_w[j] = ow * p.sm + p.off;
         a_base[j] = (unsigned)n * (unsigned)(p.Ha * p.Wa * p.Ca) * 4u + chunk * 16u;
@@ -115,7 +135,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         for (int j = 0; j < A_ROWS; ++j) {
             int th = a_h[j] + dh, tw = a_w[j] + dw;
             bool ok = th >= 0 && tw >= 0;
-            if (p.sd > 1) {                                  // dgrad of a strided conv (uniform branch)
+            if (p.sd == 2) {                                 // dgrad of a stride-2 conv (uniform branch)
+                ok = ok && ((th | tw) & 1) == 0;
+                th >>= 1;
+                tw >>= 1;
+            } else if (p.sd > 2) {
                 ok = ok && (th % p.sd == 0) && (tw % p.sd == 0);
                 th /= p.sd;
                 tw /= p.sd;
@@ -142,11 +166,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     unsigned soff_a = (unsigned)c_nxt * BK * 4, soff_b = (unsigned)kt_begin * BK * 4;
     tap_offsets(r_nxt, s_nxt);
 
-    auto issue_loads = [&]() {
+    auto issue_into = [&](f32x4* qa, f32x4* qb) {
 #pragma unroll
-        for (int j = 0; j < A_ROWS; ++j) ra[j] = buf_load16(srd_a, voff_a[j], soff_a);
+        for (int j = 0; j < A_ROWS; ++j) qa[j] = buf_load16(srd_a, voff_a[j], soff_a);
 #pragma unroll
-        for (int j = 0; j < B_ROWS; ++j) rb[j] = buf_load16(srd_w, voff_b[j], soff_b);
+        for (int j = 0; j < B_ROWS; ++j) qb[j] = buf_load16(srd_w, voff_b[j], soff_b);
         soff_a += BK * 4;
         soff_b += BK * 4;
         if (++c_nxt == kc) {                                 // next tile starts a new tap
@@ -156,16 +180,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             tap_offsets(r_nxt, s_nxt);
         }
     };
-    auto store_tile = [&](float* stage) {
+    auto store_from = [&](float* stage, const f32x4* qa, const f32x4* qb) {
         float* As = stage;
         float* Bs = stage + BM * LDS_LD;
 #pragma unroll
         for (int j = 0; j < A_ROWS; ++j)
-            *reinterpret_cast<f32x4*>(&As[(row0 + 32 * j) * LDS_LD + chunk * 4]) = ra[j];
+            *reinterpret_cast<f32x4*>(&As[(row0 + 32 * j) * LDS_LD + chunk * 4]) = qa[j];
 #pragma unroll
         for (int j = 0; j < B_ROWS; ++j)
-            *reinterpret_cast<f32x4*>(&Bs[(row0 + 32 * j) * LDS_LD + chunk * 4]) = rb[j];
+            *reinterpret_cast<f32x4*>(&Bs[(row0 + 32 * j) * LDS_LD + chunk * 4]) = qb[j];
     };
+    auto issue_loads = [&]() { issue_into(ra, rb); };
+    auto store_tile = [&](float* stage) { store_from(stage, ra, rb); };
 
     const int lr = lane & 31, lh = lane >> 5;
     const int a_rd = (wm * TM * 32 + lr) * LDS_LD + lh * 4;
@@ -177,11 +203,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     if (stamp) t_loop = __builtin_readcyclecounter();
     if (SETPRIO) __builtin_amdgcn_s_setprio(0);
 
-    int cur = 0;
-    for (int kt = 0; kt < KT; ++kt) {
-        const bool more = kt + 1 < KT;
-        if (more) issue_loads();                  // global loads stay in flight under the MFMAs
-        const float* stage = lds + (NBUF == 2 ? cur * STAGE : 0);
+    auto multiply = [&](const float* stage) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 af[TM], bf[TN];
@@ -197,15 +219,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
         }
-        if (NBUF == 2) {
-            if (more) store_tile(lds + (cur ^ 1) * STAGE);   // other stage: last read one iteration ago
-            __syncthreads();
-            cur ^= 1;
-        } else {
-            __syncthreads();
-            if (more) {
-                store_tile(lds);
+    };
+    {
+        int cur = 0;
+        for (int kt = 0; kt < KT; ++kt) {
+            const bool more = kt + 1 < KT;
+            if (more) issue_loads();                  // global loads stay in flight under the MFMAs
+            multiply(lds + (NBUF == 2 ? cur * STAGE : 0));
+            if (NBUF == 2) {
+                if (more) store_tile(lds + (cur ^ 1) * STAGE);   // other stage: last read one iteration ago
                 __syncthreads();
+                cur ^= 1;
+            } else {
+                __syncthreads();
+                if (more) {
+                    store_tile(lds);
+                    __syncthreads();
+                }
             }
         }
     }
@@ -228,6 +258,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             }
         return;
     }
+    // Full tiles (all but the last tile row) take straight-line paths: no per-element bounds test, every load of a group of
+    // eight rows in flight before the first use, ~10 vector instructions per stored value less than the general loop below.
+    const bool full_m = m0 + BM <= p.M;                    // uniform
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -235,6 +268,44 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             const int n = n0 + (wn * TN + j) * 32 + lr;
             const bool n_ok = n < p.Nout;
             const float bv = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
+            if (full_m) {
+                if (n_ok) {
+                    const size_t row = (size_t)p.ldo;
+                    float* po = p.out + (size_t)(m0 + (wm * TM + i) * 32 + 4 * lh) * row + n;
+                    if (p.mask == nullptr && !p.accumulate) {            // forward: bias (+ ReLU)
+                        if (p.relu) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float v = acc[i][j][r] + bv;
+                                po[(size_t)((r & 3) + 8 * (r >> 2)) * row] = v < 0.f ? 0.f : v;      // NaN stays NaN, like torch.relu
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) po[(size_t)((r & 3) + 8 * (r >> 2)) * row] = acc[i][j][r] + bv;
+                        }
+                    } else {                                               // dgrad: (+ previous dx) (* ReLU mask)
+                        const float* pm = p.mask != nullptr ? p.mask + (po - p.out) : nullptr;
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            float prev[8], mk[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const size_t o = (size_t)(((half * 8 + q) & 3) + 8 * ((half * 8 + q) >> 2)) * row;
+                                prev[q] = p.accumulate ? po[o] : 0.f;
+                                mk[q] = pm != nullptr ? pm[o] : 1.f;
+                            }
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const int r = half * 8 + q;
+                                float v = acc[i][j][r] + bv + prev[q];
+                                if (p.relu) v = v < 0.f ? 0.f : v;
+                                po[(size_t)((r & 3) + 8 * (r >> 2)) * row] = mk[q] > 0.f ? v : 0.f;
+                            }
+                        }
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -244,9 +315,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                     if (p.accumulate) v += p.out[idx];
                     if (p.relu) v = v < 0.f ? 0.f : v;            // NaN stays NaN, like torch.relu
                     if (p.mask != nullptr) v = p.mask[idx] > 0.f ? v : 0.f;
-#ifdef SSD_IGEMM_NOSTORE
-                    if (v == 12345.678f)          // timing experiment only: results are NOT written
-#endif
                     p.out[idx] = v;
                 }
             }
@@ -300,6 +368,8 @@ template <int BM, int BN, int WM, int WN, int NBUF>
 int launch_igemm(IgemmParams& p, hipStream_t st) {
     p.tiles_m = ssd_cdiv(p.M, BM);
     p.tiles_n = ssd_cdiv(p.Nout, BN);
+    p.rcp_howo = 1.0f / (float)(p.Ho * p.Wo);
+    p.rcp_wo = 1.0f / (float)p.Wo;
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
     hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, NBUF>), dim3(p.tiles_m * p.tiles_n, ks), dim3(256), g_lds_pad, st, p);
     SSD_CHECK_LAUNCH();
@@ -980,6 +1050,7 @@ int check_geom(const ssd_conv_geom* g) {
     const int wo = (g->W + 2 * g->pad - g->dil * (g->S - 1) - 1) / g->stride + 1;
     if (ho != g->Ho || wo != g->Wo || ho <= 0 || wo <= 0) return SSD_ERR_BAD_SHAPE;
     if ((long)g->N * g->Ho * g->Wo >= (1L << 31) || (long)g->N * g->H * g->W >= (1L << 31)) return SSD_ERR_BAD_SHAPE;
+    if (g->N >= (1 << 20) || g->H >= (1 << 20) || g->Ho >= (1 << 20)) return SSD_ERR_BAD_SHAPE;      // div_small_q quotients
     return SSD_OK;
 }
 
