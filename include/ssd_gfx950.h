@@ -130,6 +130,7 @@ int ssd_tune_set_igemm(int tile, int nbuf);
 int ssd_tune_set_igemm_stamps(uint64_t* device_buffer);   /* diagnostic: per-block shader-clock stamps (see conv_igemm.hip) */
 int ssd_tune_set_igemm_lds_pad(int bytes);   /* extra dynamic LDS per block: caps resident blocks per CU (experiments) */
 int ssd_tune_set_wgrad(int bt, int nbuf, int blocks_per_cu);
+int ssd_tune_set_wgrad_patch(int shape);     /* f32 fused 3x3 kernel: -1 least padding, 0 = 4x8 pixel patches, 1 = 1x38, 2 = 2x19 */
 
 /* conv1_1 (Model.py:136 features[0]: Conv2d(3,64,3,padding=1)+ReLU, Ci = 3): im2col of the caller's
  * NCHW image batch (Dataset.py:39 layout) into [N*H*W][32] rows (k = (r*3+s)*3 + c, columns 27..31

@@ -72,6 +72,7 @@ SIGNATURES = {
     "ssd_tune_set_igemm_lds_pad": (_I, [_I]),
     "ssd_tune_set_igemm_stamps": (_I, [_P]),
     "ssd_tune_set_wgrad": (_I, [_I, _I, _I]),
+    "ssd_tune_set_wgrad_patch": (_I, [_I]),
     "ssd_im2col_first": (_I, [_P, _P, _I, _I, _I, _P]),
     "ssd_maxpool_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ssd_maxpool_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

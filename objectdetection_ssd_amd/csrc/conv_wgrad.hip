@@ -236,10 +236,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 // ---------------------------------------------------------------------------------------------
 constexpr int PH = 4, PW = 8, HH = PH + 2, HW = PW + 2, HPIX = HH * HW;   // patch 4x8, halo 6x10 = 60 pixels
 
+// Patch shapes: 4x8 (32 pixels) is the default; 1x38 and 2x19 (38 pixels = 19 k-pairs) tile the 38- / 75- / 19-pixel
+// maps of conv3, conv4 and conv5 without the 8-33 % of padded MFMAs the 4x8 grid has there (plan_wgrad picks by waste).
+template <int PH_, int PW_>
 __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const WgradParams p) {
     constexpr int BT = 64, CHUNKS = 16, RPP = 16;
-    __shared__ __attribute__((aligned(16))) float Ys[PH * PW * BT];
-    __shared__ __attribute__((aligned(16))) float Xs[HPIX * BT];
+    constexpr int NPIX = PH_ * PW_, HH_ = PH_ + 2, HW_ = PW_ + 2, HPIX_ = HH_ * HW_;
+    constexpr int YP = (NPIX + RPP - 1) / RPP, XP = (HPIX_ + RPP - 1) / RPP;      // load passes of the block's 16 pixel rows
+    static_assert(NPIX % 2 == 0, "pixels are consumed in k-pairs");
+    __shared__ __attribute__((aligned(16))) float Ys[NPIX * BT];
+    __shared__ __attribute__((aligned(16))) float Xs[HPIX_ * BT];
     __shared__ float bias_red[256 * 4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const WgradParams p) {
     lid -= split * per_split;
     const int tile_ci = lid % p.tiles_ci, tile_co = lid / p.tiles_ci;
     const int co0 = tile_co * BT, ci0 = tile_ci * BT;
-    const int npw = (p.Wo + PW - 1) / PW, nph = (p.Ho + PH - 1) / PH;
+    const int npw = (p.Wo + PW_ - 1) / PW_, nph = (p.Ho + PH_ - 1) / PH_;
     const int per_img = npw * nph;
     const int npatch = per_img * (p.M / (p.Ho * p.Wo));
     const int pb = split * p.m_per_split;                       // here: patches per split
@@ -270,11 +276,11 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const WgradParams p) {
     const __amdgpu_buffer_rsrc_t srd_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
 
     // this thread's pixels inside a patch / halo (fixed for the whole kernel)
-    int ypy[2], ypx[2], xhy[4], xhx[4];
+    int ypy[YP], ypx[YP], xhy[XP], xhx[XP];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { const int q = prow + RPP * j; ypy[j] = q / PW; ypx[j] = q % PW; }
+    for (int j = 0; j < YP; ++j) { const int q = prow + RPP * j; ypy[j] = q / PW_; ypx[j] = q % PW_; }      // q >= NPIX: unused
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const int q = prow + RPP * j; xhy[j] = q / HW; xhx[j] = q % HW; }   // q >= 60: unused
+    for (int j = 0; j < XP; ++j) { const int q = prow + RPP * j; xhy[j] = q / HW_; xhx[j] = q % HW_; }      // q >= HPIX: unused
 
     f32x16 acc[9];
 #pragma unroll
@@ -282,40 +288,42 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const WgradParams p) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-    f32x4 ry[2], rx[4];
+    f32x4 ry[YP], rx[XP];
 
     auto issue_loads = [&](int patch) {
         const int n = patch / per_img, rem = patch - n * per_img;          // uniform: scalar unit
-        const int oh0 = (rem / npw) * PH, ow0 = (rem % npw) * PW;
+        const int oh0 = (rem / npw) * PH_, ow0 = (rem % npw) * PW_;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < YP; ++j) {
             const int oh = oh0 + ypy[j], ow = ow0 + ypx[j];
-            const bool ok = y_col_ok && oh < p.Ho && ow < p.Wo;
+            const bool ok = y_col_ok && (prow + RPP * j) < NPIX && oh < p.Ho && ow < p.Wo;
             const unsigned v = ok ? (unsigned)((n * p.Ho + oh) * p.Wo + ow) * ldy4 + y_col : OOB;
             ry[j] = buf_load16(srd_y, v, 0);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < XP; ++j) {
             const int ih = oh0 + xhy[j] - 1, iw = ow0 + xhx[j] - 1;
-            const bool ok = x_col_ok && (prow + RPP * j) < HPIX && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            const bool ok = x_col_ok && (prow + RPP * j) < HPIX_ && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
             const unsigned v = ok ? (unsigned)((n * p.H + ih) * p.W + iw) * ci4 + x_col : OOB;
             rx[j] = buf_load16(srd_x, v, 0);
         }
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            *reinterpret_cast<f32x4*>(&Ys[(prow + RPP * j) * BT + chunk * 4]) = ry[j];
-            if (do_bias) bsum += ry[j];
-        }
+        for (int j = 0; j < YP; ++j)
+            if (prow + RPP * j < NPIX) {
+                *reinterpret_cast<f32x4*>(&Ys[(prow + RPP * j) * BT + chunk * 4]) = ry[j];
+                if (do_bias) bsum += ry[j];
+            }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (prow + RPP * j < HPIX) *reinterpret_cast<f32x4*>(&Xs[(prow + RPP * j) * BT + chunk * 4]) = rx[j];
+        for (int j = 0; j < XP; ++j)
+            if (prow + RPP * j < HPIX_) *reinterpret_cast<f32x4*>(&Xs[(prow + RPP * j) * BT + chunk * 4]) = rx[j];
     };
 
-    // operand addresses: k-pair kk covers patch pixels 2kk, 2kk+1 (lane half lh): py = kk>>2, px = 2(kk&3)+lh
+    // operand addresses: k-pair kk covers patch pixels q = 2kk + lh (lane half); pixel q sits at halo position
+    // (q / PW, q % PW) + (r, s).  With an even PW both pixels of a pair are in one row and lh is a constant offset.
     const float* y_rd = Ys + lh * BT + wm * 32 + lr;
-    const float* x_rd = Xs + lh * BT + wn * 32 + lr;
+    const float* x_rd = Xs + wn * 32 + lr + (PW_ % 2 == 0 ? lh * BT : 0);
     if (pb < pe) {
         issue_loads(pb);
         store_tile();
@@ -324,14 +332,16 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const WgradParams p) {
             const bool more = patch + 1 < pe;
             if (more) issue_loads(patch + 1);
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
+            for (int kk = 0; kk < NPIX / 2; ++kk) {
                 const float a = y_rd[2 * kk * BT];
-                const int hbase = ((kk >> 2) * HW + 2 * (kk & 3)) * BT;
+                const int q0 = 2 * kk, q1 = 2 * kk + 1;
+                const int h0 = ((q0 / PW_) * HW_ + (q0 % PW_)) * BT, h1 = ((q1 / PW_) * HW_ + (q1 % PW_)) * BT;
+                const int hbase = (PW_ % 2 == 0) ? h0 : (lh ? h1 : h0);
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
                     for (int s2 = 0; s2 < 3; ++s2) {
-                        const float b = x_rd[hbase + (r * HW + s2) * BT];
+                        const float b = x_rd[hbase + (r * HW_ + s2) * BT];
                         acc[r * 3 + s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[r * 3 + s2], 0, 0, 0);
                     }
             }
@@ -558,26 +568,44 @@ __global__ __launch_bounds__(256) void bias_reduce_kernel(const float* __restric
 int g_force_bt = -1, g_force_wnbuf = -1, g_force_blocks_per_cu = -1;   // tuning aid (ssd_tune_set_wgrad)
 
 struct WgradPlan {
-    int bt, nbuf, fused, tiles_co, tiles_ci, nsplit, m_per_split;
+    int bt, nbuf, fused, shape, tiles_co, tiles_ci, nsplit, m_per_split;      // shape: 0 = 4x8 patches, 1 = 1x38, 2 = 2x19
     size_t slab_floats, bias_floats;
 };
 
 int g_force_fused = -1;          // tuning aid: 0 = never use the fused 3x3 kernel, 1 = whenever applicable
+int g_force_shape = -1;          // tuning aid: patch shape of the f32 fused kernel (0 = 4x8, 1 = 1x38, 2 = 2x19); -1 = least padding
 
 WgradPlan plan_wgrad(const ssd_conv_geom* g, bool bf16 = false) {
     WgradPlan pl;
     const int T = g->R * g->S;
     const int M = g->N * g->Ho * g->Wo;
-    // fused nine-tap kernel: measured 117-130 TFLOP/s on conv1_2..conv4_3 against 92-123 for one tap per block;
-    // below ~30 pixels per side the 4x8 patch grid wastes >= 25 % of the MFMAs (19x19 -> 5x3 patches) and the
-    // 128-wide kernel is as fast, so small maps keep the old path unless forced.
+    // fused nine-tap kernel: measured 117-130 TFLOP/s on conv1_2..conv4_3 against 92-123 for one tap per block.  Its K loop
+    // walks pixel patches, so maps that the patch grid does not tile pay for padded MFMAs: 4x8 patches waste 8 % on 75x75,
+    // 11 % on 38x38 and 33 % on 19x19, where the 38-pixel shapes (one row of 38, or 2x19) waste 1 %, 0 % and 5 %.  The
+    // shape with the least padding is taken; on a tie 2x19, then 1x38 (measured: 171 instead of 144 MFMAs per barrier pair
+    // is worth +5 % on conv1_2, and 2x19 reads 2.2x the patch as halo where 1x38 reads 3.2x).  Above 12 % padding the
+    // 128-wide one-tap kernel is as fast and the layer keeps the old path unless forced.
+    static const int SHAPES[3][2] = {{4, 8}, {1, 38}, {2, 19}};
+    double waste[3];
+    for (int k = 0; k < 3; ++k)
+        waste[k] = (double)ssd_cdiv(g->Ho, SHAPES[k][0]) * SHAPES[k][0] * ssd_cdiv(g->Wo, SHAPES[k][1]) * SHAPES[k][1] /
+                   ((double)g->Ho * g->Wo);
+    pl.shape = 0;
+    if (!bf16 && g_force_shape < 0) {
+        static const int PREF[3] = {2, 1, 0};
+        pl.shape = PREF[0];
+        for (int i = 1; i < 3; ++i)
+            if (waste[PREF[i]] < waste[pl.shape] - 0.002) pl.shape = PREF[i];
+    } else if (!bf16) {
+        pl.shape = g_force_shape;
+    }
     pl.fused = g->R == 3 && g->S == 3 && g->stride == 1 && g->dil == 1 && g->pad == 1 && g_force_fused != 0 &&
-               (g_force_fused == 1 || bf16 || (g->Ho >= 30 && g->Wo >= 30));   // bf16: the fused kernel is 6x the f32 rate, patch waste is irrelevant
+               (g_force_fused == 1 || bf16 || waste[pl.shape] <= 1.12);   // bf16: the fused kernel is 6x the f32 rate, patch waste is irrelevant
     if (pl.fused) {
         pl.bt = 64; pl.nbuf = 1;
         pl.tiles_co = ssd_cdiv(g->Co, 64);
         pl.tiles_ci = ssd_cdiv(g->Ci, 64);
-        const int npatch = g->N * ssd_cdiv(g->Ho, PH) * ssd_cdiv(g->Wo, PW);
+        const int npatch = g->N * ssd_cdiv(g->Ho, SHAPES[pl.shape][0]) * ssd_cdiv(g->Wo, SHAPES[pl.shape][1]);
         const int per_split = pl.tiles_co * pl.tiles_ci;
         const int bpc = g_force_blocks_per_cu > 0 ? g_force_blocks_per_cu : 2;       // exactly the 2 resident blocks per CU: no tail round
         int ns = ssd_cdiv(256 * bpc, per_split);
@@ -656,7 +684,10 @@ static int conv2d_wgrad_impl(const float* x, const float* dy, int ldy, float* dw
     if (pl.fused && bf16) {
         hipLaunchKernelGGL(wgrad3x3_bf16_kernel, dim3(pl.tiles_co * pl.tiles_ci * pl.nsplit), dim3(256), 0, st, p);
     } else if (pl.fused) {
-        hipLaunchKernelGGL(wgrad3x3_kernel, dim3(pl.tiles_co * pl.tiles_ci * pl.nsplit), dim3(256), 0, st, p);
+        const dim3 grid(pl.tiles_co * pl.tiles_ci * pl.nsplit);
+        if (pl.shape == 1) hipLaunchKernelGGL((wgrad3x3_kernel<1, 38>), grid, dim3(256), 0, st, p);
+        else if (pl.shape == 2) hipLaunchKernelGGL((wgrad3x3_kernel<2, 19>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((wgrad3x3_kernel<4, 8>), grid, dim3(256), 0, st, p);
     } else if (pl.bt == 128) {
         if (pl.nbuf == 2) hipLaunchKernelGGL((wgrad_kernel<128, 2>), dim3(nblk), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((wgrad_kernel<128, 1>), dim3(nblk), dim3(256), 0, st, p);
@@ -691,6 +722,13 @@ extern "C" int ssd_tune_set_wgrad(int bt, int nbuf, int blocks_per_cu) {
     g_force_bt = bt;
     g_force_wnbuf = nbuf;
     g_force_blocks_per_cu = blocks_per_cu;
+    return SSD_OK;
+}
+
+// Tuning aid: patch shape of the f32 fused kernel: -1 least padding, 0 = 4x8, 1 = 1x38, 2 = 2x19.
+extern "C" int ssd_tune_set_wgrad_patch(int shape) {
+    if (shape < -1 || shape > 2) return SSD_ERR_BAD_SHAPE;
+    g_force_shape = shape;
     return SSD_OK;
 }
 

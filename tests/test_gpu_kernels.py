@@ -230,7 +230,8 @@ def test_conv_first_via_im2col():
 
 
 VARIANT_CASES = [(2, 19, 19, 64, 64, 3, 1, 1, 1), (2, 38, 38, 128, 256, 3, 1, 1, 1), (2, 19, 19, 256, 100, 3, 1, 1, 1),
-                 (2, 10, 10, 128, 256, 3, 2, 1, 1), (3, 5, 5, 128, 256, 3, 1, 0, 1), (2, 19, 19, 512, 160, 1, 1, 0, 1)]
+                 (2, 10, 10, 128, 256, 3, 2, 1, 1), (3, 5, 5, 128, 256, 3, 1, 0, 1), (2, 19, 19, 512, 160, 1, 1, 0, 1),
+                 (1, 37, 53, 64, 96, 3, 1, 1, 1), (1, 75, 75, 64, 64, 3, 1, 1, 1)]
 
 
 @pytest.mark.parametrize("case", VARIANT_CASES)
@@ -269,9 +270,17 @@ def test_every_kernel_variant(case):
                 dw, db = ops.conv2d_wgrad(x_d, dy_d, g, ld, True)
                 _close(dw, wt.grad, tol=2e-4, what=f"wgrad bt {bt} nbuf {nbuf} bpc {bpc} {case}")
                 _close(db, b.grad, tol=2e-4, what=f"bias bt {bt} nbuf {nbuf} bpc {bpc} {case}")
+        if (k, s, p, d) == (3, 1, 1, 1):                  # fused nine-tap kernel: every patch shape (4x8, 1x38, 2x19)
+            for shape in (0, 1, 2):
+                lib.ssd_tune_set_wgrad(3, 1, -1)
+                assert lib.ssd_tune_set_wgrad_patch(shape) == 0
+                dw, db = ops.conv2d_wgrad(x_d, dy_d, g, ld, True)
+                _close(dw, wt.grad, tol=2e-4, what=f"fused wgrad patch shape {shape} {case}")
+                _close(db, b.grad, tol=2e-4, what=f"fused bias patch shape {shape} {case}")
     finally:
         lib.ssd_tune_set_igemm(-1, -1)
         lib.ssd_tune_set_wgrad(-1, -1, -1)
+        lib.ssd_tune_set_wgrad_patch(-1)
 
 
 @pytest.mark.parametrize("case", [CONV_CASES[i] for i in (0, 1, 2, 4, 5, 6, 10, 11)])

@@ -73,6 +73,18 @@ def main():
                   f"life {life.mean():.0f} (min {life.min():.0f} max {life.max():.0f})  prologue {pro.mean():.0f}  loop {loop.mean():.0f} "
                   f"= {loop.mean() / kt:.0f}/K-step  epilogue {epi.mean():.0f} | sum of block lives x64 / (256 CUs x 7) = "
                   f"{life.sum() * 64 / 1792 / 2.4e6:.3f} ms at 2.4 GHz", flush=True)
+        if which == "patch" and (k, s, pad, dil) == (3, 1, 1, 1):     # fused f32 wgrad: patch shapes 4x8 / 1x38 / 2x19 vs the one-tap kernel
+            row = []
+            for shape, lab in ((-1, "auto"), (0, "4x8"), (1, "1x38"), (2, "2x19")):
+                lib.ssd_tune_set_wgrad(3 if shape >= 0 else -1, 1, -1)
+                lib.ssd_tune_set_wgrad_patch(shape)
+                ms = timeit(lambda: ops.conv2d_wgrad(x, dy, g, ld, True))
+                row.append(f"{lab}:{fl / ms / 1e9:6.1f}")
+            lib.ssd_tune_set_wgrad(128, 1, -1)
+            ms = timeit(lambda: ops.conv2d_wgrad(x, dy, g, ld, True))
+            row.append(f"one-tap128:{fl / ms / 1e9:6.1f}")
+            lib.ssd_tune_set_wgrad(-1, -1, -1); lib.ssd_tune_set_wgrad_patch(-1)
+            print(f"wgrad patch {name:8s} " + "  ".join(row), flush=True)
         if which == "occ":                      # blocks per CU capped through extra dynamic LDS (64x64 tile, 18 KB static)
             row = []
             for pad_kb, lab in ((0, "7/CU"), (8, "6"), (14, "5"), (22, "4"), (35, "3"), (62, "2")):
