@@ -98,6 +98,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its wheel carries its own libamdhip64, and the process must end up with ONE HIP runtime.  Loading this
+    # library before torch binds it to /opt/rocm's copy instead, and the first kernel launch then fails.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         from . import build as _build          # raises if hipcc is missing
         _build.build()
