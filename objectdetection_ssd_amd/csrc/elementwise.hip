@@ -116,12 +116,22 @@ __global__ void clock_probe_kernel(unsigned long long* __restrict__ out) {
     }
 }
 
-__global__ void slab_sum_kernel(const float* __restrict__ slab, float* __restrict__ out, int n, int nslab) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        float s = 0.f;
-        for (int k = 0; k < nslab; ++k) s += slab[(size_t)k * n + i];
-        out[i] = s;
+// out[i] = sum_k slab[k][i]: 16 threads per column group stride over the slabs (16 loads in flight per column instead of one
+// dependent chain of nslab loads), then a fixed-order LDS tree -- reproducible.  blockDim = (16 columns, 16 slab lanes).
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slab, float* __restrict__ out, int n, int nslab) {
+    __shared__ float part[16][17];
+    const int c = threadIdx.x & 15, l = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + c;
+    float s = 0.f;
+    if (i < n)
+        for (int k = l; k < nslab; k += 16) s += slab[(size_t)k * n + i];
+    part[l][c] = s;
+    __syncthreads();
+    if (l == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += part[k][c];
+        out[i] = t;
     }
 }
 
@@ -459,7 +469,7 @@ extern "C" int ssd_l2norm_bwd(const float* x, const float* gamma, const float* d
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(l2norm_bwd_kernel<2>, dim3(blocks), dim3(256), 0, st, x, gamma, dy, dx, reinterpret_cast<float*>(ws), M);
     SSD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(slab_sum_kernel, dim3(ssd_cdiv(C, 256)), dim3(256), 0, st, reinterpret_cast<const float*>(ws), dgamma, C, blocks);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(ssd_cdiv(C, 16)), dim3(256), 0, st, reinterpret_cast<const float*>(ws), dgamma, C, blocks);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
 }

@@ -207,3 +207,16 @@ def test_transform_geometry_equals_reference_functions(gold_dir):
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             Dataset.preprocess_batch([np.zeros((8, 8, 3), np.uint8)])
+
+
+def test_bench_refuses_to_run_without_the_gpu():
+    """bench.py measures the HIP path only: without a GPU it must stop with a clear message, never time a fallback."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0 and "needs a GPU" in (r.stderr + r.stdout)
+    assert '"metric"' not in r.stdout
