@@ -220,6 +220,43 @@ def map_cases():
     return cases
 
 
+def write_degenerate(RL):
+    """Losses.ssd on degenerate ground truth: zero-area and zero-height boxes.  Their IoU with
+    every prior is 0, so they are matched only through the forced match (first prior on the all-zero row, Losses.py:157-160);
+    the width/height target is log(0) = -inf, the L1 loss inf, the gradients stay finite (sign(+inf) = 1)."""
+    f = np.float32
+    cases = [
+        ([np.array([[.4, .4, .4, .4], [.2, .3, .7, .8]], f)], [np.array([5., 2.], f)], 4000),
+        ([np.array([[.1, .5, .6, .5]], f), np.array([[.3, .3, .9, .8]], f)], [np.array([7.], f), np.array([1.], f)], 4001),
+        ([np.array([[.25, .25, .25, .25]], f)], [np.array([19.], f)], 4002),
+    ]
+    store = {"n_cases": np.int64(len(cases))}
+    for ci, (boxes, classes, seed) in enumerate(cases):
+        bs = len(boxes)
+        r = np.random.default_rng(seed)
+        loc = r.standard_normal((bs, 8732, 4), dtype=np.float32)
+        conf = (r.standard_normal((bs, 8732, 21), dtype=np.float32) * np.float32(2.0))
+        lt = torch.from_numpy(loc).requires_grad_(True)
+        ct = torch.from_numpy(conf).requires_grad_(True)
+        with quiet():
+            l_loc, l_conf = RL.ssd((lt, ct), [torch.from_numpy(c) for c in classes], [torch.from_numpy(b) for b in boxes])
+        cls = RL.obj_forEach_prior___.numpy().astype(np.int8)
+        (l_loc + l_conf).backward()
+        p = f"c{ci}_"
+        store[p + "seed"] = np.int64(seed)
+        store[p + "counts"] = np.asarray([b.shape[0] for b in boxes], np.int64)
+        store[p + "boxes"] = np.concatenate(boxes).astype(np.float32)
+        store[p + "classes"] = np.concatenate(classes).astype(np.float32)
+        store[p + "cls"] = cls
+        store[p + "loc_loss"] = np.float32(l_loc.item())
+        store[p + "conf_loss"] = np.float32(l_conf.item())
+        store[p + "dloc_pos"] = lt.grad.numpy()[cls != 20].astype(np.float32)
+        dconf = ct.grad.numpy()
+        store[p + "dconf_touched"] = np.nonzero(np.abs(dconf.reshape(-1, 21)).sum(1) > 0)[0].astype(np.int64)
+        store[p + "dconf_abs_sum"] = np.float64(np.abs(dconf).astype(np.float64).sum())
+    np.savez_compressed(os.path.join(GOLD, "degenerate.npz"), **store)
+
+
 def write_augment(RU):
     """The geometric half of Util.transform (Util.py:566-607): `expand`, `random_crop`, `flip` of the reference, run on
     seeded `random` streams in transform's own order.  photometric_distort and the PIL<->tensor conversions are
@@ -342,7 +379,7 @@ def write_resnet34(RM, RU):
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    if sys.argv[1:] in (["resnet34"], ["map"], ["augment"]):     # add one fixture without rewriting the others
+    if sys.argv[1:] in (["resnet34"], ["map"], ["augment"], ["degenerate"]):     # add one fixture without rewriting the others
         _install_stand_ins()
         with quiet():
             import Util as RU
@@ -352,6 +389,9 @@ def main():
             write_map(RU)
         elif sys.argv[1] == "augment":
             write_augment(RU)
+        elif sys.argv[1] == "degenerate":
+            import Losses as RL
+            write_degenerate(RL)
         else:
             write_resnet34(RM, RU)
         return
@@ -531,6 +571,7 @@ def main():
     write_resnet34(RM, RU)
     write_map(RU)
     write_augment(RU)
+    write_degenerate(RL)
     print("golden fixtures written to", GOLD)
     for f in sorted(os.listdir(GOLD)):
         print(f"  {f}: {os.path.getsize(os.path.join(GOLD, f))} bytes")

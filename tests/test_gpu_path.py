@@ -57,6 +57,29 @@ def test_ssd_loss_vs_golden_and_oracle(gold_dir, ci):
     np.testing.assert_allclose(dconf.reshape(-1, 21)[rows], z[p + "dconf_vals"], rtol=1e-3, atol=1e-6)
 
 
+@pytest.mark.parametrize("ci", range(3))
+def test_ssd_loss_degenerate_ground_truth_vs_reference(gold_dir, ci):
+    """Zero-area / zero-height ground truth (tests/golden/degenerate.npz, from the reference): forced match only, loc loss
+    inf like the reference's, finite gradients, identical classes and hard-negative set."""
+    from objectdetection_ssd_amd import Losses
+    z = np.load(os.path.join(gold_dir, "degenerate.npz"))
+    boxes, classes, loc, conf, p = split_case(z, ci)
+    lt = _t(loc).requires_grad_(True)
+    ct = _t(conf).requires_grad_(True)
+    l_loc, l_conf = Losses.ssd((lt, ct), [_t(c) for c in classes], [_t(b) for b in boxes])
+    (l_loc + l_conf).backward()
+    cls = Losses.last_match["cls"].cpu().numpy()
+    assert np.array_equal(cls.astype(np.int8), z[p + "cls"])
+    assert np.isinf(l_loc.item()) and l_loc.item() > 0 and np.isinf(z[p + "loc_loss"])
+    assert abs(l_conf.item() - float(z[p + "conf_loss"])) <= 1e-4 * max(1, abs(float(z[p + "conf_loss"])))
+    dloc, dconf = lt.grad.cpu().numpy(), ct.grad.cpu().numpy()
+    assert np.isfinite(dloc).all() and np.isfinite(dconf).all()
+    np.testing.assert_allclose(dloc[cls != 20], z[p + "dloc_pos"], rtol=1e-5, atol=1e-8)
+    touched = np.nonzero(np.abs(dconf.reshape(-1, 21)).sum(1) > 0)[0]
+    assert np.array_equal(touched, z[p + "dconf_touched"])
+    np.testing.assert_allclose(np.abs(dconf).astype(np.float64).sum(), z[p + "dconf_abs_sum"], rtol=1e-4)
+
+
 def test_ssd_loss_is_deterministic_and_rejects_bad_input():
     from objectdetection_ssd_amd import Losses
     rng = np.random.default_rng(11)

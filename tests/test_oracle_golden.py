@@ -183,3 +183,21 @@ def test_preprocess_restatement_layout():
     u8 = O.resize_bilinear_u8(a, 30, 20)
     np.testing.assert_allclose(out[1], (u8[..., 1] / 255.0 - 0.456) / 0.224, rtol=0, atol=1e-5)
     assert tuple(O.mean_filler_u8()) == (123, 116, 103)
+
+
+@pytest.mark.parametrize("ci", range(3))
+def test_degenerate_ground_truth_vs_reference(gold_dir, ci):
+    """Zero-area / zero-height boxes (tests/golden/degenerate.npz): matched through the forced match only, loc loss = inf
+    (target log(0)), finite gradients, the same positives and hard negatives as the reference."""
+    z = np.load(os.path.join(gold_dir, "degenerate.npz"))
+    boxes, classes, loc, conf, p = split_case(z, ci)
+    with np.errstate(all="ignore"):
+        out = O.multibox_loss(loc, conf, boxes, classes)
+    assert np.array_equal(out["cls"].astype(np.int8), z[p + "cls"])
+    assert np.isinf(z[p + "loc_loss"]) and np.isinf(out["loc_loss"])
+    np.testing.assert_allclose(out["conf_loss"], z[p + "conf_loss"], rtol=2e-6)
+    np.testing.assert_allclose(out["dloc"][out["pos"]], z[p + "dloc_pos"], rtol=1e-6, atol=1e-9)
+    assert np.isfinite(out["dloc"]).all()
+    touched = np.nonzero(np.abs(out["dconf"].reshape(-1, 21)).sum(1) > 0)[0]
+    assert np.array_equal(touched, z[p + "dconf_touched"])
+    np.testing.assert_allclose(np.abs(out["dconf"]).astype(np.float64).sum(), z[p + "dconf_abs_sum"], rtol=1e-5)
