@@ -161,6 +161,11 @@ int ssd_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int N, int H, int
 /* dx (+)= routed dy; if relu_mask != NULL dx = relu_mask > 0 ? dx : 0. */
 int ssd_maxpool_bwd(const float* dy, const uint8_t* argmax, float* dx, const float* relu_mask, int accumulate,
                     int N, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo, void* stream);
+/* Same gradient for a pool whose input is a ReLU output and has no other consumer: dx = relu_mask(x) * scatter(dy) computed
+ * as scatter(dy gated by y > 0), y = the pooled output (an arg-max input equals its window's output) -- reads y instead of
+ * the 4x larger x. */
+int ssd_maxpool_bwd_gated(const float* dy, const uint8_t* argmax, const float* y, float* dx, int N, int H, int W, int C,
+                          int k, int stride, int pad, int Ho, int Wo, void* stream);
 
 /* ---- conv4_3 L2 normalisation (Model.py:206-209): y = x / sqrt(sum_c x^2) * gamma_c, no epsilon */
 int ssd_l2norm_fwd(const float* x, const float* gamma, float* y, int M, int C, void* stream);

@@ -298,8 +298,11 @@ class _Engine:
                 dy = G.pop(op["y"])
                 xin = T[op["x"]]
                 am = aux[op["y"]]
-                deliver(op["x"], lambda dx, acc, mask: ops.maxpool_bwd(dy, am, tuple(xin.shape), op["k"], op["s"], op["pad"],
-                                                                       dx, mask, acc))
+                yout = T[op["y"]]
+                deliver(op["x"], lambda dx, acc, mask: (
+                    ops.maxpool_bwd(dy, am, tuple(xin.shape), op["k"], op["s"], op["pad"], dx, y_gate=yout)
+                    if (mask is not None and not acc) else          # sole consumer of a ReLU output: gate by the pooled output
+                    ops.maxpool_bwd(dy, am, tuple(xin.shape), op["k"], op["s"], op["pad"], dx, mask, acc)))
             elif kind == "l2norm":
                 dy = G.pop(op["y"])
                 xin = T[op["x"]]

@@ -178,9 +178,11 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
 }
 
 // gather form: every input element sums dy over the windows whose argmax it is
+// y_gate (optional): the pooled output.  An input that is a window's argmax equals that window's output, so gating each
+// window's dy by y > 0 is the ReLU mask x > 0 of the pool's input without reading the 4x larger x.
 __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ am, float* __restrict__ dx,
-                                   const float* __restrict__ mask, int accumulate, int N, int H, int W, int C, int k,
-                                   int stride, int pad, int Ho, int Wo) {
+                                   const float* __restrict__ mask, const float* __restrict__ y_gate, int accumulate, int N, int H,
+                                   int W, int C, int k, int stride, int pad, int Ho, int Wo) {
     const int C4 = C >> 2;
     const size_t total = (size_t)N * H * W * C4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -202,7 +204,12 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* 
                 if (ow >= Wo) continue;
                 const size_t o = (((size_t)n * Ho + oh) * Wo + ow) * C + c4 * 4;
                 const uint32_t a = *reinterpret_cast<const uint32_t*>(am + o);
-                const f32x4 d = *reinterpret_cast<const f32x4*>(dy + o);
+                f32x4 d = *reinterpret_cast<const f32x4*>(dy + o);
+                if (y_gate != nullptr) {
+                    const f32x4 yv = *reinterpret_cast<const f32x4*>(y_gate + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d[e] = yv[e] > 0.f ? d[e] : 0.f;
+                }
                 const uint32_t me = (uint32_t)(r * k + s);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -445,7 +452,19 @@ extern "C" int ssd_maxpool_bwd(const float* dy, const uint8_t* argmax, float* dx
     if (C % 4 != 0 || k <= 0 || k > 15 || stride <= 0 || pad < 0) return SSD_ERR_BAD_SHAPE;
     if (!ssd_aligned16(dy) || !ssd_aligned16(dx)) return SSD_ERR_ALIGN;
     const size_t total = (size_t)N * H * W * (C / 4);
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx, relu_mask, accumulate, N, H, W, C, k, stride, pad, Ho, Wo);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx, relu_mask,
+                       static_cast<const float*>(nullptr), accumulate, N, H, W, C, k, stride, pad, Ho, Wo);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+extern "C" int ssd_maxpool_bwd_gated(const float* dy, const uint8_t* argmax, const float* y, float* dx, int N, int H, int W, int C,
+                                     int k, int stride, int pad, int Ho, int Wo, void* stream) {
+    if (!dy || !argmax || !y || !dx) return SSD_ERR_NULL;
+    if (C % 4 != 0 || k <= 0 || k > 15 || stride <= 0 || pad < 0) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(dy) || !ssd_aligned16(dx) || !ssd_aligned16(y)) return SSD_ERR_ALIGN;
+    const size_t total = (size_t)N * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx,
+                       static_cast<const float*>(nullptr), y, 0, N, H, W, C, k, stride, pad, Ho, Wo);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
 }

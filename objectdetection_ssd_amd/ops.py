@@ -343,12 +343,28 @@ def maxpool_fwd(x: torch.Tensor, k: int, stride: int, pad: int, ceil_mode: bool,
 
 
 def maxpool_bwd(dy: torch.Tensor, argmax: torch.Tensor, in_shape, k: int, stride: int, pad: int,
-                dx: Optional[torch.Tensor] = None, relu_mask: Optional[torch.Tensor] = None, accumulate: bool = False):
+                dx: Optional[torch.Tensor] = None, relu_mask: Optional[torch.Tensor] = None, accumulate: bool = False,
+                y_gate: Optional[torch.Tensor] = None):
+    """y_gate: the pooled OUTPUT; with it (and no accumulate / relu_mask) the ReLU mask of the pool's input is applied as
+    y > 0 per window, which reads a quarter of the bytes of relu_mask = x."""
     _req(dy, "dy"); _req(argmax, "argmax", torch.uint8)
     n, h, w, c = in_shape
     _, ho, wo, c2 = dy.shape
     if c2 != c or tuple(argmax.shape) != tuple(dy.shape):
         raise ValueError("maxpool_bwd shapes")
+    if y_gate is not None:
+        if accumulate or relu_mask is not None:
+            raise ValueError("y_gate replaces relu_mask and cannot accumulate")
+        _req(y_gate, "y_gate")
+        if tuple(y_gate.shape) != tuple(dy.shape):
+            raise ValueError("y_gate must be the pooled output")
+        dx = torch.empty((n, h, w, c), device=dy.device, dtype=torch.float32) if dx is None else dx
+        _req(dx, "dx")
+        if dx.numel() != n * h * w * c:
+            raise ValueError("dx size")
+        check(_lib.load().ssd_maxpool_bwd_gated(dy.data_ptr(), argmax.data_ptr(), y_gate.data_ptr(), dx.data_ptr(), n, h, w, c, k, stride,
+                                                pad, ho, wo, _stream()), "maxpool_bwd_gated")
+        return dx
     if dx is None:
         if accumulate:
             raise ValueError("accumulate needs an existing dx")

@@ -136,6 +136,10 @@ def test_maxpool_fwd_bwd(k, s, p, ceil, hw):
     dx = ops.maxpool_bwd(_nhwc(dy).to(dev), am, tuple(xd.shape), k, s, p, relu_mask=xd)
     ref = _nhwc(x.grad * (x.detach() > 0))
     _close(dx, ref, tol=1e-6, what="maxpool bwd + mask")
+    dxg = ops.maxpool_bwd(_nhwc(dy).to(dev), am, tuple(xd.shape), k, s, p, y_gate=yd)       # same mask through the pooled output
+    assert torch.equal(dxg, dx)
+    with pytest.raises(ValueError):
+        ops.maxpool_bwd(_nhwc(dy).to(dev), am, tuple(xd.shape), k, s, p, relu_mask=xd, y_gate=yd)
     prev = torch.randn(ref.shape, generator=g)
     dx2 = ops.maxpool_bwd(_nhwc(dy).to(dev), am, tuple(xd.shape), k, s, p, dx=prev.to(dev), relu_mask=xd, accumulate=True)
     _close(dx2, (_nhwc(x.grad) + prev) * (_nhwc(x.detach()) > 0), tol=1e-6, what="maxpool bwd acc")
