@@ -69,22 +69,8 @@ __device__ __forceinline__ int div_small_q(int m, int d, float rcp) {
     return q;
 }
 
-#ifndef SSD_IGEMM_SETPRIO
-#define SSD_IGEMM_SETPRIO 0
-#endif
-constexpr int SETPRIO = SSD_IGEMM_SETPRIO;
-
-#ifndef SSD_IGEMM_WAVES
-#define SSD_IGEMM_WAVES 0
-#endif
-#if SSD_IGEMM_WAVES
-#define IGEMM_OCC __attribute__((amdgpu_waves_per_eu(SSD_IGEMM_WAVES)))
-#else
-#define IGEMM_OCC
-#endif
-
 template <int BM, int BN, int WM, int WN, int NBUF>
-__global__ __launch_bounds__(256) IGEMM_OCC void igemm_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;
     constexpr int STAGE = (BM + BN) * LDS_LD;
@@ -95,7 +81,6 @@ __global__ __launch_bounds__(256) IGEMM_OCC void igemm_kernel(const IgemmParams 
     const bool stamp = p.stamps != nullptr && (blockIdx.x & 63) == 0 && tid == 0;
     unsigned long long t_start = 0, t_loop = 0, t_epi = 0;
     if (stamp) t_start = __builtin_readcyclecounter();
-    if (SETPRIO) __builtin_amdgcn_s_setprio(3);      // prologue / epilogue instructions go ahead of the resident waves' MFMA loops
     const int wm = wave / WN, wn = wave % WN;
     const int nblk = p.tiles_m * p.tiles_n;
     const int lid = xcd_swizzle(blockIdx.x, nblk);
@@ -201,7 +186,6 @@ __global__ __launch_bounds__(256) IGEMM_OCC void igemm_kernel(const IgemmParams 
     store_tile(lds);
     __syncthreads();
     if (stamp) t_loop = __builtin_readcyclecounter();
-    if (SETPRIO) __builtin_amdgcn_s_setprio(0);
 
     auto multiply = [&](const float* stage) {
 #pragma unroll
@@ -241,7 +225,6 @@ __global__ __launch_bounds__(256) IGEMM_OCC void igemm_kernel(const IgemmParams 
     }
 
     if (stamp) t_epi = __builtin_readcyclecounter();
-    if (SETPRIO) __builtin_amdgcn_s_setprio(3);
     // ---- epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) --------
     if (p.ksplit > 1) {                                   // uniform: raw partial tile, finished by splitk_reduce_kernel
         float* slab = p.slab + (size_t)blockIdx.y * p.M * p.Nout;
