@@ -534,35 +534,42 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const WgradParams
     }
 }
 
-// out_oihw[co][ci][t] = sum_split slab[split][co][t][ci].  The split loop is unrolled into eight independent
-// partial sums (loads in flight instead of one dependent load per ~1 us); the association order is fixed, so
-// the result stays bitwise reproducible.
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Co, int Ci, int T,
-                                    int nsplit) {
+// out_oihw[co][ci][t] = sum_split slab[split][co][t][ci], and db[co] = sum_split bias_slab[split][co], in one launch.
+// Block = (output channel co, chunk of 64 input channels).  The T x 64 sums are read along ci (coalesced in the slab), parked
+// in LDS and written along the OIHW order ci*T + t, which for a fixed co is one contiguous run of 64*T floats -- no strided
+// 4-byte stores.  The split loop is unrolled into eight independent partial sums (loads in flight instead of one dependent
+// load per ~1 us); every association order is fixed, so the result stays bitwise reproducible.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Co, int Ci, int T,
+                                                           int nsplit, const float* __restrict__ bias_slab, float* __restrict__ db) {
+    __shared__ float tile[49 * 64];                              // up to 7x7 taps
+    const int chunks = (Ci + 63) / 64;
+    const int co = blockIdx.x / chunks, ci0 = (blockIdx.x % chunks) * 64;
+    const int nci = min(64, Ci - ci0);
     const size_t total = (size_t)Co * T * Ci;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int k = 0;
-        for (; k + 8 <= nsplit; k += 8)
+    for (int e = threadIdx.x; e < T * 64; e += 256) {
+        const int t = e >> 6, c = e & 63;
+        float s = 0.f;
+        if (c < nci) {
+            const size_t i = ((size_t)co * T + t) * Ci + ci0 + c;
+            float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int k = 0;
+            for (; k + 8 <= nsplit; k += 8)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] += slab[(size_t)(k + u) * total + i];
-        for (int u = 0; k < nsplit; ++k, ++u) a[u] += slab[(size_t)k * total + i];
-        const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-        const int ci = (int)(i % Ci);
-        const size_t rest = i / Ci;
-        const int t = (int)(rest % T), co = (int)(rest / T);
-        dw[((size_t)co * Ci + ci) * T + t] = s;
+                for (int u = 0; u < 8; ++u) a[u] += slab[(size_t)(k + u) * total + i];
+            for (int u = 0; k < nsplit; ++k, ++u) a[u] += slab[(size_t)k * total + i];
+            s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        }
+        tile[t * 64 + c] = s;
     }
-}
-
-// db[co] = sum_split slab[split][co]: one wave per channel, lanes stride over the splits, fixed shuffle tree
-__global__ __launch_bounds__(256) void bias_reduce_kernel(const float* __restrict__ slab, float* __restrict__ db, int Co, int nsplit) {
-    const int co = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (co >= Co) return;
-    float s = 0.f;
-    for (int k = lane; k < nsplit; k += 64) s += slab[(size_t)k * Co + co];
-    s = wave_sum(s);
-    if (lane == 0) db[co] = s;
+    __syncthreads();
+    float* dst = dw + ((size_t)co * Ci + ci0) * T;
+    for (int j = threadIdx.x; j < nci * T; j += 256) dst[j] = tile[(j % T) * 64 + j / T];
+    if (db != nullptr && ci0 == 0 && threadIdx.x < 64) {         // wave 0: lanes stride over the splits, fixed shuffle tree
+        float s = 0.f;
+        for (int k = threadIdx.x; k < nsplit; k += 64) s += bias_slab[(size_t)k * Co + co];
+        s = wave_sum(s);
+        if (threadIdx.x == 0) db[co] = s;
+    }
 }
 
 int g_force_bt = -1, g_force_wnbuf = -1, g_force_blocks_per_cu = -1;   // tuning aid (ssd_tune_set_wgrad)
@@ -696,15 +703,10 @@ static int conv2d_wgrad_impl(const float* x, const float* dy, int ldy, float* dw
         else hipLaunchKernelGGL((wgrad_kernel<64, 1>), dim3(nblk), dim3(256), 0, st, p);
     }
     SSD_CHECK_LAUNCH();
-    const size_t total = (size_t)g->Co * T * g->Ci;
-    const int rb = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, p.slab, dw_oihw, g->Co, g->Ci, T, pl.nsplit);
+    if (T > 49) return SSD_ERR_BAD_SHAPE;                      // the reduction's LDS tile holds up to 7x7 taps
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g->Co * ssd_cdiv(g->Ci, 64)), dim3(256), 0, st, p.slab, dw_oihw, g->Co, g->Ci, T,
+                       pl.nsplit, dbias ? p.bias_slab : nullptr, dbias);
     SSD_CHECK_LAUNCH();
-    if (dbias) {
-        hipLaunchKernelGGL(bias_reduce_kernel, dim3(ssd_cdiv(g->Co, 4)), dim3(256), 0, st, p.bias_slab, dbias, g->Co,
-                           pl.nsplit);
-        SSD_CHECK_LAUNCH();
-    }
     return SSD_OK;
 }
 
