@@ -486,3 +486,46 @@ def test_conv_split_k(case, ksplit):
         _close(dx, (_nhwc(x.grad) + prev.cpu()) * (mask.cpu() > 0), what=f"split-K {ksplit} dgrad {case}")
     finally:
         lib.ssd_tune_set_igemm_splitk(-1)
+
+
+FULL_SIZE_LAYERS = [  # BASELINE configs[1] geometries at batch 32: (H, Ci, Co, k, stride, pad, dil)
+    (300, 64, 64, 3, 1, 1, 1),       # conv1_2
+    (75, 256, 256, 3, 1, 1, 1),      # conv3_2
+    (38, 512, 512, 3, 1, 1, 1),      # conv4_2
+    (19, 512, 1024, 3, 1, 4, 4),     # fc6 (dilated)
+    (19, 1024, 150, 3, 1, 1, 1),     # head c_7 (split-K forward)
+    (19, 256, 512, 3, 2, 1, 1),      # seq8.2 (stride 2)
+    (3, 128, 256, 3, 1, 0, 1),       # seq11.2
+]
+
+
+@pytest.mark.parametrize("layer", FULL_SIZE_LAYERS)
+def test_conv_adjoint_identities_at_full_batch(layer):
+    """Size-independent properties at the benchmark's batch 32 (no CPU reference needed): the three convolution kernels are
+    adjoints of one another -- <conv(x; W), dy> == <x, dgrad(dy; W)> == <W, wgrad(x, dy)> (bias off), and forward is linear
+    in x.  Dots are accumulated in float64; 1e-4 relative."""
+    from objectdetection_ssd_amd import ops
+    h, ci, co, k, s, p, d = layer
+    dev = _dev()
+    g0 = torch.Generator(device=dev).manual_seed(h * 7 + co)
+    x1 = torch.randn(32, h, h, ci, device=dev, generator=g0)
+    x2 = torch.randn(32, h, h, ci, device=dev, generator=g0)
+    w = torch.randn(co, ci, k, k, device=dev, generator=g0) * (2.0 / (ci * k * k)) ** 0.5
+    g = ops.make_geom(32, h, h, ci, co, k, s, p, d)
+    ld = ops.pad32(co)
+    wf, wb = ops.weight_ohwi(w, ld), ops.weight_ihwo(w, ld)
+    dy = torch.zeros(32, g.Ho, g.Wo, ld, device=dev)
+    dy[..., :co] = torch.randn(32, g.Ho, g.Wo, co, device=dev, generator=g0)
+    y1 = ops.conv2d_fwd(x1, wf, None, g, False, ld=ld)
+    y2 = ops.conv2d_fwd(x2, wf, None, g, False, ld=ld)
+    y12 = ops.conv2d_fwd(x1 + x2, wf, None, g, False, ld=ld)
+    _close(y12, y1 + y2, tol=1e-4, what=f"linearity {layer}")
+    dx = ops.conv2d_dgrad(dy, wb, g)
+    dw, db = ops.conv2d_wgrad(x1, dy, g, ld, True)
+
+    def dot(a, b):
+        return float((a.double() * b.double()).sum())
+    lhs = dot(y1, dy)
+    for name, rhs in (("dgrad", dot(x1, dx)), ("wgrad", dot(w, dw))):
+        assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs)), (name, layer, lhs, rhs)
+    assert abs(float(db.double().sum()) - float(dy.double().sum())) <= 1e-6 * float(dy.abs().double().sum())       # bias grad = column sums
