@@ -731,3 +731,57 @@ def test_graphed_inference_forward_replays_bitwise():
     assert torch.equal(a, l1) and torch.equal(b, c1)
     with pytest.raises(ValueError):
         g(torch.zeros(1, 3, 300, 300, device=DEV))
+
+
+# ---- size-independent properties at the benchmark's batch (no CPU reference involved) --------------------------------------
+def test_loss_is_additive_over_images_at_full_batch():
+    """bs = 32: the un-normalised sums (norm_mode=1) of the batch equal the sums of its images taken alone, the positive
+    counts add up, per-image classes are unchanged -- matching and mining never look across images (Losses.py:152-167)."""
+    from objectdetection_ssd_amd import Losses
+    rng = np.random.default_rng(321)
+    boxes, classes = synth_gt(rng, 32)
+    loc = _t(rng.standard_normal((32, 8732, 4), dtype=np.float32))
+    conf = _t(rng.standard_normal((32, 8732, 21), dtype=np.float32) * np.float32(2))
+    bx, cl = [_t(b) for b in boxes], [_t(c) for c in classes]
+    l_all, c_all = Losses.ssd((loc, conf), cl, bx, norm_mode=1)
+    n_all = float(Losses.last_match["n_pos"].item())
+    cls_all = Losses.last_match["cls"].clone()
+    s_loc = s_conf = n_sum = 0.0
+    for i in range(32):
+        li, ci = Losses.ssd((loc[i:i + 1].contiguous(), conf[i:i + 1].contiguous()), cl[i:i + 1], bx[i:i + 1], norm_mode=1)
+        s_loc += float(li.item()); s_conf += float(ci.item()); n_sum += float(Losses.last_match["n_pos"].item())
+        assert torch.equal(Losses.last_match["cls"][0], cls_all[i])
+    assert n_sum == n_all
+    assert abs(s_loc - l_all.item()) <= 1e-5 * abs(l_all.item()) and abs(s_conf - c_all.item()) <= 1e-5 * abs(c_all.item())
+
+
+def test_decode_output_invariants_at_full_batch():
+    """32 images x 8732 priors through the batched decode: every kept score >= min_score, classes 0..19 in class-major order,
+    scores descending inside a class, at most top_k rows, and no two kept boxes of one class overlap by >= the NMS threshold
+    (IoU recomputed by the oracle's bit-exact formula on the returned pixel boxes is only approximate, hence the 1e-3 slack)."""
+    from objectdetection_ssd_amd import Losses
+    g = torch.Generator().manual_seed(77)
+    l = (torch.randn(32, 8732, 4, generator=g) * 0.5).to(DEV)
+    c = (torch.randn(32, 8732, 21, generator=g) * 3).to(DEV)
+    outs = Losses.inference_batch(l, c, [(500, 375)] * 32, top_k=200, min_score=0.2, iou_threshold=0.45)
+    assert len(outs) == 32
+    seen = 0
+    for boxes, classes, probs in outs:
+        if isinstance(boxes, list):
+            continue
+        seen += 1
+        b, k, p = boxes.cpu().numpy(), classes.cpu().numpy(), probs.cpu().numpy()
+        assert len(k) <= 200 and (p >= 0.2).all() and ((k >= 0) & (k <= 19)).all()
+        capped = len(k) == 200
+        if not capped:
+            assert (np.diff(k) >= 0).all()                                   # class-major
+        for cc in np.unique(k):
+            idx = np.nonzero(k == cc)[0]
+            if not capped:
+                assert (np.diff(p[idx]) <= 0).all()                          # descending inside the class
+            if idx.size > 1:
+                frac = b[idx] / np.float32([500, 375, 500, 375])
+                iou = O.iou_matrix(frac, frac)
+                np.fill_diagonal(iou, 0)
+                assert float(iou.max()) < 0.45 + 1e-3
+    assert seen >= 30
