@@ -69,6 +69,75 @@ __device__ __forceinline__ int div_small_q(int m, int d, float rcp) {
     return q;
 }
 
+// Epilogue shared by the 32x32-accumulator kernels (f32, bf16-operand, f32x3): C/D map col = lane&31,
+// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  out = [accumulate: out +] acc (+ bias) -> ReLU -> ReLU mask.
+template <int BM, int TM, int TN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                                               int lr, int lh) {
+    // Full tiles (all but the last tile row) take straight-line paths: no per-element bounds test, every load of a group of
+    // eight rows in flight before the first use, ~10 vector instructions per stored value less than the general loop below.
+    const bool full_m = m0 + BM <= p.M;                    // uniform
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + lr;
+            const bool n_ok = n < p.Nout;
+            const float bv = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
+            if (full_m) {
+                if (n_ok) {
+                    const size_t row = (size_t)p.ldo;
+                    float* po = p.out + (size_t)(m0 + (wm * TM + i) * 32 + 4 * lh) * row + n;
+                    if (p.mask == nullptr && !p.accumulate) {            // forward: bias (+ ReLU)
+                        if (p.relu) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float v = acc[i][j][r] + bv;
+                                po[(size_t)((r & 3) + 8 * (r >> 2)) * row] = v < 0.f ? 0.f : v;      // NaN stays NaN, like torch.relu
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) po[(size_t)((r & 3) + 8 * (r >> 2)) * row] = acc[i][j][r] + bv;
+                        }
+                    } else {                                               // dgrad: (+ previous dx) (* ReLU mask)
+                        const float* pm = p.mask != nullptr ? p.mask + (po - p.out) : nullptr;
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            float prev[8], mk[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const size_t o = (size_t)(((half * 8 + q) & 3) + 8 * ((half * 8 + q) >> 2)) * row;
+                                prev[q] = p.accumulate ? po[o] : 0.f;
+                                mk[q] = pm != nullptr ? pm[o] : 1.f;
+                            }
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const int r = half * 8 + q;
+                                float v = acc[i][j][r] + bv + prev[q];
+                                if (p.relu) v = v < 0.f ? 0.f : v;
+                                po[(size_t)((r & 3) + 8 * (r >> 2)) * row] = mk[q] > 0.f ? v : 0.f;
+                            }
+                        }
+                    }
+                }
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (n_ok && m < p.M) {
+                    const size_t idx = (size_t)m * p.ldo + n;
+                    float v = acc[i][j][r] + bv;
+                    if (p.accumulate) v += p.out[idx];
+                    if (p.relu) v = v < 0.f ? 0.f : v;            // NaN stays NaN, like torch.relu
+                    if (p.mask != nullptr) v = p.mask[idx] > 0.f ? v : 0.f;
+                    p.out[idx] = v;
+                }
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int NBUF>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -241,68 +310,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             }
         return;
     }
-    // Full tiles (all but the last tile row) take straight-line paths: no per-element bounds test, every load of a group of
-    // eight rows in flight before the first use, ~10 vector instructions per stored value less than the general loop below.
-    const bool full_m = m0 + BM <= p.M;                    // uniform
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wn * TN + j) * 32 + lr;
-            const bool n_ok = n < p.Nout;
-            const float bv = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
-            if (full_m) {
-                if (n_ok) {
-                    const size_t row = (size_t)p.ldo;
-                    float* po = p.out + (size_t)(m0 + (wm * TM + i) * 32 + 4 * lh) * row + n;
-                    if (p.mask == nullptr && !p.accumulate) {            // forward: bias (+ ReLU)
-                        if (p.relu) {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const float v = acc[i][j][r] + bv;
-                                po[(size_t)((r & 3) + 8 * (r >> 2)) * row] = v < 0.f ? 0.f : v;      // NaN stays NaN, like torch.relu
-                            }
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) po[(size_t)((r & 3) + 8 * (r >> 2)) * row] = acc[i][j][r] + bv;
-                        }
-                    } else {                                               // dgrad: (+ previous dx) (* ReLU mask)
-                        const float* pm = p.mask != nullptr ? p.mask + (po - p.out) : nullptr;
-#pragma unroll
-                        for (int half = 0; half < 2; ++half) {
-                            float prev[8], mk[8];
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) {
-                                const size_t o = (size_t)(((half * 8 + q) & 3) + 8 * ((half * 8 + q) >> 2)) * row;
-                                prev[q] = p.accumulate ? po[o] : 0.f;
-                                mk[q] = pm != nullptr ? pm[o] : 1.f;
-                            }
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) {
-                                const int r = half * 8 + q;
-                                float v = acc[i][j][r] + bv + prev[q];
-                                if (p.relu) v = v < 0.f ? 0.f : v;
-                                po[(size_t)((r & 3) + 8 * (r >> 2)) * row] = mk[q] > 0.f ? v : 0.f;
-                            }
-                        }
-                    }
-                }
-                continue;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (n_ok && m < p.M) {
-                    const size_t idx = (size_t)m * p.ldo + n;
-                    float v = acc[i][j][r] + bv;
-                    if (p.accumulate) v += p.out[idx];
-                    if (p.relu) v = v < 0.f ? 0.f : v;            // NaN stays NaN, like torch.relu
-                    if (p.mask != nullptr) v = p.mask[idx] > 0.f ? v : 0.f;
-                    p.out[idx] = v;
-                }
-            }
-        }
-    }
+    igemm_epilogue<BM, TM, TN>(p, acc, m0, n0, wm, wn, lr, lh);
     if (stamp) {
         unsigned long long* o = p.stamps + (size_t)(blockIdx.x >> 6) * 4;
         o[0] = t_start; o[1] = t_loop; o[2] = t_epi; o[3] = __builtin_readcyclecounter();
@@ -551,27 +559,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmParams p) {
         }
     }
 
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wn * TN + j) * 32 + lr;
-            const bool n_ok = n < p.Nout;
-            const float bv = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (n_ok && m < p.M) {
-                    const size_t idx = (size_t)m * p.ldo + n;
-                    float v = acc[i][j][r] + bv;
-                    if (p.accumulate) v += p.out[idx];
-                    if (p.relu) v = v < 0.f ? 0.f : v;
-                    if (p.mask != nullptr) v = p.mask[idx] > 0.f ? v : 0.f;
-                    p.out[idx] = v;
-                }
-            }
-        }
-    }
+    igemm_epilogue<BM, TM, TN>(p, acc, m0, n0, wm, wn, lr, lh);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -747,27 +735,7 @@ __global__ __launch_bounds__(256) void igemm_x3_kernel(const X3Params q) {
         }
     }
 
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wn * TN + j) * 32 + lr;
-            const bool n_ok = n < p.Nout;
-            const float bv = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (n_ok && m < p.M) {
-                    const size_t idx = (size_t)m * p.ldo + n;
-                    float v = acc[i][j][r] + bv;
-                    if (p.accumulate) v += p.out[idx];
-                    if (p.relu) v = v < 0.f ? 0.f : v;
-                    if (p.mask != nullptr) v = p.mask[idx] > 0.f ? v : 0.f;
-                    p.out[idx] = v;
-                }
-            }
-        }
-    }
+    igemm_epilogue<BM, TM, TN>(p, acc, m0, n0, wm, wn, lr, lh);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -912,11 +880,52 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const X3Params q) {
     }
 
     // ---- epilogue: this lane's accumulator rows are patch pixels (wm*32 + row) -------------------------------------------
+    // Patches that lie inside the map take straight-line paths (no per-element bounds test; the loads of eight rows in flight
+    // before their first use): vector instructions next to the resident MFMA loops are the expensive part of a block's edges.
+    const bool inside = oh0 + PH_ <= p.Ho && ow0 + PW_ <= p.Wo;        // uniform
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + (wn * TN + j) * 32 + lr;
         const bool n_ok = n < p.Nout;
         const float bv = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
+        if (inside) {
+            if (n_ok) {
+                const size_t row = (size_t)p.ldo;
+                float* po = p.out + ((size_t)(img * p.Ho + oh0) * p.Wo + ow0) * row + n;
+                size_t off[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pq = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    off[r] = ((size_t)(pq / PW_) * p.Wo + (pq % PW_)) * row;
+                }
+                if (p.mask == nullptr && !p.accumulate) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[j][r] + bv;
+                        if (p.relu) v = v < 0.f ? 0.f : v;
+                        po[off[r]] = v;
+                    }
+                } else {
+                    const float* pm = p.mask != nullptr ? p.mask + (po - p.out) : nullptr;
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        float prev[8], mk[8];
+#pragma unroll
+                        for (int q2 = 0; q2 < 8; ++q2) {
+                            prev[q2] = p.accumulate ? po[off[half * 8 + q2]] : 0.f;
+                            mk[q2] = pm != nullptr ? pm[off[half * 8 + q2]] : 1.f;
+                        }
+#pragma unroll
+                        for (int q2 = 0; q2 < 8; ++q2) {
+                            float v = acc[j][half * 8 + q2] + bv + prev[q2];
+                            if (p.relu) v = v < 0.f ? 0.f : v;
+                            po[off[half * 8 + q2]] = mk[q2] > 0.f ? v : 0.f;
+                        }
+                    }
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int pq = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
