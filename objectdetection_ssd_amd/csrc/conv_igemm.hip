@@ -461,8 +461,8 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmParams p) {
         const int m = m0 + row0 + 32 * j;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
-        const int n = mm / HoWo, rem = mm - n * HoWo;
-        const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+        const int n = div_small_q(mm, HoWo, p.rcp_howo), rem = mm - n * HoWo;
+        const int oh = div_small_q(rem, p.Wo, p.rcp_wo), ow = rem - oh * p.Wo;
         a_h[j] = ok ? oh * p.sm + p.off : -(1 << 24);
         a_w[j] = ow * p.sm + p.off;
         a_base[j] = (unsigned)n * (unsigned)(p.Ha * p.Wa * p.Ca) * 4u + chunk * 16u;
@@ -480,7 +480,11 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmParams p) {
         for (int j = 0; j < A_ROWS; ++j) {
             int th = a_h[j] + dh, tw = a_w[j] + dw;
             bool ok = th >= 0 && tw >= 0;
-            if (p.sd > 1) {
+            if (p.sd == 2) {
+                ok = ok && ((th | tw) & 1) == 0;
+                th >>= 1;
+                tw >>= 1;
+            } else if (p.sd > 2) {
                 ok = ok && (th % p.sd == 0) && (tw % p.sd == 0);
                 th /= p.sd;
                 tw /= p.sd;
@@ -617,8 +621,8 @@ __global__ __launch_bounds__(256) void igemm_x3_kernel(const X3Params q) {
         const int m = m0 + row0 + 32 * j;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
-        const int n = mm / HoWo, rem = mm - n * HoWo;
-        const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+        const int n = div_small_q(mm, HoWo, p.rcp_howo), rem = mm - n * HoWo;
+        const int oh = div_small_q(rem, p.Wo, p.rcp_wo), ow = rem - oh * p.Wo;
         a_h[j] = ok ? oh * p.sm + p.off : -(1 << 24);
         a_w[j] = ow * p.sm + p.off;
         a_base[j] = (unsigned)n * (unsigned)(p.Ha * p.Wa * p.Ca) * 4u + chunk * 16u;
@@ -636,7 +640,11 @@ __global__ __launch_bounds__(256) void igemm_x3_kernel(const X3Params q) {
         for (int j = 0; j < A_ROWS; ++j) {
             int th = a_h[j] + dh, tw = a_w[j] + dw;
             bool ok = th >= 0 && tw >= 0;
-            if (p.sd > 1) {
+            if (p.sd == 2) {
+                ok = ok && ((th | tw) & 1) == 0;
+                th >>= 1;
+                tw >>= 1;
+            } else if (p.sd > 2) {
                 ok = ok && (th % p.sd == 0) && (tw % p.sd == 0);
                 th /= p.sd;
                 tw /= p.sd;
@@ -975,6 +983,8 @@ template <int BM, int BN, int WM, int WN>
 int launch_igemm_x3(X3Params& q, hipStream_t st) {
     q.g.tiles_m = ssd_cdiv(q.g.M, BM);
     q.g.tiles_n = ssd_cdiv(q.g.Nout, BN);
+    q.g.rcp_howo = 1.0f / (float)(q.g.Ho * q.g.Wo);
+    q.g.rcp_wo = 1.0f / (float)q.g.Wo;
     hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN>), dim3(q.g.tiles_m * q.g.tiles_n), dim3(256), 0, st, q);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
@@ -1012,6 +1022,8 @@ template <int BM, int BN, int WM, int WN>
 int launch_igemm_bf16(IgemmParams& p, hipStream_t st) {
     p.tiles_m = ssd_cdiv(p.M, BM);
     p.tiles_n = ssd_cdiv(p.Nout, BN);
+    p.rcp_howo = 1.0f / (float)(p.Ho * p.Wo);
+    p.rcp_wo = 1.0f / (float)p.Wo;
     hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
