@@ -51,7 +51,7 @@ def synth_batch(bs: int, seed: int, dev):
     return x.to(dev), classes, boxes
 
 
-def cpu_baseline(bs: int = 4, iters: int = 2, max_threads: int = 16):
+def cpu_baseline(bs: int = 4, iters: int = 12, max_threads: int = 16):       # ~10-15 s of CPU work
     """Oracle (CPU restatement of the reference path, plain torch-CPU ops) timed on the host cores."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ssd_oracle as O
