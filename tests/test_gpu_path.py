@@ -785,3 +785,45 @@ def test_decode_output_invariants_at_full_batch():
                 np.fill_diagonal(iou, 0)
                 assert float(iou.max()) < 0.45 + 1e-3
     assert seen >= 30
+
+
+def test_dataset_class_end_to_end_on_image_files(tmp_path):
+    """`Dataset.MultiImageMultiBBoxDataset` + `collate_fn` with the reference's constructor arguments (Dataset.py:7-53) on
+    real image files: isTest=True items give the Pillow-resized, normalised batch and boxes divided by (w,h,w,h); difficult
+    objects are dropped unless keep_difficult; isTest=False items carry a drawn geometry whose pixels equal the oracle's."""
+    import random
+    from PIL import Image
+    from objectdetection_ssd_amd import Dataset
+    rng = np.random.default_rng(5)
+    paths, sizes = [], [(120, 90), (64, 200), (300, 300)]
+    for i, (h, w) in enumerate(sizes):
+        pth = str(tmp_path / f"im{i}.png")
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(pth)
+        paths.append(pth)
+    bboxes = [[[10., 20., 60., 80.], [5., 5., 30., 40.]], [[0., 0., 100., 50.]], [[30., 40., 200., 250.], [100., 100., 280., 290.]]]
+    labels = [["dog", "cat"], ["person"], ["car", "bus"]]
+    difficult = [[0, 1], [0], [0, 0]]
+    ds = Dataset.MultiImageMultiBBoxDataset(paths, bboxes, labels, difficult, [7, 8, 9], isTest=True)
+    items = [ds[i] for i in range(3)]
+    x, classes, boxes, idx = Dataset.collate_fn(items)
+    assert idx == [7, 8, 9] and tuple(x.shape) == (3, 3, 300, 300) and x.is_cuda
+    assert classes[0].tolist() == [float(Dataset.label_to_class["dog"])]          # the difficult cat is dropped
+    mean = torch.tensor(Dataset.MEAN).view(3, 1, 1)
+    std = torch.tensor(Dataset.STD).view(3, 1, 1)
+    for i, (h, w) in enumerate(sizes):
+        u8 = np.asarray(Image.open(paths[i]).convert("RGB").resize((300, 300), Image.BILINEAR))
+        ref = torch.from_numpy(u8.copy()).permute(2, 0, 1).contiguous().float().div(255).sub_(mean).div_(std)
+        assert torch.equal(x[i].cpu(), ref)
+        keep = [b for b, d in zip(bboxes[i], difficult[i]) if d == 0]
+        assert torch.equal(boxes[i], torch.tensor(keep) / torch.tensor([w, h, w, h], dtype=torch.float32))
+    kd = Dataset.MultiImageMultiBBoxDataset(paths, bboxes, labels, difficult, [7, 8, 9], isTest=True, keep_difficult=True)
+    assert kd[0][1].numel() == 2
+    tr = Dataset.MultiImageMultiBBoxDataset(paths, bboxes, labels, difficult, [7, 8, 9], isTest=False)
+    random.seed(11)
+    items = [tr[i] for i in range(3)]
+    x2, _, boxes2, _ = Dataset.collate_fn(items)
+    for i, it in enumerate(items):
+        plan = it[0].plan
+        ref = O.preprocess_image(it[0].pixels, 300, 300, canvas=plan.canvas, crop=plan.crop, flip=plan.flip)
+        assert np.array_equal(x2[i].cpu().numpy(), ref)
+        assert boxes2[i].shape[1] == 4 and boxes2[i].shape[0] == it[1].shape[0]
