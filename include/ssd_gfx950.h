@@ -241,6 +241,20 @@ typedef struct ssd_image_desc {
     int32_t crop_top, crop_left, crop_h, crop_w;
     int32_t flip, reserved;
 } ssd_image_desc;
+/* photometric_distort (Util.py:752-780) on the SOURCE images of the arena, in place, before ssd_preprocess_u8: up to four
+ * ops per image in the image's own order; kind 0 brightness, 1 contrast, 2 saturation (alpha = the enhancement factor as
+ * float32, Pillow's Image.blend argument), 3 hue (hue_delta = int(hue_factor * 255) & 255).  Bit-identical to the Pillow
+ * arithmetic torchvision's PIL back end runs.  Host and device copies of both descriptor arrays, as for the resize. */
+typedef struct ssd_photo_desc {
+    int32_t n_ops;
+    int32_t kind[4];
+    float alpha[4];
+    int32_t hue_delta[4];
+} ssd_photo_desc;
+size_t ssd_photometric_workspace(int B);
+int ssd_photometric_u8(uint8_t* arena, const ssd_image_desc* descs_dev, const ssd_image_desc* descs_host,
+                       const ssd_photo_desc* photo_dev, const ssd_photo_desc* photo_host, int B, void* workspace,
+                       size_t workspace_bytes, void* stream);
 size_t ssd_preprocess_workspace(const ssd_image_desc* descs_host, int B, int out_h, int out_w);
 int ssd_preprocess_u8(const uint8_t* arena, const ssd_image_desc* descs_dev, const ssd_image_desc* descs_host, int B,
                       int out_h, int out_w, const float* mean3_host, const float* std3_host, const uint8_t* filler3_host,

@@ -7,10 +7,10 @@ The reference resizes and normalises every image on the CPU with PIL (Dataset.py
 images travel as raw 8-bit pixels; one kernel set (csrc/preprocess.hip) then produces the normalised
 (B,3,300,300) batch, the resize being bit-identical to PIL's.
 
-Not built: `photometric_distort` (Util.py:752-780) -- its arithmetic is torchvision's `adjust_brightness / contrast /
-saturation / hue`, and torchvision is neither installed here nor vendored by the reference, so there is nothing to pin
-it against.  `plan_transform(..., photometric=False)` is therefore the default; with the flag set it only consumes the
-draws `photometric_distort` would, so that the geometry stream stays aligned with the reference's.
+`photometric_distort` (Util.py:752-780) is drawn here too (`plan_photometric`: the same shuffle and factors as the
+reference, pinned on its own function) and applied by csrc/photometric.hip.  Its arithmetic is torchvision's PIL back end,
+i.e. Pillow's ImageEnhance / blend / HSV conversions, reproduced bit for bit against Pillow; torchvision itself is absent,
+so its four thin wrappers are restated from their documented behaviour (see oracle/ssd_oracle.py).
 """
 from __future__ import annotations
 
@@ -38,6 +38,7 @@ class GeomPlan:
     canvas: Tuple[int, int, int, int]          # canvas_h, canvas_w, place_top, place_left
     crop: Tuple[int, int, int, int]            # top, left, h, w (of the canvas)
     flip: bool = False
+    photo: Tuple[Tuple[int, float], ...] = ()  # (kind, factor) in application order; kind 0 brightness, 1 contrast, 2 saturation, 3 hue
 
     @property
     def size(self) -> Tuple[int, int]:
@@ -47,6 +48,18 @@ class GeomPlan:
 
 def identity_plan(h: int, w: int) -> GeomPlan:
     return GeomPlan(h, w, (h, w, 0, 0), (0, 0, h, w), False)
+
+
+def plan_photometric(rng=random) -> Tuple[Tuple[int, float], ...]:
+    """The draws of reference Util.py:752-780: shuffle [brightness, contrast, saturation, hue], then per op a coin and one
+    factor (hue: uniform(-18/255, 18/255), the others uniform(0.5, 1.5))."""
+    order = [0, 1, 2, 3]
+    rng.shuffle(order)
+    out = []
+    for kind in order:
+        if rng.random() < 0.5:
+            out.append((kind, rng.uniform(-18 / 255., 18 / 255.) if kind == 3 else rng.uniform(0.5, 1.5)))
+    return tuple(out)
 
 
 def _iou_1xn(crop: torch.Tensor, boxes: torch.Tensor) -> torch.Tensor:
@@ -60,18 +73,13 @@ def _iou_1xn(crop: torch.Tensor, boxes: torch.Tensor) -> torch.Tensor:
     return inter / (a1 + a2 - inter)
 
 
-def plan_transform(width: int, height: int, boxes: torch.Tensor, labels: torch.Tensor, photometric: bool = False,
+def plan_transform(width: int, height: int, boxes: torch.Tensor, labels: torch.Tensor, photometric: bool = True,
                    rng=random):
     """The draws and box arithmetic of reference Util.py:566-607 `transform` for an image of the given size.
     Returns (GeomPlan, new_boxes, new_labels); boxes are pixel xyxy float32 like the reference's."""
     boxes = boxes.clone().float()
     labels = labels.clone()
-    if photometric:                            # Util.py:752-780: shuffle of four, then one coin (+ one factor) each
-        order = [0, 1, 2, 3]
-        rng.shuffle(order)
-        for _ in order:
-            if rng.random() < 0.5:
-                rng.uniform(0.5, 1.5)
+    photo = plan_photometric(rng) if photometric else ()
     h, w = height, width
     canvas = (h, w, 0, 0)
     if rng.random() < .5:                      # expand, Util.py:610-645
@@ -121,7 +129,7 @@ def plan_transform(width: int, height: int, boxes: torch.Tensor, labels: torch.T
         x0 = img_w - boxes[:, 0] - 1
         x2 = img_w - boxes[:, 2] - 1
         boxes = torch.stack((x2, boxes[:, 1], x0, boxes[:, 3]), dim=1)
-    return GeomPlan(height, width, canvas, crop, flip), boxes, labels
+    return GeomPlan(height, width, canvas, crop, flip, photo), boxes, labels
 
 
 def preprocess_batch(images: Sequence, plans: Optional[Sequence[GeomPlan]] = None, size: Tuple[int, int] = (300, 300),
@@ -159,6 +167,17 @@ def preprocess_batch(images: Sequence, plans: Optional[Sequence[GeomPlan]] = Non
         d.crop_top, d.crop_left, d.crop_h, d.crop_w = p.crop
         d.flip = int(p.flip)
     arena = host.to(device, non_blocking=True)
+    if any(p.photo for p in plans):            # photometric_distort comes first (Util.py:586), on the source pixels
+        photo = (_lib.PhotoDesc * len(arrs))()
+        for i, p in enumerate(plans):
+            if len(p.photo) > 4:
+                raise ValueError("at most four photometric ops per image")
+            photo[i].n_ops = len(p.photo)
+            for k, (kind, factor) in enumerate(p.photo):
+                photo[i].kind[k] = int(kind)
+                photo[i].alpha[k] = float(factor)
+                photo[i].hue_delta[k] = (int(factor * 255) & 0xFF) if kind == 3 else 0
+        ops.photometric_u8(arena, descs, photo)
     return ops.preprocess_u8(arena, descs, size, MEAN, STD, FILLER_U8)
 
 

@@ -26,6 +26,11 @@ class ImageDesc(C.Structure):
         "flip", "reserved")]
 
 
+class PhotoDesc(C.Structure):
+    """struct ssd_photo_desc"""
+    _fields_ = [("n_ops", C.c_int32), ("kind", C.c_int32 * 4), ("alpha", C.c_float * 4), ("hue_delta", C.c_int32 * 4)]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _F = C.c_float
@@ -50,6 +55,8 @@ SIGNATURES = {
     "ssd_tune_set_igemm_x3": (_I, [_I]),
     "ssd_tune_set_halo": (_I, [_I]),
     "ssd_clock_probe": (_I, [_P, _P]),
+    "ssd_photometric_workspace": (_Z, [_I]),
+    "ssd_photometric_u8": (_I, [_P, _P, _P, _P, _P, _I, _P, _Z, _P]),
     "ssd_preprocess_workspace": (_Z, [_P, _I, _I, _I]),
     "ssd_preprocess_u8": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "ssd_map_eval_workspace": (_Z, [_I, _I]),

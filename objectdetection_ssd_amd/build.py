@@ -20,7 +20,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fhip-fp32-co
           "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 # bit-exact box arithmetic: no fused multiply-add may be formed in these files
 PER_FILE = {"loss.hip": ["-ffp-contract=off"], "nms.hip": ["-ffp-contract=off"], "map_eval.hip": ["-ffp-contract=off"],
-            "preprocess.hip": ["-ffp-contract=off"]}
+            "preprocess.hip": ["-ffp-contract=off"], "photometric.hip": ["-ffp-contract=off"]}
 
 
 def _hipcc() -> str:

@@ -568,3 +568,21 @@ def shader_mhz(probe_a: torch.Tensor, probe_b: torch.Tensor) -> float:
     if not bool(ok.any()):
         return float("nan")
     return float((100.0 * (b[ok, 0] - a[ok, 0]).double() / (b[ok, 1] - a[ok, 1]).double()).mean())
+
+
+def photometric_u8(arena: torch.Tensor, descs, photo) -> None:
+    """In place on the arena's source images: photo = ctypes array of _lib.PhotoDesc (one per image, same order as descs)."""
+    import numpy as np
+    _req(arena, "arena", torch.uint8)
+    B = len(descs)
+    if len(photo) != B:
+        raise ValueError("one photo descriptor per image")
+    for d in descs:
+        if d.src_offset < 0 or d.src_offset + d.src_h * d.src_w * 3 > arena.numel():
+            raise ValueError("image descriptor points outside the arena")
+    lib = _lib.load()
+    ws = workspace(lib.ssd_photometric_workspace(B), arena.device, "photo")
+    d_dev = torch.from_numpy(np.frombuffer(bytes(descs), dtype=np.uint8).copy()).to(arena.device)
+    p_dev = torch.from_numpy(np.frombuffer(bytes(photo), dtype=np.uint8).copy()).to(arena.device)
+    check(lib.ssd_photometric_u8(arena.data_ptr(), d_dev.data_ptr(), C.byref(descs), p_dev.data_ptr(), C.byref(photo), B, ws.data_ptr(),
+                                 ws.numel(), _stream()), "photometric_u8")

@@ -220,6 +220,38 @@ def map_cases():
     return cases
 
 
+def write_photometric(RU):
+    """The draws of Util.photometric_distort (Util.py:752-780): the reference's own function runs on seeded `random`
+    streams with torchvision's four adjust_* functions replaced by recorders (torchvision is absent; the recorders keep
+    the __name__ the reference tests at Util.py:770), so the fixture holds the order and the factors it would apply."""
+    import random
+    log = []
+
+    def rec(kind, name):
+        def fn(img, factor):
+            log.append((kind, float(factor)))
+            return img
+        fn.__name__ = name
+        return fn
+    ft = RU.FT
+    ft.adjust_brightness = rec(0, "adjust_brightness")
+    ft.adjust_contrast = rec(1, "adjust_contrast")
+    ft.adjust_saturation = rec(2, "adjust_saturation")
+    ft.adjust_hue = rec(3, "adjust_hue")
+    store = {}
+    n = 64
+    for ci in range(n):
+        log.clear()
+        random.seed(12000 + ci)
+        RU.photometric_distort(object())
+        tail = random.random()                     # the stream position after the call
+        store[f"c{ci}_kinds"] = np.asarray([k for k, _ in log], np.int64)
+        store[f"c{ci}_factors"] = np.asarray([f for _, f in log], np.float64)
+        store[f"c{ci}_next"] = np.float64(tail)
+    store["n_cases"] = np.int64(n)
+    np.savez_compressed(os.path.join(GOLD, "photometric_draws.npz"), **store)
+
+
 def write_degenerate(RL):
     """Losses.ssd on degenerate ground truth: zero-area and zero-height boxes.  Their IoU with
     every prior is 0, so they are matched only through the forced match (first prior on the all-zero row, Losses.py:157-160);
@@ -379,7 +411,7 @@ def write_resnet34(RM, RU):
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    if sys.argv[1:] in (["resnet34"], ["map"], ["augment"], ["degenerate"]):     # add one fixture without rewriting the others
+    if sys.argv[1:] in (["resnet34"], ["map"], ["augment"], ["degenerate"], ["photometric"]):     # add one fixture without rewriting the others
         _install_stand_ins()
         with quiet():
             import Util as RU
@@ -389,6 +421,8 @@ def main():
             write_map(RU)
         elif sys.argv[1] == "augment":
             write_augment(RU)
+        elif sys.argv[1] == "photometric":
+            write_photometric(RU)
         elif sys.argv[1] == "degenerate":
             import Losses as RL
             write_degenerate(RL)
@@ -572,6 +606,7 @@ def main():
     write_map(RU)
     write_augment(RU)
     write_degenerate(RL)
+    write_photometric(RU)
     print("golden fixtures written to", GOLD)
     for f in sorted(os.listdir(GOLD)):
         print(f"  {f}: {os.path.getsize(os.path.join(GOLD, f))} bytes")

@@ -775,3 +775,86 @@ def preprocess_image(img: np.ndarray, out_h: int = 300, out_w: int = 300, canvas
     mean = torch.tensor(IMAGENET_MEAN, dtype=torch.float32).view(3, 1, 1)
     std = torch.tensor(IMAGENET_STD, dtype=torch.float32).view(3, 1, 1)
     return t.sub_(mean).div_(std).numpy()
+
+
+# ---------------------------------------------------------------------------
+# photometric_distort  (Util.py:752-780) -- SURVEY.md section 8(f) row 3, first stage of the training transform
+#
+# The reference calls torchvision's functional adjust_brightness / adjust_contrast / adjust_saturation / adjust_hue on a PIL
+# image.  torchvision is absent; its PIL back end is four thin wrappers (restated below from its documented behaviour --
+# "parity unpinned" for the wrappers) around Pillow code, and Pillow IS installed, so the arithmetic is pinned against Pillow
+# itself: ImageEnhance.{Brightness,Contrast,Color}(img).enhance(f) = Image.blend(degenerate, img, f) with degenerate = black /
+# solid int(mean(L) + .5) / the L image; Image.convert("L") = (19595 R + 38470 G + 7471 B + 0x8000) >> 16; Image.blend in
+# float32 with truncation (clipped when f is outside [0,1]); adjust_hue = RGB -> HSV (Pillow's 8-bit conversion), H += the
+# 8-bit wrap of int(hue_factor * 255), HSV -> RGB.  tests check every formula against Pillow (the two colour-space
+# conversions exhaustively over all 2^24 inputs).
+# ---------------------------------------------------------------------------
+def rgb_to_l(a: np.ndarray) -> np.ndarray:
+    r, g, b = (a[..., i].astype(np.int64) for i in range(3))
+    return ((r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16).astype(np.uint8)
+
+
+def blend_u8(in1: np.ndarray, in2: np.ndarray, alpha: float) -> np.ndarray:
+    """Pillow Image.blend(im1, im2, alpha) on uint8 arrays: float32 arithmetic, truncation, clipping outside [0,1]."""
+    al = np.float32(alpha)
+    i1 = in1.astype(np.int32)
+    t = i1.astype(np.float32) + al * (in2.astype(np.int32) - i1).astype(np.float32)
+    if 0.0 <= float(al) <= 1.0:
+        return t.astype(np.int32).astype(np.uint8)
+    return np.where(t <= 0, 0, np.where(t >= 255, 255, t.astype(np.int32))).astype(np.uint8)
+
+
+def rgb_to_hsv_u8(a: np.ndarray) -> np.ndarray:
+    r = a[..., 0].astype(np.int32); g = a[..., 1].astype(np.int32); b = a[..., 2].astype(np.int32)
+    maxc = np.maximum(r, np.maximum(g, b)); minc = np.minimum(r, np.minimum(g, b))
+    cr = (maxc - minc).astype(np.float32)
+    with np.errstate(all="ignore"):
+        s = cr / maxc.astype(np.float32)
+        rc = (maxc - r).astype(np.float32) / cr; gc = (maxc - g).astype(np.float32) / cr; bc = (maxc - b).astype(np.float32) / cr
+        h = np.where(r == maxc, (bc - gc).astype(np.float32),
+                     np.where(g == maxc, (2.0 + rc.astype(np.float64) - bc.astype(np.float64)).astype(np.float32),
+                              (4.0 + gc.astype(np.float64) - rc.astype(np.float64)).astype(np.float32)))
+        hh = np.fmod(h.astype(np.float64) / 6.0 + 1.0, 1.0).astype(np.float32)
+        uh = np.clip((hh.astype(np.float64) * 255.0).astype(np.int32), 0, 255)
+        us = np.clip((s.astype(np.float64) * 255.0).astype(np.int32), 0, 255)
+    gray = minc == maxc
+    return np.stack([np.where(gray, 0, uh), np.where(gray, 0, us), maxc], -1).astype(np.uint8)
+
+
+def hsv_to_rgb_u8(a: np.ndarray) -> np.ndarray:
+    hf = a[..., 0].astype(np.float32).astype(np.float64) * 6.0 / 255.0
+    i = np.floor(hf)
+    f = (hf - i).astype(np.float32).astype(np.float64)
+    fs = (a[..., 1].astype(np.float64) / 255.0).astype(np.float32).astype(np.float64)
+    v = a[..., 2].astype(np.int32)
+    vf = v.astype(np.float64)
+    rnd = lambda x: np.clip(np.floor(x + 0.5), 0, 255).astype(np.int32)          # noqa: E731  (C round(), then CLIP8)
+    p, q, t = rnd(vf * (1.0 - fs)), rnd(vf * (1.0 - fs * f)), rnd(vf * (1.0 - fs * (1.0 - f)))
+    k = i.astype(np.int32) % 6
+    r = np.choose(k, [v, q, p, p, t, v]); g = np.choose(k, [t, v, v, q, p, p]); b = np.choose(k, [p, p, t, v, v, q])
+    gray = a[..., 1] == 0
+    return np.stack([np.where(gray, v, r), np.where(gray, v, g), np.where(gray, v, b)], -1).astype(np.uint8)
+
+
+def hue_delta_u8(hue_factor: float) -> int:
+    """torchvision adjust_hue: the uint8 added to the H plane (int(hue_factor * 255) wrapped to 8 bits)."""
+    return int(hue_factor * 255) & 0xFF
+
+
+def photometric_apply(img: np.ndarray, ops) -> np.ndarray:
+    """ops: sequence of (kind, factor) applied in order; kind 0 brightness, 1 contrast, 2 saturation, 3 hue (Util.py:762-778)."""
+    out = img
+    for kind, factor in ops:
+        if kind == 0:
+            out = blend_u8(np.zeros_like(out), out, factor)
+        elif kind == 1:
+            lum = rgb_to_l(out)
+            mean = int(float(lum.astype(np.int64).sum()) / float(lum.size) + 0.5)
+            out = blend_u8(np.full_like(out, mean), out, factor)
+        elif kind == 2:
+            out = blend_u8(np.repeat(rgb_to_l(out)[..., None], 3, -1), out, factor)
+        else:
+            hsv = rgb_to_hsv_u8(out)
+            hsv[..., 0] = (hsv[..., 0].astype(np.int32) + hue_delta_u8(factor)).astype(np.uint8)
+            out = hsv_to_rgb_u8(hsv)
+    return out

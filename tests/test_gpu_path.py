@@ -701,7 +701,8 @@ def test_preprocess_batch_with_reference_geometry(gold_dir):
         p = f"c{ci}_"
         img = z[p + "img"]
         random.seed(int(z[p + "seed"]))
-        plan, _, _ = Dataset.plan_transform(img.shape[1], img.shape[0], torch.from_numpy(z[p + "boxes"]), torch.from_numpy(z[p + "labels"]))
+        plan, _, _ = Dataset.plan_transform(img.shape[1], img.shape[0], torch.from_numpy(z[p + "boxes"]), torch.from_numpy(z[p + "labels"]),
+                                            photometric=False)
         imgs.append(img); plans.append(plan)
     out = Dataset.preprocess_batch(imgs, plans).cpu().numpy()
     for i, (img, plan) in enumerate(zip(imgs, plans)):
@@ -824,6 +825,34 @@ def test_dataset_class_end_to_end_on_image_files(tmp_path):
     x2, _, boxes2, _ = Dataset.collate_fn(items)
     for i, it in enumerate(items):
         plan = it[0].plan
-        ref = O.preprocess_image(it[0].pixels, 300, 300, canvas=plan.canvas, crop=plan.crop, flip=plan.flip)
+        ref = O.preprocess_image(O.photometric_apply(it[0].pixels, plan.photo), 300, 300, canvas=plan.canvas, crop=plan.crop, flip=plan.flip)
         assert np.array_equal(x2[i].cpu().numpy(), ref)
         assert boxes2[i].shape[1] == 4 and boxes2[i].shape[0] == it[1].shape[0]
+
+
+def test_photometric_kernels_equal_pillow_arithmetic():
+    """photometric_distort on the device: every op alone at the extremes of its factor range and random 1-4 op sequences in
+    random order, on ragged images, bit-equal to the oracle (which tests/test_oracle_golden.py pins on Pillow itself)."""
+    from objectdetection_ssd_amd import Dataset
+    rng = np.random.default_rng(31)
+    imgs, plans, refs = [], [], []
+    singles = [(0, .5), (0, 1.5), (0, 1.0), (1, .5), (1, 1.5), (2, .5), (2, 1.5), (2, .999), (3, -18 / 255.), (3, 18 / 255.), (3, 0.0), (3, .031)]
+    for i in range(40):
+        h, w = int(rng.integers(7, 90)), int(rng.integers(7, 90))
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        if i % 6 == 0:
+            a = (a // 16 + 120).astype(np.uint8)                     # low contrast
+        if i % 9 == 0:
+            a[..., 1] = a[..., 0]; a[..., 2] = a[..., 0]              # grey: s == 0 branch of the hue path
+        if i < len(singles):
+            ops_ = (singles[i],)
+        else:
+            kinds = rng.permutation(4)[: int(rng.integers(1, 5))]
+            ops_ = tuple((int(k), float(rng.uniform(-18 / 255., 18 / 255.)) if k == 3 else float(rng.uniform(.5, 1.5))) for k in kinds)
+        plan = Dataset.identity_plan(h, w)
+        plan.photo = ops_
+        imgs.append(a); plans.append(plan)
+        refs.append(O.preprocess_image(O.photometric_apply(a, ops_), 64, 64))
+    out = Dataset.preprocess_batch(imgs, plans, size=(64, 64)).cpu().numpy()
+    for i in range(len(imgs)):
+        assert np.array_equal(out[i], refs[i]), (i, plans[i].photo)

@@ -201,3 +201,32 @@ def test_degenerate_ground_truth_vs_reference(gold_dir, ci):
     touched = np.nonzero(np.abs(out["dconf"].reshape(-1, 21)).sum(1) > 0)[0]
     assert np.array_equal(touched, z[p + "dconf_touched"])
     np.testing.assert_allclose(np.abs(out["dconf"]).astype(np.float64).sum(), z[p + "dconf_abs_sum"], rtol=1e-5)
+
+
+def test_photometric_restatement_equals_pillow():
+    """Brightness / contrast / saturation through ImageEnhance and the hue path through Pillow's HSV mode: the oracle's
+    restatement is bit-equal on random images; the two colour-space conversions are checked on all 2^24 inputs."""
+    from PIL import Image, ImageEnhance
+    rng = np.random.default_rng(1)
+    for trial in range(24):
+        h, w = int(rng.integers(5, 80)), int(rng.integers(5, 80))
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        if trial % 5 == 0:
+            a = (a // 8 + 100).astype(np.uint8)
+        f = float(rng.uniform(0.5, 1.5)); hf = float(rng.uniform(-18 / 255., 18 / 255.))
+        im = Image.fromarray(a)
+        refs = [np.asarray(ImageEnhance.Brightness(im).enhance(f)), np.asarray(ImageEnhance.Contrast(im).enhance(f)),
+                np.asarray(ImageEnhance.Color(im).enhance(f))]
+        hh, ss, vv = im.convert("HSV").split()
+        nh = np.array(hh, dtype=np.uint8)
+        with np.errstate(over="ignore"):
+            nh += np.int32(hf * 255).astype(np.uint8)              # torchvision adjust_hue's wrap-around add
+        refs.append(np.asarray(Image.merge("HSV", (Image.fromarray(nh, "L"), ss, vv)).convert("RGB")))
+        for kind in range(4):
+            assert np.array_equal(O.photometric_apply(a, [(kind, hf if kind == 3 else f)]), refs[kind]), (trial, kind)
+    g = np.arange(256, dtype=np.uint8)
+    for lo in range(0, 256, 64):                                       # all 2^24 triples, 2^22 at a time
+        c0, c1, c2 = np.meshgrid(g[lo:lo + 64], g, g, indexing="ij")
+        tri = np.stack([c0, c1, c2], -1).reshape(2048, 2048, 3)
+        assert np.array_equal(O.rgb_to_hsv_u8(tri), np.asarray(Image.fromarray(tri, "RGB").convert("HSV")))
+        assert np.array_equal(O.hsv_to_rgb_u8(tri), np.asarray(Image.fromarray(tri, "HSV").convert("RGB")))
