@@ -343,6 +343,9 @@ def main():
             peak, peak_note = 2500.0, "bf16 MFMA dense"
         else:
             peak, peak_note = round(2500.0 / 6, 1), "bf16 MFMA dense / 6 limb products per f32 product"
+        if tag.startswith("winograd"):
+            peak_note += ("; the ops of this tag are Winograd F(2x2,3x3) convolutions (input transform + 16 batched igemm_kernel<64,64> "
+                          "GEMMs + output transform): `achieved` counts the direct convolution's FLOPs, the GEMMs execute 2.25x fewer")
         out["roofline"] = {"bound": "mfma", "kernel": tag + ", ...>", "achieved": round(ach, 2),
                            "peak": peak, "peak_note": peak_note, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                            "traffic": traffic, "traffic_unit": "bytes per launch (profiles/r01_traffic.json)", "launches_timed": n, "avg_launch_ms": round(tsum / n * 1e3, 4),

@@ -126,6 +126,16 @@ int ssd_conv2d_fwd_ws(const float* x, const float* w_ohwi, const float* bias, fl
 int ssd_conv2d_dgrad_ws(const float* dy, int ldy, const float* w_ihwo, int Co_pad, float* dx, const float* relu_mask,
                         int accumulate, const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream);
 int ssd_tune_set_igemm_splitk(int k);       /* -1 automatic, 1 never split, k > 1 force k slices */
+/* ---- Winograd F(2x2,3x3) for the 3x3 / stride 1 / pad 1 layers (2.25x fewer multiplies; results differ from the direct sum
+ * at the 1e-6 level).  ssd_wino_weights transforms the OIHW filter once per update: U_fwd [16][Co][Ci] for the forward,
+ * U_bwd [16][Ci][Co_pad] (transposed, rotated filter) for dgrad; either may be NULL.  The convolutions take the transformed
+ * filter, a workspace of ssd_conv3x3_wino_workspace(g, direction) bytes, and fuse the same epilogues as the direct kernels. */
+int ssd_wino_weights(const float* w_oihw, float* U_fwd, float* U_bwd, int Co, int Ci, int Co_pad, void* stream);
+size_t ssd_conv3x3_wino_workspace(const ssd_conv_geom* g, int direction /* 0 forward, 1 dgrad */);
+int ssd_conv3x3_wino_fwd(const float* x, const float* U_fwd, const float* bias, float* y, int ldy, const ssd_conv_geom* g, int relu,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int ssd_conv3x3_wino_dgrad(const float* dy, int ldy, const float* U_bwd, int Co_pad, float* dx, const float* relu_mask,
+                           int accumulate, const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream);
 int ssd_tune_set_igemm(int tile, int nbuf);
 int ssd_tune_set_igemm_stamps(uint64_t* device_buffer);   /* diagnostic: per-block shader-clock stamps (see conv_igemm.hip) */
 int ssd_tune_set_igemm_lds_pad(int bytes);   /* extra dynamic LDS per block: caps resident blocks per CU (experiments) */

@@ -133,6 +133,7 @@ class _Engine:
         self.prof = None          # bench.py: list collecting (label, kernel tag, flops, start event, end event)
         self.bf16 = False         # True: forward / dgrad / fused-wgrad convolutions multiply bf16-rounded operands (f32 accumulate)
         self.x3 = False           # True: forward / dgrad convolutions form f32 products from three bf16 limbs per operand
+        self.wino = True          # f32 mode: Winograd F(2x2,3x3) for the 3x3 / stride-1 layers with >= WINO_MIN_CI input channels
 
     def _timed(self, label, tag, flops, fn):
         """Run fn(); when profiling, bracket it with HIP events on the current stream."""
@@ -167,6 +168,23 @@ class _Engine:
             if self.x3:
                 return ent[4], ent[5]
         return ent[2], ent[3]
+
+    WINO_MIN_CI = 256             # measured (tools/conv_bench.py wino): 1.3-1.7x on conv3_2 ... conv5_3 and the c_4 / c_7 heads, ~1.0x at 128
+
+    def _wino_ok(self, g) -> bool:
+        return (self.wino and not self.bf16 and not self.x3 and g.R == 3 and g.S == 3 and g.stride == 1 and g.dil == 1 and g.pad == 1
+                and g.Ci % 32 == 0 and g.Ci >= self.WINO_MIN_CI)
+
+    def _wino_weights(self, key: str, tensors, co_pad: int):
+        """Cached Winograd-domain filters (U_fwd [16][Co][Ci], U_bwd [16][Ci][co_pad]), refreshed when a parameter changes."""
+        sig = tuple((t.data_ptr(), t._version) for t in tensors)
+        ent = self._wcache.get("wino:" + key)
+        if ent is None or ent[0] != sig:
+            w = tensors[0] if len(tensors) == 1 else torch.cat(list(tensors), 0)
+            uf, ub = ops.wino_weights(w.detach().contiguous(), co_pad, want_bwd=True)
+            ent = (sig, uf, ub)
+            self._wcache["wino:" + key] = ent
+        return ent[1], ent[2]
 
     def _planes(self, key: str, bwd: bool):
         """bf16 mode: the limb planes of a cached layout (plane 0 feeds the halo-tile kernel); None otherwise."""
@@ -209,8 +227,14 @@ class _Engine:
             elif kind == "conv":
                 xin = T[op["x"]]
                 g = ops.make_geom(bs, xin.shape[1], xin.shape[2], op["ci"], op["co"], op["k"], op["s"], op["pad"], op["dil"])
-                wf, _ = self._layouts(op["p"], (P[op["p"] + ".weight"],), op["co"], False)
                 bias = P[op["p"] + ".bias"].detach()
+                if self._wino_ok(g):
+                    uf, _ = self._wino_weights(op["p"], (P[op["p"] + ".weight"],), op["co"])
+                    T[op["y"]] = self._timed("fwd " + op["p"], "winograd_f2x2_3x3", ops.conv_flops(g),
+                                             lambda: ops.conv2d_fwd_wino(xin, uf, bias, g, op["relu"]))
+                    aux[op["y"]] = g
+                    continue
+                wf, _ = self._layouts(op["p"], (P[op["p"] + ".weight"],), op["co"], False)
                 T[op["y"]] = self._timed("fwd " + op["p"], ops.igemm_tile(g, 0, self.bf16, self.x3) if self.prof is not None else "", ops.conv_flops(g),
                                          lambda: ops.conv2d_fwd_x3(xin, wf, bias, g, op["relu"]) if self.x3 else
                                          ops.conv2d_fwd(xin, wf, bias, g, op["relu"], bf16=self.bf16, w3=self._planes(op["p"], False)))
@@ -227,8 +251,14 @@ class _Engine:
                 co = a * (4 + N_CLASSES)
                 g = ops.make_geom(bs, xin.shape[1], xin.shape[2], op["ci"], co, 3, 1, 1, 1)
                 pre = op["p"]
-                wf, _ = self._layouts(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]), ops.pad32(co), False)
                 bias = torch.cat((P[pre + "_bb.bias"].detach(), P[pre + "_cl.bias"].detach()))
+                if self._wino_ok(g):
+                    uf, _ = self._wino_weights(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]), ops.pad32(co))
+                    packed = self._timed("fwd " + pre, "winograd_f2x2_3x3", ops.conv_flops(g),
+                                         lambda: ops.conv2d_fwd_wino(xin, uf, bias, g, False, ld=ops.pad32(co)))
+                    heads.append((op, packed, g))
+                    continue
+                wf, _ = self._layouts(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]), ops.pad32(co), False)
                 packed = self._timed("fwd " + pre, ops.igemm_tile(g, 0, self.bf16, self.x3) if self.prof is not None else "", ops.conv_flops(g),
                                      lambda: ops.conv2d_fwd_x3(xin, wf, bias, g, False, ld=ops.pad32(co)) if self.x3 else
                                      ops.conv2d_fwd(xin, wf, bias, g, False, ld=ops.pad32(co), bf16=self.bf16, w3=self._planes(pre, False)))
@@ -276,6 +306,11 @@ class _Engine:
                                          lambda: ops.conv2d_wgrad(xin, dy, g, co_pad, True, bf16=self.bf16))
                     grads[pre + "_bb.weight"], grads[pre + "_cl.weight"] = dw[:a4], dw[a4:]
                     grads[pre + "_bb.bias"], grads[pre + "_cl.bias"] = db[:a4], db[a4:]
+                if self._wino_ok(g):
+                    _, ub = self._wino_weights(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]), co_pad)
+                    deliver(op["x"], lambda dx, acc, mask: self._timed("dgrad " + pre, "winograd_f2x2_3x3", ops.conv_flops(g),
+                                                                       lambda: ops.conv2d_dgrad_wino(dy, ub, g, dx, mask, acc)))
+                    continue
                 _, wb = self._layouts(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]), co_pad, True)
                 deliver(op["x"], lambda dx, acc, mask: self._timed(
                     "dgrad " + pre, ops.igemm_tile(g, 1, self.bf16, self.x3) if self.prof is not None else "", ops.conv_flops(g),
@@ -289,6 +324,11 @@ class _Engine:
                     dw, db = self._timed("wgrad " + op["p"], ops.wgrad_tile(g) if self.prof is not None else "", ops.conv_flops(g),
                                          lambda: ops.conv2d_wgrad(xin, dy, g, g.Co, True, bf16=self.bf16))
                     grads[op["p"] + ".weight"], grads[op["p"] + ".bias"] = dw, db
+                if self._wino_ok(g):
+                    _, ub = self._wino_weights(op["p"], (P[op["p"] + ".weight"],), op["co"])
+                    deliver(op["x"], lambda dx, acc, mask: self._timed("dgrad " + op["p"], "winograd_f2x2_3x3", ops.conv_flops(g),
+                                                                       lambda: ops.conv2d_dgrad_wino(dy, ub, g, dx, mask, acc)))
+                    continue
                 _, wb = self._layouts(op["p"], (P[op["p"] + ".weight"],), op["co"], True)
                 deliver(op["x"], lambda dx, acc, mask: self._timed(
                     "dgrad " + op["p"], ops.igemm_tile(g, 1, self.bf16, self.x3) if self.prof is not None else "", ops.conv_flops(g),

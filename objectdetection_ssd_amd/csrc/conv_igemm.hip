@@ -41,6 +41,8 @@ struct IgemmParams {
     int ksplit, kt_per_split;   // split-K (small grids, deep K): blockIdx.y = split; partial tiles go to `slab`
     float* slab;                // [ksplit][M][Nout] raw partial sums, reduced by splitk_reduce_kernel
     float rcp_howo, rcp_wo;     // 1 / (Ho*Wo), 1 / Wo for div_small_q (set by launch_igemm)
+    int nbatch;                 // > 1: blockIdx.z-th problem of a batch of equal-shaped GEMMs (the 16 Winograd planes)
+    size_t batch_a, batch_w, batch_out;      // element strides between the problems of a batch
     unsigned long long* stamps; // diagnostic (ssd_tune_set_igemm_stamps): shader-clock stamps of every 64th block, else NULL
 };
 
@@ -139,7 +141,13 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, const f32x1
 }
 
 template <int BM, int BN, int WM, int WN, int NBUF>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p_in) {
+    IgemmParams p = p_in;
+    if (p.nbatch > 1) {                                   // uniform
+        p.a += (size_t)blockIdx.z * p.batch_a;
+        p.w += (size_t)blockIdx.z * p.batch_w;
+        p.out += (size_t)blockIdx.z * p.batch_out;
+    }
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;
     constexpr int STAGE = (BM + BN) * LDS_LD;
@@ -362,7 +370,8 @@ int launch_igemm(IgemmParams& p, hipStream_t st) {
     p.rcp_howo = 1.0f / (float)(p.Ho * p.Wo);
     p.rcp_wo = 1.0f / (float)p.Wo;
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, NBUF>), dim3(p.tiles_m * p.tiles_n, ks), dim3(256), g_lds_pad, st, p);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, NBUF>), dim3(p.tiles_m * p.tiles_n, ks, p.nbatch > 1 ? p.nbatch : 1), dim3(256),
+                       g_lds_pad, st, p);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
 }
@@ -1202,6 +1211,25 @@ extern "C" int ssd_tune_set_igemm_lds_pad(int bytes) {
     if (bytes < 0 || bytes > 120 * 1024) return SSD_ERR_BAD_SHAPE;
     g_lds_pad = bytes;
     return SSD_OK;
+}
+
+// Internal (not part of the C ABI): `nbatch` independent GEMMs out[b][M][N] = a[b][M][K] * w[b][N][K]^T on the 64x64 f32 kernel
+// (the sixteen planes of a Winograd F(2x2,3x3) convolution).  K % 32 == 0; rows of w beyond n_rows read as zero.
+__attribute__((visibility("hidden"))) int ssd_internal_gemm_batched(const float* a, const float* w, float* out, int M, int K, int N,
+                                                                     int n_rows, int nbatch, size_t batch_w_elems, hipStream_t st) {
+    if (K % 32 != 0 || M <= 0 || N <= 0 || nbatch <= 0 || nbatch > 65535) return SSD_ERR_BAD_SHAPE;
+    const size_t ab = (size_t)M * K * 4, wb = (size_t)n_rows * K * 4;
+    if (ab >= 0xF0000000ull || wb >= 0xF0000000ull) return SSD_ERR_BAD_SHAPE;
+    IgemmParams p{};
+    p.a = a; p.w = w; p.out = out;
+    p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+    p.Ha = 1; p.Wa = M; p.Ca = K; p.Ho = 1; p.Wo = M;
+    p.Nout = N; p.Nrows = n_rows; p.ldo = N; p.R = 1; p.S = 1;
+    p.sm = 1; p.sd = 1; p.off = 0; p.dstep = 1;
+    p.M = M; p.relu = 0; p.accumulate = 0;
+    p.ksplit = 1; p.stamps = nullptr;
+    p.nbatch = nbatch; p.batch_a = (size_t)M * K; p.batch_w = batch_w_elems; p.batch_out = (size_t)M * N;
+    return launch_igemm<64, 64, 2, 2, 1>(p, st);
 }
 
 // ---- "f32 from three bf16 limbs" entry points (opt-in; see igemm_x3_kernel) -----------------------------------

@@ -529,3 +529,36 @@ def test_conv_adjoint_identities_at_full_batch(layer):
     for name, rhs in (("dgrad", dot(x1, dx)), ("wgrad", dot(w, dw))):
         assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs)), (name, layer, lhs, rhs)
     assert abs(float(db.double().sum()) - float(dy.double().sum())) <= 1e-6 * float(dy.abs().double().sum())       # bias grad = column sums
+
+
+WINO_CASES = [(2, 19, 19, 64, 64), (1, 38, 38, 128, 256), (2, 75, 75, 32, 64), (1, 19, 19, 512, 100), (3, 10, 7, 64, 32), (1, 5, 5, 32, 32)]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_winograd_f2x2_3x3_forward_and_dgrad(case):
+    """Winograd F(2x2,3x3) == the direct 3x3 / stride 1 / pad 1 convolution (odd maps, padded channel counts, fused bias + ReLU,
+    dgrad with accumulate + mask); the transforms cost a few ulps: 1e-4 of the output scale like every f32 kernel here."""
+    from objectdetection_ssd_amd import ops
+    n, h, w, ci, co = case
+    dev = _dev()
+    full = (n, h, w, ci, co, 3, 1, 1, 1)
+    x, wt, b = _conv_data(full, seed=71)
+    x.requires_grad_(True)
+    y = F.conv2d(x, wt, b, padding=1)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(72))
+    y.backward(dy)
+    g = ops.make_geom(*full)
+    ld = ops.pad32(co)
+    uf, ub = ops.wino_weights(wt.to(dev), ld)
+    yd = ops.conv2d_fwd_wino(_nhwc(x.detach()).to(dev), uf, b.to(dev), g, True, ld=ld)
+    _close(yd[..., :co], _nhwc(F.relu(y.detach())), what=f"winograd fwd {case}")
+    if ld != co:
+        assert float(yd[..., co:].abs().max()) == 0.0
+    dy_p = torch.zeros(n, h, w, ld)
+    dy_p[..., :co] = _nhwc(dy)
+    dx = ops.conv2d_dgrad_wino(dy_p.to(dev), ub, g)
+    _close(dx, _nhwc(x.grad), what=f"winograd dgrad {case}")
+    prev = torch.randn(n, h, w, ci, generator=torch.Generator().manual_seed(73)).to(dev)
+    mask = torch.randn(n, h, w, ci, generator=torch.Generator().manual_seed(74)).clamp_min(0).to(dev)
+    dx2 = ops.conv2d_dgrad_wino(dy_p.to(dev), ub, g, dx=prev.clone(), relu_mask=mask, accumulate=True)
+    _close(dx2, (_nhwc(x.grad) + prev.cpu()) * (mask.cpu() > 0), what=f"winograd dgrad acc+mask {case}")

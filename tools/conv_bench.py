@@ -85,6 +85,15 @@ def main():
             row.append(f"one-tap128:{fl / ms / 1e9:6.1f}")
             lib.ssd_tune_set_wgrad(-1, -1, -1); lib.ssd_tune_set_wgrad_patch(-1)
             print(f"wgrad patch {name:8s} " + "  ".join(row), flush=True)
+        if which == "wino" and (k, s, pad, dil) == (3, 1, 1, 1) and ci % 32 == 0:
+            uf, ub = ops.wino_weights(w, ld)
+            print("wino", name, "ws", lib.ssd_conv3x3_wino_workspace(g, 0) / 1e6, "MB", flush=True)
+            ms0 = timeit(lambda: ops.conv2d_fwd(x, wf, b, g, True, ld=ld, out=dy))
+            ms1 = timeit(lambda: ops.conv2d_fwd_wino(x, uf, b, g, True, ld=ld))
+            ms2 = timeit(lambda: ops.conv2d_dgrad(dy, wb, g, dx, x, False))
+            ms3 = timeit(lambda: ops.conv2d_dgrad_wino(dy, ub, g, dx, x, False))
+            print(f"wino {name:8s} fwd direct {ms0:.3f} ms ({fl / ms0 / 1e9:.0f} TF/s)  winograd {ms1:.3f} ms ({fl / ms1 / 1e9:.0f} TF/s alg.)   "
+                  f"dgrad direct {ms2:.3f} ms  winograd {ms3:.3f} ms ({fl / ms3 / 1e9:.0f} TF/s alg.)", flush=True)
         if which == "occ":                      # blocks per CU capped through extra dynamic LDS (64x64 tile, 18 KB static)
             row = []
             for pad_kb, lab in ((0, "7/CU"), (8, "6"), (14, "5"), (22, "4"), (35, "3"), (62, "2")):
