@@ -205,6 +205,7 @@ def main():
     ap.add_argument("--workload", default="train", choices=("train", "resnet34", "decode", "preprocess", "map", "infer", "infer-graph"),
                     help="train = the headline line (BASELINE configs[1]); resnet34 / decode = the two halves of configs[4] "
                          "(SSD_resnet34 eval forward at 224x224; batched per-class NMS decode of SSD300-shaped outputs): replicas only")
+    ap.add_argument("--wino-min-ci", type=int, default=-1, help="tuning aid: Winograd for 3x3/s1 layers with at least this many input channels (0 = off)")
     ap.add_argument("--igemm-lds-pad", type=int, default=-1, help="tuning aid: extra dynamic LDS bytes per igemm block (-1 = library default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
@@ -240,6 +241,9 @@ def main():
     torch.manual_seed(0)                                   # same initial weights on every rank
     net = (Model.SSD_300() if args.variant == 300 else Model.SSD_512()).to(dev).train()
     net.conv_dtype = args.conv_dtype
+    if args.wino_min_ci >= 0:
+        net._engine.wino = args.wino_min_ci > 0
+        net._engine.WINO_MIN_CI = args.wino_min_ci
     trainer = FlatSGDDataParallel(net, lr=1e-4, momentum=0.9, weight_decay=5e-4)
     trainer.broadcast_parameters(0)
     bs = args.batch
