@@ -169,6 +169,7 @@ class _Engine:
                 return ent[4], ent[5]
         return ent[2], ent[3]
 
+    WINO_WGRAD_MAX_HW = 40        # Winograd weight gradient on maps up to this size (conv4_x, conv5_x: -25 % / -15 %; conv3_x: -4 %)
     WINO_MIN_CI = 256             # measured (tools/conv_bench.py wino): 1.3-1.7x on conv3_2 ... conv5_3 and the c_4 / c_7 heads, ~1.0x at 128
 
     def _wino_ok(self, g) -> bool:
@@ -321,8 +322,12 @@ class _Engine:
                 g = aux[op["y"]]
                 xin = T[op["x"]]
                 if need[op["p"] + ".weight"] or need[op["p"] + ".bias"]:
-                    dw, db = self._timed("wgrad " + op["p"], ops.wgrad_tile(g) if self.prof is not None else "", ops.conv_flops(g),
-                                         lambda: ops.conv2d_wgrad(xin, dy, g, g.Co, True, bf16=self.bf16))
+                    if self._wino_ok(g) and g.H <= self.WINO_WGRAD_MAX_HW and g.Co % 4 == 0:
+                        dw, db = self._timed("wgrad " + op["p"], "winograd_f2x2_3x3", ops.conv_flops(g),
+                                             lambda: ops.conv2d_wgrad_wino(xin, dy, g, g.Co, True))
+                    else:
+                        dw, db = self._timed("wgrad " + op["p"], ops.wgrad_tile(g) if self.prof is not None else "", ops.conv_flops(g),
+                                             lambda: ops.conv2d_wgrad(xin, dy, g, g.Co, True, bf16=self.bf16))
                     grads[op["p"] + ".weight"], grads[op["p"] + ".bias"] = dw, db
                 if self._wino_ok(g):
                     _, ub = self._wino_weights(op["p"], (P[op["p"] + ".weight"],), op["co"])

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p_in) {
     if (stamp) t_epi = __builtin_readcyclecounter();
     // ---- epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) --------
     if (p.ksplit > 1) {                                   // uniform: raw partial tile, finished by splitk_reduce_kernel
-        float* slab = p.slab + (size_t)blockIdx.y * p.M * p.Nout;
+        float* slab = p.slab + ((size_t)blockIdx.z * p.ksplit + blockIdx.y) * p.M * p.Nout;      // [batch][split][M][N]
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1215,9 +1215,11 @@ extern "C" int ssd_tune_set_igemm_lds_pad(int bytes) {
 
 // Internal (not part of the C ABI): `nbatch` independent GEMMs out[b][M][N] = a[b][M][K] * w[b][N][K]^T on the 64x64 f32 kernel
 // (the sixteen planes of a Winograd F(2x2,3x3) convolution).  K % 32 == 0; rows of w beyond n_rows read as zero.
+// ksplit > 1: every GEMM is cut into K slices that write raw partial tiles to out[b][slice][M][N] (the caller adds them up).
 __attribute__((visibility("hidden"))) int ssd_internal_gemm_batched(const float* a, const float* w, float* out, int M, int K, int N,
-                                                                     int n_rows, int nbatch, size_t batch_w_elems, hipStream_t st) {
-    if (K % 32 != 0 || M <= 0 || N <= 0 || nbatch <= 0 || nbatch > 65535) return SSD_ERR_BAD_SHAPE;
+                                                                     int n_rows, int nbatch, size_t batch_a_elems, size_t batch_w_elems,
+                                                                     int ksplit, hipStream_t st) {
+    if (K % 32 != 0 || M <= 0 || N <= 0 || nbatch <= 0 || nbatch > 65535 || ksplit < 1 || ksplit > 65535) return SSD_ERR_BAD_SHAPE;
     const size_t ab = (size_t)M * K * 4, wb = (size_t)n_rows * K * 4;
     if (ab >= 0xF0000000ull || wb >= 0xF0000000ull) return SSD_ERR_BAD_SHAPE;
     IgemmParams p{};
@@ -1228,7 +1230,13 @@ __attribute__((visibility("hidden"))) int ssd_internal_gemm_batched(const float*
     p.sm = 1; p.sd = 1; p.off = 0; p.dstep = 1;
     p.M = M; p.relu = 0; p.accumulate = 0;
     p.ksplit = 1; p.stamps = nullptr;
-    p.nbatch = nbatch; p.batch_a = (size_t)M * K; p.batch_w = batch_w_elems; p.batch_out = (size_t)M * N;
+    if (ksplit > 1) {
+        p.kt_per_split = ssd_cdiv(K / 32, ksplit);
+        p.ksplit = ssd_cdiv(K / 32, p.kt_per_split);
+        if (p.ksplit != ksplit) return SSD_ERR_BAD_SHAPE;       // the caller sized `out` for exactly ksplit slices
+        p.slab = out;
+    }
+    p.nbatch = nbatch; p.batch_a = batch_a_elems; p.batch_w = batch_w_elems; p.batch_out = (size_t)M * N;
     return launch_igemm<64, 64, 2, 2, 1>(p, st);
 }
 

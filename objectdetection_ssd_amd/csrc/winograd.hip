@@ -10,7 +10,7 @@
 #include "common.h"
 
 int ssd_internal_gemm_batched(const float* a, const float* w, float* out, int M, int K, int N, int n_rows, int nbatch,
-                              size_t batch_w_elems, hipStream_t st);
+                              size_t batch_a_elems, size_t batch_w_elems, int ksplit, hipStream_t st);
 
 namespace {
 
@@ -144,6 +144,142 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     }
 }
 
+// ---- weight gradient:  dg = G^T [ sum over tiles of (A dy A^T) (x) (B^T d B) ] G  (the adjoint of the forward) ---------------------
+// Transposed transforms: plane xi of channel c is ONE row [tile] (Tpad columns, zero beyond the last tile), so that the sum over
+// tiles is the contiguous K dimension of the f32 igemm.  Thread = (tile, 4 channels), tiles fastest: each of the 64 stores of a
+// thread is a 256-byte run across the wave.  MODE 0: B^T d B of the 4x4 input patch; MODE 1: A dy A^T of the 2x2 dy tile.
+template <int MODE>
+__global__ __launch_bounds__(256) void wino_xform_t_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int H, int W, int C,
+                                                           int TH, int TW, int Tpad) {
+    // block = 32 tiles x 32 channels: 8 lanes cover the 128-byte channel run of one tile (coalesced loads); the sixteen planes
+    // go through LDS four at a time and leave as rows [plane][channel] of 32 consecutive tiles (128-byte stores).
+    __shared__ float tr[4][32][33];
+    const int C4 = C >> 2;
+    const int cgroups = (C4 + 7) / 8;
+    const size_t tiles = (size_t)N * TH * TW;
+    const int tile_blocks = Tpad / 32;
+    const int q = threadIdx.x & 7, tl = threadIdx.x >> 3;            // channel quad within the group, tile within the block
+    for (int blk = blockIdx.x; blk < tile_blocks * cgroups; blk += gridDim.x) {
+        const int cg = blk % cgroups;
+        const size_t tile0 = (size_t)(blk / cgroups) * 32, tile = tile0 + tl;
+        const int c4 = cg * 8 + q;
+        const bool c_ok = c4 < C4;
+        f32x4 v[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b2 = 0; b2 < 4; ++b2) v[a][b2] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (tile < tiles && c_ok) {
+            const int tw = (int)(tile % TW), th = (int)((tile / TW) % TH), n = (int)(tile / ((size_t)TW * TH));
+            if (MODE == 0) {
+                f32x4 d[4][4], t[4][4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b2 = 0; b2 < 4; ++b2) {
+                        const int ih = 2 * th - 1 + a, iw = 2 * tw - 1 + b2;
+                        const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                        d[a][b2] = ok ? *reinterpret_cast<const f32x4*>(src + (((size_t)n * H + ih) * W + iw) * C + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                for (int b2 = 0; b2 < 4; ++b2) {
+                    t[0][b2] = d[0][b2] - d[2][b2]; t[1][b2] = d[1][b2] + d[2][b2]; t[2][b2] = d[2][b2] - d[1][b2]; t[3][b2] = d[1][b2] - d[3][b2];
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    v[a][0] = t[a][0] - t[a][2]; v[a][1] = t[a][1] + t[a][2]; v[a][2] = t[a][2] - t[a][1]; v[a][3] = t[a][1] - t[a][3];
+                }
+            } else {
+                f32x4 d[2][2], t[4][2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b2 = 0; b2 < 2; ++b2) {
+                        const int oh = 2 * th + a, ow = 2 * tw + b2;
+                        d[a][b2] = (oh < H && ow < W) ? *reinterpret_cast<const f32x4*>(src + (((size_t)n * H + oh) * W + ow) * C + c4 * 4)
+                                                      : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2) {             // A d: rows (1,0), (1,1), (1,-1), (0,-1)
+                    t[0][b2] = d[0][b2]; t[1][b2] = d[0][b2] + d[1][b2]; t[2][b2] = d[0][b2] - d[1][b2]; t[3][b2] = -d[1][b2];
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {                // (A d) A^T
+                    v[a][0] = t[a][0]; v[a][1] = t[a][0] + t[a][1]; v[a][2] = t[a][0] - t[a][1]; v[a][3] = -t[a][1];
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {                        // planes 4a .. 4a+3
+            __syncthreads();
+#pragma unroll
+            for (int b2 = 0; b2 < 4; ++b2)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tr[b2][q * 4 + e][tl] = v[a][b2][e];
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int row = it * 8 + (threadIdx.x >> 5), col = threadIdx.x & 31;        // row = plane-in-group * 32 + channel
+                const int b2 = row >> 5, cl = row & 31;
+                const int c = cg * 32 + cl;
+                if (c < C) dst[((size_t)(a * 4 + b2) * C + c) * Tpad + tile0 + col] = tr[b2][cl][col];
+            }
+        }
+    }
+}
+
+// dw[co][ci][3][3] = G^T Z G with Z[xi] = sum over the K slices of Zs[xi][slice][co][ci] (slices added in index order)
+__global__ void wino_wgrad_finish_kernel(const float* __restrict__ Zs, float* __restrict__ dw, int Co, int Ci, int ksplit) {
+    const size_t total = (size_t)Co * Ci;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float z[4][4];
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+            float s = 0.f;
+            for (int k = 0; k < ksplit; ++k) s += Zs[((size_t)xi * ksplit + k) * total + i];
+            z[xi >> 2][xi & 3] = s;
+        }
+        float t[3][4];                                       // G^T Z
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            t[0][b] = z[0][b] + 0.5f * (z[1][b] + z[2][b]);
+            t[1][b] = 0.5f * (z[1][b] - z[2][b]);
+            t[2][b] = 0.5f * (z[1][b] + z[2][b]) + z[3][b];
+        }
+        float* o = dw + i * 9;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {                        // (G^T Z) G
+            o[r * 3 + 0] = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
+            o[r * 3 + 1] = 0.5f * (t[r][1] - t[r][2]);
+            o[r * 3 + 2] = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+        }
+    }
+}
+
+// db[c] = sum over pixels of dy[pixel][c]: per-block partial rows, then a fixed-order sum over the blocks
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ dy, float* __restrict__ part, size_t M, int ld, int C) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + lane;
+        float s = 0.f;
+        if (c < C)
+            for (size_t m = (size_t)blockIdx.x * 4 + wv; m < M; m += (size_t)gridDim.x * 4) s += dy[m * ld + c];
+        red[wv][lane] = s;
+        __syncthreads();
+        if (wv == 0 && c < C) part[(size_t)blockIdx.x * C + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        __syncthreads();
+    }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ db, int nblk, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        float s = 0.f;
+        for (int k = 0; k < nblk; ++k) s += part[(size_t)k * C + c];
+        db[c] = s;
+    }
+}
+
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 inline int grid_for(size_t total) { const size_t b = (total + 255) / 256; return (int)(b > 8192 ? 8192 : (b == 0 ? 1 : b)); }
 
@@ -161,7 +297,7 @@ int wino_conv(const float* in, int Cin, const float* U, int U_rows, float* out, 
     float* Mx = reinterpret_cast<float*>(static_cast<char*>(ws) + vb);
     hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(tiles * (Cin / 4))), dim3(256), 0, st, in, V, N, H, W, Cin, TH, TW);
     SSD_CHECK_LAUNCH();
-    if (int e = ssd_internal_gemm_batched(V, U, Mx, (int)tiles, Cin, Cout, U_rows, 16, (size_t)U_rows * Cin, st)) return e;
+    if (int e = ssd_internal_gemm_batched(V, U, Mx, (int)tiles, Cin, Cout, U_rows, 16, tiles * Cin, (size_t)U_rows * Cin, 1, st)) return e;
     hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(tiles * (Cout / 4))), dim3(256), 0, st, Mx, out, N, H, W, Cout, Cvalid, ldo, TH, TW,
                        bias, mask, relu, accumulate);
     SSD_CHECK_LAUNCH();
@@ -219,4 +355,69 @@ extern "C" int ssd_conv3x3_wino_dgrad(const float* dy, int ldy, const float* U_b
         return SSD_ERR_ALIGN;
     return wino_conv(dy, Co_pad, U_bwd, g->Ci, dx, g->Ci, g->Ci, nullptr, relu_mask, 0, accumulate, g->N, g->H, g->W, workspace,
                      workspace_bytes, (hipStream_t)stream);
+}
+
+namespace {
+struct WinoWgradPlan { int TH, TW, Tpad, ks, cdy; size_t tiles, yb, vb, zb, pb; };
+WinoWgradPlan wino_wgrad_plan(const ssd_conv_geom* g, int ldy) {
+    WinoWgradPlan w;
+    w.TH = (g->H + 1) / 2; w.TW = (g->W + 1) / 2;
+    w.tiles = (size_t)g->N * w.TH * w.TW;
+    w.Tpad = (int)((w.tiles + 31) / 32 * 32);
+    w.cdy = ldy;
+    const int bp = ((g->Co + 63) / 64) * ((g->Ci + 63) / 64) * 16;       // 64x64 output tiles over the sixteen planes
+    int ks = (1536 + bp - 1) / bp;                                         // fill the ~1500 resident-block slots
+    const int ksteps = w.Tpad / 32;
+    if (ks > ksteps / 8) ks = ksteps / 8;
+    if (ks < 1) ks = 1;
+    const int per = (ksteps + ks - 1) / ks;
+    w.ks = (ksteps + per - 1) / per;
+    w.yb = align256((size_t)16 * ldy * w.Tpad * 4);
+    w.vb = align256((size_t)16 * g->Ci * w.Tpad * 4);
+    w.zb = align256((size_t)16 * w.ks * g->Co * g->Ci * 4);
+    w.pb = align256((size_t)256 * ldy * 4);
+    return w;
+}
+}  // namespace
+
+extern "C" size_t ssd_conv3x3_wino_wgrad_workspace(const ssd_conv_geom* g, int ldy) {
+    if (!wino_geom_ok(g) || ldy < g->Co) return 0;
+    const WinoWgradPlan w = wino_wgrad_plan(g, ldy);
+    return w.yb + w.vb + w.zb + w.pb;
+}
+
+// dw (Co,Ci,3,3) OIHW and, if asked, dbias (Co) from x (N,H,W,Ci) and dy (N,H,W,ldy; columns >= Co zero)
+extern "C" int ssd_conv3x3_wino_wgrad(const float* x, const float* dy, int ldy, float* dw_oihw, float* dbias, const ssd_conv_geom* g,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !dy || !dw_oihw || !workspace) return SSD_ERR_NULL;
+    if (!wino_geom_ok(g) || g->Ci % 4 != 0 || ldy % 4 != 0 || ldy < g->Co) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(x) || !ssd_aligned16(dy) || !ssd_aligned16(workspace)) return SSD_ERR_ALIGN;
+    const WinoWgradPlan w = wino_wgrad_plan(g, ldy);
+    if (w.tiles >= (1ull << 31)) return SSD_ERR_BAD_SHAPE;
+    if (workspace_bytes < w.yb + w.vb + w.zb + w.pb) return SSD_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* base = static_cast<char*>(workspace);
+    float* Yt = reinterpret_cast<float*>(base);
+    float* Vt = reinterpret_cast<float*>(base + w.yb);
+    float* Zs = reinterpret_cast<float*>(base + w.yb + w.vb);
+    float* part = reinterpret_cast<float*>(base + w.yb + w.vb + w.zb);
+    const int gy = (w.Tpad / 32) * ((ldy / 4 + 7) / 8), gx = (w.Tpad / 32) * ((g->Ci / 4 + 7) / 8);
+    hipLaunchKernelGGL(wino_xform_t_kernel<1>, dim3(gy > 16384 ? 16384 : gy), dim3(256), 0, st, dy, Yt, g->N, g->H, g->W, ldy, w.TH, w.TW,
+                       w.Tpad);
+    SSD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(wino_xform_t_kernel<0>, dim3(gx > 16384 ? 16384 : gx), dim3(256), 0, st, x, Vt, g->N, g->H, g->W, g->Ci, w.TH, w.TW,
+                       w.Tpad);
+    SSD_CHECK_LAUNCH();
+    if (int e = ssd_internal_gemm_batched(Yt, Vt, Zs, g->Co, w.Tpad, g->Ci, g->Ci, 16, (size_t)ldy * w.Tpad, (size_t)g->Ci * w.Tpad, w.ks, st))
+        return e;
+    hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3(grid_for((size_t)g->Co * g->Ci)), dim3(256), 0, st, Zs, dw_oihw, g->Co, g->Ci, w.ks);
+    SSD_CHECK_LAUNCH();
+    if (dbias) {
+        const size_t M = (size_t)g->N * g->H * g->W;
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(256), dim3(256), 0, st, dy, part, M, ldy, g->Co);
+        SSD_CHECK_LAUNCH();
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((g->Co + 255) / 256), dim3(256), 0, st, part, dbias, 256, g->Co);
+        SSD_CHECK_LAUNCH();
+    }
+    return SSD_OK;
 }

@@ -562,3 +562,11 @@ def test_winograd_f2x2_3x3_forward_and_dgrad(case):
     mask = torch.randn(n, h, w, ci, generator=torch.Generator().manual_seed(74)).clamp_min(0).to(dev)
     dx2 = ops.conv2d_dgrad_wino(dy_p.to(dev), ub, g, dx=prev.clone(), relu_mask=mask, accumulate=True)
     _close(dx2, (_nhwc(x.grad) + prev.cpu()) * (mask.cpu() > 0), what=f"winograd dgrad acc+mask {case}")
+    # weight gradient in the Winograd domain (adjoint transforms), bias gradient by column sums; reproducible
+    wt2 = wt.clone().requires_grad_(True); b2 = b.clone().requires_grad_(True)
+    F.conv2d(x.detach(), wt2, b2, padding=1).backward(dy)
+    dw, db = ops.conv2d_wgrad_wino(_nhwc(x.detach()).to(dev), dy_p.to(dev), g, ld, True)
+    dw_b, db_b = ops.conv2d_wgrad_wino(_nhwc(x.detach()).to(dev), dy_p.to(dev), g, ld, True)
+    _close(dw, wt2.grad, tol=2e-4, what=f"winograd wgrad {case}")
+    _close(db, b2.grad, tol=2e-4, what=f"winograd bias grad {case}")
+    assert torch.equal(dw, dw_b) and torch.equal(db, db_b)

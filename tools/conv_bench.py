@@ -92,6 +92,9 @@ def main():
             ms1 = timeit(lambda: ops.conv2d_fwd_wino(x, uf, b, g, True, ld=ld))
             ms2 = timeit(lambda: ops.conv2d_dgrad(dy, wb, g, dx, x, False))
             ms3 = timeit(lambda: ops.conv2d_dgrad_wino(dy, ub, g, dx, x, False))
+            ms4 = timeit(lambda: ops.conv2d_wgrad(x, dy, g, ld, True))
+            ms5 = timeit(lambda: ops.conv2d_wgrad_wino(x, dy, g, ld, True))
+            print(f"wino {name:8s} wgrad direct {ms4:.3f} ms ({fl / ms4 / 1e9:.0f} TF/s)  winograd {ms5:.3f} ms ({fl / ms5 / 1e9:.0f} TF/s alg.)", flush=True)
             print(f"wino {name:8s} fwd direct {ms0:.3f} ms ({fl / ms0 / 1e9:.0f} TF/s)  winograd {ms1:.3f} ms ({fl / ms1 / 1e9:.0f} TF/s alg.)   "
                   f"dgrad direct {ms2:.3f} ms  winograd {ms3:.3f} ms ({fl / ms3 / 1e9:.0f} TF/s alg.)", flush=True)
         if which == "occ":                      # blocks per CU capped through extra dynamic LDS (64x64 tile, 18 KB static)
