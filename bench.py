@@ -332,7 +332,9 @@ def main():
                 a[0] += dt; a[1] += flops; a[2] += 1
                 rows.append((label, tag, flops, dt))
             eng.prof = None
-        tag, (tsum, fsum, n) = max(agg.items(), key=lambda kv: kv[1][0])
+        # dominant KERNEL: the Winograd ops are composites (two transform kernels around sixteen batched GEMMs), listed in by_kernel
+        # but not eligible -- a roofline row has to be one kernel that the rocprof summary can be held against
+        tag, (tsum, fsum, n) = max(((k, v) for k, v in agg.items() if not k.startswith("winograd")), key=lambda kv: kv[1][0])
         ach = fsum / tsum / 1e12
         traffic = None            # HBM bytes per launch from the committed PMC passes (cannot be collected live)
         try:

@@ -140,10 +140,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, const f32x1
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NBUF>
+template <int BM, int BN, int WM, int WN, int NBUF, bool BATCHED = false>      // BATCHED: its own symbol, so profiles tell the Winograd GEMMs apart
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p_in) {
     IgemmParams p = p_in;
-    if (p.nbatch > 1) {                                   // uniform
+    if (BATCHED) {
         p.a += (size_t)blockIdx.z * p.batch_a;
         p.w += (size_t)blockIdx.z * p.batch_w;
         p.out += (size_t)blockIdx.z * p.batch_out;
@@ -363,14 +363,14 @@ int pick_ksplit(int blocks, int kt, size_t tile_elems_total) {
     return k < 2 ? 1 : k;
 }
 
-template <int BM, int BN, int WM, int WN, int NBUF>
+template <int BM, int BN, int WM, int WN, int NBUF, bool BATCHED = false>
 int launch_igemm(IgemmParams& p, hipStream_t st) {
     p.tiles_m = ssd_cdiv(p.M, BM);
     p.tiles_n = ssd_cdiv(p.Nout, BN);
     p.rcp_howo = 1.0f / (float)(p.Ho * p.Wo);
     p.rcp_wo = 1.0f / (float)p.Wo;
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, NBUF>), dim3(p.tiles_m * p.tiles_n, ks, p.nbatch > 1 ? p.nbatch : 1), dim3(256),
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, NBUF, BATCHED>), dim3(p.tiles_m * p.tiles_n, ks, BATCHED ? p.nbatch : 1), dim3(256),
                        g_lds_pad, st, p);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
@@ -1237,7 +1237,7 @@ __attribute__((visibility("hidden"))) int ssd_internal_gemm_batched(const float*
         p.slab = out;
     }
     p.nbatch = nbatch; p.batch_a = batch_a_elems; p.batch_w = batch_w_elems; p.batch_out = (size_t)M * N;
-    return launch_igemm<64, 64, 2, 2, 1>(p, st);
+    return launch_igemm<64, 64, 2, 2, 1, true>(p, st);
 }
 
 // ---- "f32 from three bf16 limbs" entry points (opt-in; see igemm_x3_kernel) -----------------------------------
