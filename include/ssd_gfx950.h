@@ -126,16 +126,17 @@ int ssd_conv2d_fwd_ws(const float* x, const float* w_ohwi, const float* bias, fl
 int ssd_conv2d_dgrad_ws(const float* dy, int ldy, const float* w_ihwo, int Co_pad, float* dx, const float* relu_mask,
                         int accumulate, const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream);
 int ssd_tune_set_igemm_splitk(int k);       /* -1 automatic, 1 never split, k > 1 force k slices */
-/* ---- Winograd F(2x2,3x3) for the 3x3 / stride 1 / pad 1 layers (2.25x fewer multiplies; results differ from the direct sum
- * at the 1e-6 level).  ssd_wino_weights transforms the OIHW filter once per update: U_fwd [16][Co][Ci] for the forward,
- * U_bwd [16][Ci][Co_pad] (transposed, rotated filter) for dgrad; either may be NULL.  The convolutions take the transformed
- * filter, a workspace of ssd_conv3x3_wino_workspace(g, direction) bytes, and fuse the same epilogues as the direct kernels. */
-int ssd_wino_weights(const float* w_oihw, float* U_fwd, float* U_bwd, int Co, int Ci, int Co_pad, void* stream);
-size_t ssd_conv3x3_wino_workspace(const ssd_conv_geom* g, int direction /* 0 forward, 1 dgrad */);
+/* ---- Winograd F(mo x mo, 3x3), mo = 2 or 4, for the 3x3 / stride 1 / pad 1 layers: (mo+2)^2 multiplies per mo x mo output tile
+ * instead of 9 mo^2 (2.25x / 4x fewer).  Results differ from the direct sum at the 1e-6 (mo = 2) / 1e-5 (mo = 4) level of the
+ * output scale.  ssd_wino_weights transforms the OIHW filter once per update: U_fwd [P][Co][Ci] for the forward, U_bwd
+ * [P][Ci][Co_pad] (transposed, rotated filter) for dgrad, P = (mo+2)^2; either may be NULL.  The convolutions take the
+ * transformed filter, a workspace of ssd_conv3x3_wino_workspace(g, direction, mo) bytes, and fuse the direct kernels' epilogues. */
+int ssd_wino_weights(const float* w_oihw, float* U_fwd, float* U_bwd, int Co, int Ci, int Co_pad, int mo, void* stream);
+size_t ssd_conv3x3_wino_workspace(const ssd_conv_geom* g, int direction /* 0 forward, 1 dgrad */, int mo);
 int ssd_conv3x3_wino_fwd(const float* x, const float* U_fwd, const float* bias, float* y, int ldy, const ssd_conv_geom* g, int relu,
-                         void* workspace, size_t workspace_bytes, void* stream);
+                         int mo, void* workspace, size_t workspace_bytes, void* stream);
 int ssd_conv3x3_wino_dgrad(const float* dy, int ldy, const float* U_bwd, int Co_pad, float* dx, const float* relu_mask,
-                           int accumulate, const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream);
+                           int accumulate, const ssd_conv_geom* g, int mo, void* workspace, size_t workspace_bytes, void* stream);
 /* Winograd weight gradient: dg = G^T [ sum over tiles (A dy A^T) (x) (B^T d B) ] G -- transposed transforms of dy and x, sixteen
  * batched (split-K) f32-MFMA GEMMs over the tile dimension, inverse transform to OIHW; dbias (may be NULL) by column sums. */
 size_t ssd_conv3x3_wino_wgrad_workspace(const ssd_conv_geom* g, int ldy);

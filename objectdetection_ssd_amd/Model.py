@@ -169,8 +169,9 @@ class _Engine:
                 return ent[4], ent[5]
         return ent[2], ent[3]
 
+    WINO_TILE = 4                 # forward / dgrad output tile: F(4x4,3x3) (36 multiplies per 16 outputs; ~1e-5 of the output scale) or 2
     WINO_WGRAD_MAX_HW = 40        # Winograd weight gradient on maps up to this size (conv4_x, conv5_x: -25 % / -15 %; conv3_x: -4 %)
-    WINO_MIN_CI = 256             # measured (tools/conv_bench.py wino): 1.3-1.7x on conv3_2 ... conv5_3 and the c_4 / c_7 heads, ~1.0x at 128
+    WINO_MIN_CI = 64              # measured in the step with F(4x4): 256 -> 836, 128 -> 872, 64 -> 879 images/s (F(2x2): only >= 256 paid)
 
     def _wino_ok(self, g) -> bool:
         return (self.wino and not self.bf16 and not self.x3 and g.R == 3 and g.S == 3 and g.stride == 1 and g.dil == 1 and g.pad == 1
@@ -182,7 +183,7 @@ class _Engine:
         ent = self._wcache.get("wino:" + key)
         if ent is None or ent[0] != sig:
             w = tensors[0] if len(tensors) == 1 else torch.cat(list(tensors), 0)
-            uf, ub = ops.wino_weights(w.detach().contiguous(), co_pad, want_bwd=True)
+            uf, ub = ops.wino_weights(w.detach().contiguous(), co_pad, want_bwd=True, mo=self.WINO_TILE)
             ent = (sig, uf, ub)
             self._wcache["wino:" + key] = ent
         return ent[1], ent[2]

@@ -280,26 +280,167 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, float* __res
     }
 }
 
+// ---- F(4x4, 3x3): 36 multiplies per 4x4 output tile (4x fewer than direct, 1.78x fewer than F(2x2)); 6x6 input patches, planes
+// 2.25x the tensor.  Interpolation points 0, +-1, +-2, inf (Lavin & Gray); coefficients up to 8 and 1/24, so the f32 result is
+// less exact than F(2x2)'s (measured ~1e-5 of the output scale) -- used where that still clears the 1e-4 bar.
+__device__ constexpr float W4_BT[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
+                                          {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+__device__ constexpr float W4_G[6][3] = {{0.25f, 0, 0}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                                         {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0, 0, 1}};
+__device__ constexpr float W4_AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+
+__global__ void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Co, int Ci, int Nrows, int K, int mode) {
+    const size_t total = (size_t)Nrows * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K), n = (int)(i / K);
+        const int co = mode == 0 ? n : k, ci = mode == 0 ? k : n;
+        float g[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                g[r][s] = (co < Co && ci < Ci) ? w[((size_t)co * Ci + ci) * 9 + (mode == 0 ? r * 3 + s : (2 - r) * 3 + (2 - s))] : 0.f;
+        float t[6][3];
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) t[a][s] = W4_G[a][0] * g[0][s] + W4_G[a][1] * g[1][s] + W4_G[a][2] * g[2][s];
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b)
+                U[((size_t)(a * 6 + b) * Nrows + n) * K + k] = W4_G[b][0] * t[a][0] + W4_G[b][1] * t[a][1] + W4_G[b][2] * t[a][2];
+    }
+}
+
+__global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int H, int W, int C,
+                                                          int TH, int TW) {
+    const int C4 = C >> 2;
+    const size_t tiles = (size_t)N * TH * TW, total = tiles * C4;
+    const size_t plane = tiles * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        const size_t tile = i / C4;
+        const int tw = (int)(tile % TW), th = (int)((tile / TW) % TH), n = (int)(tile / ((size_t)TW * TH));
+        f32x4 t[6][6];                                       // B^T d, one input row at a time
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            f32x4 d[6];
+            const int iw = 4 * tw - 1 + b;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const int ih = 4 * th - 1 + a;
+                const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                d[a] = ok ? *reinterpret_cast<const f32x4*>(x + (((size_t)n * H + ih) * W + iw) * C + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (W4_BT[a][k] != 0.f) acc += W4_BT[a][k] * d[k];
+                t[a][b] = acc;
+            }
+        }
+        float* dst = V + tile * C + c4 * 4;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (W4_BT[b][k] != 0.f) acc += W4_BT[b][k] * t[a][k];
+                *reinterpret_cast<f32x4*>(dst + (size_t)(a * 6 + b) * plane) = acc;
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ Mx, float* __restrict__ out, int N, int H, int W, int C,
+                                                           int Cvalid, int ldo, int TH, int TW, const float* __restrict__ bias,
+                                                           const float* __restrict__ mask, int relu, int accumulate) {
+    const int C4 = C >> 2;
+    const size_t tiles = (size_t)N * TH * TW, total = tiles * C4;
+    const size_t plane = tiles * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        const size_t tile = i / C4;
+        const int tw = (int)(tile % TW), th = (int)((tile / TW) % TH), n = (int)(tile / ((size_t)TW * TH));
+        const float* src = Mx + tile * C + c4 * 4;
+        f32x4 t[4][6];                                       // A^T m, one plane column at a time
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            f32x4 m[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) m[a] = *reinterpret_cast<const f32x4*>(src + (size_t)(a * 6 + b) * plane);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (W4_AT[a][k] != 0.f) acc += W4_AT[a][k] * m[k];
+                t[a][b] = acc;
+            }
+        }
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (bias != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = c4 * 4 + e < Cvalid ? bias[c4 * 4 + e] : 0.f;
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int oh = 4 * th + a;
+            if (oh >= H) continue;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int ow = 4 * tw + b;
+                if (ow >= W) continue;
+                f32x4 v = bv;
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (W4_AT[b][k] != 0.f) v += W4_AT[b][k] * t[a][k];
+                const size_t idx = (((size_t)n * H + oh) * W + ow) * ldo + c4 * 4;
+                if (accumulate) v += *reinterpret_cast<const f32x4*>(out + idx);
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
+                }
+                if (mask != nullptr) {
+                    const f32x4 mk = *reinterpret_cast<const f32x4*>(mask + idx);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(out + idx) = v;
+            }
+        }
+    }
+}
+
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 inline int grid_for(size_t total) { const size_t b = (total + 255) / 256; return (int)(b > 8192 ? 8192 : (b == 0 ? 1 : b)); }
 
-// one F(2x2,3x3) convolution: in (N,H,W,Cin) -> out (N,H,W,ldo) first Cout channels
-int wino_conv(const float* in, int Cin, const float* U, int U_rows, float* out, int ldo, int Cout, const float* bias, const float* mask,
-              int relu, int accumulate, int N, int H, int W, void* ws, size_t ws_bytes, hipStream_t st) {
-    const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+// one Winograd convolution, F(mo x mo, 3x3) with mo = 2 or 4: in (N,H,W,Cin) -> out (N,H,W,ldo) first Cout channels
+int wino_conv(int mo, const float* in, int Cin, const float* U, int U_rows, float* out, int ldo, int Cout, const float* bias,
+              const float* mask, int relu, int accumulate, int N, int H, int W, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int TH = (H + mo - 1) / mo, TW = (W + mo - 1) / mo, P = (mo + 2) * (mo + 2);
     const size_t tiles = (size_t)N * TH * TW;
     const int Cvalid = Cout;
     Cout = (Cout + 3) / 4 * 4;                 // the GEMM and the output transform work on whole 4-channel vectors: the filter rows
     if (tiles >= (1ull << 31) || Cin % 32 != 0 || Cout > ldo) return SSD_ERR_BAD_SHAPE;     // beyond Cvalid read as zero
-    const size_t vb = align256(16 * tiles * Cin * 4), mb = align256(16 * tiles * Cout * 4);
+    const size_t vb = align256((size_t)P * tiles * Cin * 4), mb = align256((size_t)P * tiles * Cout * 4);
     if (ws_bytes < vb + mb) return SSD_ERR_WORKSPACE;
     float* V = static_cast<float*>(ws);
     float* Mx = reinterpret_cast<float*>(static_cast<char*>(ws) + vb);
-    hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(tiles * (Cin / 4))), dim3(256), 0, st, in, V, N, H, W, Cin, TH, TW);
+    if (mo == 2) hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(tiles * (Cin / 4))), dim3(256), 0, st, in, V, N, H, W, Cin, TH, TW);
+    else hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(tiles * (Cin / 4))), dim3(256), 0, st, in, V, N, H, W, Cin, TH, TW);
     SSD_CHECK_LAUNCH();
-    if (int e = ssd_internal_gemm_batched(V, U, Mx, (int)tiles, Cin, Cout, U_rows, 16, tiles * Cin, (size_t)U_rows * Cin, 1, st)) return e;
-    hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(tiles * (Cout / 4))), dim3(256), 0, st, Mx, out, N, H, W, Cout, Cvalid, ldo, TH, TW,
-                       bias, mask, relu, accumulate);
+    if (int e = ssd_internal_gemm_batched(V, U, Mx, (int)tiles, Cin, Cout, U_rows, P, tiles * Cin, (size_t)U_rows * Cin, 1, st)) return e;
+    if (mo == 2)
+        hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(tiles * (Cout / 4))), dim3(256), 0, st, Mx, out, N, H, W, Cout, Cvalid, ldo, TH, TW,
+                           bias, mask, relu, accumulate);
+    else
+        hipLaunchKernelGGL(wino4_output_kernel, dim3(grid_for(tiles * (Cout / 4))), dim3(256), 0, st, Mx, out, N, H, W, Cout, Cvalid, ldo, TH,
+                           TW, bias, mask, relu, accumulate);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
 }
@@ -311,49 +452,51 @@ bool wino_geom_ok(const ssd_conv_geom* g) {
 
 }  // namespace
 
-// U_fwd: [16][Co][Ci]; U_bwd: [16][Ci][Co_pad] (either may be NULL)
-extern "C" int ssd_wino_weights(const float* w_oihw, float* U_fwd, float* U_bwd, int Co, int Ci, int Co_pad, void* stream) {
+// mo = 2: F(2x2,3x3), P = 16 planes; mo = 4: F(4x4,3x3), P = 36 planes.  U_fwd: [P][Co][Ci]; U_bwd: [P][Ci][Co_pad] (either may be NULL)
+extern "C" int ssd_wino_weights(const float* w_oihw, float* U_fwd, float* U_bwd, int Co, int Ci, int Co_pad, int mo, void* stream) {
     if (!w_oihw || (!U_fwd && !U_bwd)) return SSD_ERR_NULL;
-    if (Co <= 0 || Ci <= 0 || Co_pad < Co) return SSD_ERR_BAD_SHAPE;
+    if (Co <= 0 || Ci <= 0 || Co_pad < Co || (mo != 2 && mo != 4)) return SSD_ERR_BAD_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     if (U_fwd) {
-        hipLaunchKernelGGL(wino_weight_kernel, dim3(grid_for((size_t)Co * Ci)), dim3(256), 0, st, w_oihw, U_fwd, Co, Ci, Co, Ci, 0);
+        if (mo == 2) hipLaunchKernelGGL(wino_weight_kernel, dim3(grid_for((size_t)Co * Ci)), dim3(256), 0, st, w_oihw, U_fwd, Co, Ci, Co, Ci, 0);
+        else hipLaunchKernelGGL(wino4_weight_kernel, dim3(grid_for((size_t)Co * Ci)), dim3(256), 0, st, w_oihw, U_fwd, Co, Ci, Co, Ci, 0);
         SSD_CHECK_LAUNCH();
     }
     if (U_bwd) {
-        hipLaunchKernelGGL(wino_weight_kernel, dim3(grid_for((size_t)Ci * Co_pad)), dim3(256), 0, st, w_oihw, U_bwd, Co, Ci, Ci, Co_pad, 1);
+        if (mo == 2) hipLaunchKernelGGL(wino_weight_kernel, dim3(grid_for((size_t)Ci * Co_pad)), dim3(256), 0, st, w_oihw, U_bwd, Co, Ci, Ci, Co_pad, 1);
+        else hipLaunchKernelGGL(wino4_weight_kernel, dim3(grid_for((size_t)Ci * Co_pad)), dim3(256), 0, st, w_oihw, U_bwd, Co, Ci, Ci, Co_pad, 1);
         SSD_CHECK_LAUNCH();
     }
     return SSD_OK;
 }
 
-extern "C" size_t ssd_conv3x3_wino_workspace(const ssd_conv_geom* g, int direction) {
-    if (!wino_geom_ok(g)) return 0;
-    const size_t tiles = (size_t)g->N * ((g->H + 1) / 2) * ((g->W + 1) / 2);
+extern "C" size_t ssd_conv3x3_wino_workspace(const ssd_conv_geom* g, int direction, int mo) {
+    if (!wino_geom_ok(g) || (mo != 2 && mo != 4)) return 0;
+    const size_t tiles = (size_t)g->N * ((g->H + mo - 1) / mo) * ((g->W + mo - 1) / mo), P = (size_t)(mo + 2) * (mo + 2);
     const int co_pad = (g->Co + 31) / 32 * 32;
     const size_t cin = direction == 0 ? g->Ci : co_pad, cout = direction == 0 ? (size_t)(g->Co + 3) / 4 * 4 : (size_t)(g->Ci + 3) / 4 * 4;
-    return align256(16 * tiles * cin * 4) + align256(16 * tiles * cout * 4);
+    return align256(P * tiles * cin * 4) + align256(P * tiles * cout * 4);
 }
 
 extern "C" int ssd_conv3x3_wino_fwd(const float* x, const float* U_fwd, const float* bias, float* y, int ldy, const ssd_conv_geom* g,
-                                    int relu, void* workspace, size_t workspace_bytes, void* stream) {
+                                    int relu, int mo, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !U_fwd || !y || !workspace) return SSD_ERR_NULL;
-    if (!wino_geom_ok(g) || g->Ci % 32 != 0 || ldy < (g->Co + 3) / 4 * 4) return SSD_ERR_BAD_SHAPE;
-    if (!ssd_aligned16(x) || !ssd_aligned16(y) || !ssd_aligned16(workspace) || !ssd_aligned16(U_fwd) || (bias && !ssd_aligned16(bias)) ||
-        ldy % 4 != 0)
-        return SSD_ERR_ALIGN;
-    return wino_conv(x, g->Ci, U_fwd, g->Co, y, ldy, g->Co, bias, nullptr, relu, 0, g->N, g->H, g->W, workspace, workspace_bytes,
+    if (!wino_geom_ok(g) || g->Ci % 32 != 0 || ldy < (g->Co + 3) / 4 * 4 || (mo != 2 && mo != 4)) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(x) || !ssd_aligned16(y) || !ssd_aligned16(workspace) || !ssd_aligned16(U_fwd) || ldy % 4 != 0) return SSD_ERR_ALIGN;
+    return wino_conv(mo, x, g->Ci, U_fwd, g->Co, y, ldy, g->Co, bias, nullptr, relu, 0, g->N, g->H, g->W, workspace, workspace_bytes,
                      (hipStream_t)stream);
 }
 
 extern "C" int ssd_conv3x3_wino_dgrad(const float* dy, int ldy, const float* U_bwd, int Co_pad, float* dx, const float* relu_mask,
-                                      int accumulate, const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream) {
+                                      int accumulate, const ssd_conv_geom* g, int mo, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
     if (!dy || !U_bwd || !dx || !workspace) return SSD_ERR_NULL;
-    if (!wino_geom_ok(g) || Co_pad % 32 != 0 || Co_pad < g->Co || ldy != Co_pad || g->Ci % 4 != 0) return SSD_ERR_BAD_SHAPE;
+    if (!wino_geom_ok(g) || Co_pad % 32 != 0 || Co_pad < g->Co || ldy != Co_pad || g->Ci % 4 != 0 || (mo != 2 && mo != 4))
+        return SSD_ERR_BAD_SHAPE;
     if (!ssd_aligned16(dy) || !ssd_aligned16(dx) || !ssd_aligned16(workspace) || !ssd_aligned16(U_bwd) ||
         (relu_mask && !ssd_aligned16(relu_mask)))
         return SSD_ERR_ALIGN;
-    return wino_conv(dy, Co_pad, U_bwd, g->Ci, dx, g->Ci, g->Ci, nullptr, relu_mask, 0, accumulate, g->N, g->H, g->W, workspace,
+    return wino_conv(mo, dy, Co_pad, U_bwd, g->Ci, dx, g->Ci, g->Ci, nullptr, relu_mask, 0, accumulate, g->N, g->H, g->W, workspace,
                      workspace_bytes, (hipStream_t)stream);
 }
 

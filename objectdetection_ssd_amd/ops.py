@@ -588,24 +588,32 @@ def photometric_u8(arena: torch.Tensor, descs, photo) -> None:
                                  ws.numel(), _stream()), "photometric_u8")
 
 
-# ---- Winograd F(2x2,3x3) -------------------------------------------------------------------------
-def wino_weights(w_oihw: torch.Tensor, co_pad: Optional[int] = None, want_bwd: bool = True):
-    """(Co,Ci,3,3) -> U_fwd (16,Co,Ci) and, if asked, U_bwd (16,Ci,co_pad) for conv2d_fwd_wino / conv2d_dgrad_wino."""
+# ---- Winograd F(mo x mo, 3x3), mo = 2 or 4 --------------------------------------------------------
+def wino_weights(w_oihw: torch.Tensor, co_pad: Optional[int] = None, want_bwd: bool = True, mo: int = 2):
+    """(Co,Ci,3,3) -> U_fwd (P,Co,Ci) and, if asked, U_bwd (P,Ci,co_pad), P = (mo+2)^2, for conv2d_fwd_wino / conv2d_dgrad_wino."""
     _req(w_oihw, "weight")
     co, ci, r, s = w_oihw.shape
-    if (r, s) != (3, 3):
-        raise ValueError("Winograd F(2x2,3x3) needs 3x3 filters")
+    if (r, s) != (3, 3) or mo not in (2, 4):
+        raise ValueError("Winograd needs 3x3 filters and mo in (2, 4)")
     co_pad = pad32(co) if co_pad is None else co_pad
-    uf = torch.empty((16, co, ci), device=w_oihw.device, dtype=torch.float32)
-    ub = torch.empty((16, ci, co_pad), device=w_oihw.device, dtype=torch.float32) if want_bwd else None
-    check(_lib.load().ssd_wino_weights(w_oihw.data_ptr(), uf.data_ptr(), _ptr(ub), co, ci, co_pad, _stream()), "wino_weights")
+    P = (mo + 2) ** 2
+    uf = torch.empty((P, co, ci), device=w_oihw.device, dtype=torch.float32)
+    ub = torch.empty((P, ci, co_pad), device=w_oihw.device, dtype=torch.float32) if want_bwd else None
+    check(_lib.load().ssd_wino_weights(w_oihw.data_ptr(), uf.data_ptr(), _ptr(ub), co, ci, co_pad, mo, _stream()), "wino_weights")
     return uf, ub
+
+
+def _wino_mo(u: torch.Tensor) -> int:
+    if u.shape[0] not in (16, 36):
+        raise ValueError("transformed filter must have 16 or 36 planes")
+    return 2 if u.shape[0] == 16 else 4
 
 
 def conv2d_fwd_wino(x: torch.Tensor, u_fwd: torch.Tensor, bias: Optional[torch.Tensor], g: ConvGeom, relu: bool,
                     ld: Optional[int] = None) -> torch.Tensor:
     _req(x, "x"); _req(u_fwd, "u_fwd")
-    if tuple(x.shape) != (g.N, g.H, g.W, g.Ci) or tuple(u_fwd.shape) != (16, g.Co, g.Ci):
+    mo = _wino_mo(u_fwd)
+    if tuple(x.shape) != (g.N, g.H, g.W, g.Ci) or tuple(u_fwd.shape[1:]) != (g.Co, g.Ci):
         raise ValueError("conv2d_fwd_wino: shapes do not match the geometry")
     if bias is not None:
         _req(bias, "bias")
@@ -613,11 +621,11 @@ def conv2d_fwd_wino(x: torch.Tensor, u_fwd: torch.Tensor, bias: Optional[torch.T
     out = torch.empty((g.N, g.H, g.W, ld), device=x.device, dtype=torch.float32) if ld == g.Co else \
         torch.zeros((g.N, g.H, g.W, ld), device=x.device, dtype=torch.float32)
     lib = _lib.load()
-    nbytes = lib.ssd_conv3x3_wino_workspace(C.byref(g), 0)
+    nbytes = lib.ssd_conv3x3_wino_workspace(C.byref(g), 0, mo)
     if nbytes == 0:
         raise ValueError("conv2d_fwd_wino: not a 3x3 / stride 1 / pad 1 geometry")
     ws = workspace(nbytes, x.device, "wino")
-    check(lib.ssd_conv3x3_wino_fwd(x.data_ptr(), u_fwd.data_ptr(), _ptr(bias), out.data_ptr(), ld, C.byref(g), int(relu), ws.data_ptr(),
+    check(lib.ssd_conv3x3_wino_fwd(x.data_ptr(), u_fwd.data_ptr(), _ptr(bias), out.data_ptr(), ld, C.byref(g), int(relu), mo, ws.data_ptr(),
                                    ws.numel(), _stream()), "conv2d_fwd_wino")
     return out
 
@@ -625,8 +633,9 @@ def conv2d_fwd_wino(x: torch.Tensor, u_fwd: torch.Tensor, bias: Optional[torch.T
 def conv2d_dgrad_wino(dy: torch.Tensor, u_bwd: torch.Tensor, g: ConvGeom, dx: Optional[torch.Tensor] = None,
                       relu_mask: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
     _req(dy, "dy"); _req(u_bwd, "u_bwd")
+    mo = _wino_mo(u_bwd)
     co_pad = u_bwd.shape[2]
-    if dy.numel() != g.N * g.H * g.W * co_pad or tuple(u_bwd.shape[:2]) != (16, g.Ci):
+    if dy.numel() != g.N * g.H * g.W * co_pad or u_bwd.shape[1] != g.Ci:
         raise ValueError("conv2d_dgrad_wino: shapes do not match the geometry")
     if dx is None:
         if accumulate:
@@ -636,9 +645,9 @@ def conv2d_dgrad_wino(dy: torch.Tensor, u_bwd: torch.Tensor, g: ConvGeom, dx: Op
     if relu_mask is not None:
         _req(relu_mask, "relu_mask")
     lib = _lib.load()
-    ws = workspace(lib.ssd_conv3x3_wino_workspace(C.byref(g), 1), dy.device, "wino")
+    ws = workspace(lib.ssd_conv3x3_wino_workspace(C.byref(g), 1, mo), dy.device, "wino")
     check(lib.ssd_conv3x3_wino_dgrad(dy.data_ptr(), co_pad, u_bwd.data_ptr(), co_pad, dx.data_ptr(), _ptr(relu_mask), int(accumulate),
-                                     C.byref(g), ws.data_ptr(), ws.numel(), _stream()), "conv2d_dgrad_wino")
+                                     C.byref(g), mo, ws.data_ptr(), ws.numel(), _stream()), "conv2d_dgrad_wino")
     return dx
 
 

@@ -535,6 +535,33 @@ WINO_CASES = [(2, 19, 19, 64, 64), (1, 38, 38, 128, 256), (2, 75, 75, 32, 64), (
 
 
 @pytest.mark.parametrize("case", WINO_CASES)
+def test_winograd_f4x4_3x3_forward_and_dgrad(case):
+    """F(4x4,3x3): 36 multiplies per 4x4 tile.  Its f32 error is larger than F(2x2)'s (coefficients up to 8 and 1/24) -- judged
+    against an f64 convolution it has to stay within 1e-4 of the output scale, the bar of every f32 kernel here."""
+    from objectdetection_ssd_amd import ops
+    n, h, w, ci, co = case
+    dev = _dev()
+    full = (n, h, w, ci, co, 3, 1, 1, 1)
+    x, wt, b = _conv_data(full, seed=81)
+    x64 = x.double().requires_grad_(True)
+    y64 = F.conv2d(x64, wt.double(), b.double(), padding=1)
+    dy = torch.randn(y64.shape, generator=torch.Generator().manual_seed(82))
+    y64.backward(dy.double())
+    g = ops.make_geom(*full)
+    ld = ops.pad32(co)
+    uf, ub = ops.wino_weights(wt.to(dev), ld, mo=4)
+    assert uf.shape[0] == 36
+    yd = ops.conv2d_fwd_wino(_nhwc(x).to(dev), uf, b.to(dev), g, False, ld=ld)
+    _close(yd[..., :co], _nhwc(y64.detach()), what=f"winograd F(4x4) fwd {case}")
+    dy_p = torch.zeros(n, h, w, ld)
+    dy_p[..., :co] = _nhwc(dy)
+    dx = ops.conv2d_dgrad_wino(dy_p.to(dev), ub, g)
+    _close(dx, _nhwc(x64.grad), what=f"winograd F(4x4) dgrad {case}")
+    e = float((yd[..., :co].cpu().double() - _nhwc(y64.detach())).abs().max() / max(1.0, float(y64.abs().max())))
+    print(f"F(4x4,3x3) {case}: max err / scale {e:.2e}")
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
 def test_winograd_f2x2_3x3_forward_and_dgrad(case):
     """Winograd F(2x2,3x3) == the direct 3x3 / stride 1 / pad 1 convolution (odd maps, padded channel counts, fused bias + ReLU,
     dgrad with accumulate + mask); the transforms cost a few ulps: 1e-4 of the output scale like every f32 kernel here."""

@@ -87,7 +87,7 @@ def main():
             print(f"wgrad patch {name:8s} " + "  ".join(row), flush=True)
         if which == "wino" and (k, s, pad, dil) == (3, 1, 1, 1) and ci % 32 == 0:
             uf, ub = ops.wino_weights(w, ld)
-            print("wino", name, "ws", lib.ssd_conv3x3_wino_workspace(g, 0) / 1e6, "MB", flush=True)
+            print("wino", name, "ws", lib.ssd_conv3x3_wino_workspace(g, 0, 2) / 1e6, "MB", flush=True)
             ms0 = timeit(lambda: ops.conv2d_fwd(x, wf, b, g, True, ld=ld, out=dy))
             ms1 = timeit(lambda: ops.conv2d_fwd_wino(x, uf, b, g, True, ld=ld))
             ms2 = timeit(lambda: ops.conv2d_dgrad(dy, wb, g, dx, x, False))
@@ -95,6 +95,10 @@ def main():
             ms4 = timeit(lambda: ops.conv2d_wgrad(x, dy, g, ld, True))
             ms5 = timeit(lambda: ops.conv2d_wgrad_wino(x, dy, g, ld, True))
             print(f"wino {name:8s} wgrad direct {ms4:.3f} ms ({fl / ms4 / 1e9:.0f} TF/s)  winograd {ms5:.3f} ms ({fl / ms5 / 1e9:.0f} TF/s alg.)", flush=True)
+            uf4, ub4 = ops.wino_weights(w, ld, mo=4)
+            ms6 = timeit(lambda: ops.conv2d_fwd_wino(x, uf4, b, g, True, ld=ld))
+            ms7 = timeit(lambda: ops.conv2d_dgrad_wino(dy, ub4, g, dx, x, False))
+            print(f"wino {name:8s} F(4x4): fwd {ms6:.3f} ms ({fl / ms6 / 1e9:.0f} TF/s alg.)  dgrad {ms7:.3f} ms ({fl / ms7 / 1e9:.0f} TF/s alg.)", flush=True)
             print(f"wino {name:8s} fwd direct {ms0:.3f} ms ({fl / ms0 / 1e9:.0f} TF/s)  winograd {ms1:.3f} ms ({fl / ms1 / 1e9:.0f} TF/s alg.)   "
                   f"dgrad direct {ms2:.3f} ms  winograd {ms3:.3f} ms ({fl / ms3 / 1e9:.0f} TF/s alg.)", flush=True)
         if which == "occ":                      # blocks per CU capped through extra dynamic LDS (64x64 tile, 18 KB static)
