@@ -207,6 +207,7 @@ def main():
                          "(SSD_resnet34 eval forward at 224x224; batched per-class NMS decode of SSD300-shaped outputs): replicas only")
     ap.add_argument("--wino-min-ci", type=int, default=-1, help="tuning aid: Winograd for 3x3/s1 layers with at least this many input channels (0 = off)")
     ap.add_argument("--wino-tile", type=int, default=-1, choices=(-1, 2, 4), help="tuning aid: Winograd output tile of forward / dgrad")
+    ap.add_argument("--wino-wgrad-min-ci", type=int, default=-1, help="tuning aid: Winograd weight gradient from this many input channels")
     ap.add_argument("--wino-wgrad-max-hw", type=int, default=-1, help="tuning aid: Winograd weight gradient on maps up to this size (0 = off)")
     ap.add_argument("--igemm-lds-pad", type=int, default=-1, help="tuning aid: extra dynamic LDS bytes per igemm block (-1 = library default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -248,6 +249,8 @@ def main():
         net._engine.WINO_MIN_CI = args.wino_min_ci
     if args.wino_tile > 0:
         net._engine.WINO_TILE = args.wino_tile
+    if args.wino_wgrad_min_ci >= 0:
+        net._engine.WINO_WGRAD_MIN_CI = args.wino_wgrad_min_ci
     if args.wino_wgrad_max_hw >= 0:
         net._engine.WINO_WGRAD_MAX_HW = args.wino_wgrad_max_hw
     trainer = FlatSGDDataParallel(net, lr=1e-4, momentum=0.9, weight_decay=5e-4)

@@ -139,8 +139,8 @@ int ssd_conv3x3_wino_dgrad(const float* dy, int ldy, const float* U_bwd, int Co_
                            int accumulate, const ssd_conv_geom* g, int mo, void* workspace, size_t workspace_bytes, void* stream);
 /* Winograd weight gradient: dg = G^T [ sum over tiles (A dy A^T) (x) (B^T d B) ] G -- transposed transforms of dy and x, sixteen
  * batched (split-K) f32-MFMA GEMMs over the tile dimension, inverse transform to OIHW; dbias (may be NULL) by column sums. */
-size_t ssd_conv3x3_wino_wgrad_workspace(const ssd_conv_geom* g, int ldy);
-int ssd_conv3x3_wino_wgrad(const float* x, const float* dy, int ldy, float* dw_oihw, float* dbias, const ssd_conv_geom* g,
+size_t ssd_conv3x3_wino_wgrad_workspace(const ssd_conv_geom* g, int ldy, int mo);
+int ssd_conv3x3_wino_wgrad(const float* x, const float* dy, int ldy, float* dw_oihw, float* dbias, const ssd_conv_geom* g, int mo,
                            void* workspace, size_t workspace_bytes, void* stream);
 int ssd_tune_set_igemm(int tile, int nbuf);
 int ssd_tune_set_igemm_stamps(uint64_t* device_buffer);   /* diagnostic: per-block shader-clock stamps (see conv_igemm.hip) */

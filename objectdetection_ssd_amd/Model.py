@@ -170,7 +170,8 @@ class _Engine:
         return ent[2], ent[3]
 
     WINO_TILE = 4                 # forward / dgrad output tile: F(4x4,3x3) (36 multiplies per 16 outputs; ~1e-5 of the output scale) or 2
-    WINO_WGRAD_MAX_HW = 40        # Winograd weight gradient on maps up to this size (conv4_x, conv5_x: -25 % / -15 %; conv3_x: -4 %)
+    WINO_WGRAD_MAX_HW = 80        # Winograd weight gradient on maps up to this size and from this many input channels: with F(4x4)
+    WINO_WGRAD_MIN_CI = 256       # conv3_2 ... conv5_3 gain 25-50 %; the 150-pixel / 128-channel layers lose to the fused direct kernel
     WINO_MIN_CI = 64              # measured in the step with F(4x4): 256 -> 836, 128 -> 872, 64 -> 879 images/s (F(2x2): only >= 256 paid)
 
     def _wino_ok(self, g) -> bool:
@@ -323,9 +324,9 @@ class _Engine:
                 g = aux[op["y"]]
                 xin = T[op["x"]]
                 if need[op["p"] + ".weight"] or need[op["p"] + ".bias"]:
-                    if self._wino_ok(g) and g.H <= self.WINO_WGRAD_MAX_HW and g.Co % 4 == 0:
+                    if self._wino_ok(g) and g.H <= self.WINO_WGRAD_MAX_HW and g.Ci >= self.WINO_WGRAD_MIN_CI and g.Co % 4 == 0:
                         dw, db = self._timed("wgrad " + op["p"], "winograd_f2x2_3x3", ops.conv_flops(g),
-                                             lambda: ops.conv2d_wgrad_wino(xin, dy, g, g.Co, True))
+                                             lambda: ops.conv2d_wgrad_wino(xin, dy, g, g.Co, True, mo=self.WINO_TILE))
                     else:
                         dw, db = self._timed("wgrad " + op["p"], ops.wgrad_tile(g) if self.prof is not None else "", ops.conv_flops(g),
                                              lambda: ops.conv2d_wgrad(xin, dy, g, g.Co, True, bf16=self.bf16))

@@ -416,6 +416,104 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
     }
 }
 
+// F(4x4,3x3) weight gradient pieces: transposed transforms into rows [plane][channel][tile] (36 planes), inverse transform.
+template <int MODE>
+__global__ __launch_bounds__(256) void wino4_xform_t_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int H, int W, int C,
+                                                            int TH, int TW, int Tpad) {
+    __shared__ float tr[6][32][33];
+    const int C4 = C >> 2;
+    const int cgroups = (C4 + 7) / 8;
+    const size_t tiles = (size_t)N * TH * TW;
+    const int tile_blocks = Tpad / 32;
+    const int q = threadIdx.x & 7, tl = threadIdx.x >> 3;
+    for (int blk = blockIdx.x; blk < tile_blocks * cgroups; blk += gridDim.x) {
+        const int cg = blk % cgroups;
+        const size_t tile0 = (size_t)(blk / cgroups) * 32, tile = tile0 + tl;
+        const int c4 = cg * 8 + q;
+        const bool live = tile < tiles && c4 < C4;
+        const int tw = live ? (int)(tile % TW) : 0, th = live ? (int)((tile / TW) % TH) : 0, n = live ? (int)(tile / ((size_t)TW * TH)) : 0;
+        f32x4 t[6][6];                                       // first-dimension transform, one source column at a time
+        constexpr int NS = MODE == 0 ? 6 : 4;                // source patch edge: 6x6 input pixels / 4x4 dy pixels
+#pragma unroll
+        for (int b2 = 0; b2 < NS; ++b2) {
+            f32x4 d[NS];
+#pragma unroll
+            for (int a = 0; a < NS; ++a) {
+                const int ih = MODE == 0 ? 4 * th - 1 + a : 4 * th + a, iw = MODE == 0 ? 4 * tw - 1 + b2 : 4 * tw + b2;
+                const bool ok = live && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                d[a] = ok ? *reinterpret_cast<const f32x4*>(src + (((size_t)n * H + ih) * W + iw) * C + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    const float cf = MODE == 0 ? W4_BT[a][k] : W4_AT[k][a];      // B^T d   |   A dy  (A = (A^T)^T)
+                    if (cf != 0.f) acc += cf * d[k];
+                }
+                t[a][b2] = acc;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {                        // planes (a, 0..5): second-dimension transform, then out through LDS
+            __syncthreads();
+#pragma unroll
+            for (int b2 = 0; b2 < 6; ++b2) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    const float cf = MODE == 0 ? W4_BT[b2][k] : W4_AT[k][b2];
+                    if (cf != 0.f) acc += cf * t[a][k];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tr[b2][q * 4 + e][tl] = acc[e];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 24; ++it) {
+                const int row = it * 8 + (threadIdx.x >> 5), col = threadIdx.x & 31;        // row = plane-in-group * 32 + channel
+                const int b2 = row >> 5, cl = row & 31;
+                const int c = cg * 32 + cl;
+                if (c < C) dst[((size_t)(a * 6 + b2) * C + c) * Tpad + tile0 + col] = tr[b2][cl][col];
+            }
+        }
+    }
+}
+
+__global__ void wino4_wgrad_finish_kernel(const float* __restrict__ Zs, float* __restrict__ dw, int Co, int Ci, int ksplit) {
+    const size_t total = (size_t)Co * Ci;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float t[3][6];                                       // G^T Z, one plane column at a time
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            float z[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                float sum = 0.f;
+                for (int k = 0; k < ksplit; ++k) sum += Zs[((size_t)(a * 6 + b) * ksplit + k) * total + i];
+                z[a] = sum;
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                float acc = 0.f;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) acc += W4_G[a][r] * z[a];
+                t[r][b] = acc;
+            }
+        }
+        float* o = dw + i * 9;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s2 = 0; s2 < 3; ++s2) {
+                float acc = 0.f;
+#pragma unroll
+                for (int b = 0; b < 6; ++b) acc += t[r][b] * W4_G[b][s2];
+                o[r * 3 + s2] = acc;
+            }
+    }
+}
+
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 inline int grid_for(size_t total) { const size_t b = (total + 255) / 256; return (int)(b > 8192 ? 8192 : (b == 0 ? 1 : b)); }
 
@@ -501,41 +599,42 @@ extern "C" int ssd_conv3x3_wino_dgrad(const float* dy, int ldy, const float* U_b
 }
 
 namespace {
-struct WinoWgradPlan { int TH, TW, Tpad, ks, cdy; size_t tiles, yb, vb, zb, pb; };
-WinoWgradPlan wino_wgrad_plan(const ssd_conv_geom* g, int ldy) {
+struct WinoWgradPlan { int TH, TW, Tpad, ks, cdy, P; size_t tiles, yb, vb, zb, pb; };
+WinoWgradPlan wino_wgrad_plan(const ssd_conv_geom* g, int ldy, int mo) {
     WinoWgradPlan w;
-    w.TH = (g->H + 1) / 2; w.TW = (g->W + 1) / 2;
+    w.P = (mo + 2) * (mo + 2);
+    w.TH = (g->H + mo - 1) / mo; w.TW = (g->W + mo - 1) / mo;
     w.tiles = (size_t)g->N * w.TH * w.TW;
     w.Tpad = (int)((w.tiles + 31) / 32 * 32);
     w.cdy = ldy;
-    const int bp = ((g->Co + 63) / 64) * ((g->Ci + 63) / 64) * 16;       // 64x64 output tiles over the sixteen planes
+    const int bp = ((g->Co + 63) / 64) * ((g->Ci + 63) / 64) * w.P;      // 64x64 output tiles over the planes
     int ks = (1536 + bp - 1) / bp;                                         // fill the ~1500 resident-block slots
     const int ksteps = w.Tpad / 32;
     if (ks > ksteps / 8) ks = ksteps / 8;
     if (ks < 1) ks = 1;
     const int per = (ksteps + ks - 1) / ks;
     w.ks = (ksteps + per - 1) / per;
-    w.yb = align256((size_t)16 * ldy * w.Tpad * 4);
-    w.vb = align256((size_t)16 * g->Ci * w.Tpad * 4);
-    w.zb = align256((size_t)16 * w.ks * g->Co * g->Ci * 4);
+    w.yb = align256((size_t)w.P * ldy * w.Tpad * 4);
+    w.vb = align256((size_t)w.P * g->Ci * w.Tpad * 4);
+    w.zb = align256((size_t)w.P * w.ks * g->Co * g->Ci * 4);
     w.pb = align256((size_t)256 * ldy * 4);
     return w;
 }
 }  // namespace
 
-extern "C" size_t ssd_conv3x3_wino_wgrad_workspace(const ssd_conv_geom* g, int ldy) {
-    if (!wino_geom_ok(g) || ldy < g->Co) return 0;
-    const WinoWgradPlan w = wino_wgrad_plan(g, ldy);
+extern "C" size_t ssd_conv3x3_wino_wgrad_workspace(const ssd_conv_geom* g, int ldy, int mo) {
+    if (!wino_geom_ok(g) || ldy < g->Co || (mo != 2 && mo != 4)) return 0;
+    const WinoWgradPlan w = wino_wgrad_plan(g, ldy, mo);
     return w.yb + w.vb + w.zb + w.pb;
 }
 
-// dw (Co,Ci,3,3) OIHW and, if asked, dbias (Co) from x (N,H,W,Ci) and dy (N,H,W,ldy; columns >= Co zero)
+// dw (Co,Ci,3,3) OIHW and, if asked, dbias (Co) from x (N,H,W,Ci) and dy (N,H,W,ldy; columns >= Co zero); mo = 2 or 4
 extern "C" int ssd_conv3x3_wino_wgrad(const float* x, const float* dy, int ldy, float* dw_oihw, float* dbias, const ssd_conv_geom* g,
-                                      void* workspace, size_t workspace_bytes, void* stream) {
+                                      int mo, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !dy || !dw_oihw || !workspace) return SSD_ERR_NULL;
-    if (!wino_geom_ok(g) || g->Ci % 4 != 0 || ldy % 4 != 0 || ldy < g->Co) return SSD_ERR_BAD_SHAPE;
+    if (!wino_geom_ok(g) || g->Ci % 4 != 0 || ldy % 4 != 0 || ldy < g->Co || (mo != 2 && mo != 4)) return SSD_ERR_BAD_SHAPE;
     if (!ssd_aligned16(x) || !ssd_aligned16(dy) || !ssd_aligned16(workspace)) return SSD_ERR_ALIGN;
-    const WinoWgradPlan w = wino_wgrad_plan(g, ldy);
+    const WinoWgradPlan w = wino_wgrad_plan(g, ldy, mo);
     if (w.tiles >= (1ull << 31)) return SSD_ERR_BAD_SHAPE;
     if (workspace_bytes < w.yb + w.vb + w.zb + w.pb) return SSD_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -545,15 +644,21 @@ extern "C" int ssd_conv3x3_wino_wgrad(const float* x, const float* dy, int ldy, 
     float* Zs = reinterpret_cast<float*>(base + w.yb + w.vb);
     float* part = reinterpret_cast<float*>(base + w.yb + w.vb + w.zb);
     const int gy = (w.Tpad / 32) * ((ldy / 4 + 7) / 8), gx = (w.Tpad / 32) * ((g->Ci / 4 + 7) / 8);
-    hipLaunchKernelGGL(wino_xform_t_kernel<1>, dim3(gy > 16384 ? 16384 : gy), dim3(256), 0, st, dy, Yt, g->N, g->H, g->W, ldy, w.TH, w.TW,
-                       w.Tpad);
+    const dim3 gyd(gy > 16384 ? 16384 : gy), gxd(gx > 16384 ? 16384 : gx);
+    if (mo == 2) {
+        hipLaunchKernelGGL(wino_xform_t_kernel<1>, gyd, dim3(256), 0, st, dy, Yt, g->N, g->H, g->W, ldy, w.TH, w.TW, w.Tpad);
+        hipLaunchKernelGGL(wino_xform_t_kernel<0>, gxd, dim3(256), 0, st, x, Vt, g->N, g->H, g->W, g->Ci, w.TH, w.TW, w.Tpad);
+    } else {
+        hipLaunchKernelGGL(wino4_xform_t_kernel<1>, gyd, dim3(256), 0, st, dy, Yt, g->N, g->H, g->W, ldy, w.TH, w.TW, w.Tpad);
+        hipLaunchKernelGGL(wino4_xform_t_kernel<0>, gxd, dim3(256), 0, st, x, Vt, g->N, g->H, g->W, g->Ci, w.TH, w.TW, w.Tpad);
+    }
     SSD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(wino_xform_t_kernel<0>, dim3(gx > 16384 ? 16384 : gx), dim3(256), 0, st, x, Vt, g->N, g->H, g->W, g->Ci, w.TH, w.TW,
-                       w.Tpad);
-    SSD_CHECK_LAUNCH();
-    if (int e = ssd_internal_gemm_batched(Yt, Vt, Zs, g->Co, w.Tpad, g->Ci, g->Ci, 16, (size_t)ldy * w.Tpad, (size_t)g->Ci * w.Tpad, w.ks, st))
+    if (int e = ssd_internal_gemm_batched(Yt, Vt, Zs, g->Co, w.Tpad, g->Ci, g->Ci, w.P, (size_t)ldy * w.Tpad, (size_t)g->Ci * w.Tpad, w.ks, st))
         return e;
-    hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3(grid_for((size_t)g->Co * g->Ci)), dim3(256), 0, st, Zs, dw_oihw, g->Co, g->Ci, w.ks);
+    if (mo == 2)
+        hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3(grid_for((size_t)g->Co * g->Ci)), dim3(256), 0, st, Zs, dw_oihw, g->Co, g->Ci, w.ks);
+    else
+        hipLaunchKernelGGL(wino4_wgrad_finish_kernel, dim3(grid_for((size_t)g->Co * g->Ci)), dim3(256), 0, st, Zs, dw_oihw, g->Co, g->Ci, w.ks);
     SSD_CHECK_LAUNCH();
     if (dbias) {
         const size_t M = (size_t)g->N * g->H * g->W;

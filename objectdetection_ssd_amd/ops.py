@@ -651,18 +651,18 @@ def conv2d_dgrad_wino(dy: torch.Tensor, u_bwd: torch.Tensor, g: ConvGeom, dx: Op
     return dx
 
 
-def conv2d_wgrad_wino(x: torch.Tensor, dy: torch.Tensor, g: ConvGeom, ldy: int, want_bias: bool = True):
-    """Winograd F(2x2,3x3) weight gradient -> (dw (Co,Ci,3,3) OIHW, dbias (Co,) or None)."""
+def conv2d_wgrad_wino(x: torch.Tensor, dy: torch.Tensor, g: ConvGeom, ldy: int, want_bias: bool = True, mo: int = 2):
+    """Winograd F(mo x mo, 3x3) weight gradient, mo = 2 or 4 -> (dw (Co,Ci,3,3) OIHW, dbias (Co,) or None)."""
     _req(x, "x"); _req(dy, "dy")
     if tuple(x.shape) != (g.N, g.H, g.W, g.Ci) or dy.numel() != g.N * g.H * g.W * ldy:
         raise ValueError("conv2d_wgrad_wino: shapes do not match the geometry")
     lib = _lib.load()
-    nbytes = lib.ssd_conv3x3_wino_wgrad_workspace(C.byref(g), ldy)
+    nbytes = lib.ssd_conv3x3_wino_wgrad_workspace(C.byref(g), ldy, mo)
     if nbytes == 0:
         raise ValueError("conv2d_wgrad_wino: not a 3x3 / stride 1 / pad 1 geometry")
     ws = workspace(nbytes, x.device, "wino")
     dw = torch.empty((g.Co, g.Ci, 3, 3), device=x.device, dtype=torch.float32)
     db = torch.empty((g.Co,), device=x.device, dtype=torch.float32) if want_bias else None
-    check(lib.ssd_conv3x3_wino_wgrad(x.data_ptr(), dy.data_ptr(), ldy, dw.data_ptr(), _ptr(db), C.byref(g), ws.data_ptr(), ws.numel(),
+    check(lib.ssd_conv3x3_wino_wgrad(x.data_ptr(), dy.data_ptr(), ldy, dw.data_ptr(), _ptr(db), C.byref(g), mo, ws.data_ptr(), ws.numel(),
                                      _stream()), "conv2d_wgrad_wino")
     return dw, db

@@ -557,8 +557,15 @@ def test_winograd_f4x4_3x3_forward_and_dgrad(case):
     dy_p[..., :co] = _nhwc(dy)
     dx = ops.conv2d_dgrad_wino(dy_p.to(dev), ub, g)
     _close(dx, _nhwc(x64.grad), what=f"winograd F(4x4) dgrad {case}")
-    e = float((yd[..., :co].cpu().double() - _nhwc(y64.detach())).abs().max() / max(1.0, float(y64.abs().max())))
-    print(f"F(4x4,3x3) {case}: max err / scale {e:.2e}")
+    e = float((yd[..., :co].cpu().double() - _nhwc(y64.detach())).abs().max() / max(1.0, float(y64.detach().abs().max())))
+    # weight gradient in the F(4x4) domain against f64
+    w64 = wt.double().requires_grad_(True); b64 = b.double().requires_grad_(True)
+    F.conv2d(x.double(), w64, b64, padding=1).backward(dy.double())
+    dw, db = ops.conv2d_wgrad_wino(_nhwc(x).to(dev), dy_p.to(dev), g, ld, True, mo=4)
+    _close(dw, w64.grad, tol=2e-4, what=f"winograd F(4x4) wgrad {case}")
+    _close(db, b64.grad, tol=2e-4, what=f"winograd F(4x4) bias grad {case}")
+    ew = float((dw.cpu().double() - w64.grad).abs().max() / max(1.0, float(w64.grad.abs().max())))
+    print(f"F(4x4,3x3) {case}: fwd max err / scale {e:.2e}, wgrad {ew:.2e}")
 
 
 @pytest.mark.parametrize("case", WINO_CASES)

@@ -98,6 +98,8 @@ def main():
             uf4, ub4 = ops.wino_weights(w, ld, mo=4)
             ms6 = timeit(lambda: ops.conv2d_fwd_wino(x, uf4, b, g, True, ld=ld))
             ms7 = timeit(lambda: ops.conv2d_dgrad_wino(dy, ub4, g, dx, x, False))
+            ms8 = timeit(lambda: ops.conv2d_wgrad_wino(x, dy, g, ld, True, mo=4))
+            print(f"wino {name:8s} F(4x4) wgrad {ms8:.3f} ms ({fl / ms8 / 1e9:.0f} TF/s alg.)", flush=True)
             print(f"wino {name:8s} F(4x4): fwd {ms6:.3f} ms ({fl / ms6 / 1e9:.0f} TF/s alg.)  dgrad {ms7:.3f} ms ({fl / ms7 / 1e9:.0f} TF/s alg.)", flush=True)
             print(f"wino {name:8s} fwd direct {ms0:.3f} ms ({fl / ms0 / 1e9:.0f} TF/s)  winograd {ms1:.3f} ms ({fl / ms1 / 1e9:.0f} TF/s alg.)   "
                   f"dgrad direct {ms2:.3f} ms  winograd {ms3:.3f} ms ({fl / ms3 / 1e9:.0f} TF/s alg.)", flush=True)
