@@ -142,6 +142,10 @@ int ssd_conv3x3_wino_dgrad(const float* dy, int ldy, const float* U_bwd, int Co_
 size_t ssd_conv3x3_wino_wgrad_workspace(const ssd_conv_geom* g, int ldy, int mo);
 int ssd_conv3x3_wino_wgrad(const float* x, const float* dy, int ldy, float* dw_oihw, float* dbias, const ssd_conv_geom* g, int mo,
                            void* workspace, size_t workspace_bytes, void* stream);
+/* Measurement aid: arm / read back per-launch timings (library-owned HIP events) of the batched Winograd GEMM kernel.
+ * collect() returns the number of (milliseconds, executed FLOPs) pairs written; the caller synchronises the stream first. */
+int ssd_prof_gemm_begin(void);
+int ssd_prof_gemm_collect(float* ms_out, double* flops_out, int max);
 int ssd_tune_set_igemm(int tile, int nbuf);
 int ssd_tune_set_igemm_stamps(uint64_t* device_buffer);   /* diagnostic: per-block shader-clock stamps (see conv_igemm.hip) */
 int ssd_tune_set_igemm_lds_pad(int bytes);   /* extra dynamic LDS per block: caps resident blocks per CU (experiments) */

@@ -1213,6 +1213,12 @@ extern "C" int ssd_tune_set_igemm_lds_pad(int bytes) {
     return SSD_OK;
 }
 
+constexpr int PROF_MAX = 1024;
+static bool g_prof_on = false;
+static int g_prof_n = 0;
+static hipEvent_t g_prof_ev[2 * PROF_MAX] = {};
+static double g_prof_flops[PROF_MAX];
+
 // Internal (not part of the C ABI): `nbatch` independent GEMMs out[b][M][N] = a[b][M][K] * w[b][N][K]^T on the 64x64 f32 kernel
 // (the sixteen planes of a Winograd F(2x2,3x3) convolution).  K % 32 == 0; rows of w beyond n_rows read as zero.
 // ksplit > 1: every GEMM is cut into K slices that write raw partial tiles to out[b][slice][M][N] (the caller adds them up).
@@ -1237,7 +1243,37 @@ __attribute__((visibility("hidden"))) int ssd_internal_gemm_batched(const float*
         p.slab = out;
     }
     p.nbatch = nbatch; p.batch_a = batch_a_elems; p.batch_w = batch_w_elems; p.batch_out = (size_t)M * N;
+    if (g_prof_on && g_prof_n < PROF_MAX) {              // measurement aid: this launch alone between two events of the library
+        const int i = g_prof_n++;
+        g_prof_flops[i] = 2.0 * M * K * N * nbatch;
+        (void)hipEventRecord(g_prof_ev[2 * i], st);
+        const int e = launch_igemm<64, 64, 2, 2, 1, true>(p, st);
+        (void)hipEventRecord(g_prof_ev[2 * i + 1], st);
+        return e;
+    }
     return launch_igemm<64, 64, 2, 2, 1, true>(p, st);
+}
+
+// Measurement aid (bench.py): time every batched Winograd GEMM launch by itself, so that the kernel's own rate can be held
+// against its rocprof row.  begin() creates the events on first use and arms the recorder; collect() (after the caller has
+// synchronised) returns up to `max` (milliseconds, executed FLOPs) pairs in launch order and disarms it.
+extern "C" int ssd_prof_gemm_begin(void) {
+    for (int i = 0; i < 2 * PROF_MAX; ++i)
+        if (g_prof_ev[i] == nullptr && hipEventCreate(&g_prof_ev[i]) != hipSuccess) return SSD_ERR_LAUNCH;
+    g_prof_n = 0;
+    g_prof_on = true;
+    return SSD_OK;
+}
+extern "C" int ssd_prof_gemm_collect(float* ms_out, double* flops_out, int max) {
+    g_prof_on = false;
+    if (!ms_out || !flops_out) return SSD_ERR_NULL;
+    int n = 0;
+    for (; n < g_prof_n && n < max; ++n) {
+        if (hipEventElapsedTime(&ms_out[n], g_prof_ev[2 * n], g_prof_ev[2 * n + 1]) != hipSuccess) return -n - 100;
+        flops_out[n] = g_prof_flops[n];
+    }
+    g_prof_n = 0;
+    return n;
 }
 
 // ---- "f32 from three bf16 limbs" entry points (opt-in; see igemm_x3_kernel) -----------------------------------
