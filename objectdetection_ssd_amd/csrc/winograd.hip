@@ -256,27 +256,46 @@ __global__ void wino_wgrad_finish_kernel(const float* __restrict__ Zs, float* __
     }
 }
 
-// db[c] = sum over pixels of dy[pixel][c]: per-block partial rows, then a fixed-order sum over the blocks
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ dy, float* __restrict__ part, size_t M, int ld, int C) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int c0 = 0; c0 < C; c0 += 64) {
-        const int c = c0 + lane;
-        float s = 0.f;
-        if (c < C)
-            for (size_t m = (size_t)blockIdx.x * 4 + wv; m < M; m += (size_t)gridDim.x * 4) s += dy[m * ld + c];
-        red[wv][lane] = s;
+// db[c] = sum over pixels of dy[pixel][c]: per-block partial rows, then a fixed-order sum over the blocks (reproducible).
+// partial: a block covers 1024 / C4' consecutive pixel rows per sweep with 16-byte loads along the channels (C4' = channel quads
+// rounded up to a power of two <= 256); rows of one block are combined through LDS in row order.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ dy, float* __restrict__ part, size_t M, int ld, int C,
+                                                             int cq_pow2) {
+    __shared__ f32x4 red[256];
+    const int C4 = (C + 3) / 4, rpi = 256 / cq_pow2;            // rows per sweep
+    const int cq = threadIdx.x % cq_pow2, r = threadIdx.x / cq_pow2;
+    for (int q0 = 0; q0 < C4; q0 += cq_pow2) {
+        const int q = q0 + cq;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (q < C4 && q * 4 + 3 < ld)
+            for (size_t m = (size_t)blockIdx.x * rpi + r; m < M; m += (size_t)gridDim.x * rpi) s += *reinterpret_cast<const f32x4*>(dy + m * ld + q * 4);
+        red[threadIdx.x] = s;
         __syncthreads();
-        if (wv == 0 && c < C) part[(size_t)blockIdx.x * C + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (r == 0 && q < C4) {
+            f32x4 t = red[cq];
+            for (int k = 1; k < rpi; ++k) t += red[k * cq_pow2 + cq];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (q * 4 + e < C) part[(size_t)blockIdx.x * C + q * 4 + e] = t[e];
+        }
         __syncthreads();
     }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ db, int nblk, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C) {
-        float s = 0.f;
-        for (int k = 0; k < nblk; ++k) s += part[(size_t)k * C + c];
-        db[c] = s;
+// final: 16 channels per block, 16 lanes stride over the partial rows of each channel, combined in lane order
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ db, int nblk, int C) {
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, l = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    float s = 0.f;
+    if (c < C)
+        for (int k = l; k < nblk; k += 16) s += part[(size_t)k * C + c];
+    red[l][cl] = s;
+    __syncthreads();
+    if (l == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
+        db[c] = t;
     }
 }
 
@@ -599,6 +618,7 @@ extern "C" int ssd_conv3x3_wino_dgrad(const float* dy, int ldy, const float* U_b
 }
 
 namespace {
+constexpr int COLSUM_BLOCKS = 512;
 struct WinoWgradPlan { int TH, TW, Tpad, ks, cdy, P; size_t tiles, yb, vb, zb, pb; };
 WinoWgradPlan wino_wgrad_plan(const ssd_conv_geom* g, int ldy, int mo) {
     WinoWgradPlan w;
@@ -617,7 +637,7 @@ WinoWgradPlan wino_wgrad_plan(const ssd_conv_geom* g, int ldy, int mo) {
     w.yb = align256((size_t)w.P * ldy * w.Tpad * 4);
     w.vb = align256((size_t)w.P * g->Ci * w.Tpad * 4);
     w.zb = align256((size_t)w.P * w.ks * g->Co * g->Ci * 4);
-    w.pb = align256((size_t)256 * ldy * 4);
+    w.pb = align256((size_t)COLSUM_BLOCKS * ldy * 4);
     return w;
 }
 }  // namespace
@@ -662,9 +682,11 @@ extern "C" int ssd_conv3x3_wino_wgrad(const float* x, const float* dy, int ldy, 
     SSD_CHECK_LAUNCH();
     if (dbias) {
         const size_t M = (size_t)g->N * g->H * g->W;
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3(256), dim3(256), 0, st, dy, part, M, ldy, g->Co);
+        int cq = 1;
+        while (cq < (g->Co + 3) / 4 && cq < 256) cq <<= 1;
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(COLSUM_BLOCKS), dim3(256), 0, st, dy, part, M, ldy, g->Co, cq);
         SSD_CHECK_LAUNCH();
-        hipLaunchKernelGGL(colsum_final_kernel, dim3((g->Co + 255) / 256), dim3(256), 0, st, part, dbias, 256, g->Co);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((g->Co + 15) / 16), dim3(256), 0, st, part, dbias, COLSUM_BLOCKS, g->Co);
         SSD_CHECK_LAUNCH();
     }
     return SSD_OK;
