@@ -305,8 +305,12 @@ class _Engine:
                 xin = T[op["x"]]
                 a4 = 4 * op["a"]
                 if any(need[pre + s] for s in ("_bb.weight", "_bb.bias", "_cl.weight", "_cl.bias")):
-                    dw, db = self._timed("wgrad " + pre, ops.wgrad_tile(g) if self.prof is not None else "", ops.conv_flops(g),
-                                         lambda: ops.conv2d_wgrad(xin, dy, g, co_pad, True, bf16=self.bf16))
+                    if self._wino_ok(g) and 19 <= g.H <= self.WINO_WGRAD_MAX_HW and g.Ci >= self.WINO_WGRAD_MIN_CI:
+                        dw, db = self._timed("wgrad " + pre, "winograd_f2x2_3x3", ops.conv_flops(g),
+                                             lambda: ops.conv2d_wgrad_wino(xin, dy, g, co_pad, True, mo=self.WINO_TILE))
+                    else:
+                        dw, db = self._timed("wgrad " + pre, ops.wgrad_tile(g) if self.prof is not None else "", ops.conv_flops(g),
+                                             lambda: ops.conv2d_wgrad(xin, dy, g, co_pad, True, bf16=self.bf16))
                     grads[pre + "_bb.weight"], grads[pre + "_cl.weight"] = dw[:a4], dw[a4:]
                     grads[pre + "_bb.bias"], grads[pre + "_cl.bias"] = db[:a4], db[a4:]
                 if self._wino_ok(g):
