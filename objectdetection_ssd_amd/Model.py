@@ -453,6 +453,17 @@ class SSD_300(nn.Module):
         self._engine.x3 = value == "f32x3"
         self._engine._wcache.clear()
 
+    @property
+    def winograd(self) -> bool:
+        """f32 mode: Winograd F(4x4,3x3) for forward / dgrad of the 3x3 stride-1 layers and the deep weight gradients (default on:
+        ~1e-5 of the output scale from the direct sum, 1.5x the step rate).  False = exact-f32 MFMA direct kernels everywhere."""
+        return self._engine.wino
+
+    @winograd.setter
+    def winograd(self, value: bool) -> None:
+        self._engine.wino = bool(value)
+        self._engine._wcache.clear()
+
     def get_norm(self):
         return torch.norm(self.fc6) + torch.norm(self.fc6_b) + torch.norm(self.fc7) + torch.norm(self.fc7_b)
 

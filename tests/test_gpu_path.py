@@ -870,16 +870,16 @@ def test_winograd_engine_equals_direct_engine():
     boxes, classes = synth_gt(np.random.default_rng(17), 2)
     bx, cl = [_t(b) for b in boxes], [_t(c) for c in classes]
     res = {}
+    assert net.winograd is True                     # default
     for mode in (True, False):
-        net._engine.wino = mode
-        net._engine._wcache.clear()
+        net.winograd = mode
         net.zero_grad()
         loc, conf = net(x)
         l1, l2 = Losses.ssd((loc, conf), cl, bx)
         (l1 + l2).backward()
         res[mode] = (loc.detach().clone(), conf.detach().clone(), l1.item(), l2.item(),
                      {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None})
-    net._engine.wino = True
+    net.winograd = True
     (la, ca, a1, a2, ga), (lb, cb, b1, b2, gb) = res[True], res[False]
     assert float((la - lb).abs().max()) <= 1e-4 * max(1.0, float(lb.abs().max()))
     assert float((ca - cb).abs().max()) <= 1e-4 * max(1.0, float(cb.abs().max()))
