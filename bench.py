@@ -316,6 +316,11 @@ def main():
                       "step_tflops_per_gpu": round(TRAIN_GFLOP_PER_IMAGE * ips / world / 1e3, 2),
                       "step_frac_of_f32_mfma_peak": round(TRAIN_GFLOP_PER_IMAGE * ips / world / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
                       "last_loss_per_rank": round(loss, 5), "n_pos_global_last": n_pos,
+                      "conv_algorithm": ("f32 throughout; Winograd F(%dx%d,3x3) for forward / dgrad of the 3x3 stride-1 layers with >= %d input "
+                                         "channels and for the weight gradients of those with >= %d channels on maps <= %d px, direct MFMA "
+                                         "kernels for the rest" % (net._engine.WINO_TILE, net._engine.WINO_TILE, net._engine.WINO_MIN_CI,
+                                                                   net._engine.WINO_WGRAD_MIN_CI, net._engine.WINO_WGRAD_MAX_HW))
+                      if (net._engine.wino and args.conv_dtype == "f32") else "direct MFMA kernels",
                       "host_enqueue_ms_per_step": round(host_ms, 2),
                       "shader_clock_mhz_during_timed_steps": round(mhz, 0),
                       "f32_mfma_peak_at_that_clock_tflops": round(PEAK_F32_MFMA_TFLOPS * mhz / 2400.0, 1)}}
