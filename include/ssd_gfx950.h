@@ -286,7 +286,9 @@ int ssd_preprocess_u8(const uint8_t* arena, const ssd_image_desc* descs_dev, con
 int ssd_clock_probe(uint64_t* out32, void* stream);
 
 /* ---- fused SGD (train.py:53-55: momentum .9, weight decay 5e-4; bias lr 2x) on a flat buffer;
- * grad_scale multiplies the gradient first (1/n_pos_global in data-parallel runs). */
+ * grad_scale multiplies the gradient first (1/n_pos_global in data-parallel runs).  Per element, each line rounded once:
+ *   g' = fma(weight_decay, p, g * scale);  buf = first_step ? g' : (momentum * buf) + g';  p = fma(-lr, buf, p)
+ * which is torch.optim.SGD's own rounding sequence, so the two stay bit-identical.  momentum == 0: call with first_step = 1. */
 int ssd_sgd_momentum(float* param, const float* grad, float* momentum_buf, size_t n, float lr, float momentum,
                      float weight_decay, const float* grad_scale_dev, int first_step, void* stream);
 

@@ -345,16 +345,26 @@ __global__ void heads_gather_kernel(const float* __restrict__ dloc, const float*
 // ---------------------------------------------------------------------------------------
 // SGD with momentum and weight decay (torch.optim.SGD semantics, train.py:53-55):
 //   g = grad*scale + wd*p ; buf = first ? g : mom*buf + g ; p -= lr*buf
+// The rounding sequence is the one torch's foreach path performs with its separate launches -- add(grad, p, alpha=wd) and
+// add_(p, buf, alpha=-lr) are single fused multiply-adds, mul_(buf, mom) and add_(buf, g) round separately -- so a run through
+// this kernel and a run through torch.optim.SGD stay bit-identical.
 // ---------------------------------------------------------------------------------------
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, size_t n, float lr,
                            float mom, float wd, const float* __restrict__ scale, int first) {
+#pragma clang fp contract(off)
     const float sc = scale ? *scale : 1.f;
+    const float neg_lr = -lr;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float w = p[i];
-        const float d = g[i] * sc + wd * w;
-        const float b = first ? d : mom * buf[i] + d;
+        const float gs = scale ? g[i] * sc : g[i];
+        const float d = wd != 0.f ? __builtin_fmaf(wd, w, gs) : gs;
+        float b = d;
+        if (!first) {
+            const float mb = mom * buf[i];
+            b = mb + d;
+        }
         buf[i] = b;
-        p[i] = w - lr * b;
+        p[i] = __builtin_fmaf(neg_lr, b, w);
     }
 }
 

@@ -397,6 +397,105 @@ def test_flat_sgd_data_parallel_step_equals_torch_sgd():
         assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (k, err)
 
 
+def test_fused_sgd_optimizer_is_bitwise_torch_sgd():
+    """(f)-1: optim.SGD built exactly like train.py:44-55 -- parameters, momentum buffers and state_dict after several steps are
+    bit-identical to torch.optim.SGD's, including a parameter that gets its first gradient late and a checkpoint hand-over in
+    both directions (train_function.py:27,116)."""
+    from objectdetection_ssd_amd.optim import SGD
+    g = torch.Generator().manual_seed(77)
+    shapes = [(64, 3, 3, 3), (64,), (150, 256, 3, 3), (150,), (1, 512, 1, 1), (7,), (33, 5)]
+    lr = 1e-4
+
+    def make():
+        ps = [torch.nn.Parameter(torch.randn(s, generator=torch.Generator().manual_seed(i)).to(DEV)) for i, s in enumerate(shapes)]
+        biases = [p for p in ps if p.dim() == 1]
+        others = [p for p in ps if p.dim() != 1]
+        return ps, [{"params": biases, "lr": 2 * lr}, {"params": others}]
+
+    pa, ga = make()
+    pb, gb = make()
+    ref = torch.optim.SGD(params=ga, lr=lr, momentum=0.9, weight_decay=5e-4)
+    opt = SGD(params=gb, lr=lr, momentum=0.9, weight_decay=5e-4)
+    assert [sorted(k for k in grp if k != "params") for grp in opt.state_dict()["param_groups"]] == \
+           [sorted(k for k in grp if k != "params") for grp in ref.state_dict()["param_groups"]]
+
+    def run(o_ref, o_new, p_ref, p_new, steps, skip):
+        for it in range(steps):
+            o_ref.zero_grad(); o_new.zero_grad()
+            for i, (a, b) in enumerate(zip(p_ref, p_new)):
+                if i == 5 and it < skip:
+                    continue                              # no gradient yet: torch leaves this parameter untouched
+                gr = (torch.randn(a.shape, generator=g) * 10).to(DEV)
+                a.grad = gr.clone(); b.grad = gr.clone()
+            o_ref.step(); o_new.step()
+            for i, (a, b) in enumerate(zip(p_ref, p_new)):
+                assert torch.equal(a.detach(), b.detach()), (it, i)
+
+    run(ref, opt, pa, pb, 4, skip=2)
+    sa, sb = ref.state_dict(), opt.state_dict()
+    assert sa["state"].keys() == sb["state"].keys()
+    for k in sa["state"]:
+        assert torch.equal(sa["state"][k]["momentum_buffer"], sb["state"][k]["momentum_buffer"]), k
+    # hand the checkpoints over crosswise and keep going
+    pc, gc_ = make(); pd, gd = make()
+    with torch.no_grad():
+        for dst, src in zip(pc, pa): dst.copy_(src)
+        for dst, src in zip(pd, pa): dst.copy_(src)
+    ref2 = torch.optim.SGD(params=gc_, lr=lr, momentum=0.9, weight_decay=5e-4)
+    opt2 = SGD(params=gd, lr=lr, momentum=0.9, weight_decay=5e-4)
+    ref2.load_state_dict(sb)                             # ours -> torch
+    opt2.load_state_dict(sa)                             # torch -> ours
+    for grp in opt2.param_groups:
+        grp["lr"] = grp["lr"] * 3                         # train_function.py:29-30 rewrites lr after a resume
+    for grp in ref2.param_groups:
+        grp["lr"] = grp["lr"] * 3
+    run(ref2, opt2, pc, pd, 3, skip=0)
+    # plain SGD (momentum 0, no decay) keeps no state, like torch
+    pe, ge = make(); pf, gf = make()
+    r3, o3 = torch.optim.SGD(ge, lr=1e-2), SGD(gf, lr=1e-2)
+    run(r3, o3, pe, pf, 2, skip=0)
+    assert all("momentum_buffer" not in st or st["momentum_buffer"] is None for st in o3.state.values())
+    with pytest.raises(ValueError):
+        SGD(gf, lr=1e-2, nesterov=True, momentum=0.9)
+
+
+def test_fused_sgd_optimizer_in_the_callers_loop():
+    """train.py's optimizer construction with optim.SGD in place of torch.optim.SGD: after three iterations of the caller's loop
+    the two models hold bit-identical weights (the path itself is deterministic), and the re-laid weight caches follow the
+    in-place update."""
+    from objectdetection_ssd_amd import Losses, Model
+    from objectdetection_ssd_amd.optim import SGD
+    lr, bs = 1e-4, 2
+    x = _t(np.random.default_rng(51).standard_normal((bs, 3, 300, 300), dtype=np.float32))
+    boxes, classes = synth_gt(np.random.default_rng(52), bs)
+    cl = [_t(c) for c in classes]
+    bx = [_t(b) for b in boxes]
+    params = O.ssd300_random_params(7)
+    a = Model.SSD_300(); _load_params(a, params); a = a.to(DEV).train()
+    b = Model.SSD_300(); _load_params(b, params); b = b.to(DEV).train()
+    ba, oa = _sgd_groups(a.named_parameters())
+    bb, ob = _sgd_groups(b.named_parameters())
+    opt_a = torch.optim.SGD(params=[{"params": ba, "lr": 2 * lr}, {"params": oa}], lr=lr, momentum=0.9, weight_decay=5e-4)
+    opt_b = SGD(params=[{"params": bb, "lr": 2 * lr}, {"params": ob}], lr=lr, momentum=0.9, weight_decay=5e-4)
+    losses = []
+    for _ in range(3):
+        step = []
+        for net, opt in ((a, opt_a), (b, opt_b)):
+            opt.zero_grad()
+            l1, l2 = Losses.ssd(net(x), cl, bx)
+            (l1 + l2).backward()
+            opt.step()
+            step.append((l1.item(), l2.item()))
+        losses.append(step)
+        assert step[0] == step[1], losses
+    assert losses[2][1] != losses[0][1]                   # the forward sees the updated weights
+    na, nb = dict(a.named_parameters()), dict(b.named_parameters())
+    for k in a._engine.names:
+        assert torch.equal(na[k].detach(), nb[k].detach()), k
+    sd = b.state_dict()                                   # checkpoint layout is unchanged by the flat storage
+    assert set(sd.keys()) == set(a.state_dict().keys())
+
+
 def test_inference_batch_equals_single_image_calls(gold_dir):
     """(f)-4: the batched decode gives, image by image, exactly what `inference` gives (incl. an empty image)"""
     from objectdetection_ssd_amd import Losses
