@@ -209,6 +209,7 @@ def main():
     ap.add_argument("--wino-tile", type=int, default=-1, choices=(-1, 2, 4), help="tuning aid: Winograd output tile of forward / dgrad")
     ap.add_argument("--wino-wgrad-min-ci", type=int, default=-1, help="tuning aid: Winograd weight gradient from this many input channels")
     ap.add_argument("--wino-wgrad-max-hw", type=int, default=-1, help="tuning aid: Winograd weight gradient on maps up to this size (0 = off)")
+    ap.add_argument("--no-fuse-pool", action="store_true", help="tuning aid: conv -> ReLU -> 2x2 pool as separate kernels")
     ap.add_argument("--igemm-lds-pad", type=int, default=-1, help="tuning aid: extra dynamic LDS bytes per igemm block (-1 = library default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
@@ -253,6 +254,8 @@ def main():
         net._engine.WINO_WGRAD_MIN_CI = args.wino_wgrad_min_ci
     if args.wino_wgrad_max_hw >= 0:
         net._engine.WINO_WGRAD_MAX_HW = args.wino_wgrad_max_hw
+    if args.no_fuse_pool:
+        net._engine.fuse_pool = False
     trainer = FlatSGDDataParallel(net, lr=1e-4, momentum=0.9, weight_decay=5e-4)
     trainer.broadcast_parameters(0)
     bs = args.batch

@@ -137,6 +137,13 @@ int ssd_conv3x3_wino_fwd(const float* x, const float* U_fwd, const float* bias, 
                          int mo, void* workspace, size_t workspace_bytes, void* stream);
 int ssd_conv3x3_wino_dgrad(const float* dy, int ldy, const float* U_bwd, int Co_pad, float* dx, const float* relu_mask,
                            int accumulate, const ssd_conv_geom* g, int mo, void* workspace, size_t workspace_bytes, void* stream);
+/* conv3x3 -> ReLU -> MaxPool2d(2, 2, ceil_mode) in one pass (Model.py:135-137 via the VGG layer list: conv1_2, conv2_2, conv3_3 and
+ * their pools): F(4x4,3x3) whose output transform reduces each 4x4 tile to its four pool windows, so the full-resolution
+ * activation -- read by nothing but the pool -- is never written.  y_pooled (N,Ho,Wo,Co), Ho = H/2 (ceil_mode: (H+1)/2); argmax
+ * (may be NULL) in ssd_maxpool_fwd's encoding, for ssd_maxpool_bwd / ssd_maxpool_bwd_gated.  Co % 4 == 0; workspace as
+ * ssd_conv3x3_wino_workspace(g, 0, 4).  Equal, bit for bit, to ssd_conv3x3_wino_fwd(relu = 1, mo = 4) followed by ssd_maxpool_fwd. */
+int ssd_conv3x3_wino_fwd_pool(const float* x, const float* U_fwd, const float* bias, float* y_pooled, uint8_t* argmax,
+                              const ssd_conv_geom* g, int ceil_mode, void* workspace, size_t workspace_bytes, void* stream);
 /* Winograd weight gradient: dg = G^T [ sum over tiles (A dy A^T) (x) (B^T d B) ] G -- transposed transforms of dy and x, sixteen
  * batched (split-K) f32-MFMA GEMMs over the tile dimension, inverse transform to OIHW; dbias (may be NULL) by column sums. */
 size_t ssd_conv3x3_wino_wgrad_workspace(const ssd_conv_geom* g, int ldy, int mo);

@@ -119,6 +119,14 @@ def param_names(op_list: List[dict]) -> List[str]:
     return names
 
 
+class _Elided:
+    """Stands in the activation table for a tensor that a fused kernel consumed without writing it: shape only.  In the backward it
+    takes the ReLU-mask slot of its pool, which then gates by the pooled output (`maxpool_bwd(..., y_gate=)`)."""
+
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+
 class _Engine:
     """Runs the op list on the current HIP stream.  Holds only caches (re-laid-out weights)."""
 
@@ -130,6 +138,14 @@ class _Engine:
         for op in self.ops:
             self.consumers[op["x"]] = self.consumers.get(op["x"], 0) + 1
         self.relu_out = {op["y"] for op in self.ops if op["op"] == "conv_first" or (op["op"] == "conv" and op["relu"])}
+        # conv -> ReLU -> MaxPool2d(2, 2) where nothing else reads the convolution (conv1_2, conv2_2, conv3_3): one fused pass
+        self.pool_after: Dict[str, dict] = {}
+        for op in self.ops:
+            readers = [o for o in self.ops if o["x"] == op["y"]] if op["op"] == "conv" else []
+            if (len(readers) == 1 and readers[0]["op"] == "pool" and (readers[0]["k"], readers[0]["s"], readers[0]["pad"]) == (2, 2, 0)
+                    and op["relu"] and op["co"] % 4 == 0):
+                self.pool_after[op["y"]] = readers[0]
+        self.fuse_pool = True     # Winograd F(4x4) layers in pool_after write the pooled map + argmax only
         self.prof = None          # bench.py: list collecting (label, kernel tag, flops, start event, end event)
         self.bf16 = False         # True: forward / dgrad / fused-wgrad convolutions multiply bf16-rounded operands (f32 accumulate)
         self.x3 = False           # True: forward / dgrad convolutions form f32 products from three bf16 limbs per operand
@@ -233,6 +249,13 @@ class _Engine:
                 bias = P[op["p"] + ".bias"].detach()
                 if self._wino_ok(g):
                     uf, _ = self._wino_weights(op["p"], (P[op["p"] + ".weight"],), op["co"])
+                    pl = self.pool_after.get(op["y"]) if (self.fuse_pool and self.WINO_TILE == 4) else None
+                    if pl is not None:
+                        yp, am = self._timed("fwd " + op["p"], "winograd_f2x2_3x3", ops.conv_flops(g),
+                                             lambda: ops.conv2d_fwd_wino_pool(xin, uf, bias, g, pl["ceil"], want_argmax=save))
+                        T[op["y"]] = _Elided((bs, g.H, g.W, op["co"]))      # never materialised: its only reader is the pool
+                        T[pl["y"]], aux[pl["y"]], aux[op["y"]] = yp, am, g
+                        continue
                     T[op["y"]] = self._timed("fwd " + op["p"], "winograd_f2x2_3x3", ops.conv_flops(g),
                                              lambda: ops.conv2d_fwd_wino(xin, uf, bias, g, op["relu"]))
                     aux[op["y"]] = g
@@ -243,6 +266,8 @@ class _Engine:
                                          ops.conv2d_fwd(xin, wf, bias, g, op["relu"], bf16=self.bf16, w3=self._planes(op["p"], False)))
                 aux[op["y"]] = g
             elif kind == "pool":
+                if op["y"] in T:                                  # produced by the convolution before it
+                    continue
                 y, am = ops.maxpool_fwd(T[op["x"]], op["k"], op["s"], op["pad"], op["ceil"], want_argmax=save)
                 T[op["y"]] = y
                 aux[op["y"]] = am

@@ -435,6 +435,86 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
     }
 }
 
+// Output transform + bias + ReLU + the 2x2 / stride-2 max pool that follows (conv1_2, conv2_2, conv3_3): a 4x4 output tile holds
+// exactly four pool windows, so the full-resolution activation -- which only the pool reads -- never goes to memory.  Window scan
+// order, NaN rule and argmax encoding are maxpool_fwd_kernel's (elementwise.hip), windows cut by the map's edge (ceil mode) included.
+__global__ __launch_bounds__(256) void wino4_output_pool_kernel(const float* __restrict__ Mx, float* __restrict__ yp, uint8_t* __restrict__ am,
+                                                                int N, int H, int W, int C, int TH, int TW, const float* __restrict__ bias,
+                                                                int Ho, int Wo) {
+    const int C4 = C >> 2;
+    const size_t tiles = (size_t)N * TH * TW, total = tiles * C4;
+    const size_t plane = tiles * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        const size_t tile = i / C4;
+        const int tw = (int)(tile % TW), th = (int)((tile / TW) % TH), n = (int)(tile / ((size_t)TW * TH));
+        const float* src = Mx + tile * C + c4 * 4;
+        f32x4 t[4][6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            f32x4 m[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) m[a] = *reinterpret_cast<const f32x4*>(src + (size_t)(a * 6 + b) * plane);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (W4_AT[a][k] != 0.f) acc += W4_AT[a][k] * m[k];
+                t[a][b] = acc;
+            }
+        }
+        const f32x4 bv = bias != nullptr ? *reinterpret_cast<const f32x4*>(bias + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa) {
+            const int oh = 2 * th + pa;
+            f32x4 y[2][4];                                   // the two activation rows this pooled row reads
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    f32x4 v = bv;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k)
+                        if (W4_AT[b][k] != 0.f) v += W4_AT[b][k] * t[2 * pa + r][k];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
+                    y[r][b] = v;
+                }
+            if (oh >= Ho) continue;
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                const int ow = 2 * tw + pb;
+                if (ow >= Wo) continue;
+                f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                int bi[4] = {0, 0, 0, 0};
+                bool first = true;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    if (2 * oh + r >= H) continue;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        if (2 * ow + q >= W) continue;
+                        const f32x4 v = y[r][2 * pb + q];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (first || v[e] > best[e] || v[e] != v[e]) {
+                                best[e] = v[e];
+                                bi[e] = r * 2 + q;
+                            }
+                        first = false;
+                    }
+                }
+                const size_t o = (((size_t)n * Ho + oh) * Wo + ow) * C4 + c4;
+                *reinterpret_cast<f32x4*>(yp + o * 4) = best;
+                if (am != nullptr)
+                    *reinterpret_cast<uint32_t*>(am + o * 4) =
+                        (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+            }
+        }
+    }
+}
+
 // F(4x4,3x3) weight gradient pieces: transposed transforms into rows [plane][channel][tile] (36 planes), inverse transform.
 template <int MODE>
 __global__ __launch_bounds__(256) void wino4_xform_t_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int H, int W, int C,
@@ -537,8 +617,10 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 inline int grid_for(size_t total) { const size_t b = (total + 255) / 256; return (int)(b > 8192 ? 8192 : (b == 0 ? 1 : b)); }
 
 // one Winograd convolution, F(mo x mo, 3x3) with mo = 2 or 4: in (N,H,W,Cin) -> out (N,H,W,ldo) first Cout channels
+struct PooledOut { float* y; uint8_t* argmax; int Ho, Wo; };     // destination of the fused conv -> ReLU -> 2x2/s2 max pool form
 int wino_conv(int mo, const float* in, int Cin, const float* U, int U_rows, float* out, int ldo, int Cout, const float* bias,
-              const float* mask, int relu, int accumulate, int N, int H, int W, void* ws, size_t ws_bytes, hipStream_t st) {
+              const float* mask, int relu, int accumulate, int N, int H, int W, void* ws, size_t ws_bytes, hipStream_t st,
+              const PooledOut* pooled = nullptr) {
     const int TH = (H + mo - 1) / mo, TW = (W + mo - 1) / mo, P = (mo + 2) * (mo + 2);
     const size_t tiles = (size_t)N * TH * TW;
     const int Cvalid = Cout;
@@ -552,7 +634,10 @@ int wino_conv(int mo, const float* in, int Cin, const float* U, int U_rows, floa
     else hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(tiles * (Cin / 4))), dim3(256), 0, st, in, V, N, H, W, Cin, TH, TW);
     SSD_CHECK_LAUNCH();
     if (int e = ssd_internal_gemm_batched(V, U, Mx, (int)tiles, Cin, Cout, U_rows, P, tiles * Cin, (size_t)U_rows * Cin, 1, st)) return e;
-    if (mo == 2)
+    if (pooled != nullptr)
+        hipLaunchKernelGGL(wino4_output_pool_kernel, dim3(grid_for(tiles * (Cout / 4))), dim3(256), 0, st, Mx, pooled->y, pooled->argmax, N, H, W,
+                           Cout, TH, TW, bias, pooled->Ho, pooled->Wo);
+    else if (mo == 2)
         hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(tiles * (Cout / 4))), dim3(256), 0, st, Mx, out, N, H, W, Cout, Cvalid, ldo, TH, TW,
                            bias, mask, relu, accumulate);
     else
@@ -602,6 +687,19 @@ extern "C" int ssd_conv3x3_wino_fwd(const float* x, const float* U_fwd, const fl
     if (!ssd_aligned16(x) || !ssd_aligned16(y) || !ssd_aligned16(workspace) || !ssd_aligned16(U_fwd) || ldy % 4 != 0) return SSD_ERR_ALIGN;
     return wino_conv(mo, x, g->Ci, U_fwd, g->Co, y, ldy, g->Co, bias, nullptr, relu, 0, g->N, g->H, g->W, workspace, workspace_bytes,
                      (hipStream_t)stream);
+}
+
+extern "C" int ssd_conv3x3_wino_fwd_pool(const float* x, const float* U_fwd, const float* bias, float* y_pooled, uint8_t* argmax,
+                                         const ssd_conv_geom* g, int ceil_mode, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !U_fwd || !y_pooled || !workspace) return SSD_ERR_NULL;
+    if (!wino_geom_ok(g) || g->Ci % 32 != 0 || g->Co % 4 != 0) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(x) || !ssd_aligned16(y_pooled) || !ssd_aligned16(workspace) || !ssd_aligned16(U_fwd) || (bias && !ssd_aligned16(bias)) ||
+        (argmax && ((uintptr_t)argmax & 3)))
+        return SSD_ERR_ALIGN;
+    const PooledOut po = {y_pooled, argmax, ceil_mode ? (g->H + 1) / 2 : g->H / 2, ceil_mode ? (g->W + 1) / 2 : g->W / 2};
+    if (po.Ho <= 0 || po.Wo <= 0) return SSD_ERR_BAD_SHAPE;
+    return wino_conv(4, x, g->Ci, U_fwd, g->Co, nullptr, g->Co, g->Co, bias, nullptr, 1, 0, g->N, g->H, g->W, workspace, workspace_bytes,
+                     (hipStream_t)stream, &po);
 }
 
 extern "C" int ssd_conv3x3_wino_dgrad(const float* dy, int ldy, const float* U_bwd, int Co_pad, float* dx, const float* relu_mask,

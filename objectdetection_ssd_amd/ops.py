@@ -630,6 +630,30 @@ def conv2d_fwd_wino(x: torch.Tensor, u_fwd: torch.Tensor, bias: Optional[torch.T
     return out
 
 
+def conv2d_fwd_wino_pool(x: torch.Tensor, u_fwd: torch.Tensor, bias: Optional[torch.Tensor], g: ConvGeom, ceil_mode: bool,
+                         want_argmax: bool = True):
+    """conv3x3 -> ReLU -> max pool 2x2 / stride 2 in one pass (F(4x4,3x3) filters): (pooled y, argmax or None), the pair
+    `conv2d_fwd_wino(relu=True)` + `maxpool_fwd(2, 2, 0)` returns, without the full-resolution activation in between."""
+    _req(x, "x"); _req(u_fwd, "u_fwd")
+    if _wino_mo(u_fwd) != 4:
+        raise ValueError("conv2d_fwd_wino_pool: needs F(4x4,3x3) filters")
+    if tuple(x.shape) != (g.N, g.H, g.W, g.Ci) or tuple(u_fwd.shape[1:]) != (g.Co, g.Ci) or g.Co % 4 != 0:
+        raise ValueError("conv2d_fwd_wino_pool: shapes do not match the geometry")
+    if bias is not None:
+        _req(bias, "bias")
+    ho, wo = pool_out(g.H, 2, 2, 0, ceil_mode), pool_out(g.W, 2, 2, 0, ceil_mode)
+    y = torch.empty((g.N, ho, wo, g.Co), device=x.device, dtype=torch.float32)
+    am = torch.empty((g.N, ho, wo, g.Co), device=x.device, dtype=torch.uint8) if want_argmax else None
+    lib = _lib.load()
+    nbytes = lib.ssd_conv3x3_wino_workspace(C.byref(g), 0, 4)
+    if nbytes == 0:
+        raise ValueError("conv2d_fwd_wino_pool: not a 3x3 / stride 1 / pad 1 geometry")
+    ws = workspace(nbytes, x.device, "wino")
+    check(lib.ssd_conv3x3_wino_fwd_pool(x.data_ptr(), u_fwd.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(am), C.byref(g), int(ceil_mode),
+                                        ws.data_ptr(), ws.numel(), _stream()), "conv2d_fwd_wino_pool")
+    return y, am
+
+
 def conv2d_dgrad_wino(dy: torch.Tensor, u_bwd: torch.Tensor, g: ConvGeom, dx: Optional[torch.Tensor] = None,
                       relu_mask: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
     _req(dy, "dy"); _req(u_bwd, "u_bwd")

@@ -568,6 +568,32 @@ def test_winograd_f4x4_3x3_forward_and_dgrad(case):
     print(f"F(4x4,3x3) {case}: fwd max err / scale {e:.2e}, wgrad {ew:.2e}")
 
 
+@pytest.mark.parametrize("case", [(2, 22, 22, 32, 8, False), (1, 75, 75, 32, 12, True), (2, 9, 13, 64, 4, False), (1, 15, 11, 32, 8, True),
+                                  (1, 150, 150, 64, 64, False)])
+def test_winograd_forward_fused_with_maxpool(case):
+    """conv3x3 -> ReLU -> MaxPool2d(2,2[,ceil]) in one pass == the F(4x4) convolution followed by the pool kernel, bit for bit
+    (values and argmax codes), on even, odd and non-multiple-of-4 maps in both rounding modes; and the pooled result is the
+    f64 convolution's within the f32 bar."""
+    from objectdetection_ssd_amd import ops
+    n, h, w, ci, co, ceil = case
+    dev = _dev()
+    full = (n, h, w, ci, co, 3, 1, 1, 1)
+    x, wt, b = _conv_data(full, seed=91)
+    g = ops.make_geom(*full)
+    uf, _ = ops.wino_weights(wt.to(dev), co, want_bwd=False, mo=4)
+    xd = _nhwc(x).to(dev)
+    y_full = ops.conv2d_fwd_wino(xd, uf, b.to(dev), g, True)
+    y_ref, am_ref = ops.maxpool_fwd(y_full, 2, 2, 0, ceil)
+    yp, am = ops.conv2d_fwd_wino_pool(xd, uf, b.to(dev), g, ceil)
+    assert yp.shape == y_ref.shape and am.shape == am_ref.shape
+    assert torch.equal(yp, y_ref), f"pooled values differ {case}"
+    assert torch.equal(am, am_ref), f"argmax codes differ {case}"
+    yp2, am2 = ops.conv2d_fwd_wino_pool(xd, uf, b.to(dev), g, ceil, want_argmax=False)
+    assert am2 is None and torch.equal(yp2, yp)
+    y64 = F.max_pool2d(F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1)), 2, 2, 0, ceil_mode=ceil)
+    _close(yp, _nhwc(y64), what=f"fused conv+pool {case}")
+
+
 @pytest.mark.parametrize("case", WINO_CASES)
 def test_winograd_f2x2_3x3_forward_and_dgrad(case):
     """Winograd F(2x2,3x3) == the direct 3x3 / stride 1 / pad 1 convolution (odd maps, padded channel counts, fused bias + ReLU,
