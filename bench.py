@@ -320,7 +320,7 @@ def main():
                       "step_frac_of_f32_mfma_peak": round(TRAIN_GFLOP_PER_IMAGE * ips / world / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
                       "last_loss_per_rank": round(loss, 5), "n_pos_global_last": n_pos,
                       "conv_algorithm": ("f32 throughout; Winograd F(%dx%d,3x3) for forward / dgrad of the 3x3 stride-1 layers with >= %d input "
-                                         "channels and for the weight gradients of those with >= %d channels on maps <= %d px, direct MFMA "
+                                         "channels (the 2x2 max pools fused into its output transform) and for the weight gradients of those with >= %d channels on maps <= %d px, direct MFMA "
                                          "kernels for the rest" % (net._engine.WINO_TILE, net._engine.WINO_TILE, net._engine.WINO_MIN_CI,
                                                                    net._engine.WINO_WGRAD_MIN_CI, net._engine.WINO_WGRAD_MAX_HW))
                       if (net._engine.wino and args.conv_dtype == "f32") else "direct MFMA kernels",
