@@ -210,6 +210,7 @@ def main():
     ap.add_argument("--wino-wgrad-min-ci", type=int, default=-1, help="tuning aid: Winograd weight gradient from this many input channels")
     ap.add_argument("--wino-wgrad-max-hw", type=int, default=-1, help="tuning aid: Winograd weight gradient on maps up to this size (0 = off)")
     ap.add_argument("--no-fuse-pool", action="store_true", help="tuning aid: conv -> ReLU -> 2x2 pool as separate kernels")
+    ap.add_argument("--wino-wgrad-nt", action="store_true", help="tuning aid: Winograd weight gradient on transposed planes (NT GEMM)")
     ap.add_argument("--igemm-lds-pad", type=int, default=-1, help="tuning aid: extra dynamic LDS bytes per igemm block (-1 = library default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
@@ -239,6 +240,9 @@ def main():
     if args.workload != "train":
         return aux_workload(args, world, rank, dev)
 
+    if args.wino_wgrad_nt:
+        from objectdetection_ssd_amd import _lib
+        _lib.check(_lib.load().ssd_tune_set_wino_wgrad_tn(0), "tune")
     if args.igemm_lds_pad >= 0:
         from objectdetection_ssd_amd import _lib
         _lib.check(_lib.load().ssd_tune_set_igemm_lds_pad(args.igemm_lds_pad), "tune")

@@ -149,6 +149,7 @@ int ssd_conv3x3_wino_fwd_pool(const float* x, const float* U_fwd, const float* b
 size_t ssd_conv3x3_wino_wgrad_workspace(const ssd_conv_geom* g, int ldy, int mo);
 int ssd_conv3x3_wino_wgrad(const float* x, const float* dy, int ldy, float* dw_oihw, float* dbias, const ssd_conv_geom* g, int mo,
                            void* workspace, size_t workspace_bytes, void* stream);
+int ssd_tune_set_wino_wgrad_tn(int on);   /* 1 (default): F(4x4) weight gradient on untransposed planes + TN GEMM; 0: transposed planes */
 /* Measurement aid: arm / read back per-launch timings (library-owned HIP events) of the batched Winograd GEMM kernel.
  * collect() returns the number of (milliseconds, executed FLOPs) pairs written; the caller synchronises the stream first. */
 int ssd_prof_gemm_begin(void);

@@ -579,6 +579,133 @@ __global__ __launch_bounds__(256) void wino4_xform_t_kernel(const float* __restr
     }
 }
 
+// ---- weight gradient without transposed copies --------------------------------------------------------------------------------
+// dy tiles into the plane layout of the forward transforms: Y[plane][tile][channel] = A dy A^T (4x4 block -> 6x6 planes)
+__global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__ dy, float* __restrict__ Y, int N, int H, int W, int C,
+                                                       int TH, int TW) {
+    const int C4 = C >> 2;
+    const size_t tiles = (size_t)N * TH * TW, total = tiles * C4;
+    const size_t plane = tiles * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        const size_t tile = i / C4;
+        const int tw = (int)(tile % TW), th = (int)((tile / TW) % TH), n = (int)(tile / ((size_t)TW * TH));
+        f32x4 t[6][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            f32x4 d[4];
+            const int iw = 4 * tw + b;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int ih = 4 * th + a;
+                d[a] = (ih < H && iw < W) ? *reinterpret_cast<const f32x4*>(dy + (((size_t)n * H + ih) * W + iw) * C + c4 * 4)
+                                          : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (W4_AT[k][a] != 0.f) acc += W4_AT[k][a] * d[k];
+                t[a][b] = acc;
+            }
+        }
+        float* dst = Y + tile * C + c4 * 4;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (W4_AT[k][b] != 0.f) acc += W4_AT[k][b] * t[a][k];
+                *reinterpret_cast<f32x4*>(dst + (size_t)(a * 6 + b) * plane) = acc;
+            }
+    }
+}
+
+// Batched C[m][n] = sum_k A[k][m] B[k][n] on v_mfma_f32_32x32x2_f32: both operands arrive with the reduction index as the slow
+// dimension (rows = tiles, columns = channels -- the layout the forward transforms write), so a 32-row slab of each goes to LDS
+// exactly as it lies in memory and an MFMA lane fetches its operand with one ds_read_b32 (lanes 0-31 walk the columns of row 2q,
+// lanes 32-63 those of row 2q+1; row stride 96 floats puts the two half-waves on disjoint banks).  64x64 tile, four waves 2x2,
+// split-K over blockIdx.y into out[batch][split][M][N].  Rows beyond K and columns beyond lda / ldb read as zero (buffer range check).
+struct TnParams {
+    const float* a; const float* b; float* out;
+    int M, N, K, lda, ldb, tiles_m, tiles_n, ksplit, ksteps_per_split;
+    size_t batch_a, batch_b;
+    unsigned a_bytes, b_bytes;
+};
+constexpr int TN_LD = 96;
+__device__ __forceinline__ f32x4 tn_load16(__amdgpu_buffer_rsrc_t srd, unsigned voff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)voff, 0, 0));
+}
+__global__ __launch_bounds__(256) void wino_gemm_tn_kernel(const TnParams p) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * 32 * TN_LD];
+    float* As = lds;
+    float* Bs = lds + 32 * TN_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int lid = xcd_swizzle(blockIdx.x, nblk);
+    const int m0 = (lid / p.tiles_n) * 64, n0 = (lid % p.tiles_n) * 64;
+    const int by = blockIdx.y, bz = blockIdx.z;
+    const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a + (size_t)bz * p.batch_a), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b + (size_t)bz * p.batch_b), 0, (int)p.b_bytes, 0x00020000);
+    const int mchunk = tid & 15, krow = tid >> 4;
+    const unsigned OOB = 0xFFFFFFF0u;
+    const int col_a = m0 + mchunk * 4, col_b = n0 + mchunk * 4;
+    const bool ok_a = col_a < p.lda, ok_b = col_b < p.ldb;
+    const int ksteps = (p.K + 31) / 32;
+    const int kt_begin = by * p.ksteps_per_split;
+    const int KT = min(ksteps - kt_begin, p.ksteps_per_split);
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    f32x4 ra[2], rb[2];
+    auto issue = [&](int kt) {
+        const int k0 = (kt_begin + kt) * 32 + krow;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            ra[j] = tn_load16(srd_a, ok_a ? (unsigned)(((size_t)(k0 + 16 * j) * p.lda + col_a) * 4) : OOB);
+            rb[j] = tn_load16(srd_b, ok_b ? (unsigned)(((size_t)(k0 + 16 * j) * p.ldb + col_b) * 4) : OOB);
+        }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            *reinterpret_cast<f32x4*>(&As[(krow + 16 * j) * TN_LD + mchunk * 4]) = ra[j];
+            *reinterpret_cast<f32x4*>(&Bs[(krow + 16 * j) * TN_LD + mchunk * 4]) = rb[j];
+        }
+    };
+    const int lr = lane & 31, lh = lane >> 5;
+    const int a_rd = lh * TN_LD + wm * 32 + lr, b_rd = lh * TN_LD + wn * 32 + lr;
+    if (KT > 0) {
+        issue(0);
+        store();
+    }
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const bool more = kt + 1 < KT;
+        if (more) issue(kt + 1);
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[a_rd + 2 * q * TN_LD], Bs[b_rd + 2 * q * TN_LD], acc, 0, 0, 0);
+        __syncthreads();
+        if (more) {
+            store();
+            __syncthreads();
+        }
+    }
+    float* out = p.out + ((size_t)bz * p.ksplit + by) * p.M * p.N;
+    const int n = n0 + wn * 32 + lr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < p.M && n < p.N) out[(size_t)m * p.N + n] = acc[r];
+    }
+}
+
 __global__ void wino4_wgrad_finish_kernel(const float* __restrict__ Zs, float* __restrict__ dw, int Co, int Ci, int ksplit) {
     const size_t total = (size_t)Co * Ci;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -717,6 +844,7 @@ extern "C" int ssd_conv3x3_wino_dgrad(const float* dy, int ldy, const float* U_b
 
 namespace {
 constexpr int COLSUM_BLOCKS = 512;
+int g_wgrad_tn = 1;               // F(4x4) weight gradient on untransposed planes + the TN GEMM (0: transposed planes + the NT GEMM)
 struct WinoWgradPlan { int TH, TW, Tpad, ks, cdy, P; size_t tiles, yb, vb, zb, pb; };
 WinoWgradPlan wino_wgrad_plan(const ssd_conv_geom* g, int ldy, int mo) {
     WinoWgradPlan w;
@@ -739,6 +867,11 @@ WinoWgradPlan wino_wgrad_plan(const ssd_conv_geom* g, int ldy, int mo) {
     return w;
 }
 }  // namespace
+
+extern "C" int ssd_tune_set_wino_wgrad_tn(int on) {
+    g_wgrad_tn = on ? 1 : 0;
+    return SSD_OK;
+}
 
 extern "C" size_t ssd_conv3x3_wino_wgrad_workspace(const ssd_conv_geom* g, int ldy, int mo) {
     if (!wino_geom_ok(g) || ldy < g->Co || (mo != 2 && mo != 4)) return 0;
@@ -763,7 +896,24 @@ extern "C" int ssd_conv3x3_wino_wgrad(const float* x, const float* dy, int ldy, 
     float* part = reinterpret_cast<float*>(base + w.yb + w.vb + w.zb);
     const int gy = (w.Tpad / 32) * ((ldy / 4 + 7) / 8), gx = (w.Tpad / 32) * ((g->Ci / 4 + 7) / 8);
     const dim3 gyd(gy > 16384 ? 16384 : gy), gxd(gx > 16384 ? 16384 : gx);
-    if (mo == 2) {
+    if (mo == 4 && g_wgrad_tn) {
+        // planes in the forward layout [plane][tile][channel]; the GEMM reduces over the tile rows of both
+        hipLaunchKernelGGL(wino4_dy_kernel, dim3(grid_for(w.tiles * (ldy / 4))), dim3(256), 0, st, dy, Yt, g->N, g->H, g->W, ldy, w.TH, w.TW);
+        hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(w.tiles * (g->Ci / 4))), dim3(256), 0, st, x, Vt, g->N, g->H, g->W, g->Ci, w.TH, w.TW);
+        SSD_CHECK_LAUNCH();
+        TnParams q;
+        q.a = Yt; q.b = Vt; q.out = Zs;
+        q.M = g->Co; q.N = g->Ci; q.K = (int)w.tiles; q.lda = ldy; q.ldb = g->Ci;
+        q.tiles_m = (g->Co + 63) / 64; q.tiles_n = (g->Ci + 63) / 64;
+        const int ksteps = (q.K + 31) / 32;
+        q.ksplit = w.ks;
+        q.ksteps_per_split = (ksteps + w.ks - 1) / w.ks;
+        q.batch_a = w.tiles * ldy; q.batch_b = w.tiles * g->Ci;
+        if (q.batch_a * 4 >= 0xFFFFFFF0ull || q.batch_b * 4 >= 0xFFFFFFF0ull) return SSD_ERR_BAD_SHAPE;
+        q.a_bytes = (unsigned)(q.batch_a * 4); q.b_bytes = (unsigned)(q.batch_b * 4);
+        hipLaunchKernelGGL(wino_gemm_tn_kernel, dim3(q.tiles_m * q.tiles_n, w.ks, w.P), dim3(256), 0, st, q);
+        SSD_CHECK_LAUNCH();
+    } else if (mo == 2) {
         hipLaunchKernelGGL(wino_xform_t_kernel<1>, gyd, dim3(256), 0, st, dy, Yt, g->N, g->H, g->W, ldy, w.TH, w.TW, w.Tpad);
         hipLaunchKernelGGL(wino_xform_t_kernel<0>, gxd, dim3(256), 0, st, x, Vt, g->N, g->H, g->W, g->Ci, w.TH, w.TW, w.Tpad);
     } else {
@@ -771,8 +921,9 @@ extern "C" int ssd_conv3x3_wino_wgrad(const float* x, const float* dy, int ldy, 
         hipLaunchKernelGGL(wino4_xform_t_kernel<0>, gxd, dim3(256), 0, st, x, Vt, g->N, g->H, g->W, g->Ci, w.TH, w.TW, w.Tpad);
     }
     SSD_CHECK_LAUNCH();
-    if (int e = ssd_internal_gemm_batched(Yt, Vt, Zs, g->Co, w.Tpad, g->Ci, g->Ci, w.P, (size_t)ldy * w.Tpad, (size_t)g->Ci * w.Tpad, w.ks, st))
-        return e;
+    if (!(mo == 4 && g_wgrad_tn))
+        if (int e = ssd_internal_gemm_batched(Yt, Vt, Zs, g->Co, w.Tpad, g->Ci, g->Ci, w.P, (size_t)ldy * w.Tpad, (size_t)g->Ci * w.Tpad, w.ks, st))
+            return e;
     if (mo == 2)
         hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3(grid_for((size_t)g->Co * g->Ci)), dim3(256), 0, st, Zs, dw_oihw, g->Co, g->Ci, w.ks);
     else
