@@ -141,14 +141,24 @@ int ssd_conv3x3_wino_dgrad(const float* dy, int ldy, const float* U_bwd, int Co_
  * their pools): F(4x4,3x3) whose output transform reduces each 4x4 tile to its four pool windows, so the full-resolution
  * activation -- read by nothing but the pool -- is never written.  y_pooled (N,Ho,Wo,Co), Ho = H/2 (ceil_mode: (H+1)/2); argmax
  * (may be NULL) in ssd_maxpool_fwd's encoding, for ssd_maxpool_bwd / ssd_maxpool_bwd_gated.  Co % 4 == 0; workspace as
- * ssd_conv3x3_wino_workspace(g, 0, 4).  Equal, bit for bit, to ssd_conv3x3_wino_fwd(relu = 1, mo = 4) followed by ssd_maxpool_fwd. */
+ * ssd_conv3x3_wino_workspace(g, 0, 4).  Equal, bit for bit, to ssd_conv3x3_wino_fwd(relu = 1, mo = 4) followed by ssd_maxpool_fwd.
+ * planes_keep (may be NULL): see ssd_conv3x3_wino_fwd_keep. */
 int ssd_conv3x3_wino_fwd_pool(const float* x, const float* U_fwd, const float* bias, float* y_pooled, uint8_t* argmax,
-                              const ssd_conv_geom* g, int ceil_mode, void* workspace, size_t workspace_bytes, void* stream);
+                              const ssd_conv_geom* g, int ceil_mode, float* planes_keep, void* workspace, size_t workspace_bytes,
+                              void* stream);
+/* F(4x4,3x3) forward that leaves the transformed input B^T d B in planes_keep -- 36 x tiles x Ci floats, tiles = N ceil(H/4) ceil(W/4),
+ * layout [plane][tile][channel] -- for ssd_conv3x3_wino_wgrad_planes, which then skips transforming x a second time in the backward
+ * pass (the planes are 2.25x the activation; 288 GB of HBM pay for that).  Otherwise ssd_conv3x3_wino_fwd with mo = 4. */
+int ssd_conv3x3_wino_fwd_keep(const float* x, const float* U_fwd, const float* bias, float* y, int ldy, const ssd_conv_geom* g, int relu,
+                              float* planes_keep, void* workspace, size_t workspace_bytes, void* stream);
 /* Winograd weight gradient: dg = G^T [ sum over tiles (A dy A^T) (x) (B^T d B) ] G -- transposed transforms of dy and x, sixteen
  * batched (split-K) f32-MFMA GEMMs over the tile dimension, inverse transform to OIHW; dbias (may be NULL) by column sums. */
 size_t ssd_conv3x3_wino_wgrad_workspace(const ssd_conv_geom* g, int ldy, int mo);
 int ssd_conv3x3_wino_wgrad(const float* x, const float* dy, int ldy, float* dw_oihw, float* dbias, const ssd_conv_geom* g, int mo,
                            void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the x planes a ..._fwd_keep / ..._fwd_pool call kept (F(4x4) only); workspace as ssd_conv3x3_wino_wgrad_workspace(g, ldy, 4). */
+int ssd_conv3x3_wino_wgrad_planes(const float* planes, const float* dy, int ldy, float* dw_oihw, float* dbias, const ssd_conv_geom* g,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 int ssd_tune_set_wino_wgrad_tn(int on);   /* 1 (default): F(4x4) weight gradient on untransposed planes + TN GEMM; 0: transposed planes */
 /* Measurement aid: arm / read back per-launch timings (library-owned HIP events) of the batched Winograd GEMM kernel.
  * collect() returns the number of (milliseconds, executed FLOPs) pairs written; the caller synchronises the stream first. */

@@ -145,6 +145,7 @@ class _Engine:
             if (len(readers) == 1 and readers[0]["op"] == "pool" and (readers[0]["k"], readers[0]["s"], readers[0]["pad"]) == (2, 2, 0)
                     and op["relu"] and op["co"] % 4 == 0):
                 self.pool_after[op["y"]] = readers[0]
+        self.keep_planes = True   # training forward keeps the F(4x4) input planes of the layers whose weight gradient is Winograd
         self.fuse_pool = True     # Winograd F(4x4) layers in pool_after write the pooled map + argmax only
         self.prof = None          # bench.py: list collecting (label, kernel tag, flops, start event, end event)
         self.bf16 = False         # True: forward / dgrad / fused-wgrad convolutions multiply bf16-rounded operands (f32 accumulate)
@@ -193,6 +194,11 @@ class _Engine:
     def _wino_ok(self, g) -> bool:
         return (self.wino and not self.bf16 and not self.x3 and g.R == 3 and g.S == 3 and g.stride == 1 and g.dil == 1 and g.pad == 1
                 and g.Ci % 32 == 0 and g.Ci >= self.WINO_MIN_CI)
+
+    def _wino_wgrad_ok(self, g, head: bool) -> bool:
+        """Weight gradient of this layer in the Winograd domain (else: the fused direct kernels)."""
+        return (self._wino_ok(g) and g.H <= self.WINO_WGRAD_MAX_HW and g.Ci >= self.WINO_WGRAD_MIN_CI
+                and (g.H >= 19 if head else g.Co % 4 == 0))
 
     def _wino_weights(self, key: str, tensors, co_pad: int):
         """Cached Winograd-domain filters (U_fwd [16][Co][Ci], U_bwd [16][Ci][co_pad]), refreshed when a parameter changes."""
@@ -250,14 +256,21 @@ class _Engine:
                 if self._wino_ok(g):
                     uf, _ = self._wino_weights(op["p"], (P[op["p"] + ".weight"],), op["co"])
                     pl = self.pool_after.get(op["y"]) if (self.fuse_pool and self.WINO_TILE == 4) else None
+                    # training: the transformed input stays for the weight gradient, which multiplies the same planes
+                    keep = save and self.keep_planes and self.WINO_TILE == 4 and self._wino_wgrad_ok(g, False)
                     if pl is not None:
-                        yp, am = self._timed("fwd " + op["p"], "winograd_f2x2_3x3", ops.conv_flops(g),
-                                             lambda: ops.conv2d_fwd_wino_pool(xin, uf, bias, g, pl["ceil"], want_argmax=save))
+                        res = self._timed("fwd " + op["p"], "winograd_f2x2_3x3", ops.conv_flops(g),
+                                          lambda: ops.conv2d_fwd_wino_pool(xin, uf, bias, g, pl["ceil"], want_argmax=save, keep_planes=keep))
                         T[op["y"]] = _Elided((bs, g.H, g.W, op["co"]))      # never materialised: its only reader is the pool
-                        T[pl["y"]], aux[pl["y"]], aux[op["y"]] = yp, am, g
+                        T[pl["y"]], aux[pl["y"]], aux[op["y"]] = res[0], res[1], g
+                        if keep:
+                            aux["planes:" + op["p"]] = res[2]
                         continue
-                    T[op["y"]] = self._timed("fwd " + op["p"], "winograd_f2x2_3x3", ops.conv_flops(g),
-                                             lambda: ops.conv2d_fwd_wino(xin, uf, bias, g, op["relu"]))
+                    res = self._timed("fwd " + op["p"], "winograd_f2x2_3x3", ops.conv_flops(g),
+                                      lambda: ops.conv2d_fwd_wino(xin, uf, bias, g, op["relu"], keep_planes=keep))
+                    T[op["y"]] = res[0] if keep else res
+                    if keep:
+                        aux["planes:" + op["p"]] = res[1]
                     aux[op["y"]] = g
                     continue
                 wf, _ = self._layouts(op["p"], (P[op["p"] + ".weight"],), op["co"], False)
@@ -282,9 +295,12 @@ class _Engine:
                 bias = torch.cat((P[pre + "_bb.bias"].detach(), P[pre + "_cl.bias"].detach()))
                 if self._wino_ok(g):
                     uf, _ = self._wino_weights(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]), ops.pad32(co))
-                    packed = self._timed("fwd " + pre, "winograd_f2x2_3x3", ops.conv_flops(g),
-                                         lambda: ops.conv2d_fwd_wino(xin, uf, bias, g, False, ld=ops.pad32(co)))
-                    heads.append((op, packed, g))
+                    keep = save and self.keep_planes and self.WINO_TILE == 4 and self._wino_wgrad_ok(g, True)
+                    res = self._timed("fwd " + pre, "winograd_f2x2_3x3", ops.conv_flops(g),
+                                      lambda: ops.conv2d_fwd_wino(xin, uf, bias, g, False, ld=ops.pad32(co), keep_planes=keep))
+                    if keep:
+                        aux["planes:" + pre] = res[1]
+                    heads.append((op, res[0] if keep else res, g))
                     continue
                 wf, _ = self._layouts(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]), ops.pad32(co), False)
                 packed = self._timed("fwd " + pre, ops.igemm_tile(g, 0, self.bf16, self.x3) if self.prof is not None else "", ops.conv_flops(g),
@@ -330,9 +346,10 @@ class _Engine:
                 xin = T[op["x"]]
                 a4 = 4 * op["a"]
                 if any(need[pre + s] for s in ("_bb.weight", "_bb.bias", "_cl.weight", "_cl.bias")):
-                    if self._wino_ok(g) and 19 <= g.H <= self.WINO_WGRAD_MAX_HW and g.Ci >= self.WINO_WGRAD_MIN_CI:
+                    if self._wino_wgrad_ok(g, True):
                         dw, db = self._timed("wgrad " + pre, "winograd_f2x2_3x3", ops.conv_flops(g),
-                                             lambda: ops.conv2d_wgrad_wino(xin, dy, g, co_pad, True, mo=self.WINO_TILE))
+                                             lambda: ops.conv2d_wgrad_wino(xin, dy, g, co_pad, True, mo=self.WINO_TILE,
+                                                                           planes=aux.pop("planes:" + pre, None)))
                     else:
                         dw, db = self._timed("wgrad " + pre, ops.wgrad_tile(g) if self.prof is not None else "", ops.conv_flops(g),
                                              lambda: ops.conv2d_wgrad(xin, dy, g, co_pad, True, bf16=self.bf16))
@@ -353,9 +370,10 @@ class _Engine:
                 g = aux[op["y"]]
                 xin = T[op["x"]]
                 if need[op["p"] + ".weight"] or need[op["p"] + ".bias"]:
-                    if self._wino_ok(g) and g.H <= self.WINO_WGRAD_MAX_HW and g.Ci >= self.WINO_WGRAD_MIN_CI and g.Co % 4 == 0:
+                    if self._wino_wgrad_ok(g, False):
                         dw, db = self._timed("wgrad " + op["p"], "winograd_f2x2_3x3", ops.conv_flops(g),
-                                             lambda: ops.conv2d_wgrad_wino(xin, dy, g, g.Co, True, mo=self.WINO_TILE))
+                                             lambda: ops.conv2d_wgrad_wino(xin, dy, g, g.Co, True, mo=self.WINO_TILE,
+                                                                           planes=aux.pop("planes:" + op["p"], None)))
                     else:
                         dw, db = self._timed("wgrad " + op["p"], ops.wgrad_tile(g) if self.prof is not None else "", ops.conv_flops(g),
                                              lambda: ops.conv2d_wgrad(xin, dy, g, g.Co, True, bf16=self.bf16))

@@ -747,7 +747,7 @@ inline int grid_for(size_t total) { const size_t b = (total + 255) / 256; return
 struct PooledOut { float* y; uint8_t* argmax; int Ho, Wo; };     // destination of the fused conv -> ReLU -> 2x2/s2 max pool form
 int wino_conv(int mo, const float* in, int Cin, const float* U, int U_rows, float* out, int ldo, int Cout, const float* bias,
               const float* mask, int relu, int accumulate, int N, int H, int W, void* ws, size_t ws_bytes, hipStream_t st,
-              const PooledOut* pooled = nullptr) {
+              const PooledOut* pooled = nullptr, float* V_keep = nullptr) {
     const int TH = (H + mo - 1) / mo, TW = (W + mo - 1) / mo, P = (mo + 2) * (mo + 2);
     const size_t tiles = (size_t)N * TH * TW;
     const int Cvalid = Cout;
@@ -755,7 +755,7 @@ int wino_conv(int mo, const float* in, int Cin, const float* U, int U_rows, floa
     if (tiles >= (1ull << 31) || Cin % 32 != 0 || Cout > ldo) return SSD_ERR_BAD_SHAPE;     // beyond Cvalid read as zero
     const size_t vb = align256((size_t)P * tiles * Cin * 4), mb = align256((size_t)P * tiles * Cout * 4);
     if (ws_bytes < vb + mb) return SSD_ERR_WORKSPACE;
-    float* V = static_cast<float*>(ws);
+    float* V = V_keep != nullptr ? V_keep : static_cast<float*>(ws);       // kept planes: the weight gradient multiplies them again
     float* Mx = reinterpret_cast<float*>(static_cast<char*>(ws) + vb);
     if (mo == 2) hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(tiles * (Cin / 4))), dim3(256), 0, st, in, V, N, H, W, Cin, TH, TW);
     else hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(tiles * (Cin / 4))), dim3(256), 0, st, in, V, N, H, W, Cin, TH, TW);
@@ -816,17 +816,28 @@ extern "C" int ssd_conv3x3_wino_fwd(const float* x, const float* U_fwd, const fl
                      (hipStream_t)stream);
 }
 
+extern "C" int ssd_conv3x3_wino_fwd_keep(const float* x, const float* U_fwd, const float* bias, float* y, int ldy, const ssd_conv_geom* g,
+                                         int relu, float* planes_keep, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !U_fwd || !y || !workspace || !planes_keep) return SSD_ERR_NULL;
+    if (!wino_geom_ok(g) || g->Ci % 32 != 0 || ldy < (g->Co + 3) / 4 * 4) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(x) || !ssd_aligned16(y) || !ssd_aligned16(workspace) || !ssd_aligned16(U_fwd) || !ssd_aligned16(planes_keep) || ldy % 4 != 0)
+        return SSD_ERR_ALIGN;
+    return wino_conv(4, x, g->Ci, U_fwd, g->Co, y, ldy, g->Co, bias, nullptr, relu, 0, g->N, g->H, g->W, workspace, workspace_bytes,
+                     (hipStream_t)stream, nullptr, planes_keep);
+}
+
 extern "C" int ssd_conv3x3_wino_fwd_pool(const float* x, const float* U_fwd, const float* bias, float* y_pooled, uint8_t* argmax,
-                                         const ssd_conv_geom* g, int ceil_mode, void* workspace, size_t workspace_bytes, void* stream) {
+                                         const ssd_conv_geom* g, int ceil_mode, float* planes_keep, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
     if (!x || !U_fwd || !y_pooled || !workspace) return SSD_ERR_NULL;
     if (!wino_geom_ok(g) || g->Ci % 32 != 0 || g->Co % 4 != 0) return SSD_ERR_BAD_SHAPE;
     if (!ssd_aligned16(x) || !ssd_aligned16(y_pooled) || !ssd_aligned16(workspace) || !ssd_aligned16(U_fwd) || (bias && !ssd_aligned16(bias)) ||
-        (argmax && ((uintptr_t)argmax & 3)))
+        (argmax && ((uintptr_t)argmax & 3)) || (planes_keep && !ssd_aligned16(planes_keep)))
         return SSD_ERR_ALIGN;
     const PooledOut po = {y_pooled, argmax, ceil_mode ? (g->H + 1) / 2 : g->H / 2, ceil_mode ? (g->W + 1) / 2 : g->W / 2};
     if (po.Ho <= 0 || po.Wo <= 0) return SSD_ERR_BAD_SHAPE;
     return wino_conv(4, x, g->Ci, U_fwd, g->Co, nullptr, g->Co, g->Co, bias, nullptr, 1, 0, g->N, g->H, g->W, workspace, workspace_bytes,
-                     (hipStream_t)stream, &po);
+                     (hipStream_t)stream, &po, planes_keep);
 }
 
 extern "C" int ssd_conv3x3_wino_dgrad(const float* dy, int ldy, const float* U_bwd, int Co_pad, float* dx, const float* relu_mask,
@@ -880,11 +891,28 @@ extern "C" size_t ssd_conv3x3_wino_wgrad_workspace(const ssd_conv_geom* g, int l
 }
 
 // dw (Co,Ci,3,3) OIHW and, if asked, dbias (Co) from x (N,H,W,Ci) and dy (N,H,W,ldy; columns >= Co zero); mo = 2 or 4
+namespace {
+int wino_wgrad(const float* x, const float* planes, const float* dy, int ldy, float* dw_oihw, float* dbias, const ssd_conv_geom* g, int mo,
+               void* workspace, size_t workspace_bytes, void* stream);
+}
 extern "C" int ssd_conv3x3_wino_wgrad(const float* x, const float* dy, int ldy, float* dw_oihw, float* dbias, const ssd_conv_geom* g,
                                       int mo, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!x || !dy || !dw_oihw || !workspace) return SSD_ERR_NULL;
+    if (!x) return SSD_ERR_NULL;
+    if (!ssd_aligned16(x)) return SSD_ERR_ALIGN;
+    return wino_wgrad(x, nullptr, dy, ldy, dw_oihw, dbias, g, mo, workspace, workspace_bytes, stream);
+}
+extern "C" int ssd_conv3x3_wino_wgrad_planes(const float* planes, const float* dy, int ldy, float* dw_oihw, float* dbias,
+                                             const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!planes) return SSD_ERR_NULL;
+    if (!ssd_aligned16(planes)) return SSD_ERR_ALIGN;
+    return wino_wgrad(nullptr, planes, dy, ldy, dw_oihw, dbias, g, 4, workspace, workspace_bytes, stream);
+}
+namespace {
+int wino_wgrad(const float* x, const float* planes, const float* dy, int ldy, float* dw_oihw, float* dbias, const ssd_conv_geom* g, int mo,
+               void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dy || !dw_oihw || !workspace) return SSD_ERR_NULL;
     if (!wino_geom_ok(g) || g->Ci % 4 != 0 || ldy % 4 != 0 || ldy < g->Co || (mo != 2 && mo != 4)) return SSD_ERR_BAD_SHAPE;
-    if (!ssd_aligned16(x) || !ssd_aligned16(dy) || !ssd_aligned16(workspace)) return SSD_ERR_ALIGN;
+    if (!ssd_aligned16(dy) || !ssd_aligned16(workspace)) return SSD_ERR_ALIGN;
     const WinoWgradPlan w = wino_wgrad_plan(g, ldy, mo);
     if (w.tiles >= (1ull << 31)) return SSD_ERR_BAD_SHAPE;
     if (workspace_bytes < w.yb + w.vb + w.zb + w.pb) return SSD_ERR_WORKSPACE;
@@ -896,13 +924,16 @@ extern "C" int ssd_conv3x3_wino_wgrad(const float* x, const float* dy, int ldy, 
     float* part = reinterpret_cast<float*>(base + w.yb + w.vb + w.zb);
     const int gy = (w.Tpad / 32) * ((ldy / 4 + 7) / 8), gx = (w.Tpad / 32) * ((g->Ci / 4 + 7) / 8);
     const dim3 gyd(gy > 16384 ? 16384 : gy), gxd(gx > 16384 ? 16384 : gx);
-    if (mo == 4 && g_wgrad_tn) {
-        // planes in the forward layout [plane][tile][channel]; the GEMM reduces over the tile rows of both
+    if (mo == 4 && (g_wgrad_tn || planes != nullptr)) {
+        // planes in the forward layout [plane][tile][channel]; the GEMM reduces over the tile rows of both.  The x planes are the
+        // forward convolution's own B^T d B when the caller kept them.
         hipLaunchKernelGGL(wino4_dy_kernel, dim3(grid_for(w.tiles * (ldy / 4))), dim3(256), 0, st, dy, Yt, g->N, g->H, g->W, ldy, w.TH, w.TW);
-        hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(w.tiles * (g->Ci / 4))), dim3(256), 0, st, x, Vt, g->N, g->H, g->W, g->Ci, w.TH, w.TW);
+        if (planes == nullptr)
+            hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(w.tiles * (g->Ci / 4))), dim3(256), 0, st, x, Vt, g->N, g->H, g->W, g->Ci, w.TH,
+                               w.TW);
         SSD_CHECK_LAUNCH();
         TnParams q;
-        q.a = Yt; q.b = Vt; q.out = Zs;
+        q.a = Yt; q.b = planes != nullptr ? planes : Vt; q.out = Zs;
         q.M = g->Co; q.N = g->Ci; q.K = (int)w.tiles; q.lda = ldy; q.ldb = g->Ci;
         q.tiles_m = (g->Co + 63) / 64; q.tiles_n = (g->Ci + 63) / 64;
         const int ksteps = (q.K + 31) / 32;
@@ -921,7 +952,7 @@ extern "C" int ssd_conv3x3_wino_wgrad(const float* x, const float* dy, int ldy, 
         hipLaunchKernelGGL(wino4_xform_t_kernel<0>, gxd, dim3(256), 0, st, x, Vt, g->N, g->H, g->W, g->Ci, w.TH, w.TW, w.Tpad);
     }
     SSD_CHECK_LAUNCH();
-    if (!(mo == 4 && g_wgrad_tn))
+    if (!(mo == 4 && (g_wgrad_tn || planes != nullptr)))
         if (int e = ssd_internal_gemm_batched(Yt, Vt, Zs, g->Co, w.Tpad, g->Ci, g->Ci, w.P, (size_t)ldy * w.Tpad, (size_t)g->Ci * w.Tpad, w.ks, st))
             return e;
     if (mo == 2)
@@ -940,3 +971,4 @@ extern "C" int ssd_conv3x3_wino_wgrad(const float* x, const float* dy, int ldy, 
     }
     return SSD_OK;
 }
+}  // namespace

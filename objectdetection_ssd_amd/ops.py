@@ -609,8 +609,19 @@ def _wino_mo(u: torch.Tensor) -> int:
     return 2 if u.shape[0] == 16 else 4
 
 
+def wino_planes_shape(g: ConvGeom):
+    return (36, g.N * ((g.H + 3) // 4) * ((g.W + 3) // 4), g.Ci)
+
+
+def wino_planes(g: ConvGeom, device) -> torch.Tensor:
+    """Buffer for the F(4x4) transformed input of a convolution, [36][tiles][Ci] (include/ssd_gfx950.h ssd_conv3x3_wino_fwd_keep)."""
+    tiles = g.N * ((g.H + 3) // 4) * ((g.W + 3) // 4)
+    return torch.empty((36, tiles, g.Ci), device=device, dtype=torch.float32)
+
+
 def conv2d_fwd_wino(x: torch.Tensor, u_fwd: torch.Tensor, bias: Optional[torch.Tensor], g: ConvGeom, relu: bool,
-                    ld: Optional[int] = None) -> torch.Tensor:
+                    ld: Optional[int] = None, keep_planes: bool = False):
+    """keep_planes: also return the transformed input (F(4x4) only) for `conv2d_wgrad_wino(..., planes=)` -> (y, planes)."""
     _req(x, "x"); _req(u_fwd, "u_fwd")
     mo = _wino_mo(u_fwd)
     if tuple(x.shape) != (g.N, g.H, g.W, g.Ci) or tuple(u_fwd.shape[1:]) != (g.Co, g.Ci):
@@ -625,13 +636,20 @@ def conv2d_fwd_wino(x: torch.Tensor, u_fwd: torch.Tensor, bias: Optional[torch.T
     if nbytes == 0:
         raise ValueError("conv2d_fwd_wino: not a 3x3 / stride 1 / pad 1 geometry")
     ws = workspace(nbytes, x.device, "wino")
+    if keep_planes:
+        if mo != 4:
+            raise ValueError("conv2d_fwd_wino: keep_planes needs F(4x4,3x3) filters")
+        planes = wino_planes(g, x.device)
+        check(lib.ssd_conv3x3_wino_fwd_keep(x.data_ptr(), u_fwd.data_ptr(), _ptr(bias), out.data_ptr(), ld, C.byref(g), int(relu),
+                                            planes.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "conv2d_fwd_wino")
+        return out, planes
     check(lib.ssd_conv3x3_wino_fwd(x.data_ptr(), u_fwd.data_ptr(), _ptr(bias), out.data_ptr(), ld, C.byref(g), int(relu), mo, ws.data_ptr(),
                                    ws.numel(), _stream()), "conv2d_fwd_wino")
     return out
 
 
 def conv2d_fwd_wino_pool(x: torch.Tensor, u_fwd: torch.Tensor, bias: Optional[torch.Tensor], g: ConvGeom, ceil_mode: bool,
-                         want_argmax: bool = True):
+                         want_argmax: bool = True, keep_planes: bool = False):
     """conv3x3 -> ReLU -> max pool 2x2 / stride 2 in one pass (F(4x4,3x3) filters): (pooled y, argmax or None), the pair
     `conv2d_fwd_wino(relu=True)` + `maxpool_fwd(2, 2, 0)` returns, without the full-resolution activation in between."""
     _req(x, "x"); _req(u_fwd, "u_fwd")
@@ -649,9 +667,10 @@ def conv2d_fwd_wino_pool(x: torch.Tensor, u_fwd: torch.Tensor, bias: Optional[to
     if nbytes == 0:
         raise ValueError("conv2d_fwd_wino_pool: not a 3x3 / stride 1 / pad 1 geometry")
     ws = workspace(nbytes, x.device, "wino")
+    planes = wino_planes(g, x.device) if keep_planes else None
     check(lib.ssd_conv3x3_wino_fwd_pool(x.data_ptr(), u_fwd.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(am), C.byref(g), int(ceil_mode),
-                                        ws.data_ptr(), ws.numel(), _stream()), "conv2d_fwd_wino_pool")
-    return y, am
+                                        _ptr(planes), ws.data_ptr(), ws.numel(), _stream()), "conv2d_fwd_wino_pool")
+    return (y, am, planes) if keep_planes else (y, am)
 
 
 def conv2d_dgrad_wino(dy: torch.Tensor, u_bwd: torch.Tensor, g: ConvGeom, dx: Optional[torch.Tensor] = None,
@@ -675,18 +694,33 @@ def conv2d_dgrad_wino(dy: torch.Tensor, u_bwd: torch.Tensor, g: ConvGeom, dx: Op
     return dx
 
 
-def conv2d_wgrad_wino(x: torch.Tensor, dy: torch.Tensor, g: ConvGeom, ldy: int, want_bias: bool = True, mo: int = 2):
-    """Winograd F(mo x mo, 3x3) weight gradient, mo = 2 or 4 -> (dw (Co,Ci,3,3) OIHW, dbias (Co,) or None)."""
-    _req(x, "x"); _req(dy, "dy")
-    if tuple(x.shape) != (g.N, g.H, g.W, g.Ci) or dy.numel() != g.N * g.H * g.W * ldy:
+def conv2d_wgrad_wino(x: Optional[torch.Tensor], dy: torch.Tensor, g: ConvGeom, ldy: int, want_bias: bool = True, mo: int = 2,
+                      planes: Optional[torch.Tensor] = None):
+    """Winograd F(mo x mo, 3x3) weight gradient, mo = 2 or 4 -> (dw (Co,Ci,3,3) OIHW, dbias (Co,) or None).
+    planes: the transformed input the forward kept (`conv2d_fwd_wino(..., keep_planes=True)`); x is then not read."""
+    _req(dy, "dy")
+    if planes is not None:
+        _req(planes, "planes")
+        if mo != 4 or tuple(planes.shape) != tuple(wino_planes_shape(g)):
+            raise ValueError("conv2d_wgrad_wino: planes do not match the geometry")
+    else:
+        _req(x, "x")
+        if tuple(x.shape) != (g.N, g.H, g.W, g.Ci):
+            raise ValueError("conv2d_wgrad_wino: shapes do not match the geometry")
+    if dy.numel() != g.N * g.H * g.W * ldy:
         raise ValueError("conv2d_wgrad_wino: shapes do not match the geometry")
     lib = _lib.load()
     nbytes = lib.ssd_conv3x3_wino_wgrad_workspace(C.byref(g), ldy, mo)
     if nbytes == 0:
         raise ValueError("conv2d_wgrad_wino: not a 3x3 / stride 1 / pad 1 geometry")
-    ws = workspace(nbytes, x.device, "wino")
-    dw = torch.empty((g.Co, g.Ci, 3, 3), device=x.device, dtype=torch.float32)
-    db = torch.empty((g.Co,), device=x.device, dtype=torch.float32) if want_bias else None
+    dev = dy.device
+    ws = workspace(nbytes, dev, "wino")
+    dw = torch.empty((g.Co, g.Ci, 3, 3), device=dev, dtype=torch.float32)
+    db = torch.empty((g.Co,), device=dev, dtype=torch.float32) if want_bias else None
+    if planes is not None:
+        check(lib.ssd_conv3x3_wino_wgrad_planes(planes.data_ptr(), dy.data_ptr(), ldy, dw.data_ptr(), _ptr(db), C.byref(g), ws.data_ptr(),
+                                                ws.numel(), _stream()), "conv2d_wgrad_wino")
+        return dw, db
     check(lib.ssd_conv3x3_wino_wgrad(x.data_ptr(), dy.data_ptr(), ldy, dw.data_ptr(), _ptr(db), C.byref(g), mo, ws.data_ptr(), ws.numel(),
                                      _stream()), "conv2d_wgrad_wino")
     return dw, db

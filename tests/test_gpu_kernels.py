@@ -566,6 +566,20 @@ def test_winograd_f4x4_3x3_forward_and_dgrad(case):
     _close(db, b64.grad, tol=2e-4, what=f"winograd F(4x4) bias grad {case}")
     ew = float((dw.cpu().double() - w64.grad).abs().max() / max(1.0, float(w64.grad.abs().max())))
     print(f"F(4x4,3x3) {case}: fwd max err / scale {e:.2e}, wgrad {ew:.2e}")
+    # the forward can leave its transformed input behind; the weight gradient on those planes is the same computation
+    yk, planes = ops.conv2d_fwd_wino(_nhwc(x).to(dev), uf, b.to(dev), g, False, ld=ld, keep_planes=True)
+    assert torch.equal(yk, yd) and tuple(planes.shape) == ops.wino_planes_shape(g)
+    dw_p, db_p = ops.conv2d_wgrad_wino(None, dy_p.to(dev), g, ld, True, mo=4, planes=planes)
+    assert torch.equal(dw_p, dw) and torch.equal(db_p, db)
+    # and the transposed-plane formulation (NT GEMM) of the same gradient agrees
+    from objectdetection_ssd_amd import _lib
+    _lib.check(_lib.load().ssd_tune_set_wino_wgrad_tn(0))
+    try:
+        dw_t, db_t = ops.conv2d_wgrad_wino(_nhwc(x).to(dev), dy_p.to(dev), g, ld, True, mo=4)
+    finally:
+        _lib.check(_lib.load().ssd_tune_set_wino_wgrad_tn(1))
+    _close(dw_t, w64.grad, tol=2e-4, what=f"winograd F(4x4) wgrad, transposed planes {case}")
+    _close(dw_t, dw, tol=2e-5, what=f"winograd F(4x4) wgrad TN vs NT {case}")
 
 
 @pytest.mark.parametrize("case", [(2, 22, 22, 32, 8, False), (1, 75, 75, 32, 12, True), (2, 9, 13, 64, 4, False), (1, 15, 11, 32, 8, True),
@@ -590,6 +604,9 @@ def test_winograd_forward_fused_with_maxpool(case):
     assert torch.equal(am, am_ref), f"argmax codes differ {case}"
     yp2, am2 = ops.conv2d_fwd_wino_pool(xd, uf, b.to(dev), g, ceil, want_argmax=False)
     assert am2 is None and torch.equal(yp2, yp)
+    yp3, am3, planes = ops.conv2d_fwd_wino_pool(xd, uf, b.to(dev), g, ceil, keep_planes=True)
+    _, planes_ref = ops.conv2d_fwd_wino(xd, uf, b.to(dev), g, True, keep_planes=True)
+    assert torch.equal(yp3, yp) and torch.equal(am3, am) and torch.equal(planes, planes_ref)
     y64 = F.max_pool2d(F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1)), 2, 2, 0, ceil_mode=ceil)
     _close(yp, _nhwc(y64), what=f"fused conv+pool {case}")
 
