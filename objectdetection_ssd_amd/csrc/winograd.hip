@@ -299,6 +299,29 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     }
 }
 
+// final for the partial rows wino4_dy_kernel<true> leaves (row stride ldp = channels rounded up to 4): 16 channels per block as four
+// 16-byte quads, 64 lanes stride over the rows of each quad with two sums in flight, combined in lane order
+__global__ __launch_bounds__(256) void colsum_final4_kernel(const float* __restrict__ part, float* __restrict__ db, int nblk, int C, int ldp) {
+    __shared__ f32x4 red[64][5];
+    const int q = threadIdx.x & 3, l = threadIdx.x >> 2;
+    const int c0 = (blockIdx.x * 4 + q) * 4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    if (c0 < ldp)
+        for (int k = l; k < nblk; k += 128) {
+            s0 += *reinterpret_cast<const f32x4*>(part + (size_t)k * ldp + c0);
+            if (k + 64 < nblk) s1 += *reinterpret_cast<const f32x4*>(part + (size_t)(k + 64) * ldp + c0);
+        }
+    red[l][q] = s0 + s1;
+    __syncthreads();
+    if (l == 0 && c0 < ldp) {
+        f32x4 t = red[0][q];
+        for (int k = 1; k < 64; ++k) t += red[k][q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c0 + e < C) db[c0 + e] = t[e];
+    }
+}
+
 // ---- F(4x4, 3x3): 36 multiplies per 4x4 output tile (4x fewer than direct, 1.78x fewer than F(2x2)); 6x6 input patches, planes
 // 2.25x the tensor.  Interpolation points 0, +-1, +-2, inf (Lavin & Gray); coefficients up to 8 and 1/24, so the f32 result is
 // less exact than F(2x2)'s (measured ~1e-5 of the output scale) -- used where that still clears the 1e-4 bar.
@@ -581,9 +604,13 @@ __global__ __launch_bounds__(256) void wino4_xform_t_kernel(const float* __restr
 
 // ---- weight gradient without transposed copies --------------------------------------------------------------------------------
 // dy tiles into the plane layout of the forward transforms: Y[plane][tile][channel] = A dy A^T (4x4 block -> 6x6 planes)
+// BIAS: the pass also leaves per-block column sums of dy (the bias gradient) in part[block][Cvalid]; the launch makes the thread
+// count a multiple of C/4, so a thread keeps its channel quad over the grid-stride loop, and a block combines its threads in a fixed order.
+template <bool BIAS>
 __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__ dy, float* __restrict__ Y, int N, int H, int W, int C,
-                                                       int TH, int TW) {
+                                                       int TH, int TW, float* __restrict__ part, int Cvalid) {
     const int C4 = C >> 2;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     const size_t tiles = (size_t)N * TH * TW, total = tiles * C4;
     const size_t plane = tiles * C;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -601,6 +628,7 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
                 d[a] = (ih < H && iw < W) ? *reinterpret_cast<const f32x4*>(dy + (((size_t)n * H + ih) * W + iw) * C + c4 * 4)
                                           : f32x4{0.f, 0.f, 0.f, 0.f};
             }
+            if (BIAS) bsum += (d[0] + d[1]) + (d[2] + d[3]);
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -621,6 +649,19 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
                     if (W4_AT[k][b] != 0.f) acc += W4_AT[k][b] * t[a][k];
                 *reinterpret_cast<f32x4*>(dst + (size_t)(a * 6 + b) * plane) = acc;
             }
+    }
+    if (BIAS) {
+        __shared__ f32x4 red[256];
+        red[threadIdx.x] = bsum;
+        __syncthreads();
+        if ((int)threadIdx.x < C4) {
+            f32x4 t = red[threadIdx.x];
+            for (int k = threadIdx.x + C4; k < 256; k += C4) t += red[k];
+            const int c4 = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % C4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c4 * 4 + e < Cvalid) part[(size_t)blockIdx.x * ((Cvalid + 3) / 4 * 4) + c4 * 4 + e] = t[e];
+        }
     }
 }
 
@@ -706,37 +747,44 @@ __global__ __launch_bounds__(256) void wino_gemm_tn_kernel(const TnParams p) {
     }
 }
 
-__global__ void wino4_wgrad_finish_kernel(const float* __restrict__ Zs, float* __restrict__ dw, int Co, int Ci, int ksplit) {
-    const size_t total = (size_t)Co * Ci;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        float t[3][6];                                       // G^T Z, one plane column at a time
+// four neighbouring (co, ci) entries per thread: 16-byte loads of the 36 x ksplit partial planes, 144 contiguous output bytes
+__global__ __launch_bounds__(256) void wino4_wgrad_finish_kernel(const float* __restrict__ Zs, float* __restrict__ dw, int Co, int Ci, int ksplit) {
+    const size_t total = (size_t)Co * Ci, quads = total >> 2;          // Ci % 4 == 0
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (size_t)gridDim.x * 256) {
+        const size_t i = q * 4;
+        f32x4 t[3][6];                                       // G^T Z, one plane column at a time
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
-            float z[6];
+            f32x4 z[6];
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
-                float sum = 0.f;
-                for (int k = 0; k < ksplit; ++k) sum += Zs[((size_t)(a * 6 + b) * ksplit + k) * total + i];
+                const float* src = Zs + (size_t)(a * 6 + b) * ksplit * total + i;
+                f32x4 sum = *reinterpret_cast<const f32x4*>(src);
+                for (int k = 1; k < ksplit; ++k) sum += *reinterpret_cast<const f32x4*>(src + (size_t)k * total);
                 z[a] = sum;
             }
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                float acc = 0.f;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int a = 0; a < 6; ++a) acc += W4_G[a][r] * z[a];
                 t[r][b] = acc;
             }
         }
-        float* o = dw + i * 9;
+        float flat[36];                                      // [entry][3x3 tap], as the four OIHW entries lie in memory
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int s2 = 0; s2 < 3; ++s2) {
-                float acc = 0.f;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int b = 0; b < 6; ++b) acc += t[r][b] * W4_G[b][s2];
-                o[r * 3 + s2] = acc;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) flat[e * 9 + r * 3 + s2] = acc[e];
             }
+        f32x4* o = reinterpret_cast<f32x4*>(dw + i * 9);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) o[j] = f32x4{flat[4 * j], flat[4 * j + 1], flat[4 * j + 2], flat[4 * j + 3]};
     }
 }
 
@@ -855,6 +903,7 @@ extern "C" int ssd_conv3x3_wino_dgrad(const float* dy, int ldy, const float* U_b
 
 namespace {
 constexpr int COLSUM_BLOCKS = 512;
+constexpr int DY_BIAS_BLOCKS = 2048;      // >= COLSUM_BLOCKS: rows of the bias-gradient partial buffer
 int g_wgrad_tn = 1;               // F(4x4) weight gradient on untransposed planes + the TN GEMM (0: transposed planes + the NT GEMM)
 struct WinoWgradPlan { int TH, TW, Tpad, ks, cdy, P; size_t tiles, yb, vb, zb, pb; };
 WinoWgradPlan wino_wgrad_plan(const ssd_conv_geom* g, int ldy, int mo) {
@@ -874,7 +923,7 @@ WinoWgradPlan wino_wgrad_plan(const ssd_conv_geom* g, int ldy, int mo) {
     w.yb = align256((size_t)w.P * ldy * w.Tpad * 4);
     w.vb = align256((size_t)w.P * g->Ci * w.Tpad * 4);
     w.zb = align256((size_t)w.P * w.ks * g->Co * g->Ci * 4);
-    w.pb = align256((size_t)COLSUM_BLOCKS * ldy * 4);
+    w.pb = align256((size_t)DY_BIAS_BLOCKS * ldy * 4);
     return w;
 }
 }  // namespace
@@ -912,7 +961,7 @@ int wino_wgrad(const float* x, const float* planes, const float* dy, int ldy, fl
                void* workspace, size_t workspace_bytes, void* stream) {
     if (!dy || !dw_oihw || !workspace) return SSD_ERR_NULL;
     if (!wino_geom_ok(g) || g->Ci % 4 != 0 || ldy % 4 != 0 || ldy < g->Co || (mo != 2 && mo != 4)) return SSD_ERR_BAD_SHAPE;
-    if (!ssd_aligned16(dy) || !ssd_aligned16(workspace)) return SSD_ERR_ALIGN;
+    if (!ssd_aligned16(dy) || !ssd_aligned16(workspace) || !ssd_aligned16(dw_oihw)) return SSD_ERR_ALIGN;
     const WinoWgradPlan w = wino_wgrad_plan(g, ldy, mo);
     if (w.tiles >= (1ull << 31)) return SSD_ERR_BAD_SHAPE;
     if (workspace_bytes < w.yb + w.vb + w.zb + w.pb) return SSD_ERR_WORKSPACE;
@@ -924,10 +973,24 @@ int wino_wgrad(const float* x, const float* planes, const float* dy, int ldy, fl
     float* part = reinterpret_cast<float*>(base + w.yb + w.vb + w.zb);
     const int gy = (w.Tpad / 32) * ((ldy / 4 + 7) / 8), gx = (w.Tpad / 32) * ((g->Ci / 4 + 7) / 8);
     const dim3 gyd(gy > 16384 ? 16384 : gy), gxd(gx > 16384 ? 16384 : gx);
+    int dy_bias_blocks = 0;
     if (mo == 4 && (g_wgrad_tn || planes != nullptr)) {
         // planes in the forward layout [plane][tile][channel]; the GEMM reduces over the tile rows of both.  The x planes are the
         // forward convolution's own B^T d B when the caller kept them.
-        hipLaunchKernelGGL(wino4_dy_kernel, dim3(grid_for(w.tiles * (ldy / 4))), dim3(256), 0, st, dy, Yt, g->N, g->H, g->W, ldy, w.TH, w.TW);
+        const int c4 = ldy / 4;
+        if (dbias != nullptr && c4 <= 256) {                 // bias gradient from the same pass over dy
+            int gcd = 256, r = c4;
+            while (r) { const int tmp = gcd % r; gcd = r; r = tmp; }
+            const int unit = c4 / gcd;                       // grid must be a multiple of this
+            int blocks = grid_for(w.tiles * c4);
+            if (blocks > DY_BIAS_BLOCKS) blocks = DY_BIAS_BLOCKS;
+            blocks = (blocks + unit - 1) / unit * unit;
+            if (blocks > DY_BIAS_BLOCKS) blocks -= unit;
+            dy_bias_blocks = blocks;
+            hipLaunchKernelGGL(wino4_dy_kernel<true>, dim3(blocks), dim3(256), 0, st, dy, Yt, g->N, g->H, g->W, ldy, w.TH, w.TW, part, g->Co);
+        } else
+            hipLaunchKernelGGL(wino4_dy_kernel<false>, dim3(grid_for(w.tiles * c4)), dim3(256), 0, st, dy, Yt, g->N, g->H, g->W, ldy, w.TH, w.TW,
+                               static_cast<float*>(nullptr), 0);
         if (planes == nullptr)
             hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(w.tiles * (g->Ci / 4))), dim3(256), 0, st, x, Vt, g->N, g->H, g->W, g->Ci, w.TH,
                                w.TW);
@@ -958,9 +1021,13 @@ int wino_wgrad(const float* x, const float* planes, const float* dy, int ldy, fl
     if (mo == 2)
         hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3(grid_for((size_t)g->Co * g->Ci)), dim3(256), 0, st, Zs, dw_oihw, g->Co, g->Ci, w.ks);
     else
-        hipLaunchKernelGGL(wino4_wgrad_finish_kernel, dim3(grid_for((size_t)g->Co * g->Ci)), dim3(256), 0, st, Zs, dw_oihw, g->Co, g->Ci, w.ks);
+        hipLaunchKernelGGL(wino4_wgrad_finish_kernel, dim3(grid_for((size_t)g->Co * g->Ci / 4)), dim3(256), 0, st, Zs, dw_oihw, g->Co, g->Ci, w.ks);
     SSD_CHECK_LAUNCH();
-    if (dbias) {
+    if (dbias && dy_bias_blocks > 0) {
+        const int ldp = (g->Co + 3) / 4 * 4;
+        hipLaunchKernelGGL(colsum_final4_kernel, dim3((ldp + 15) / 16), dim3(256), 0, st, part, dbias, dy_bias_blocks, g->Co, ldp);
+        SSD_CHECK_LAUNCH();
+    } else if (dbias) {
         const size_t M = (size_t)g->N * g->H * g->W;
         int cq = 1;
         while (cq < (g->Co + 3) / 4 && cq < 256) cq <<= 1;
