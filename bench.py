@@ -212,6 +212,7 @@ def main():
     ap.add_argument("--no-fuse-pool", action="store_true", help="tuning aid: conv -> ReLU -> 2x2 pool as separate kernels")
     ap.add_argument("--wino-wgrad-nt", action="store_true", help="tuning aid: Winograd weight gradient on transposed planes (NT GEMM)")
     ap.add_argument("--no-keep-planes", action="store_true", help="tuning aid: the Winograd weight gradient transforms x again")
+    ap.add_argument("--no-dual-dy", action="store_true", help="tuning aid: weight and data gradient transform dy separately")
     ap.add_argument("--igemm-lds-pad", type=int, default=-1, help="tuning aid: extra dynamic LDS bytes per igemm block (-1 = library default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
@@ -263,6 +264,8 @@ def main():
         net._engine.fuse_pool = False
     if args.no_keep_planes:
         net._engine.keep_planes = False
+    if args.no_dual_dy:
+        net._engine.dual_dy = False
     trainer = FlatSGDDataParallel(net, lr=1e-4, momentum=0.9, weight_decay=5e-4)
     trainer.broadcast_parameters(0)
     bs = args.batch

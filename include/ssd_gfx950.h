@@ -156,9 +156,13 @@ int ssd_conv3x3_wino_fwd_keep(const float* x, const float* U_fwd, const float* b
 size_t ssd_conv3x3_wino_wgrad_workspace(const ssd_conv_geom* g, int ldy, int mo);
 int ssd_conv3x3_wino_wgrad(const float* x, const float* dy, int ldy, float* dw_oihw, float* dbias, const ssd_conv_geom* g, int mo,
                            void* workspace, size_t workspace_bytes, void* stream);
-/* The same with the x planes a ..._fwd_keep / ..._fwd_pool call kept (F(4x4) only); workspace as ssd_conv3x3_wino_wgrad_workspace(g, ldy, 4). */
+/* The same with the x planes a ..._fwd_keep / ..._fwd_pool call kept (F(4x4) only); workspace as ssd_conv3x3_wino_wgrad_workspace(g, ldy, 4).
+ * dgrad_planes_out (may be NULL; 36 x tiles x ldy floats): the pass over dy also writes B^T dy B, the input planes of this layer's
+ * data gradient, which ssd_conv3x3_wino_dgrad_planes (Co_pad = ldy) then takes instead of transforming dy again. */
 int ssd_conv3x3_wino_wgrad_planes(const float* planes, const float* dy, int ldy, float* dw_oihw, float* dbias, const ssd_conv_geom* g,
-                                  void* workspace, size_t workspace_bytes, void* stream);
+                                  float* dgrad_planes_out, void* workspace, size_t workspace_bytes, void* stream);
+int ssd_conv3x3_wino_dgrad_planes(const float* dy_planes, const float* U_bwd, int Co_pad, float* dx, const float* relu_mask,
+                                  int accumulate, const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream);
 int ssd_tune_set_wino_wgrad_tn(int on);   /* 1 (default): F(4x4) weight gradient on untransposed planes + TN GEMM; 0: transposed planes */
 /* Measurement aid: arm / read back per-launch timings (library-owned HIP events) of the batched Winograd GEMM kernel.
  * collect() returns the number of (milliseconds, executed FLOPs) pairs written; the caller synchronises the stream first. */

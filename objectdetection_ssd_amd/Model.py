@@ -145,6 +145,7 @@ class _Engine:
             if (len(readers) == 1 and readers[0]["op"] == "pool" and (readers[0]["k"], readers[0]["s"], readers[0]["pad"]) == (2, 2, 0)
                     and op["relu"] and op["co"] % 4 == 0):
                 self.pool_after[op["y"]] = readers[0]
+        self.dual_dy = True       # backward: one pass over dy writes the planes of the weight gradient AND of the data gradient
         self.keep_planes = True   # training forward keeps the F(4x4) input planes of the layers whose weight gradient is Winograd
         self.fuse_pool = True     # Winograd F(4x4) layers in pool_after write the pooled map + argmax only
         self.prof = None          # bench.py: list collecting (label, kernel tag, flops, start event, end event)
@@ -345,11 +346,16 @@ class _Engine:
                 dy = ops.heads_gather(dloc, dconf, co_pad, bs, g.Ho * g.Wo, op["a"], off)
                 xin = T[op["x"]]
                 a4 = 4 * op["a"]
+                dyp = None
                 if any(need[pre + s] for s in ("_bb.weight", "_bb.bias", "_cl.weight", "_cl.bias")):
                     if self._wino_wgrad_ok(g, True):
-                        dw, db = self._timed("wgrad " + pre, "winograd_f2x2_3x3", ops.conv_flops(g),
-                                             lambda: ops.conv2d_wgrad_wino(xin, dy, g, co_pad, True, mo=self.WINO_TILE,
-                                                                           planes=aux.pop("planes:" + pre, None)))
+                        kept = aux.pop("planes:" + pre, None)
+                        dual = kept is not None and self.dual_dy        # one pass over dy feeds the weight and the data gradient
+                        res = self._timed("wgrad " + pre, "winograd_f2x2_3x3", ops.conv_flops(g),
+                                          lambda: ops.conv2d_wgrad_wino(xin, dy, g, co_pad, True, mo=self.WINO_TILE, planes=kept,
+                                                                        dgrad_planes=dual))
+                        dw, db = res[0], res[1]
+                        dyp = res[2] if dual else None
                     else:
                         dw, db = self._timed("wgrad " + pre, ops.wgrad_tile(g) if self.prof is not None else "", ops.conv_flops(g),
                                              lambda: ops.conv2d_wgrad(xin, dy, g, co_pad, True, bf16=self.bf16))
@@ -358,7 +364,7 @@ class _Engine:
                 if self._wino_ok(g):
                     _, ub = self._wino_weights(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]), co_pad)
                     deliver(op["x"], lambda dx, acc, mask: self._timed("dgrad " + pre, "winograd_f2x2_3x3", ops.conv_flops(g),
-                                                                       lambda: ops.conv2d_dgrad_wino(dy, ub, g, dx, mask, acc)))
+                                                                       lambda: ops.conv2d_dgrad_wino(dy, ub, g, dx, mask, acc, planes=dyp)))
                     continue
                 _, wb = self._layouts(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]), co_pad, True)
                 deliver(op["x"], lambda dx, acc, mask: self._timed(
@@ -369,11 +375,16 @@ class _Engine:
                 dy = G.pop(op["y"])
                 g = aux[op["y"]]
                 xin = T[op["x"]]
+                dyp = None
                 if need[op["p"] + ".weight"] or need[op["p"] + ".bias"]:
                     if self._wino_wgrad_ok(g, False):
-                        dw, db = self._timed("wgrad " + op["p"], "winograd_f2x2_3x3", ops.conv_flops(g),
-                                             lambda: ops.conv2d_wgrad_wino(xin, dy, g, g.Co, True, mo=self.WINO_TILE,
-                                                                           planes=aux.pop("planes:" + op["p"], None)))
+                        kept = aux.pop("planes:" + op["p"], None)
+                        dual = kept is not None and self.dual_dy and g.Co % 32 == 0
+                        res = self._timed("wgrad " + op["p"], "winograd_f2x2_3x3", ops.conv_flops(g),
+                                          lambda: ops.conv2d_wgrad_wino(xin, dy, g, g.Co, True, mo=self.WINO_TILE, planes=kept,
+                                                                        dgrad_planes=dual))
+                        dw, db = res[0], res[1]
+                        dyp = res[2] if dual else None
                     else:
                         dw, db = self._timed("wgrad " + op["p"], ops.wgrad_tile(g) if self.prof is not None else "", ops.conv_flops(g),
                                              lambda: ops.conv2d_wgrad(xin, dy, g, g.Co, True, bf16=self.bf16))
@@ -381,7 +392,7 @@ class _Engine:
                 if self._wino_ok(g):
                     _, ub = self._wino_weights(op["p"], (P[op["p"] + ".weight"],), op["co"])
                     deliver(op["x"], lambda dx, acc, mask: self._timed("dgrad " + op["p"], "winograd_f2x2_3x3", ops.conv_flops(g),
-                                                                       lambda: ops.conv2d_dgrad_wino(dy, ub, g, dx, mask, acc)))
+                                                                       lambda: ops.conv2d_dgrad_wino(dy, ub, g, dx, mask, acc, planes=dyp)))
                     continue
                 _, wb = self._layouts(op["p"], (P[op["p"] + ".weight"],), op["co"], True)
                 deliver(op["x"], lambda dx, acc, mask: self._timed(

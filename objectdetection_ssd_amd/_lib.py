@@ -80,7 +80,8 @@ SIGNATURES = {
     "ssd_conv3x3_wino_fwd": (_I, [_P, _P, _P, _P, _I, _G, _I, _I, _P, _Z, _P]),
     "ssd_conv3x3_wino_fwd_pool": (_I, [_P, _P, _P, _P, _P, _G, _I, _P, _P, _Z, _P]),
     "ssd_conv3x3_wino_fwd_keep": (_I, [_P, _P, _P, _P, _I, _G, _I, _P, _P, _Z, _P]),
-    "ssd_conv3x3_wino_wgrad_planes": (_I, [_P, _P, _I, _P, _P, _G, _P, _Z, _P]),
+    "ssd_conv3x3_wino_wgrad_planes": (_I, [_P, _P, _I, _P, _P, _G, _P, _P, _Z, _P]),
+    "ssd_conv3x3_wino_dgrad_planes": (_I, [_P, _P, _I, _P, _P, _I, _G, _P, _Z, _P]),
     "ssd_conv3x3_wino_dgrad": (_I, [_P, _I, _P, _I, _P, _P, _I, _G, _I, _P, _Z, _P]),
     "ssd_conv3x3_wino_wgrad_workspace": (_Z, [_G, _I, _I]),
     "ssd_conv3x3_wino_wgrad": (_I, [_P, _P, _I, _P, _P, _G, _I, _P, _Z, _P]),

@@ -606,9 +606,11 @@ __global__ __launch_bounds__(256) void wino4_xform_t_kernel(const float* __restr
 // dy tiles into the plane layout of the forward transforms: Y[plane][tile][channel] = A dy A^T (4x4 block -> 6x6 planes)
 // BIAS: the pass also leaves per-block column sums of dy (the bias gradient) in part[block][Cvalid]; the launch makes the thread
 // count a multiple of C/4, so a thread keeps its channel quad over the grid-stride loop, and a block combines its threads in a fixed order.
+// Vd (optional): the same pass also writes B^T dy B of the 6x6 patch around each block -- the input planes of this layer's dgrad
+// (wino4_input_kernel's output) -- so dy is read from HBM once for both; the 4x4 block is the patch's interior and comes from cache.
 template <bool BIAS>
 __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__ dy, float* __restrict__ Y, int N, int H, int W, int C,
-                                                       int TH, int TW, float* __restrict__ part, int Cvalid) {
+                                                       int TH, int TW, float* __restrict__ part, int Cvalid, float* __restrict__ Vd) {
     const int C4 = C >> 2;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     const size_t tiles = (size_t)N * TH * TW, total = tiles * C4;
@@ -617,6 +619,39 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
         const int c4 = (int)(i % C4);
         const size_t tile = i / C4;
         const int tw = (int)(tile % TW), th = (int)((tile / TW) % TH), n = (int)(tile / ((size_t)TW * TH));
+        if (Vd != nullptr) {                                 // uniform: the dgrad planes, as wino4_input_kernel forms them
+            f32x4 u[6][6];
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                f32x4 d[6];
+                const int iw = 4 * tw - 1 + b;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    const int ih = 4 * th - 1 + a;
+                    const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                    d[a] = ok ? *reinterpret_cast<const f32x4*>(dy + (((size_t)n * H + ih) * W + iw) * C + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 6; ++k)
+                        if (W4_BT[a][k] != 0.f) acc += W4_BT[a][k] * d[k];
+                    u[a][b] = acc;
+                }
+            }
+            float* dv = Vd + tile * C + c4 * 4;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = 0; b < 6; ++b) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 6; ++k)
+                        if (W4_BT[b][k] != 0.f) acc += W4_BT[b][k] * u[a][k];
+                    *reinterpret_cast<f32x4*>(dv + (size_t)(a * 6 + b) * plane) = acc;
+                }
+        }
         f32x4 t[6][4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
@@ -752,25 +787,22 @@ __global__ __launch_bounds__(256) void wino4_wgrad_finish_kernel(const float* __
     const size_t total = (size_t)Co * Ci, quads = total >> 2;          // Ci % 4 == 0
     for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (size_t)gridDim.x * 256) {
         const size_t i = q * 4;
-        f32x4 t[3][6];                                       // G^T Z, one plane column at a time
+        f32x4 z[6][6];                                       // all 36 planes in flight at once, then the remaining K slices in order
 #pragma unroll
-        for (int b = 0; b < 6; ++b) {
-            f32x4 z[6];
+        for (int pl = 0; pl < 36; ++pl) z[pl / 6][pl % 6] = *reinterpret_cast<const f32x4*>(Zs + (size_t)pl * ksplit * total + i);
+        for (int k = 1; k < ksplit; ++k)
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                const float* src = Zs + (size_t)(a * 6 + b) * ksplit * total + i;
-                f32x4 sum = *reinterpret_cast<const f32x4*>(src);
-                for (int k = 1; k < ksplit; ++k) sum += *reinterpret_cast<const f32x4*>(src + (size_t)k * total);
-                z[a] = sum;
-            }
+            for (int pl = 0; pl < 36; ++pl) z[pl / 6][pl % 6] += *reinterpret_cast<const f32x4*>(Zs + ((size_t)pl * ksplit + k) * total + i);
+        f32x4 t[3][6];                                       // G^T Z
+#pragma unroll
+        for (int b = 0; b < 6; ++b)
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int a = 0; a < 6; ++a) acc += W4_G[a][r] * z[a];
+                for (int a = 0; a < 6; ++a) acc += W4_G[a][r] * z[a][b];
                 t[r][b] = acc;
             }
-        }
         float flat[36];                                      // [entry][3x3 tap], as the four OIHW entries lie in memory
 #pragma unroll
         for (int r = 0; r < 3; ++r)
@@ -795,7 +827,7 @@ inline int grid_for(size_t total) { const size_t b = (total + 255) / 256; return
 struct PooledOut { float* y; uint8_t* argmax; int Ho, Wo; };     // destination of the fused conv -> ReLU -> 2x2/s2 max pool form
 int wino_conv(int mo, const float* in, int Cin, const float* U, int U_rows, float* out, int ldo, int Cout, const float* bias,
               const float* mask, int relu, int accumulate, int N, int H, int W, void* ws, size_t ws_bytes, hipStream_t st,
-              const PooledOut* pooled = nullptr, float* V_keep = nullptr) {
+              const PooledOut* pooled = nullptr, float* V_keep = nullptr, const float* V_given = nullptr) {
     const int TH = (H + mo - 1) / mo, TW = (W + mo - 1) / mo, P = (mo + 2) * (mo + 2);
     const size_t tiles = (size_t)N * TH * TW;
     const int Cvalid = Cout;
@@ -805,7 +837,8 @@ int wino_conv(int mo, const float* in, int Cin, const float* U, int U_rows, floa
     if (ws_bytes < vb + mb) return SSD_ERR_WORKSPACE;
     float* V = V_keep != nullptr ? V_keep : static_cast<float*>(ws);       // kept planes: the weight gradient multiplies them again
     float* Mx = reinterpret_cast<float*>(static_cast<char*>(ws) + vb);
-    if (mo == 2) hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(tiles * (Cin / 4))), dim3(256), 0, st, in, V, N, H, W, Cin, TH, TW);
+    if (V_given != nullptr) V = const_cast<float*>(V_given);                // input planes already formed (by the dy pass of the wgrad)
+    else if (mo == 2) hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(tiles * (Cin / 4))), dim3(256), 0, st, in, V, N, H, W, Cin, TH, TW);
     else hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(tiles * (Cin / 4))), dim3(256), 0, st, in, V, N, H, W, Cin, TH, TW);
     SSD_CHECK_LAUNCH();
     if (int e = ssd_internal_gemm_batched(V, U, Mx, (int)tiles, Cin, Cout, U_rows, P, tiles * Cin, (size_t)U_rows * Cin, 1, st)) return e;
@@ -942,23 +975,34 @@ extern "C" size_t ssd_conv3x3_wino_wgrad_workspace(const ssd_conv_geom* g, int l
 // dw (Co,Ci,3,3) OIHW and, if asked, dbias (Co) from x (N,H,W,Ci) and dy (N,H,W,ldy; columns >= Co zero); mo = 2 or 4
 namespace {
 int wino_wgrad(const float* x, const float* planes, const float* dy, int ldy, float* dw_oihw, float* dbias, const ssd_conv_geom* g, int mo,
-               void* workspace, size_t workspace_bytes, void* stream);
+               float* dgrad_planes, void* workspace, size_t workspace_bytes, void* stream);
 }
 extern "C" int ssd_conv3x3_wino_wgrad(const float* x, const float* dy, int ldy, float* dw_oihw, float* dbias, const ssd_conv_geom* g,
                                       int mo, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x) return SSD_ERR_NULL;
     if (!ssd_aligned16(x)) return SSD_ERR_ALIGN;
-    return wino_wgrad(x, nullptr, dy, ldy, dw_oihw, dbias, g, mo, workspace, workspace_bytes, stream);
+    return wino_wgrad(x, nullptr, dy, ldy, dw_oihw, dbias, g, mo, nullptr, workspace, workspace_bytes, stream);
 }
 extern "C" int ssd_conv3x3_wino_wgrad_planes(const float* planes, const float* dy, int ldy, float* dw_oihw, float* dbias,
-                                             const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream) {
+                                             const ssd_conv_geom* g, float* dgrad_planes_out, void* workspace, size_t workspace_bytes,
+                                             void* stream) {
     if (!planes) return SSD_ERR_NULL;
-    if (!ssd_aligned16(planes)) return SSD_ERR_ALIGN;
-    return wino_wgrad(nullptr, planes, dy, ldy, dw_oihw, dbias, g, 4, workspace, workspace_bytes, stream);
+    if (!ssd_aligned16(planes) || (dgrad_planes_out && !ssd_aligned16(dgrad_planes_out))) return SSD_ERR_ALIGN;
+    return wino_wgrad(nullptr, planes, dy, ldy, dw_oihw, dbias, g, 4, dgrad_planes_out, workspace, workspace_bytes, stream);
+}
+extern "C" int ssd_conv3x3_wino_dgrad_planes(const float* dy_planes, const float* U_bwd, int Co_pad, float* dx, const float* relu_mask,
+                                             int accumulate, const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dy_planes || !U_bwd || !dx || !workspace) return SSD_ERR_NULL;
+    if (!wino_geom_ok(g) || Co_pad % 32 != 0 || Co_pad < g->Co || g->Ci % 4 != 0) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(dy_planes) || !ssd_aligned16(dx) || !ssd_aligned16(workspace) || !ssd_aligned16(U_bwd) ||
+        (relu_mask && !ssd_aligned16(relu_mask)))
+        return SSD_ERR_ALIGN;
+    return wino_conv(4, nullptr, Co_pad, U_bwd, g->Ci, dx, g->Ci, g->Ci, nullptr, relu_mask, 0, accumulate, g->N, g->H, g->W, workspace,
+                     workspace_bytes, (hipStream_t)stream, nullptr, nullptr, dy_planes);
 }
 namespace {
 int wino_wgrad(const float* x, const float* planes, const float* dy, int ldy, float* dw_oihw, float* dbias, const ssd_conv_geom* g, int mo,
-               void* workspace, size_t workspace_bytes, void* stream) {
+               float* dgrad_planes, void* workspace, size_t workspace_bytes, void* stream) {
     if (!dy || !dw_oihw || !workspace) return SSD_ERR_NULL;
     if (!wino_geom_ok(g) || g->Ci % 4 != 0 || ldy % 4 != 0 || ldy < g->Co || (mo != 2 && mo != 4)) return SSD_ERR_BAD_SHAPE;
     if (!ssd_aligned16(dy) || !ssd_aligned16(workspace) || !ssd_aligned16(dw_oihw)) return SSD_ERR_ALIGN;
@@ -974,6 +1018,7 @@ int wino_wgrad(const float* x, const float* planes, const float* dy, int ldy, fl
     const int gy = (w.Tpad / 32) * ((ldy / 4 + 7) / 8), gx = (w.Tpad / 32) * ((g->Ci / 4 + 7) / 8);
     const dim3 gyd(gy > 16384 ? 16384 : gy), gxd(gx > 16384 ? 16384 : gx);
     int dy_bias_blocks = 0;
+    if (dgrad_planes != nullptr && !(mo == 4 && (g_wgrad_tn || planes != nullptr))) return SSD_ERR_BAD_SHAPE;
     if (mo == 4 && (g_wgrad_tn || planes != nullptr)) {
         // planes in the forward layout [plane][tile][channel]; the GEMM reduces over the tile rows of both.  The x planes are the
         // forward convolution's own B^T d B when the caller kept them.
@@ -987,10 +1032,11 @@ int wino_wgrad(const float* x, const float* planes, const float* dy, int ldy, fl
             blocks = (blocks + unit - 1) / unit * unit;
             if (blocks > DY_BIAS_BLOCKS) blocks -= unit;
             dy_bias_blocks = blocks;
-            hipLaunchKernelGGL(wino4_dy_kernel<true>, dim3(blocks), dim3(256), 0, st, dy, Yt, g->N, g->H, g->W, ldy, w.TH, w.TW, part, g->Co);
+            hipLaunchKernelGGL(wino4_dy_kernel<true>, dim3(blocks), dim3(256), 0, st, dy, Yt, g->N, g->H, g->W, ldy, w.TH, w.TW, part, g->Co,
+                               dgrad_planes);
         } else
             hipLaunchKernelGGL(wino4_dy_kernel<false>, dim3(grid_for(w.tiles * c4)), dim3(256), 0, st, dy, Yt, g->N, g->H, g->W, ldy, w.TH, w.TW,
-                               static_cast<float*>(nullptr), 0);
+                               static_cast<float*>(nullptr), 0, dgrad_planes);
         if (planes == nullptr)
             hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(w.tiles * (g->Ci / 4))), dim3(256), 0, st, x, Vt, g->N, g->H, g->W, g->Ci, w.TH,
                                w.TW);

@@ -673,31 +673,46 @@ def conv2d_fwd_wino_pool(x: torch.Tensor, u_fwd: torch.Tensor, bias: Optional[to
     return (y, am, planes) if keep_planes else (y, am)
 
 
-def conv2d_dgrad_wino(dy: torch.Tensor, u_bwd: torch.Tensor, g: ConvGeom, dx: Optional[torch.Tensor] = None,
-                      relu_mask: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
-    _req(dy, "dy"); _req(u_bwd, "u_bwd")
+def conv2d_dgrad_wino(dy: Optional[torch.Tensor], u_bwd: torch.Tensor, g: ConvGeom, dx: Optional[torch.Tensor] = None,
+                      relu_mask: Optional[torch.Tensor] = None, accumulate: bool = False,
+                      planes: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """planes: B^T dy B as `conv2d_wgrad_wino(..., dgrad_planes=True)` left it ((36, tiles, Co_pad), F(4x4)); dy is then not read."""
+    _req(u_bwd, "u_bwd")
     mo = _wino_mo(u_bwd)
     co_pad = u_bwd.shape[2]
-    if dy.numel() != g.N * g.H * g.W * co_pad or u_bwd.shape[1] != g.Ci:
-        raise ValueError("conv2d_dgrad_wino: shapes do not match the geometry")
+    dev = u_bwd.device
+    if planes is not None:
+        _req(planes, "planes")
+        if mo != 4 or tuple(planes.shape) != (36, wino_planes_shape(g)[1], co_pad) or u_bwd.shape[1] != g.Ci:
+            raise ValueError("conv2d_dgrad_wino: planes do not match the geometry")
+    else:
+        _req(dy, "dy")
+        if dy.numel() != g.N * g.H * g.W * co_pad or u_bwd.shape[1] != g.Ci:
+            raise ValueError("conv2d_dgrad_wino: shapes do not match the geometry")
     if dx is None:
         if accumulate:
             raise ValueError("accumulate needs an existing dx")
-        dx = torch.empty((g.N, g.H, g.W, g.Ci), device=dy.device, dtype=torch.float32)
+        dx = torch.empty((g.N, g.H, g.W, g.Ci), device=dev, dtype=torch.float32)
     _req(dx, "dx")
     if relu_mask is not None:
         _req(relu_mask, "relu_mask")
     lib = _lib.load()
-    ws = workspace(lib.ssd_conv3x3_wino_workspace(C.byref(g), 1, mo), dy.device, "wino")
+    ws = workspace(lib.ssd_conv3x3_wino_workspace(C.byref(g), 1, mo), dev, "wino")
+    if planes is not None:
+        check(lib.ssd_conv3x3_wino_dgrad_planes(planes.data_ptr(), u_bwd.data_ptr(), co_pad, dx.data_ptr(), _ptr(relu_mask), int(accumulate),
+                                                C.byref(g), ws.data_ptr(), ws.numel(), _stream()), "conv2d_dgrad_wino")
+        return dx
     check(lib.ssd_conv3x3_wino_dgrad(dy.data_ptr(), co_pad, u_bwd.data_ptr(), co_pad, dx.data_ptr(), _ptr(relu_mask), int(accumulate),
                                      C.byref(g), mo, ws.data_ptr(), ws.numel(), _stream()), "conv2d_dgrad_wino")
     return dx
 
 
 def conv2d_wgrad_wino(x: Optional[torch.Tensor], dy: torch.Tensor, g: ConvGeom, ldy: int, want_bias: bool = True, mo: int = 2,
-                      planes: Optional[torch.Tensor] = None):
+                      planes: Optional[torch.Tensor] = None, dgrad_planes: bool = False):
     """Winograd F(mo x mo, 3x3) weight gradient, mo = 2 or 4 -> (dw (Co,Ci,3,3) OIHW, dbias (Co,) or None).
-    planes: the transformed input the forward kept (`conv2d_fwd_wino(..., keep_planes=True)`); x is then not read."""
+    planes: the transformed input the forward kept (`conv2d_fwd_wino(..., keep_planes=True)`); x is then not read.
+    dgrad_planes (needs planes): the pass over dy also forms this layer's dgrad input planes -> (dw, dbias, planes_dy (36, tiles, ldy))
+    for `conv2d_dgrad_wino(None, ..., planes=planes_dy)`."""
     _req(dy, "dy")
     if planes is not None:
         _req(planes, "planes")
@@ -717,10 +732,13 @@ def conv2d_wgrad_wino(x: Optional[torch.Tensor], dy: torch.Tensor, g: ConvGeom, 
     ws = workspace(nbytes, dev, "wino")
     dw = torch.empty((g.Co, g.Ci, 3, 3), device=dev, dtype=torch.float32)
     db = torch.empty((g.Co,), device=dev, dtype=torch.float32) if want_bias else None
+    if dgrad_planes and planes is None:
+        raise ValueError("conv2d_wgrad_wino: dgrad_planes needs the kept forward planes")
     if planes is not None:
-        check(lib.ssd_conv3x3_wino_wgrad_planes(planes.data_ptr(), dy.data_ptr(), ldy, dw.data_ptr(), _ptr(db), C.byref(g), ws.data_ptr(),
-                                                ws.numel(), _stream()), "conv2d_wgrad_wino")
-        return dw, db
+        pd = torch.empty((36, planes.shape[1], ldy), device=dev, dtype=torch.float32) if dgrad_planes else None
+        check(lib.ssd_conv3x3_wino_wgrad_planes(planes.data_ptr(), dy.data_ptr(), ldy, dw.data_ptr(), _ptr(db), C.byref(g), _ptr(pd),
+                                                ws.data_ptr(), ws.numel(), _stream()), "conv2d_wgrad_wino")
+        return (dw, db, pd) if dgrad_planes else (dw, db)
     check(lib.ssd_conv3x3_wino_wgrad(x.data_ptr(), dy.data_ptr(), ldy, dw.data_ptr(), _ptr(db), C.byref(g), mo, ws.data_ptr(), ws.numel(),
                                      _stream()), "conv2d_wgrad_wino")
     return dw, db

@@ -571,6 +571,10 @@ def test_winograd_f4x4_3x3_forward_and_dgrad(case):
     assert torch.equal(yk, yd) and tuple(planes.shape) == ops.wino_planes_shape(g)
     dw_p, db_p = ops.conv2d_wgrad_wino(None, dy_p.to(dev), g, ld, True, mo=4, planes=planes)
     assert torch.equal(dw_p, dw) and torch.equal(db_p, db)
+    # ... and the same pass over dy can leave the data gradient's input planes: dgrad on them == dgrad on dy
+    dw_q, db_q, dy_planes = ops.conv2d_wgrad_wino(None, dy_p.to(dev), g, ld, True, mo=4, planes=planes, dgrad_planes=True)
+    assert torch.equal(dw_q, dw) and torch.equal(db_q, db)
+    assert torch.equal(ops.conv2d_dgrad_wino(None, ub, g, planes=dy_planes), dx)
     # and the transposed-plane formulation (NT GEMM) of the same gradient agrees
     from objectdetection_ssd_amd import _lib
     _lib.check(_lib.load().ssd_tune_set_wino_wgrad_tn(0))
