@@ -387,7 +387,7 @@ def main():
             peak, peak_note = round(2500.0 / 6, 1), "bf16 MFMA dense / 6 limb products per f32 product"
         if tag == gemm_tag:
             peak_note += ("; this is the batched GEMM inside the Winograd ops, timed by itself: `achieved` is its EXECUTED rate (4/9 resp. 1/4 of "
-                          "the direct convolution's FLOPs plus tile padding); the ops it serves are the `winograd_f2x2_3x3` row of by_kernel, in "
+                          "the direct convolution's FLOPs plus tile padding); the ops it serves are the `winograd_3x3` row of by_kernel, in "
                           "direct-convolution FLOPs")
         if tag.startswith("winograd"):
             peak_note += ("; the ops of this tag are Winograd F(2x2,3x3) convolutions (input transform + 16 batched igemm_kernel<64,64> "

@@ -260,14 +260,14 @@ class _Engine:
                     # training: the transformed input stays for the weight gradient, which multiplies the same planes
                     keep = save and self.keep_planes and self.WINO_TILE == 4 and self._wino_wgrad_ok(g, False)
                     if pl is not None:
-                        res = self._timed("fwd " + op["p"], "winograd_f2x2_3x3", ops.conv_flops(g),
+                        res = self._timed("fwd " + op["p"], "winograd_3x3", ops.conv_flops(g),
                                           lambda: ops.conv2d_fwd_wino_pool(xin, uf, bias, g, pl["ceil"], want_argmax=save, keep_planes=keep))
                         T[op["y"]] = _Elided((bs, g.H, g.W, op["co"]))      # never materialised: its only reader is the pool
                         T[pl["y"]], aux[pl["y"]], aux[op["y"]] = res[0], res[1], g
                         if keep:
                             aux["planes:" + op["p"]] = res[2]
                         continue
-                    res = self._timed("fwd " + op["p"], "winograd_f2x2_3x3", ops.conv_flops(g),
+                    res = self._timed("fwd " + op["p"], "winograd_3x3", ops.conv_flops(g),
                                       lambda: ops.conv2d_fwd_wino(xin, uf, bias, g, op["relu"], keep_planes=keep))
                     T[op["y"]] = res[0] if keep else res
                     if keep:
@@ -297,7 +297,7 @@ class _Engine:
                 if self._wino_ok(g):
                     uf, _ = self._wino_weights(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]), ops.pad32(co))
                     keep = save and self.keep_planes and self.WINO_TILE == 4 and self._wino_wgrad_ok(g, True)
-                    res = self._timed("fwd " + pre, "winograd_f2x2_3x3", ops.conv_flops(g),
+                    res = self._timed("fwd " + pre, "winograd_3x3", ops.conv_flops(g),
                                       lambda: ops.conv2d_fwd_wino(xin, uf, bias, g, False, ld=ops.pad32(co), keep_planes=keep))
                     if keep:
                         aux["planes:" + pre] = res[1]
@@ -351,7 +351,7 @@ class _Engine:
                     if self._wino_wgrad_ok(g, True):
                         kept = aux.pop("planes:" + pre, None)
                         dual = kept is not None and self.dual_dy        # one pass over dy feeds the weight and the data gradient
-                        res = self._timed("wgrad " + pre, "winograd_f2x2_3x3", ops.conv_flops(g),
+                        res = self._timed("wgrad " + pre, "winograd_3x3", ops.conv_flops(g),
                                           lambda: ops.conv2d_wgrad_wino(xin, dy, g, co_pad, True, mo=self.WINO_TILE, planes=kept,
                                                                         dgrad_planes=dual))
                         dw, db = res[0], res[1]
@@ -363,7 +363,7 @@ class _Engine:
                     grads[pre + "_bb.bias"], grads[pre + "_cl.bias"] = db[:a4], db[a4:]
                 if self._wino_ok(g):
                     _, ub = self._wino_weights(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]), co_pad)
-                    deliver(op["x"], lambda dx, acc, mask: self._timed("dgrad " + pre, "winograd_f2x2_3x3", ops.conv_flops(g),
+                    deliver(op["x"], lambda dx, acc, mask: self._timed("dgrad " + pre, "winograd_3x3", ops.conv_flops(g),
                                                                        lambda: ops.conv2d_dgrad_wino(dy, ub, g, dx, mask, acc, planes=dyp)))
                     continue
                 _, wb = self._layouts(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]), co_pad, True)
@@ -380,7 +380,7 @@ class _Engine:
                     if self._wino_wgrad_ok(g, False):
                         kept = aux.pop("planes:" + op["p"], None)
                         dual = kept is not None and self.dual_dy and g.Co % 32 == 0
-                        res = self._timed("wgrad " + op["p"], "winograd_f2x2_3x3", ops.conv_flops(g),
+                        res = self._timed("wgrad " + op["p"], "winograd_3x3", ops.conv_flops(g),
                                           lambda: ops.conv2d_wgrad_wino(xin, dy, g, g.Co, True, mo=self.WINO_TILE, planes=kept,
                                                                         dgrad_planes=dual))
                         dw, db = res[0], res[1]
@@ -391,7 +391,7 @@ class _Engine:
                     grads[op["p"] + ".weight"], grads[op["p"] + ".bias"] = dw, db
                 if self._wino_ok(g):
                     _, ub = self._wino_weights(op["p"], (P[op["p"] + ".weight"],), op["co"])
-                    deliver(op["x"], lambda dx, acc, mask: self._timed("dgrad " + op["p"], "winograd_f2x2_3x3", ops.conv_flops(g),
+                    deliver(op["x"], lambda dx, acc, mask: self._timed("dgrad " + op["p"], "winograd_3x3", ops.conv_flops(g),
                                                                        lambda: ops.conv2d_dgrad_wino(dy, ub, g, dx, mask, acc, planes=dyp)))
                     continue
                 _, wb = self._layouts(op["p"], (P[op["p"] + ".weight"],), op["co"], True)
