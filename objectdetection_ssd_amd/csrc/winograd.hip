@@ -782,17 +782,32 @@ __global__ __launch_bounds__(256) void wino_gemm_tn_kernel(const TnParams p) {
     }
 }
 
-// four neighbouring (co, ci) entries per thread: 16-byte loads of the 36 x ksplit partial planes, 144 contiguous output bytes
-__global__ __launch_bounds__(256) void wino4_wgrad_finish_kernel(const float* __restrict__ Zs, float* __restrict__ dw, int Co, int Ci, int ksplit) {
+// Split-K partial planes Zs[plane][split][Co*Ci] summed in place into split 0, in split order: one thread per (plane, 4 entries).  The
+// finish kernel below has only Co*Ci/4 threads -- 16 blocks for a 128 x 128 filter -- so with many splits the sum is taken here, wide, first.
+__global__ __launch_bounds__(256) void wino_splitk_sum_kernel(float* __restrict__ Zs, size_t total, int P, int ksplit) {
+    const size_t quads = total >> 2, n = quads * P;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
+        const size_t pl = idx / quads, q = idx - pl * quads;
+        float* src = Zs + pl * ksplit * total + q * 4;
+        f32x4 sum = *reinterpret_cast<const f32x4*>(src);
+        for (int k = 1; k < ksplit; ++k) sum += *reinterpret_cast<const f32x4*>(src + (size_t)k * total);
+        *reinterpret_cast<f32x4*>(src) = sum;
+    }
+}
+
+// four neighbouring (co, ci) entries per thread: 16-byte loads of the 36 x ksplit partial planes (plane stride pstride floats), 144
+// contiguous output bytes
+__global__ __launch_bounds__(256) void wino4_wgrad_finish_kernel(const float* __restrict__ Zs, float* __restrict__ dw, int Co, int Ci, int ksplit,
+                                                                 size_t pstride) {
     const size_t total = (size_t)Co * Ci, quads = total >> 2;          // Ci % 4 == 0
     for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (size_t)gridDim.x * 256) {
         const size_t i = q * 4;
         f32x4 z[6][6];                                       // all 36 planes in flight at once, then the remaining K slices in order
 #pragma unroll
-        for (int pl = 0; pl < 36; ++pl) z[pl / 6][pl % 6] = *reinterpret_cast<const f32x4*>(Zs + (size_t)pl * ksplit * total + i);
+        for (int pl = 0; pl < 36; ++pl) z[pl / 6][pl % 6] = *reinterpret_cast<const f32x4*>(Zs + (size_t)pl * pstride + i);
         for (int k = 1; k < ksplit; ++k)
 #pragma unroll
-            for (int pl = 0; pl < 36; ++pl) z[pl / 6][pl % 6] += *reinterpret_cast<const f32x4*>(Zs + ((size_t)pl * ksplit + k) * total + i);
+            for (int pl = 0; pl < 36; ++pl) z[pl / 6][pl % 6] += *reinterpret_cast<const f32x4*>(Zs + (size_t)pl * pstride + (size_t)k * total + i);
         f32x4 t[3][6];                                       // G^T Z
 #pragma unroll
         for (int b = 0; b < 6; ++b)
@@ -1067,7 +1082,17 @@ int wino_wgrad(const float* x, const float* planes, const float* dy, int ldy, fl
     if (mo == 2)
         hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3(grid_for((size_t)g->Co * g->Ci)), dim3(256), 0, st, Zs, dw_oihw, g->Co, g->Ci, w.ks);
     else
-        hipLaunchKernelGGL(wino4_wgrad_finish_kernel, dim3(grid_for((size_t)g->Co * g->Ci / 4)), dim3(256), 0, st, Zs, dw_oihw, g->Co, g->Ci, w.ks);
+    {
+        const size_t total = (size_t)g->Co * g->Ci;
+        int ks_left = w.ks;
+        if (w.ks > 1 && total / 4 < 65536) {                 // few entries, many splits: sum the splits with a wide grid first
+            hipLaunchKernelGGL(wino_splitk_sum_kernel, dim3(grid_for(total / 4 * w.P)), dim3(256), 0, st, Zs, total, w.P, w.ks);
+            SSD_CHECK_LAUNCH();
+            ks_left = 1;
+        }
+        hipLaunchKernelGGL(wino4_wgrad_finish_kernel, dim3(grid_for(total / 4)), dim3(256), 0, st, Zs, dw_oihw, g->Co, g->Ci, ks_left,
+                           (size_t)w.ks * total);
+    }
     SSD_CHECK_LAUNCH();
     if (dbias && dy_bias_blocks > 0) {
         const int ldp = (g->Co + 3) / 4 * 4;
