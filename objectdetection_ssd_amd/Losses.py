@@ -63,6 +63,16 @@ class _MultiBoxLoss(torch.autograd.Function):
         return ctx.dloc * g_loc, ctx.dconf * g_conf, None, None, None, None
 
 
+def _image_starts(start, dev: torch.device) -> torch.Tensor:
+    """Device copy of the per-image box offsets.  A plain `.to(dev)` of a pageable host tensor makes the host wait for everything
+    queued on the stream -- in the train step that drains the whole forward and leaves the loss and the small head / aux backward
+    kernels launch-bound behind it -- so the offsets go up from pinned memory without blocking."""
+    host = torch.tensor(start, dtype=torch.int32)
+    if dev.type == "cuda":
+        return host.pin_memory().to(dev, non_blocking=True)
+    return host.to(dev)
+
+
 def _pack_targets(tr_classes: Sequence[torch.Tensor], tr_bboxs: Sequence[torch.Tensor], dev: torch.device):
     counts = [int(b.shape[0]) for b in tr_bboxs]
     if len(counts) == 0 or any(c == 0 for c in counts):
@@ -75,8 +85,7 @@ def _pack_targets(tr_classes: Sequence[torch.Tensor], tr_bboxs: Sequence[torch.T
         start.append(start[-1] + c)
     gt = torch.cat([b.reshape(-1, 4) for b in tr_bboxs]).to(device=dev, dtype=torch.float32).contiguous()
     cls = torch.cat([c.reshape(-1) for c in tr_classes]).to(device=dev, dtype=torch.float32).contiguous()
-    img_start = torch.tensor(start, dtype=torch.int32).to(dev)
-    return gt, cls, img_start
+    return gt, cls, _image_starts(start, dev)
 
 
 def ssd(outputs, tr_classes, tr_bboxs, norm_mode: int = 0):
