@@ -270,3 +270,48 @@ def test_fused_sgd_optimizer_interface():
     w.grad, b.grad = torch.ones_like(w), torch.ones_like(b)
     with pytest.raises(ValueError, match="on the GPU"):
         ours.step()
+
+
+def test_winograd_entry_points_validate_before_launching():
+    """Error convention of the C ABI (include/ssd_gfx950.h: 0 or a negative ssd_status, never a throw): the Winograd entry points
+    reject NULL / misaligned pointers, unsupported geometry and a short workspace before anything is enqueued -- so this runs
+    without a GPU, with made-up pointer values that are never dereferenced."""
+    import ctypes as C
+    from objectdetection_ssd_amd import _lib, ops
+    lib = _lib.load()
+    OK_PTR, ODD_PTR = 0x10000, 0x10004
+    g = ops.make_geom(2, 38, 38, 64, 64, 3, 1, 1, 1)
+    gb = C.byref(g)
+    ws_fwd = lib.ssd_conv3x3_wino_workspace(gb, 0, 4)
+    assert ws_fwd == 2 * 36 * 2 * 10 * 10 * 64 * 4                     # V and M planes: 36 x tiles x channels floats each
+    assert lib.ssd_conv3x3_wino_workspace(gb, 0, 3) == 0                # only F(2x2) and F(4x4) exist
+    # forward fused with the pool
+    f = lib.ssd_conv3x3_wino_fwd_pool
+    assert f(None, OK_PTR, None, OK_PTR, None, gb, 0, None, OK_PTR, ws_fwd, None) == -3
+    assert f(OK_PTR, OK_PTR, None, ODD_PTR, None, gb, 0, None, OK_PTR, ws_fwd, None) == -5
+    assert f(OK_PTR, OK_PTR, None, OK_PTR, None, gb, 0, ODD_PTR, OK_PTR, ws_fwd, None) == -5
+    assert f(OK_PTR, OK_PTR, None, OK_PTR, None, gb, 0, None, OK_PTR, ws_fwd - 1, None) == -2
+    g5 = ops.make_geom(2, 38, 38, 64, 64, 5, 1, 2, 1)
+    assert f(OK_PTR, OK_PTR, None, OK_PTR, None, C.byref(g5), 0, None, OK_PTR, ws_fwd, None) == -1
+    g2 = ops.make_geom(2, 38, 38, 64, 62, 3, 1, 1, 1)                  # the pooled form needs whole channel quads
+    assert f(OK_PTR, OK_PTR, None, OK_PTR, None, C.byref(g2), 0, None, OK_PTR, ws_fwd, None) == -1
+    # forward that keeps its planes
+    k = lib.ssd_conv3x3_wino_fwd_keep
+    assert k(OK_PTR, OK_PTR, None, OK_PTR, 64, gb, 1, None, OK_PTR, ws_fwd, None) == -3
+    assert k(OK_PTR, OK_PTR, None, OK_PTR, 60, gb, 1, OK_PTR, OK_PTR, ws_fwd, None) == -1
+    assert k(OK_PTR, OK_PTR, None, OK_PTR, 64, gb, 1, OK_PTR, OK_PTR, 16, None) == -2
+    # weight gradient on kept planes, data gradient on the planes its dy pass leaves
+    ws_w = lib.ssd_conv3x3_wino_wgrad_workspace(gb, 64, 4)
+    assert ws_w > 0
+    w = lib.ssd_conv3x3_wino_wgrad_planes
+    assert w(None, OK_PTR, 64, OK_PTR, None, gb, None, OK_PTR, ws_w, None) == -3
+    assert w(OK_PTR, OK_PTR, 64, ODD_PTR, None, gb, None, OK_PTR, ws_w, None) == -5
+    assert w(OK_PTR, OK_PTR, 62, OK_PTR, None, gb, None, OK_PTR, ws_w, None) == -1
+    assert w(OK_PTR, OK_PTR, 64, OK_PTR, None, gb, None, OK_PTR, ws_w - 1, None) == -2
+    d = lib.ssd_conv3x3_wino_dgrad_planes
+    ws_d = lib.ssd_conv3x3_wino_workspace(gb, 1, 4)
+    assert d(None, OK_PTR, 64, OK_PTR, None, 0, gb, OK_PTR, ws_d, None) == -3
+    assert d(OK_PTR, OK_PTR, 48, OK_PTR, None, 0, gb, OK_PTR, ws_d, None) == -1      # Co_pad must be a multiple of 32 and >= Co
+    assert d(OK_PTR, OK_PTR, 64, OK_PTR, ODD_PTR, 0, gb, OK_PTR, ws_d, None) == -5
+    assert d(OK_PTR, OK_PTR, 64, OK_PTR, None, 0, gb, OK_PTR, 16, None) == -2
+    assert lib.ssd_status_string(-5).startswith(b"pointer")
