@@ -227,6 +227,42 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* 
     }
 }
 
+// scatter form for the 2x2 / stride-2 / no-pad pool whose windows tile the whole input (the gated case: sole consumer, no accumulate):
+// one thread per window and channel quad reads dy, the argmax codes and the gate once and writes the window's (up to) four inputs --
+// the gather form above reads each of them from all four inputs of the window.
+__global__ __launch_bounds__(256) void maxpool2_bwd_scatter_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ am,
+                                                                   const float* __restrict__ y_gate, float* __restrict__ dx, int N, int H, int W,
+                                                                   int C, int Ho, int Wo) {
+    const int C4 = C >> 2;
+    const size_t total = (size_t)N * Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        size_t rest = i / C4;
+        const int ow = (int)(rest % Wo);
+        rest /= Wo;
+        const int oh = (int)(rest % Ho), n = (int)(rest / Ho);
+        f32x4 d = *reinterpret_cast<const f32x4*>(dy + i * 4);
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y_gate + i * 4);
+        const uint32_t a = *reinterpret_cast<const uint32_t*>(am + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = yv[e] > 0.f ? d[e] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int ih = 2 * oh + r;
+            if (ih >= H) continue;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int iw = 2 * ow + q;
+                if (iw >= W) continue;
+                f32x4 g;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = ((a >> (8 * e)) & 0xffu) == (uint32_t)(r * 2 + q) ? d[e] : 0.f;
+                *reinterpret_cast<f32x4*>(dx + ((((size_t)n * H + ih) * W + iw) * C4 + c4) * 4) = g;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // L2 norm over channels: one wave per pixel, C = 512 -> 8 floats per lane
 // ---------------------------------------------------------------------------------------
@@ -472,6 +508,12 @@ extern "C" int ssd_maxpool_bwd_gated(const float* dy, const uint8_t* argmax, con
     if (!dy || !argmax || !y || !dx) return SSD_ERR_NULL;
     if (C % 4 != 0 || k <= 0 || k > 15 || stride <= 0 || pad < 0) return SSD_ERR_BAD_SHAPE;
     if (!ssd_aligned16(dy) || !ssd_aligned16(dx) || !ssd_aligned16(y)) return SSD_ERR_ALIGN;
+    if (k == 2 && stride == 2 && pad == 0 && 2 * Ho >= H && 2 * Wo >= W && ((uintptr_t)argmax & 3) == 0) {
+        hipLaunchKernelGGL(maxpool2_bwd_scatter_kernel, dim3(grid_for((size_t)N * Ho * Wo * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy,
+                           argmax, y, dx, N, H, W, C, Ho, Wo);
+        SSD_CHECK_LAUNCH();
+        return SSD_OK;
+    }
     const size_t total = (size_t)N * H * W * (C / 4);
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx,
                        static_cast<const float*>(nullptr), y, 0, N, H, W, C, k, stride, pad, Ho, Wo);
