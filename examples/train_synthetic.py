@@ -40,14 +40,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=20)        # train.py:29
+    ap.add_argument("--fused-sgd", action="store_true", help="objectdetection_ssd_amd.optim.SGD in place of torch.optim.SGD (same results)")
     a = ap.parse_args()
     device = torch.device("cuda")
     cnn = SSD_300().to(device)
     biases = [p for n, p in cnn.named_parameters() if p.requires_grad and n.endswith(".bias")]
     not_biases = [p for n, p in cnn.named_parameters() if p.requires_grad and not n.endswith(".bias")]
     lr = 1e-4
-    optimizer = torch.optim.SGD(params=[{"params": biases, "lr": 2 * lr}, {"params": not_biases}], lr=lr, momentum=0.9,
-                                weight_decay=5e-4)          # train.py:53-55
+    if a.fused_sgd:
+        from objectdetection_ssd_amd.optim import SGD
+    else:
+        SGD = torch.optim.SGD
+    optimizer = SGD(params=[{"params": biases, "lr": 2 * lr}, {"params": not_biases}], lr=lr, momentum=0.9,
+                    weight_decay=5e-4)                      # train.py:53-55
     cnn.train()
     t0 = time.time()
     for count, (inputs, classes, bboxes) in enumerate(batches(a.steps, a.batch, device)):
