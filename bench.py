@@ -213,6 +213,8 @@ def main():
     ap.add_argument("--wino-wgrad-nt", action="store_true", help="tuning aid: Winograd weight gradient on transposed planes (NT GEMM)")
     ap.add_argument("--no-keep-planes", action="store_true", help="tuning aid: the Winograd weight gradient transforms x again")
     ap.add_argument("--no-dual-dy", action="store_true", help="tuning aid: weight and data gradient transform dy separately")
+    ap.add_argument("--overlap-allreduce", action="store_true",
+                    help="all-reduce the gradient buffer in slices while the backward is still running (ddp.py overlap=True; opt-in)")
     ap.add_argument("--igemm-lds-pad", type=int, default=-1, help="tuning aid: extra dynamic LDS bytes per igemm block (-1 = library default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
@@ -266,7 +268,7 @@ def main():
         net._engine.keep_planes = False
     if args.no_dual_dy:
         net._engine.dual_dy = False
-    trainer = FlatSGDDataParallel(net, lr=1e-4, momentum=0.9, weight_decay=5e-4)
+    trainer = FlatSGDDataParallel(net, lr=1e-4, momentum=0.9, weight_decay=5e-4, overlap=args.overlap_allreduce)
     trainer.broadcast_parameters(0)
     bs = args.batch
     x, classes, boxes = synth_batch(bs, 1234 + rank, dev)
@@ -324,7 +326,7 @@ def main():
            "config": {"workload": ("" if args.variant == 300 else "[build-defined SSD512, FLOP figures below are the SSD300 ones] ") +
                                   f"SSD300-VGG16 train step (fwd + MultiBox loss + bwd + all-reduce + SGD), "
                                   f"batch {bs}/GPU, 300x300x3, 21 classes, 8732 priors (BASELINE configs[1])",
-                      "global_batch": bs * world, "per_gpu_batch": bs, "parallelism": f"dp{world}",
+                      "global_batch": bs * world, "per_gpu_batch": bs, "parallelism": f"dp{world}" + (" (gradient all-reduce overlapped with backward)" if args.overlap_allreduce else ""),
                       "train_gflop_per_image": TRAIN_GFLOP_PER_IMAGE,
                       "step_tflops_per_gpu": round(TRAIN_GFLOP_PER_IMAGE * ips / world / 1e3, 2),
                       "step_frac_of_f32_mfma_peak": round(TRAIN_GFLOP_PER_IMAGE * ips / world / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),

@@ -127,6 +127,19 @@ class _Elided:
         self.shape = tuple(shape)
 
 
+class _SinkDict(dict):
+    """Gradient table of one backward pass that tells a listener about every entry as soon as it exists (ddp.py starts the
+    all-reduce of a bucket when its last gradient has been computed, while the rest of the backward is still running)."""
+
+    def __init__(self, sink):
+        super().__init__()
+        self._sink = sink
+
+    def __setitem__(self, name, tensor):
+        super().__setitem__(name, tensor)
+        self._sink(name, tensor)
+
+
 class _Engine:
     """Runs the op list on the current HIP stream.  Holds only caches (re-laid-out weights)."""
 
@@ -145,6 +158,7 @@ class _Engine:
             if (len(readers) == 1 and readers[0]["op"] == "pool" and (readers[0]["k"], readers[0]["s"], readers[0]["pad"]) == (2, 2, 0)
                     and op["relu"] and op["co"] % 4 == 0):
                 self.pool_after[op["y"]] = readers[0]
+        self.grad_sink = None     # callable(name, gradient): called during backward the moment a parameter's gradient is ready
         self.dual_dy = True       # backward: one pass over dy writes the planes of the weight gradient AND of the data gradient
         self.keep_planes = True   # training forward keeps the F(4x4) input planes of the layers whose weight gradient is Winograd
         self.fuse_pool = True     # Winograd F(4x4) layers in pool_after write the pooled map + argmax only
@@ -327,7 +341,7 @@ class _Engine:
         dconf = dconf.contiguous()
         G: Dict[str, torch.Tensor] = {}
         arrived: Dict[str, int] = {}
-        grads: Dict[str, torch.Tensor] = {}
+        grads: Dict[str, torch.Tensor] = _SinkDict(self.grad_sink) if self.grad_sink is not None else {}
 
         def deliver(name, fn):
             """fn(dx, accumulate, mask) -> dx; mask only when this is the last contribution to a post-ReLU tensor."""

@@ -61,6 +61,26 @@ def _worker(rank, world, port, q):
             p.grad = torch.randn(p.shape, generator=g)
         local = [p.grad.clone() for p in tr.params]
         tr.reduce_gradients(torch.tensor(n_pos))
+        # --- the overlapped exchange (slices all-reduced as the backward fills them) gives the same buffer ---------------
+        net2 = _Tiny()
+        net2._engine.grad_sink = None
+        tr2 = FlatSGDDataParallel(net2, lr=0.1, overlap=True, bucket_bytes=256)       # 256 B buckets: several slices even here
+        assert net2._engine.grad_sink is not None and len(tr2._bucket_rng) >= 2
+        assert tr2._bucket_rng[0][0] == 0 and tr2._bucket_rng[-1][1] == tr2.n_w
+        tr2.zero_grad()
+        by_name = dict(zip(tr.names, local))
+        for nm in ["g", "b.bias", "b.weight", "a.bias", "a.weight"]:              # the order a backward pass produces them in
+            net2._engine.grad_sink(nm, by_name[nm])
+        tr2.reduce_gradients(torch.tensor(n_pos))
+        assert torch.equal(tr2.flat_grad[:tr2.n + 1], tr.flat_grad[:tr.n + 1]), "overlapped exchange differs"
+        assert float(tr2.inv_npos) == float(tr.inv_npos)
+        tr2.zero_grad()
+        net2._engine.grad_sink("g", by_name["g"])
+        try:
+            tr2.reduce_gradients(torch.tensor(n_pos))
+            raise AssertionError("incomplete backward must be refused")
+        except RuntimeError as e:
+            assert "did not deliver" in str(e)
         sums = torch.tensor([float(mine["loc_loss"]) * n_pos, float(mine["conf_loss"]) * n_pos, n_pos], dtype=torch.float64)
         dist.all_reduce(sums)
         gathered = [None] * world

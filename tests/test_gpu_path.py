@@ -496,6 +496,33 @@ def test_fused_sgd_optimizer_in_the_callers_loop():
     assert set(sd.keys()) == set(a.state_dict().keys())
 
 
+def test_overlapped_gradient_exchange_equals_the_single_allreduce_path():
+    """ddp.FlatSGDDataParallel(overlap=True): the engine reports every gradient the moment it exists, slices of the flat buffer
+    are handed to the collective as they fill up; at world size 1 the bookkeeping runs without the collectives and the weights
+    after three steps must be bit-identical to the plain path."""
+    from objectdetection_ssd_amd import Losses, Model
+    from objectdetection_ssd_amd.ddp import FlatSGDDataParallel
+    lr, bs = 1e-4, 2
+    x = _t(np.random.default_rng(61).standard_normal((bs, 3, 300, 300), dtype=np.float32))
+    boxes, classes = synth_gt(np.random.default_rng(62), bs)
+    cl = [_t(c) for c in classes]
+    bx = [_t(b) for b in boxes]
+    params = O.ssd300_random_params(8)
+    a = Model.SSD_300(); _load_params(a, params); a = a.to(DEV).train()
+    b = Model.SSD_300(); _load_params(b, params); b = b.to(DEV).train()
+    da = FlatSGDDataParallel(a, lr=lr, momentum=0.9, weight_decay=5e-4)
+    db = FlatSGDDataParallel(b, lr=lr, momentum=0.9, weight_decay=5e-4, overlap=True, bucket_bytes=8 << 20)
+    assert len(db._bucket_rng) >= 8 and sum(db._need) == len(db.w_names)
+    for _ in range(3):
+        for net, tr in ((a, da), (b, db)):
+            tr.zero_grad()
+            l1, l2 = Losses.ssd(net(x), cl, bx, norm_mode=1)
+            (l1 + l2).backward()
+            tr.reduce_and_step(Losses.last_match["n_pos"])
+    assert torch.equal(da.flat_param, db.flat_param)
+    assert torch.equal(da.flat_grad[:da.n + 1], db.flat_grad[:db.n + 1])
+
+
 def test_inference_batch_equals_single_image_calls(gold_dir):
     """(f)-4: the batched decode gives, image by image, exactly what `inference` gives (incl. an empty image)"""
     from objectdetection_ssd_amd import Losses
