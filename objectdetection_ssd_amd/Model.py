@@ -202,8 +202,9 @@ class _Engine:
         return ent[2], ent[3]
 
     WINO_TILE = 4                 # forward / dgrad output tile: F(4x4,3x3) (36 multiplies per 16 outputs; ~1e-5 of the output scale) or 2
-    WINO_WGRAD_MAX_HW = 150       # Winograd weight gradient on maps up to this size and from this many input channels: with F(4x4)
-    WINO_WGRAD_MIN_CI = 128       # conv2_2 ... conv5_3 gain 25-50 %; the 64-channel layers (conv1_2, conv2_1) lose to the fused direct kernel
+    WINO_WGRAD_MAX_HW = 512       # Winograd weight gradient on maps up to this size and from this many input channels.  Steps measured in
+    WINO_WGRAD_MIN_CI = 64        # the train step: (80, 256) 985 -> (150, 128) 1018 images/s; once the forward planes were kept and one pass
+                                  # over dy fed both gradients, the 64-channel layers paid too: + conv2_1 +0.7 %, + conv1_2 +3.8 %
     WINO_MIN_CI = 64              # measured in the step with F(4x4): 256 -> 836, 128 -> 872, 64 -> 879 images/s (F(2x2): only >= 256 paid)
 
     def _wino_ok(self, g) -> bool:
