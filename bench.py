@@ -51,32 +51,78 @@ def synth_batch(bs: int, seed: int, dev):
     return x.to(dev), classes, boxes
 
 
-def cpu_baseline(bs: int = 4, iters: int = 12, max_threads: int = 16):       # ~10-15 s of CPU work
-    """Oracle (CPU restatement of the reference path, plain torch-CPU ops) timed on the host cores."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import ssd_oracle as O
-    cores = os.cpu_count() or 1
+def host_cores():
+    n = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    cores = max(1, min(cores, max_threads))      # the box's CPU share for one GPU is 16 cores; 256 threads thrash
+    return n
+
+
+def cpu_baseline(max_threads: int = 16):
+    """the oracle (CPU restatement of the reference path: the same ATen CPU kernels the reference
+    dispatches to) timed on this box's host cores for the same synthetic step at bs=2 and bs=32, fwd / loss / bwd / SGD
+    separately.  Bounded sample (~20-30 s): bs=2 2 warm-up + 5 timed, bs=32 1 warm-up + 2 timed, median.  Also returns the
+    oracle's losses of the bs=32 batch at the seed-0 weights (first iteration, before any update) for `loss_delta_vs_cpu`."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ssd_oracle as O
+    have = host_cores()
+    cores = max(1, min(have, max_threads))       # one GPU's CPU share on the box is 16 cores; more threads than that thrash
     torch.set_num_threads(cores)
-    params = {k: v.requires_grad_(True) for k, v in O.ssd300_random_params(0).items()}
-    opt = torch.optim.SGD(list(params.values()), lr=1e-4, momentum=0.9, weight_decay=5e-4)
-    x, classes, boxes = synth_batch(bs, 1234, "cpu")
-    times = []
-    for it in range(iters + 1):
-        t0 = time.perf_counter()
-        opt.zero_grad()
-        loc, conf = O.ssd300_forward(x, params)
-        l1, l2 = O.multibox_loss_torch(loc, conf, boxes, classes)
-        (l1 + l2).backward()
-        opt.step()
-        times.append(time.perf_counter() - t0)
-    t = float(np.median(times[1:]))
-    return {"value": round(bs / t, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle torch-CPU train step (fwd+loss+bwd+SGD), bs={bs}, median of {iters} after 1 warm-up"}
+    res, first_losses = {}, None
+    for bs, warm, iters in ((2, 2, 5), (PER_GPU_BATCH, 1, 2)):
+        params = {k: v.requires_grad_(True) for k, v in O.ssd300_random_params(0).items()}
+        opt = torch.optim.SGD(list(params.values()), lr=1e-4, momentum=0.9, weight_decay=5e-4)
+        x, classes, boxes = synth_batch(bs, 1234, "cpu")
+        rows = []
+        for it in range(warm + iters):
+            t0 = time.perf_counter()
+            opt.zero_grad()
+            loc, conf = O.ssd300_forward(x, params)
+            t1 = time.perf_counter()
+            l1, l2 = O.multibox_loss_torch(loc, conf, boxes, classes)
+            t2 = time.perf_counter()
+            (l1 + l2).backward()
+            t3 = time.perf_counter()
+            opt.step()
+            t4 = time.perf_counter()
+            rows.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3))
+            if it == 0 and bs == PER_GPU_BATCH:
+                first_losses = (float(l1), float(l2))
+        med = np.median(np.asarray(rows[warm:]), axis=0)
+        res[bs] = {"images_per_sec": round(bs / float(med.sum()), 3), "fwd_s": round(float(med[0]), 4), "loss_s": round(float(med[1]), 4),
+                   "bwd_s": round(float(med[2]), 4), "sgd_s": round(float(med[3]), 4), "warmup": warm, "timed": iters}
+    cpu_model = ""
+    try:
+        cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        pass
+    out = {"value": res[PER_GPU_BATCH]["images_per_sec"], "unit": "images/sec", "cores": cores, "host_cores": have, "cpu": cpu_model,
+           "kind": "port",
+           "sample": f"oracle torch-CPU train step (fwd+loss+bwd+SGD) on the bench's own synthetic batch, bs={PER_GPU_BATCH}: 1 warm-up + 2 timed "
+                     f"(value); bs=2: 2 warm-up + 5 timed; medians; {cores} threads of {have} host cores",
+           "bs2": res[2], f"bs{PER_GPU_BATCH}": res[PER_GPU_BATCH]}
+    return out, first_losses
+
+
+def gpu_losses_at_oracle_weights(dev, bs: int, conv_dtype: str = "f32"):
+    """The HIP path's (loc_loss, conf_loss) for the bench batch at the oracle's seed-0 weights -- what `cpu_baseline` evaluated
+    on the CPU (reference normalisation, norm_mode 0)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ssd_oracle as O
+    from objectdetection_ssd_amd import Losses, Model
+    net = Model.SSD_300()
+    named = dict(net.named_parameters())
+    with torch.no_grad():
+        for k, v in O.ssd300_random_params(0).items():
+            named[k].copy_(v)
+    net = net.to(dev).train()
+    net.conv_dtype = conv_dtype
+    x, classes, boxes = synth_batch(bs, 1234, dev)
+    with torch.no_grad():
+        l1, l2 = Losses.ssd(net(x), classes, boxes)
+    return float(l1.item()), float(l2.item())
 
 
 def aux_workload(args, world, rank, dev):
@@ -218,25 +264,60 @@ def main():
     ap.add_argument("--igemm-lds-pad", type=int, default=-1, help="tuning aid: extra dynamic LDS bytes per igemm block (-1 = library default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="plumbing check: start the ranks, init the process group, all-reduce one number, print the world size and stop "
+                         "before anything touches a GPU")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # `python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, one process per GPU, BEFORE
+    # anything in this process touches the GPU (a process that has initialised HIP must not be replaced or forked into ranks).
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
+
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_env != args.gpus:
+        # a launcher that started a different number of ranks than --gpus says would silently mislabel the line
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world_env} ranks")
+    if args.rendezvous_only:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group("gloo" if args.backend == "nccl" and not torch.cuda.is_available() else args.backend,
+                                rank=rank, world_size=world_env)
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        world = dist.get_world_size()
+        assert world == args.gpus == int(t.item()), (world, args.gpus, float(t))
+        if rank == 0:
+            print(json.dumps({"rendezvous": True, "n_gpus": world, "backend": dist.get_backend(), "ranks_counted": int(t.item())}))
+        dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the gfx950 HIP extension is the only compute path")
     if args.one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    world = 1
+    if world_env > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
-    if args.gpus != world and rank == 0:
-        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+        world = dist.get_world_size()            # n_gpus of the JSON line is the world size RCCL actually formed
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: process group has {world} ranks, --gpus says {args.gpus}")
 
     from objectdetection_ssd_amd import Losses, Model
     from objectdetection_ssd_amd.ddp import FlatSGDDataParallel
@@ -328,8 +409,10 @@ def main():
                                   f"batch {bs}/GPU, 300x300x3, 21 classes, 8732 priors (BASELINE configs[1])",
                       "global_batch": bs * world, "per_gpu_batch": bs, "parallelism": f"dp{world}" + (" (gradient all-reduce overlapped with backward)" if args.overlap_allreduce else ""),
                       "train_gflop_per_image": TRAIN_GFLOP_PER_IMAGE,
-                      "step_tflops_per_gpu": round(TRAIN_GFLOP_PER_IMAGE * ips / world / 1e3, 2),
-                      "step_frac_of_f32_mfma_peak": round(TRAIN_GFLOP_PER_IMAGE * ips / world / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+                      "direct_conv_tflops_per_gpu": round(TRAIN_GFLOP_PER_IMAGE * ips / world / 1e3, 2),
+                      "direct_conv_flops_over_f32_mfma_peak": round(TRAIN_GFLOP_PER_IMAGE * ips / world / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+                      "direct_conv_note": "algorithmic (direct-convolution) FLOPs of the step / time: a speed-up-over-direct figure, NOT a roofline "
+                                          "fraction (Winograd executes 1/4 .. 4/9 of them); the executed fraction is roofline.step_executed_frac",
                       "last_loss_per_rank": round(loss, 5), "n_pos_global_last": n_pos,
                       "conv_algorithm": ("f32 throughout; Winograd F(%dx%d,3x3) for forward / dgrad of the 3x3 stride-1 layers with >= %d input "
                                          "channels (the 2x2 max pools fused into its output transform) and for the weight gradients of those with >= %d channels on maps <= %d px, direct MFMA "
@@ -351,6 +434,7 @@ def main():
         from objectdetection_ssd_amd import _lib as _l
         import ctypes as _C
         gemm_tag = "igemm_kernel<64, 64, 2, 2, 1, true"
+        exec_flops = 0.0
         for _ in range(3):
             eng.prof = []
             _l.check(_l.load().ssd_prof_gemm_begin(), "prof")        # the batched Winograd GEMM launches, each by itself
@@ -361,7 +445,8 @@ def main():
             for i in range(max(ng, 0)):
                 a = agg.setdefault(gemm_tag, [0.0, 0.0, 0])
                 a[0] += ms_buf[i] * 1e-3; a[1] += fl_buf[i]; a[2] += 1
-            for label, tag, flops, e0, e1 in eng.prof:
+            for label, tag, flops, e0, e1, executed in eng.prof:
+                exec_flops += executed
                 dt = e0.elapsed_time(e1) * 1e-3
                 a = agg.setdefault(tag, [0.0, 0.0, 0])
                 a[0] += dt; a[1] += flops; a[2] += 1
@@ -398,6 +483,10 @@ def main():
                            "peak": peak, "peak_note": peak_note, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                            "traffic": traffic, "traffic_unit": "bytes per launch (profiles/r01_traffic.json)", "launches_timed": n, "avg_launch_ms": round(tsum / n * 1e3, 4),
                            "avg_launch_gflop": round(fsum / n / 1e9, 3),
+                           "step_executed_gflop": round(exec_flops / 3 / 1e9, 1),
+                           "step_executed_frac": round(exec_flops / 3 / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                           "step_executed_note": "MFMA FLOPs the step's convolution kernels execute (Winograd layers: 36 multiplies per 4x4 tile) / "
+                                                 "ms_per_step / f32 MFMA peak -- the whole-step roofline fraction",
                            "all_conv_kernels_tflops": round(sum(a[1] for a in agg.values()) / sum(a[0] for a in agg.values()) / 1e12, 2),
                            "by_kernel": {k: {"ms_per_step": round(a[0] / 3 * 1e3, 3), "tflops": round(a[1] / a[0] / 1e12, 2),
                                              "launches_per_step": a[2] // 3} for k, a in sorted(agg.items())}}
@@ -412,7 +501,15 @@ def main():
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"], cpu_losses = cpu_baseline()
+        if args.variant == 300 and cpu_losses is not None:
+            # BASELINE.json metric: "loss delta vs CPU" -- same seeded batch, same seed-0 weights, HIP path vs the oracle
+            g1, g2 = gpu_losses_at_oracle_weights(dev, PER_GPU_BATCH, args.conv_dtype)
+            out["loss_delta_vs_cpu"] = {"loc": abs(g1 - cpu_losses[0]), "conf": abs(g2 - cpu_losses[1]),
+                                        "gpu": [g1, g2], "cpu": list(cpu_losses), "batch": PER_GPU_BATCH,
+                                        "tolerance": 1e-4, "conv_dtype": args.conv_dtype,
+                                        "within_tolerance": bool(abs(g1 - cpu_losses[0]) <= 1e-4 * max(1.0, abs(cpu_losses[0])) and
+                                                                 abs(g2 - cpu_losses[1]) <= 1e-4 * max(1.0, abs(cpu_losses[1])))}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -132,13 +132,67 @@ def plan_transform(width: int, height: int, boxes: torch.Tensor, labels: torch.T
     return GeomPlan(height, width, canvas, crop, flip, photo), boxes, labels
 
 
-def preprocess_batch(images: Sequence, plans: Optional[Sequence[GeomPlan]] = None, size: Tuple[int, int] = (300, 300),
-                     device=None) -> torch.Tensor:
-    """images: HWC uint8 RGB arrays / tensors / PIL images of any sizes -> (B,3,H,W) float32 on the GPU
-    (Resize + ToTensor + Normalize of Dataset.py:10-13 after the plans' geometry).  One host->device copy."""
-    if not torch.cuda.is_available():
-        raise RuntimeError("preprocess_batch() runs on the gfx950 HIP kernels only (no CPU fallback)")
-    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+class RawBatch:
+    """A batch as it leaves a DataLoader worker: the images' 8-bit pixels packed into ONE CPU uint8 tensor plus each image's
+    geometry / photometric plan -- plain host data, picklable, no GPU touched (reference train.py:29,40 runs `collate_fn`
+    inside `num_workers=2` forked workers, which must not initialise HIP).  The caller's own `inputs = inputs.to(device)`
+    (train_function.py:61) is where the work happens, in the main process: one pinned upload, then the photometric and
+    resize / normalise kernels -> the (B,3,H,W) float32 device tensor `cnn(inputs)` expects."""
+
+    def __init__(self, arena: torch.Tensor, offsets: Sequence[int], plans: Sequence[GeomPlan], size: Tuple[int, int] = (300, 300)):
+        if arena.dtype != torch.uint8 or arena.dim() != 1 or arena.is_cuda:
+            raise ValueError("RawBatch: arena must be a 1-D CPU uint8 tensor")
+        if len(offsets) != len(plans) or not plans:
+            raise ValueError("RawBatch: one offset and one plan per image, at least one image")
+        self.arena, self.offsets, self.plans, self.out_hw = arena, list(offsets), list(plans), tuple(size)
+
+    # what train_function.py reads from `inputs` (`.shape[0]`, `.size(0)`) also works before `.to(device)`
+    @property
+    def shape(self) -> torch.Size:
+        return torch.Size((len(self.plans), 3) + self.out_hw)
+
+    def size(self, dim: Optional[int] = None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def __len__(self) -> int:
+        return len(self.plans)
+
+    def pin_memory(self) -> "RawBatch":          # DataLoader(pin_memory=True) calls this in its pinning thread (main process)
+        return RawBatch(self.arena.pin_memory(), self.offsets, self.plans, self.out_hw)
+
+    def cuda(self, device=None) -> torch.Tensor:
+        return self.to(torch.device("cuda", torch.cuda.current_device()) if device is None else device)
+
+    def to(self, device, *args, **kwargs) -> torch.Tensor:
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("RawBatch.to(): the resize / normalise kernels run on the gfx950 GPU only (no CPU fallback); "
+                               f"got device {device}")
+        descs = (_lib.ImageDesc * len(self.plans))()
+        for d, p, o in zip(descs, self.plans, self.offsets):
+            d.src_offset, d.src_h, d.src_w = o, p.src_h, p.src_w
+            d.canvas_h, d.canvas_w, d.place_top, d.place_left = p.canvas
+            d.crop_top, d.crop_left, d.crop_h, d.crop_w = p.crop
+            d.flip = int(p.flip)
+        host = self.arena if self.arena.is_pinned() else self.arena.pin_memory()
+        with torch.cuda.device(device):
+            arena = host.to(device, non_blocking=True)
+            if any(p.photo for p in self.plans):       # photometric_distort comes first (Util.py:586), on the source pixels
+                photo = (_lib.PhotoDesc * len(self.plans))()
+                for i, p in enumerate(self.plans):
+                    if len(p.photo) > 4:
+                        raise ValueError("at most four photometric ops per image")
+                    photo[i].n_ops = len(p.photo)
+                    for k, (kind, factor) in enumerate(p.photo):
+                        photo[i].kind[k] = int(kind)
+                        photo[i].alpha[k] = float(factor)
+                        photo[i].hue_delta[k] = (int(factor * 255) & 0xFF) if kind == 3 else 0
+                ops.photometric_u8(arena, descs, photo)
+            return ops.preprocess_u8(arena, descs, self.out_hw, MEAN, STD, FILLER_U8)
+
+
+def pack_batch(images: Sequence, plans: Optional[Sequence[GeomPlan]] = None, size: Tuple[int, int] = (300, 300)) -> RawBatch:
+    """images: HWC uint8 RGB arrays / tensors / PIL images of any sizes -> RawBatch (host only; safe in a DataLoader worker)."""
     arrs = []
     for im in images:
         a = im.numpy() if torch.is_tensor(im) else np.asarray(im)
@@ -154,37 +208,30 @@ def preprocess_batch(images: Sequence, plans: Optional[Sequence[GeomPlan]] = Non
     for a in arrs:
         offs.append(total)
         total += (a.size + 255) & ~255
-    host = torch.empty(total, dtype=torch.uint8).pin_memory()
+    host = torch.zeros(total, dtype=torch.uint8)
     hv = host.numpy()
-    descs = (_lib.ImageDesc * len(arrs))()
-    for i, (a, p, o) in enumerate(zip(arrs, plans, offs)):
+    for a, p, o in zip(arrs, plans, offs):
         if (p.src_h, p.src_w) != a.shape[:2]:
             raise ValueError("plan does not belong to this image")
         hv[o:o + a.size] = a.reshape(-1)
-        d = descs[i]
-        d.src_offset, d.src_h, d.src_w = o, a.shape[0], a.shape[1]
-        d.canvas_h, d.canvas_w, d.place_top, d.place_left = p.canvas
-        d.crop_top, d.crop_left, d.crop_h, d.crop_w = p.crop
-        d.flip = int(p.flip)
-    arena = host.to(device, non_blocking=True)
-    if any(p.photo for p in plans):            # photometric_distort comes first (Util.py:586), on the source pixels
-        photo = (_lib.PhotoDesc * len(arrs))()
-        for i, p in enumerate(plans):
-            if len(p.photo) > 4:
-                raise ValueError("at most four photometric ops per image")
-            photo[i].n_ops = len(p.photo)
-            for k, (kind, factor) in enumerate(p.photo):
-                photo[i].kind[k] = int(kind)
-                photo[i].alpha[k] = float(factor)
-                photo[i].hue_delta[k] = (int(factor * 255) & 0xFF) if kind == 3 else 0
-        ops.photometric_u8(arena, descs, photo)
-    return ops.preprocess_u8(arena, descs, size, MEAN, STD, FILLER_U8)
+    return RawBatch(host, offs, plans, size)
+
+
+def preprocess_batch(images: Sequence, plans: Optional[Sequence[GeomPlan]] = None, size: Tuple[int, int] = (300, 300),
+                     device=None) -> torch.Tensor:
+    """images: HWC uint8 RGB arrays / tensors / PIL images of any sizes -> (B,3,H,W) float32 on the GPU
+    (Resize + ToTensor + Normalize of Dataset.py:10-13 after the plans' geometry).  One host->device copy."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("preprocess_batch() runs on the gfx950 HIP kernels only (no CPU fallback)")
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    return pack_batch(images, plans, size).to(device)
 
 
 class MultiImageMultiBBoxDataset(torch.utils.data.Dataset):
     """Reference Dataset.py:7-39 with the same constructor.  `__getitem__` returns the RAW 8-bit image and its
-    geometry plan instead of a normalised tensor: `(RawImage, classes, standardized_bbox, index)`; `collate_fn`
-    (run in the main process) turns the RawImages of a batch into the normalised device tensor."""
+    geometry plan instead of a normalised tensor: `(RawImage, classes, standardized_bbox, index)` -- host work only, as it
+    runs in DataLoader workers; `collate_fn` packs a batch's RawImages into a `RawBatch` whose `.to(device)` (the caller's
+    own line train_function.py:61, main process) makes the normalised device tensor."""
 
     def __init__(self, all_images, all_multi_bboxes, all_multi_labels, all_difficulties, all_indices, isTest=False,
                  keep_difficult=False):
@@ -201,34 +248,50 @@ class MultiImageMultiBBoxDataset(torch.utils.data.Dataset):
 
     def __getitem__(self, index):
         from PIL import Image
-        image = np.asarray(Image.open(self.images_list[index]).convert("RGB"))
+        from .Util import transform
+        image = RawImage.of(Image.open(self.images_list[index]).convert("RGB"))
         c = torch.Tensor([label_to_class[i] for i in self.multi_labels_list[index]])
         bboxes = torch.Tensor(self.multi_bbox_list[index])
         if self.keep_difficult is False:
             keep = self.all_difficulties[index] == 0
             bboxes, c = bboxes[keep], c[keep]
-        h, w = image.shape[:2]
-        plan = identity_plan(h, w)
         if self.isTest is False:
-            plan, bboxes, c = plan_transform(w, h, bboxes, c)
-        pw, ph = plan.size
-        standardized_bbox = bboxes / torch.FloatTensor([pw, ph, pw, ph]).unsqueeze(0)
-        return RawImage(image, plan), c, standardized_bbox, self.all_indices[index]
+            image, bboxes, c = transform(image, bboxes, c)            # Dataset.py:33
+        w, h = image.size                                             # Dataset.py:35
+        standardized_bbox = bboxes / torch.FloatTensor([w, h, w, h]).unsqueeze(0)
+        return image, c, standardized_bbox, self.all_indices[index]
 
 
 @dataclass
 class RawImage:
+    """8-bit HWC pixels of one image and the geometry / photometric plan drawn for it; `.size` = (width, height) of the
+    augmented image, what the reference reads from its PIL image at Dataset.py:35."""
     pixels: np.ndarray
     plan: GeomPlan
 
+    @staticmethod
+    def of(image) -> "RawImage":
+        if isinstance(image, RawImage):
+            return image
+        a = np.ascontiguousarray(np.asarray(image.convert("RGB") if hasattr(image, "convert") else image))
+        if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+            raise ValueError("image must be a PIL image or an HWC uint8 RGB array")
+        return RawImage(a, identity_plan(a.shape[0], a.shape[1]))
+
+    @property
+    def size(self) -> Tuple[int, int]:
+        return self.plan.size
+
 
 def collate_fn(batch):
-    """Reference Dataset.py:41-53; RawImage entries are resized / normalised on the GPU in one launch set."""
+    """Reference Dataset.py:41-53: (images, classes, boxes, indices) of a list of samples.  Host work only (it runs in the
+    DataLoader's workers): RawImage entries are packed into one `RawBatch`; already-normalised tensors are stacked like the
+    reference does."""
     images, classes, boxes, indices = [], [], [], []
     for b in batch:
         images.append(b[0]); classes.append(b[1]); boxes.append(b[2]); indices.append(b[3])
     if images and isinstance(images[0], RawImage):
-        x = preprocess_batch([r.pixels for r in images], [r.plan for r in images])
+        x = pack_batch([r.pixels for r in images], [r.plan for r in images])
     else:
         x = torch.stack(images, dim=0)
     return x, classes, boxes, indices

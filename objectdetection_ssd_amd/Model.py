@@ -171,11 +171,14 @@ class _Engine:
         """Run fn(); when profiling, bracket it with HIP events on the current stream."""
         if self.prof is None:
             return fn()
+        executed = flops
+        if isinstance(flops, tuple):          # (direct-convolution FLOPs, FLOPs the Winograd GEMMs execute)
+            flops, executed = flops
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         out = fn()
         e1.record()
-        self.prof.append((label, tag, flops, e0, e1))
+        self.prof.append((label, tag, flops, e0, e1, executed))
         return out
 
     # -- weights ----------------------------------------------------------------------------
@@ -245,6 +248,11 @@ class _Engine:
                                "(there is no CPU fallback)")
         x = x.contiguous()
         bs = x.shape[0]
+        if save:
+            # A training forward re-lays every weight: the parameters change each step anyway, and the cache key
+            # (data_ptr, _version) cannot see writes through `.data` (p.data.mul_(), dist.broadcast(p.data), EMA swaps).
+            # The backward of this step reads what this forward stored.
+            self._wcache.clear()
         T = {"x": x}
         aux = {}
         heads = []
@@ -275,14 +283,14 @@ class _Engine:
                     # training: the transformed input stays for the weight gradient, which multiplies the same planes
                     keep = save and self.keep_planes and self.WINO_TILE == 4 and self._wino_wgrad_ok(g, False)
                     if pl is not None:
-                        res = self._timed("fwd " + op["p"], "winograd_3x3", ops.conv_flops(g),
+                        res = self._timed("fwd " + op["p"], "winograd_3x3", ops.wino_flops(g),
                                           lambda: ops.conv2d_fwd_wino_pool(xin, uf, bias, g, pl["ceil"], want_argmax=save, keep_planes=keep))
                         T[op["y"]] = _Elided((bs, g.H, g.W, op["co"]))      # never materialised: its only reader is the pool
                         T[pl["y"]], aux[pl["y"]], aux[op["y"]] = res[0], res[1], g
                         if keep:
                             aux["planes:" + op["p"]] = res[2]
                         continue
-                    res = self._timed("fwd " + op["p"], "winograd_3x3", ops.conv_flops(g),
+                    res = self._timed("fwd " + op["p"], "winograd_3x3", ops.wino_flops(g),
                                       lambda: ops.conv2d_fwd_wino(xin, uf, bias, g, op["relu"], keep_planes=keep))
                     T[op["y"]] = res[0] if keep else res
                     if keep:
@@ -312,7 +320,7 @@ class _Engine:
                 if self._wino_ok(g):
                     uf, _ = self._wino_weights(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]), ops.pad32(co))
                     keep = save and self.keep_planes and self.WINO_TILE == 4 and self._wino_wgrad_ok(g, True)
-                    res = self._timed("fwd " + pre, "winograd_3x3", ops.conv_flops(g),
+                    res = self._timed("fwd " + pre, "winograd_3x3", ops.wino_flops(g),
                                       lambda: ops.conv2d_fwd_wino(xin, uf, bias, g, False, ld=ops.pad32(co), keep_planes=keep))
                     if keep:
                         aux["planes:" + pre] = res[1]
@@ -366,7 +374,7 @@ class _Engine:
                     if self._wino_wgrad_ok(g, True):
                         kept = aux.pop("planes:" + pre, None)
                         dual = kept is not None and self.dual_dy        # one pass over dy feeds the weight and the data gradient
-                        res = self._timed("wgrad " + pre, "winograd_3x3", ops.conv_flops(g),
+                        res = self._timed("wgrad " + pre, "winograd_3x3", ops.wino_flops(g),
                                           lambda: ops.conv2d_wgrad_wino(xin, dy, g, co_pad, True, mo=self.WINO_TILE, planes=kept,
                                                                         dgrad_planes=dual))
                         dw, db = res[0], res[1]
@@ -378,7 +386,7 @@ class _Engine:
                     grads[pre + "_bb.bias"], grads[pre + "_cl.bias"] = db[:a4], db[a4:]
                 if self._wino_ok(g):
                     _, ub = self._wino_weights(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]), co_pad)
-                    deliver(op["x"], lambda dx, acc, mask: self._timed("dgrad " + pre, "winograd_3x3", ops.conv_flops(g),
+                    deliver(op["x"], lambda dx, acc, mask: self._timed("dgrad " + pre, "winograd_3x3", ops.wino_flops(g),
                                                                        lambda: ops.conv2d_dgrad_wino(dy, ub, g, dx, mask, acc, planes=dyp)))
                     continue
                 _, wb = self._layouts(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]), co_pad, True)
@@ -395,7 +403,7 @@ class _Engine:
                     if self._wino_wgrad_ok(g, False):
                         kept = aux.pop("planes:" + op["p"], None)
                         dual = kept is not None and self.dual_dy and g.Co % 32 == 0
-                        res = self._timed("wgrad " + op["p"], "winograd_3x3", ops.conv_flops(g),
+                        res = self._timed("wgrad " + op["p"], "winograd_3x3", ops.wino_flops(g),
                                           lambda: ops.conv2d_wgrad_wino(xin, dy, g, g.Co, True, mo=self.WINO_TILE, planes=kept,
                                                                         dgrad_planes=dual))
                         dw, db = res[0], res[1]
@@ -406,7 +414,7 @@ class _Engine:
                     grads[op["p"] + ".weight"], grads[op["p"] + ".bias"] = dw, db
                 if self._wino_ok(g):
                     _, ub = self._wino_weights(op["p"], (P[op["p"] + ".weight"],), op["co"])
-                    deliver(op["x"], lambda dx, acc, mask: self._timed("dgrad " + op["p"], "winograd_3x3", ops.conv_flops(g),
+                    deliver(op["x"], lambda dx, acc, mask: self._timed("dgrad " + op["p"], "winograd_3x3", ops.wino_flops(g),
                                                                        lambda: ops.conv2d_dgrad_wino(dy, ub, g, dx, mask, acc, planes=dyp)))
                     continue
                 _, wb = self._layouts(op["p"], (P[op["p"] + ".weight"],), op["co"], True)
@@ -532,6 +540,25 @@ class SSD_300(nn.Module):
     def winograd(self, value: bool) -> None:
         self._engine.wino = bool(value)
         self._engine._wcache.clear()
+
+    def invalidate_weight_cache(self) -> None:
+        """Drop the re-laid (OHWI / IHWO / Winograd-domain) copies of the weights.  A training forward always rebuilds them;
+        an inference forward reuses them while every parameter's `(data_ptr, _version)` is unchanged.  In-place updates through
+        autograd-visible ops (`p.mul_()`, `p.copy_()` under `no_grad`, optimizers, `load_state_dict`, `.to()`) change that key;
+        writes through `p.data` (`p.data.copy_()`, `dist.broadcast(p.data, 0)`, EMA weight swaps) do NOT -- call this after
+        them before the next `.eval()` forward (and re-capture any `graphed_forward`)."""
+        self._engine._wcache.clear()
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        if hasattr(self, "_engine"):
+            self._engine._wcache.clear()
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._engine._wcache.clear()
+        return out
 
     def get_norm(self):
         return torch.norm(self.fc6) + torch.norm(self.fc6_b) + torch.norm(self.fc7) + torch.norm(self.fc7_b)

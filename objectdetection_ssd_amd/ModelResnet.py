@@ -112,6 +112,11 @@ class SSD_resnet34(nn.Module):
         return nn.Sequential(nn.Conv2d(in_channels, out_channels, kernel_size=kernel, stride=stride, padding=padding),
                              nn.BatchNorm2d(out_channels), nn.Dropout2d(p=0.4))
 
+    def invalidate_weight_cache(self) -> None:
+        """Drop the BatchNorm-folded kernel-layout weights.  They are rebuilt when any tensor's `(data_ptr, _version)` changes;
+        writes through `.data` change neither, so call this after such a write (same contract as `SSD_300`)."""
+        self._cache.clear()
+
     # -- prepared (BatchNorm-folded, kernel-layout) weights, rebuilt when any tensor of the module changes ---------------------
     def _signature(self):
         return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))

@@ -1,10 +1,11 @@
 """Host-side mirror of the box utilities the hot path imports from the
 reference's Util.py (names and argument meaning kept; bodies are ours).
 
-Only what `Losses.py` / `train_function.py` pull in through `from Util import *`
-for the SSD300 path lives here: prior boxes, box coders, IoU, the class table
-and `device`.  Dataset lists, augmentation and drawing are out of scope
-(SURVEY.md section 2, rows 13-18).
+What `Losses.py` / `train_function.py` pull in through `from Util import *` and what
+`train.py:6` / `Dataset.py:4` import by name lives here: prior boxes, box coders, the
+class table, `device`, the (empty) VOC lists, `transform` (as a geometry plan: the
+pixels are made on the GPU) and `get_map`.  VOC XML parsing and drawing are out of
+scope.
 """
 from __future__ import annotations
 
@@ -21,8 +22,12 @@ class_to_label = ['aeroplane', 'bicycle', 'bird', 'boat', 'bottle', 'bus', 'car'
                   'tvmonitor', 'bg']
 label_to_class = {name: i for i, name in enumerate(class_to_label)}
 
-# filled by callers that have a dataset (reference: DataLists.py); empty here
+# The VOC lists reference Util.py:16 re-exports from DataLists.py (train.py:6 imports all four): filled by callers that have a
+# dataset; empty here (the VOC XML walk is host I/O outside the path -- SURVEY.md section 2 row 13)
 all_images = {"train": [], "test": []}
+all_multi_bboxes = {"train": [], "test": []}
+all_multi_labels = {"train": [], "test": []}
+all_difficulties = {"train": [], "test": []}
 
 _GRID = (38, 19, 10, 5, 3, 1)
 _SCALE = (0.1, 0.2, 0.375, 0.55, 0.725, 0.9)
@@ -105,6 +110,18 @@ def subsampling(x: torch.Tensor, step) -> torch.Tensor:
         if s is not None:
             x = x.index_select(d, torch.arange(0, x.shape[d], s, device=x.device))
     return x
+
+
+def transform(image, boxes, labels):
+    """Reference Util.py:566-607 (`from Util import transform`, Dataset.py:4): photometric distortion, expand, random crop,
+    flip, with the reference's `random` draws in its order and its box arithmetic -- as a PLAN.  `image` is a PIL image, an HWC
+    uint8 array or a `Dataset.RawImage`; the returned image is a `Dataset.RawImage` (source pixels + plan, `.size` = the
+    augmented (width, height)): the pixels are produced later, on the GPU, by `Dataset.RawBatch.to(device)`."""
+    from .Dataset import RawImage, plan_transform
+    raw = RawImage.of(image)
+    h, w = raw.pixels.shape[:2]
+    plan, new_boxes, new_labels = plan_transform(w, h, boxes, labels)
+    return RawImage(raw.pixels, plan), new_boxes, new_labels
 
 
 def create_ancs_xywh_zoom_ratio() -> torch.Tensor:

@@ -16,6 +16,7 @@
 // feeds four 32x32x2 MFMAs per read.  The k order inside a K step is permuted
 // (lane half h takes k = 8q+4h+e): A and B use the same permutation, so the sum is
 // the same set of products.
+#include <atomic>
 #include "common.h"
 
 namespace {
@@ -1214,8 +1215,8 @@ extern "C" int ssd_tune_set_igemm_lds_pad(int bytes) {
 }
 
 constexpr int PROF_MAX = 1024;
-static bool g_prof_on = false;
-static int g_prof_n = 0;
+static std::atomic<bool> g_prof_on{false};        // forward (caller thread) and backward (autograd thread) both launch GEMMs:
+static std::atomic<int> g_prof_n{0};              // slots of the recorder are claimed atomically
 static hipEvent_t g_prof_ev[2 * PROF_MAX] = {};
 static double g_prof_flops[PROF_MAX];
 
@@ -1243,8 +1244,8 @@ __attribute__((visibility("hidden"))) int ssd_internal_gemm_batched(const float*
         p.slab = out;
     }
     p.nbatch = nbatch; p.batch_a = batch_a_elems; p.batch_w = batch_w_elems; p.batch_out = (size_t)M * N;
-    if (g_prof_on && g_prof_n < PROF_MAX) {              // measurement aid: this launch alone between two events of the library
-        const int i = g_prof_n++;
+    const int i = g_prof_on.load(std::memory_order_acquire) ? g_prof_n.fetch_add(1, std::memory_order_relaxed) : PROF_MAX;
+    if (i < PROF_MAX) {                                  // measurement aid: this launch alone between two events of the library
         g_prof_flops[i] = 2.0 * M * K * N * nbatch;
         (void)hipEventRecord(g_prof_ev[2 * i], st);
         const int e = launch_igemm<64, 64, 2, 2, 1, true>(p, st);
@@ -1260,19 +1261,20 @@ __attribute__((visibility("hidden"))) int ssd_internal_gemm_batched(const float*
 extern "C" int ssd_prof_gemm_begin(void) {
     for (int i = 0; i < 2 * PROF_MAX; ++i)
         if (g_prof_ev[i] == nullptr && hipEventCreate(&g_prof_ev[i]) != hipSuccess) return SSD_ERR_LAUNCH;
-    g_prof_n = 0;
-    g_prof_on = true;
+    g_prof_n.store(0);
+    g_prof_on.store(true, std::memory_order_release);
     return SSD_OK;
 }
 extern "C" int ssd_prof_gemm_collect(float* ms_out, double* flops_out, int max) {
-    g_prof_on = false;
+    g_prof_on.store(false);
     if (!ms_out || !flops_out) return SSD_ERR_NULL;
     int n = 0;
-    for (; n < g_prof_n && n < max; ++n) {
+    const int recorded = g_prof_n.load() < PROF_MAX ? g_prof_n.load() : PROF_MAX;
+    for (; n < recorded && n < max; ++n) {
         if (hipEventElapsedTime(&ms_out[n], g_prof_ev[2 * n], g_prof_ev[2 * n + 1]) != hipSuccess) return -n - 100;
         flops_out[n] = g_prof_flops[n];
     }
-    g_prof_n = 0;
+    g_prof_n.store(0);
     return n;
 }
 

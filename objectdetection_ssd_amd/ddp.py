@@ -23,14 +23,20 @@ import torch.distributed as dist
 from . import ops
 
 
-class FlatSGDDataParallel:
+class FlatSGDDataParallel(torch.optim.Optimizer):
+    """The data-parallel optimizer of the step.  It IS a `torch.optim.Optimizer` with the two parameter groups of reference
+    train.py:53-55 in the same order (`param_groups[0]` = biases at 2x lr, `param_groups[1]` = the rest), so the caller's
+    `StepLR(optimizer, ...)` (train.py:57), `for g in optimizer.param_groups: g['lr'] = lr` (train_function.py:29-30),
+    `optimizer.state_dict()` / `load_state_dict()` (train_function.py:27,116) work on it: lr / momentum / weight decay are read
+    from the groups at every step, and the state dict carries one `momentum_buffer` per parameter (views of the flat momentum
+    buffer), so a resumed run continues with its momentum instead of restarting it."""
+
     def __init__(self, model, lr: float = 1e-4, momentum: float = 0.9, weight_decay: float = 5e-4,
                  bias_lr_mult: float = 2.0, process_group=None, overlap: bool = False, bucket_bytes: int = 16 << 20):
         """overlap: start the all-reduce of a slice of the flat gradient buffer as soon as the backward has produced all of it
         (asynchronous collectives on the process group's stream, `bucket_bytes` per slice), instead of one all-reduce after the
         backward.  Same sums, same result; opt-in until it has been timed on a multi-GPU node."""
         self.model = model
-        self.lr, self.momentum, self.wd, self.bias_mult = lr, momentum, weight_decay, bias_lr_mult
         self.group = process_group
         named = dict(model.named_parameters())
         names = [n for n in model._engine.names if named[n].requires_grad]
@@ -39,6 +45,9 @@ class FlatSGDDataParallel:
         self.b_names = [n for n in names if n.endswith(".bias")]
         self.names = self.w_names + self.b_names
         self.params: List[torch.nn.Parameter] = [named[n] for n in self.names]
+        n_wn = len(self.w_names)
+        super().__init__([{"params": self.params[n_wn:], "lr": lr * bias_lr_mult}, {"params": self.params[:n_wn]}],
+                         dict(lr=lr, momentum=momentum, dampening=0.0, weight_decay=weight_decay, nesterov=False))
         dev = self.params[0].device      # flat buffers live where the model lives (the SGD kernel itself is GPU-only)
         sizes = [p.numel() for p in self.params]
         slots = [(s + 3) // 4 * 4 for s in sizes]              # every parameter starts 16-byte aligned
@@ -50,6 +59,7 @@ class FlatSGDDataParallel:
         self.flat_mom = torch.zeros(self.n, device=dev, dtype=torch.float32)
         self.inv_npos = torch.ones(1, device=dev, dtype=torch.float32)
         self.grad_views = []
+        self.mom_views = []
         off = 0
         with torch.no_grad():
             for p, sz, slot in zip(self.params, sizes, slots):
@@ -57,7 +67,9 @@ class FlatSGDDataParallel:
                 view.copy_(p.data)
                 p.data = view                                  # parameters now live in the flat buffer
                 self.grad_views.append(self.flat_grad[off:off + sz].view_as(p))
+                self.mom_views.append(self.flat_mom[off:off + sz].view_as(p))
                 off += slot
+        self._has_momentum = False       # False: the next step starts the momentum buffer from the gradient, as torch.optim.SGD does
         self.steps = 0
         model._engine._wcache.clear()
         # -- overlapped exchange: contiguous slices of the weight segment, filled from the back of the network first ------------
@@ -94,7 +106,49 @@ class FlatSGDDataParallel:
             dist.broadcast(self.flat_param, src, group=self.group)
             self.model._engine._wcache.clear()
 
-    def zero_grad(self) -> None:
+    # the values of train.py:53-55 as the step reads them (lr schedulers and the caller's lr reset write the groups)
+    @property
+    def lr(self) -> float:
+        return float(self.param_groups[1]["lr"])
+
+    @lr.setter
+    def lr(self, value: float) -> None:
+        ratio = self.param_groups[0]["lr"] / self.param_groups[1]["lr"] if self.param_groups[1]["lr"] else 2.0
+        self.param_groups[1]["lr"] = float(value)
+        self.param_groups[0]["lr"] = float(value) * ratio
+
+    def load_state_dict(self, state_dict) -> None:
+        """Restores lr / momentum / weight decay of both groups and every parameter's momentum buffer INTO the flat momentum
+        buffer; the step after a restore continues the momentum (a restore without buffers starts it afresh, like torch)."""
+        super().load_state_dict(state_dict)
+        have = [self.state.get(p, {}).get("momentum_buffer") for p in self.params]
+        if any(h is not None for h in have) and not all(h is not None for h in have):
+            raise ValueError("FlatSGDDataParallel.load_state_dict: momentum buffers for only some of the parameters")
+        self._has_momentum = all(h is not None for h in have)
+        with torch.no_grad():
+            if self._has_momentum:
+                for p, h, mv in zip(self.params, have, self.mom_views):
+                    mv.copy_(h.to(mv.device, torch.float32).reshape(mv.shape))
+                    self.state[p]["momentum_buffer"] = mv
+            else:
+                self.flat_mom.zero_()
+        self.steps = int(state_dict.get("flat_steps", self.steps)) if isinstance(state_dict, dict) else self.steps
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["flat_steps"] = self.steps
+        return sd
+
+    def step(self, closure=None):
+        """`optimizer.step()` of the caller's loop = `apply_sgd()`; the gradient exchange (`reduce_gradients`) comes first."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self.apply_sgd()
+        return loss
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
         for p in self.params:
             p.grad = None
         if self.overlap:                               # a step that died half-way must not leak its bookkeeping into the next
@@ -146,11 +200,21 @@ class FlatSGDDataParallel:
         torch.reciprocal(self.flat_grad[self.n:self.n + 1], out=self.inv_npos)
 
     def apply_sgd(self) -> None:
-        first = self.steps == 0
+        first = not self._has_momentum
+        gb, gw = self.param_groups
+        for g in (gb, gw):
+            if g.get("dampening", 0) != 0 or g.get("nesterov", False):
+                raise ValueError("FlatSGDDataParallel: dampening / nesterov are not part of the reference's step (train.py:53-55)")
         ops.sgd_momentum_(self.flat_param[:self.n_w], self.flat_grad[:self.n_w], self.flat_mom[:self.n_w],
-                          self.lr, self.momentum, self.wd, self.inv_npos, first)
+                          float(gw["lr"]), float(gw["momentum"]), float(gw["weight_decay"]), self.inv_npos,
+                          first or gw["momentum"] == 0)
         ops.sgd_momentum_(self.flat_param[self.n_w:], self.flat_grad[self.n_w:self.n], self.flat_mom[self.n_w:],
-                          self.lr * self.bias_mult, self.momentum, self.wd, self.inv_npos, first)
+                          float(gb["lr"]), float(gb["momentum"]), float(gb["weight_decay"]), self.inv_npos,
+                          first or gb["momentum"] == 0)
+        if first and (gw["momentum"] != 0 or gb["momentum"] != 0):
+            for p, mv in zip(self.params, self.mom_views):
+                self.state[p]["momentum_buffer"] = mv          # torch.optim.SGD's state layout: checkpoints carry the momentum
+            self._has_momentum = True
         self.steps += 1
         self.model._engine._wcache.clear()        # parameters changed in place: re-lay weights next forward
 

@@ -18,11 +18,18 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+_current_device = torch.cuda.current_device
+
+
 def _req(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a tensor")
     if not t.is_cuda:
         raise RuntimeError(f"{name}: the gfx950 path needs a device tensor (got {t.device}); there is no CPU fallback")
+    if t.device.index != _current_device():
+        # the kernels are enqueued on the CURRENT device's stream (`_stream()`): a tensor of another GPU would be a foreign pointer there
+        raise RuntimeError(f"{name}: tensor lives on {t.device} but the current device is cuda:{_current_device()}; run the call under "
+                           f"`torch.cuda.device({t.device.index})` (one process per GPU: `torch.cuda.set_device(local_rank)`)")
     if t.dtype != dtype:
         raise ValueError(f"{name}: expected {dtype}, got {t.dtype}")
     if not t.is_contiguous():
@@ -71,6 +78,13 @@ def wgrad_tile(g: ConvGeom) -> str:
 def conv_flops(g: ConvGeom) -> float:
     """algorithmic FLOPs of one pass (fwd, dgrad or wgrad all cost 2*M*Co*K)"""
     return 2.0 * g.N * g.Ho * g.Wo * g.Co * g.R * g.S * g.Ci
+
+
+def wino_flops(g: ConvGeom):
+    """(direct-convolution FLOPs, FLOPs the 36 batched GEMMs of the F(4x4,3x3) form execute: 36 multiplies per 4x4 output tile
+    instead of 144, on the tile grid padded to multiples of 4, output channels padded to 32)"""
+    tiles = g.N * ((g.H + 3) // 4) * ((g.W + 3) // 4)
+    return conv_flops(g), 2.0 * 36 * tiles * pad32(g.Co) * g.Ci
 
 
 # ---- weights ---------------------------------------------------------------------------

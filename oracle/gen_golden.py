@@ -409,8 +409,51 @@ def write_resnet34(RM, RU):
                         ancs_zoom_ratio=RU.create_ancs_xywh_zoom_ratio().numpy().astype(np.float32))
 
 
+def write_import_names():
+    """tests/golden/import_names.json: every name the reference's callers (train.py, train_function.py, Dataset.py) take from the four
+    modules the drop-in replaces, read from their source with `ast` (nothing is imported or executed).  For `from X import *` the
+    names the file then USES without binding them itself are listed under "star_used"."""
+    import ast
+    import builtins
+    import json
+    mods = ("Model", "Losses", "Util", "Dataset")
+    out = {}
+    for fn in ("train.py", "train_function.py", "Dataset.py"):
+        tree = ast.parse(open(os.path.join(REF, fn)).read(), fn)
+        explicit, star, bound, loaded = {}, [], set(), set()
+        for node in ast.walk(tree):
+            if isinstance(node, ast.ImportFrom):
+                if node.module in mods:
+                    for a in node.names:
+                        if a.name == "*":
+                            star.append(node.module)
+                        else:
+                            explicit.setdefault(node.module, []).append(a.name)
+                for a in node.names:
+                    bound.add(a.asname or a.name)
+            elif isinstance(node, ast.Import):
+                for a in node.names:
+                    bound.add((a.asname or a.name).split(".")[0])
+            elif isinstance(node, (ast.FunctionDef, ast.ClassDef)):
+                bound.add(node.name)
+                if isinstance(node, ast.FunctionDef):
+                    for a in node.args.args + node.args.kwonlyargs:
+                        bound.add(a.arg)
+            elif isinstance(node, ast.Name):
+                (bound if isinstance(node.ctx, (ast.Store, ast.Del)) else loaded).add(node.id)
+            elif isinstance(node, ast.arg):
+                bound.add(node.arg)
+        used = sorted(n for n in loaded - bound if not hasattr(builtins, n)) if star else []
+        out[fn] = {"explicit": {k: sorted(v) for k, v in explicit.items()}, "star": star, "star_used": used}
+    with open(os.path.join(GOLD, "import_names.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print(json.dumps(out, indent=1, sort_keys=True))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if sys.argv[1:] == ["imports"]:
+        return write_import_names()
     if sys.argv[1:] in (["resnet34"], ["map"], ["augment"], ["degenerate"], ["photometric"]):     # add one fixture without rewriting the others
         _install_stand_ins()
         with quiet():
@@ -607,6 +650,7 @@ def main():
     write_augment(RU)
     write_degenerate(RL)
     write_photometric(RU)
+    write_import_names()
     print("golden fixtures written to", GOLD)
     for f in sorted(os.listdir(GOLD)):
         print(f"  {f}: {os.path.getsize(os.path.join(GOLD, f))} bytes")

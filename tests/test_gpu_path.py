@@ -932,7 +932,9 @@ def test_dataset_class_end_to_end_on_image_files(tmp_path):
     difficult = [[0, 1], [0], [0, 0]]
     ds = Dataset.MultiImageMultiBBoxDataset(paths, bboxes, labels, difficult, [7, 8, 9], isTest=True)
     items = [ds[i] for i in range(3)]
-    x, classes, boxes, idx = Dataset.collate_fn(items)
+    raw, classes, boxes, idx = Dataset.collate_fn(items)
+    assert isinstance(raw, Dataset.RawBatch) and not raw.arena.is_cuda and raw.shape[0] == raw.size(0) == 3
+    x = raw.to(DEV)                                                               # train_function.py:61
     assert idx == [7, 8, 9] and tuple(x.shape) == (3, 3, 300, 300) and x.is_cuda
     assert classes[0].tolist() == [float(Dataset.label_to_class["dog"])]          # the difficult cat is dropped
     mean = torch.tensor(Dataset.MEAN).view(3, 1, 1)
@@ -949,11 +951,44 @@ def test_dataset_class_end_to_end_on_image_files(tmp_path):
     random.seed(11)
     items = [tr[i] for i in range(3)]
     x2, _, boxes2, _ = Dataset.collate_fn(items)
+    x2 = x2.to(DEV)
     for i, it in enumerate(items):
         plan = it[0].plan
         ref = O.preprocess_image(O.photometric_apply(it[0].pixels, plan.photo), 300, 300, canvas=plan.canvas, crop=plan.crop, flip=plan.flip)
         assert np.array_equal(x2[i].cpu().numpy(), ref)
         assert boxes2[i].shape[1] == 4 and boxes2[i].shape[0] == it[1].shape[0]
+
+
+def test_dataloader_with_the_references_arguments_and_worker_processes(tmp_path):
+    """train.py:29,40: `DataLoader(ds, batch_size=.., shuffle=True, num_workers=2, collate_fn=collate_fn)` AFTER the model is on
+    the GPU (train.py:43 comes later in the file, but train_model iterates the loaders with HIP long initialised).  `collate_fn`
+    runs in the forked workers and must stay host-only; `inputs.to(device)` in the main process renders the batch.  Every
+    batch equals the single-process result for the same plans."""
+    from PIL import Image
+    from objectdetection_ssd_amd import Dataset
+    torch.zeros(1, device=DEV)                                                    # HIP is up in the parent before the fork
+    rng = np.random.default_rng(9)
+    paths, n = [], 6
+    for i in range(n):
+        h, w = int(rng.integers(40, 120)), int(rng.integers(40, 120))
+        pth = str(tmp_path / f"w{i}.png")
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(pth)
+        paths.append(pth)
+    bboxes = [[[2., 3., 30., 35.]] for _ in range(n)]
+    labels = [["dog"] for _ in range(n)]
+    ds = Dataset.MultiImageMultiBBoxDataset(paths, bboxes, labels, [[0]] * n, list(range(n)))
+    dl = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=True, num_workers=2, collate_fn=Dataset.collate_fn)
+    seen = []
+    for inputs, classes, boxes, indices in dl:
+        assert isinstance(inputs, Dataset.RawBatch) and not inputs.arena.is_cuda
+        plans = inputs.plans
+        x = inputs.to(DEV)
+        assert x.is_cuda and tuple(x.shape) == (2, 3, 300, 300) and bool(torch.isfinite(x).all())
+        again = Dataset.preprocess_batch([np.asarray(Image.open(paths[i]).convert("RGB")) for i in indices], plans)
+        assert torch.equal(x, again)
+        assert all(b.shape[1] == 4 for b in boxes) and len(classes) == 2
+        seen += indices
+    assert sorted(seen) == list(range(n))
 
 
 def test_photometric_kernels_equal_pillow_arithmetic():

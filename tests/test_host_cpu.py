@@ -104,22 +104,85 @@ def test_product_path_refuses_cpu_tensors():
         Losses.ssd((torch.zeros(1, 8732, 4), torch.zeros(1, 8732, 21)), [torch.zeros(0)], [torch.zeros(0, 4)])
 
 
-def test_dropin_module_names():
+def test_dropin_module_names(gold_dir):
+    """Every name the reference's callers import from Model / Losses / Util / Dataset resolves after install_dropin():
+    tests/golden/import_names.json is read off train.py, train_function.py and Dataset.py with `ast` by oracle/gen_golden.py
+    (train.py:1-6, train_function.py:3-4, Dataset.py:1-6)."""
+    import importlib
+    import json
     import sys
     import objectdetection_ssd_amd as pkg
+    names = json.load(open(os.path.join(gold_dir, "import_names.json")))
+    assert set(names) == {"train.py", "train_function.py", "Dataset.py"}
+    assert "all_multi_bboxes" in names["train.py"]["explicit"]["Util"] and "transform" in names["Dataset.py"]["explicit"]["Util"]
     saved = {k: sys.modules.get(k) for k in ("Model", "Losses", "Util", "Dataset")}
     try:
+        for k in saved:
+            sys.modules.pop(k, None)
         pkg.install_dropin()
         from Losses import ancs_xywh, ancs_xyxy, device, inference, ssd  # noqa: F401
         from Model import SSD_300, SSD_resnet34  # noqa: F401
         from Util import class_to_label, get_map, create_ancs_xywh_zoom_ratio  # noqa: F401
         from Dataset import MultiImageMultiBBoxDataset, collate_fn  # noqa: F401
+        for fn, spec in names.items():
+            for mod, wanted in spec["explicit"].items():
+                m = importlib.import_module(mod)
+                assert m.__name__.startswith("objectdetection_ssd_amd."), (fn, mod, m.__name__)
+                for n in wanted:
+                    assert hasattr(m, n), f"{fn}: from {mod} import {n}"
+            ns = {}
+            for mod in spec["star"]:
+                exec(f"from {mod} import *", ns)
+            for n in spec["star_used"]:
+                assert n in ns, f"{fn}: `{n}` is used after star imports of {spec['star']}"
+        import Util
+        for lst in ("all_images", "all_multi_bboxes", "all_multi_labels", "all_difficulties"):       # train.py:12,22-25 index them by phase
+            assert set(getattr(Util, lst)) >= {"train"}
+        # hot path only: the reference's own Util / Dataset stay whatever `import Util` finds
+        for k in saved:
+            sys.modules.pop(k, None)
+        pkg.install_dropin(dataset=False)
+        assert sys.modules["Model"].__name__ == "objectdetection_ssd_amd.Model" and "Util" not in sys.modules and "Dataset" not in sys.modules
     finally:
         for k, v in saved.items():
             if v is None:
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_collate_fn_is_host_only_in_dataloader_workers(tmp_path):
+    """train.py:29,40 hands `collate_fn` to `DataLoader(num_workers=2)`: it runs in forked workers and must never touch the
+    GPU.  The batch comes back as a `Dataset.RawBatch` of host data; rendering it is `.to(device)` in the main process, and
+    there is no CPU rendering to fall back to."""
+    from PIL import Image
+    from objectdetection_ssd_amd import Dataset, Util
+    rng = np.random.default_rng(3)
+    paths, n = [], 5
+    for i in range(n):
+        h, w = int(rng.integers(30, 90)), int(rng.integers(30, 90))
+        pth = str(tmp_path / f"i{i}.png")
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(pth)
+        paths.append(pth)
+    ds = Dataset.MultiImageMultiBBoxDataset(paths, [[[1., 2., 20., 25.], [3., 3., 15., 28.]]] * n, [["dog", "cat"]] * n, [[0, 1]] * n,
+                                            list(range(n)))
+    dl = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=True, num_workers=2, collate_fn=Dataset.collate_fn)
+    seen = []
+    for inputs, classes, boxes, indices in dl:
+        assert isinstance(inputs, Dataset.RawBatch) and inputs.arena.dtype == torch.uint8 and not inputs.arena.is_cuda
+        bs = len(indices)
+        assert inputs.shape == (bs, 3, 300, 300) and inputs.size(0) == bs               # train_function.py:64,98
+        assert all(c.tolist() == [float(Util.label_to_class["dog"])] or c.numel() == 0 for c in classes)    # difficult cat dropped
+        for p, idx in zip(inputs.plans, indices):
+            with Image.open(paths[idx]) as im:
+                assert (p.src_w, p.src_h) == im.size
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            inputs.to("cpu")
+        seen += indices
+    assert sorted(seen) == list(range(n))
+    # Util.transform keeps the reference's signature (Dataset.py:33) and returns an image with `.size`
+    img, b, l = Util.transform(Image.open(paths[0]), torch.tensor([[1., 2., 20., 25.]]), torch.tensor([3.]))
+    assert isinstance(img, Dataset.RawImage) and img.size == img.plan.size and b.shape[1] == 4 and b.shape[0] == l.shape[0]
 
 
 def test_state_dict_layout_equals_reference_checkpoint_layout(gold_dir, tmp_path):
@@ -221,6 +284,27 @@ def test_bench_refuses_to_run_without_the_gpu():
                        timeout=300)
     assert r.returncode != 0 and "needs a GPU" in (r.stderr + r.stdout)
     assert '"metric"' not in r.stdout
+
+
+def test_bench_gpus_n_starts_n_ranks_itself():
+    """`python bench.py --gpus 2` (no launcher around it, as the driver runs it) must form a 2-rank process group by itself, and a
+    launcher that started a different number of ranks than --gpus says must be refused -- the line can never time one GPU and
+    label it N.  `--rendezvous-only` stops after the process group's first all-reduce, before any GPU is touched."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-device",
+                        "--rendezvous-only"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout                                        # rank 0 only
+    out = json.loads(line[0])
+    assert out == {"rendezvous": True, "n_gpus": 2, "backend": "gloo", "ranks_counted": 2}
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rendezvous-only"], capture_output=True, text=True,
+                         timeout=300, env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"))
+    assert bad.returncode != 0 and "WORLD_SIZE=4" in (bad.stderr + bad.stdout) and '"metric"' not in bad.stdout
 
 
 def test_photometric_draws_equal_reference(gold_dir):
