@@ -370,8 +370,58 @@ def ssd300_random_params(seed: int = 0, variant: int = 300):
     return out
 
 
-def ssd300_forward(x, params, return_features: bool = False, variant: int = 300):
+def bf16_round(t):
+    """f32 -> nearest-even bf16 -> f32 (what `v_cvt_pk_bf16_f32` does to a convolution operand on its way into LDS)."""
+    import torch
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def _conv_bf16_operands():
+    """conv2d of BASELINE.json configs[2] ("bf16 convs"): operands rounded to bf16, products accumulated in f32, tensors and
+    bias in f32.  Forward y = conv(r(x), r(w)) + b; data gradient dx = conv^T(r(dy), r(w)); weight gradient corr(r(x), r(dy))
+    for the 3x3 / stride 1 / pad 1 / dilation 1 layers (the fused bf16 weight-gradient kernel) and corr(x, dy) in plain f32 for
+    every other geometry (1x1, dilated, strided, unpadded: those weight gradients stay on the f32 kernels); the bias gradient
+    is the f32 sum of the unrounded dy.  `wgrad_f32=True` forces the f32 weight gradient (conv1_1: its weight gradient runs
+    through the im2col buffer on the f32 kernel)."""
+    import torch
+    import torch.nn.functional as F
+
+    class ConvBf16Operands(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w, b, stride, padding, dilation, wgrad_f32):
+            ctx.save_for_backward(x, w)
+            ctx.cfg = (stride, padding, dilation, wgrad_f32)
+            return F.conv2d(bf16_round(x), bf16_round(w), b, stride=stride, padding=padding, dilation=dilation)
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, w = ctx.saved_tensors
+            stride, padding, dilation, wgrad_f32 = ctx.cfg
+            dx = dw = db = None
+            if ctx.needs_input_grad[0]:
+                dx = torch.nn.grad.conv2d_input(x.shape, bf16_round(w), bf16_round(dy), stride=stride, padding=padding, dilation=dilation)
+            if ctx.needs_input_grad[1]:
+                fused = (tuple(w.shape[2:]) == (3, 3) and stride == 1 and padding == 1 and dilation == 1 and not wgrad_f32)
+                xa, da = (bf16_round(x), bf16_round(dy)) if fused else (x, dy)
+                dw = torch.nn.grad.conv2d_weight(xa, w.shape, da, stride=stride, padding=padding, dilation=dilation)
+            if ctx.needs_input_grad[2]:
+                db = dy.sum(dim=(0, 2, 3))
+            return dx, dw, db, None, None, None, None
+
+    def conv(x, w, b=None, stride=1, padding=0, dilation=1, wgrad_f32=False):
+        return ConvBf16Operands.apply(x, w, b, stride, padding, dilation, wgrad_f32)
+    return conv
+
+
+_VGG_ACT = ("a1_1", "a1_2", "a2_1", "a2_2", "a3_1", "a3_2", "a3_3", "a4_1", "a4_2", "a4_3", "a5_1", "a5_2", "a5_3")
+
+
+def ssd300_forward(x, params, return_features: bool = False, variant: int = 300, operand_round: str = None, acts: dict = None):
     """x (bs,3,300,300) f32 NCHW torch tensor -> loc (bs,8732,4), conf (bs,8732,21).
+    operand_round="bf16": every convolution multiplies bf16-rounded operands with f32 accumulation (`_conv_bf16_operands`:
+    BASELINE.json configs[2]); pools, L2-norm, biases, ReLU and the tensors between layers stay f32.
+    acts: optional dict, filled with every post-ReLU activation (NCHW, detached) under the build's tensor names
+    (a1_1 .. a5_3, a6, a7, a8a, a8, ... , n4_3): lets a test follow the two computations layer by layer.
 
     Model.py:203-235: conv1_1..conv4_3 with 2x2/s2 pools (third one
     ceil_mode, :137); L2-norm over channels * gamma, no epsilon (:206-209);
@@ -382,13 +432,19 @@ def ssd300_forward(x, params, return_features: bool = False, variant: int = 300)
     """
     import torch
     import torch.nn.functional as F
+    if operand_round not in (None, "bf16"):
+        raise ValueError("operand_round must be None or 'bf16'")
+    conv2d = F.conv2d if operand_round is None else _conv_bf16_operands()
+    first = {} if operand_round is None else {"wgrad_f32": True}
     feats = {}
     h = x
     pools_after = {2: False, 4: False, 7: True, 10: False}   # conv ordinal -> ceil_mode
     for li, idx in enumerate(VGG_CONV_IDX):
-        h = F.relu(F.conv2d(h, params[f"model.features.{idx}.weight"],
-                            params[f"model.features.{idx}.bias"], padding=1))
+        h = F.relu(conv2d(h, params[f"model.features.{idx}.weight"],
+                          params[f"model.features.{idx}.bias"], padding=1, **(first if li == 0 else {})))
         n = li + 1
+        if acts is not None:
+            acts[_VGG_ACT[li]] = h.detach()
         if n == 10:
             feats["conv4_3"] = h
         if n in pools_after:
@@ -397,18 +453,26 @@ def ssd300_forward(x, params, return_features: bool = False, variant: int = 300)
     c43 = feats["conv4_3"]
     norm = c43.pow(2).sum(dim=1, keepdim=True).sqrt()
     c43n = c43 / norm * params["rescaling_conv_4_3"]
-    h = F.relu(F.conv2d(h, params["conv_fc6.weight"], params["conv_fc6.bias"], padding=4, dilation=4))
-    h = F.relu(F.conv2d(h, params["conv_fc7.weight"], params["conv_fc7.bias"]))
+    h = F.relu(conv2d(h, params["conv_fc6.weight"], params["conv_fc6.bias"], padding=4, dilation=4))
+    if acts is not None:
+        acts["n4_3"], acts["a6"] = c43n.detach(), h.detach()
+    h = F.relu(conv2d(h, params["conv_fc7.weight"], params["conv_fc7.bias"]))
+    if acts is not None:
+        acts["a7"] = h.detach()
     srcs = [c43n, h]
     for name, _, _, _, stride, pad in (AUX if variant == 300 else AUX_512):
-        h = F.relu(F.conv2d(h, params[f"{name}.0.weight"], params[f"{name}.0.bias"]))
-        h = F.relu(F.conv2d(h, params[f"{name}.2.weight"], params[f"{name}.2.bias"], stride=stride, padding=pad))
+        h = F.relu(conv2d(h, params[f"{name}.0.weight"], params[f"{name}.0.bias"]))
+        if acts is not None:
+            acts["a" + name[3:] + "a"] = h.detach()
+        h = F.relu(conv2d(h, params[f"{name}.2.weight"], params[f"{name}.2.bias"], stride=stride, padding=pad))
+        if acts is not None:
+            acts["a" + name[3:]] = h.detach()
         srcs.append(h)
     bs = x.shape[0]
     locs, confs = [], []
     for (name, _, _), s in zip(HEADS if variant == 300 else HEADS_512, srcs):
-        bb = F.conv2d(s, params[f"{name}_bb.weight"], params[f"{name}_bb.bias"], padding=1)
-        cl = F.conv2d(s, params[f"{name}_cl.weight"], params[f"{name}_cl.bias"], padding=1)
+        bb = conv2d(s, params[f"{name}_bb.weight"], params[f"{name}_bb.bias"], padding=1)
+        cl = conv2d(s, params[f"{name}_cl.weight"], params[f"{name}_cl.bias"], padding=1)
         locs.append(bb.permute(0, 2, 3, 1).reshape(bs, -1, 4))
         confs.append(cl.permute(0, 2, 3, 1).reshape(bs, -1, 21))
     loc, conf = torch.cat(locs, 1), torch.cat(confs, 1)

@@ -1,0 +1,122 @@
+"""Shared by tests/test_gpu_path.py and tools/grad_bars.py: the gradient-distance measurements whose results are committed
+as tests/golden/grad_bars.json (measured on an MI355X by tools/grad_bars.py) and then held as per-tensor bars by the tests
+(bar = max(2 x measured, floor)).  TEST INFRASTRUCTURE: imports the oracle."""
+import json
+import os
+
+import numpy as np
+import torch
+
+import ssd_oracle as O
+from helpers import synth_gt
+
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BARS_PATH = os.path.join(ROOT, "tests", "golden", "grad_bars.json")
+FLOOR_REL = 2e-5          # relative-L2 distances below this are summation-order noise
+FLOOR_NORM = 1e-5         # same for | ||g|| - ||ref|| | / ||ref||
+ENGINES = ("wino", "direct")
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def load_bars():
+    with open(BARS_PATH) as f:
+        return json.load(f)
+
+
+def bar(table, metric, name, floor=FLOOR_REL):
+    return max(2.0 * float(table[metric][name]), floor)
+
+
+def set_engine(net, engine, conv_dtype="f32"):
+    net.conv_dtype = conv_dtype
+    net.winograd = engine == "wino"
+
+
+def train_step(net, x, classes, boxes):
+    """one forward + loss + backward on device tensors -> (loc, conf, l1, l2, {name: grad})"""
+    from objectdetection_ssd_amd import Losses
+    net.train()
+    net.zero_grad()
+    loc, conf = net(x)
+    l1, l2 = Losses.ssd((loc, conf), classes, boxes)
+    (l1 + l2).backward()
+    torch.cuda.synchronize()
+    grads = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+    return loc.detach(), conf.detach(), float(l1.item()), float(l2.item()), grads
+
+
+def f64_case():
+    """bs 2, one GT per prior scale so that all six maps carry positives"""
+    x = np.random.default_rng(515).standard_normal((2, 3, 300, 300), dtype=np.float32)
+    boxes = [np.array([[.05, .05, .95, .95], [.1, .3, .475, .675], [.40, .40, .50, .52]], np.float32),
+             np.array([[.0, .1, .9, 1.], [.55, .5, .75, .7], [.2, .2, .75, .75], [.15, .1, .875, .825]], np.float32)]
+    classes = [np.array([1., 5., 12.], np.float32), np.array([7., 0., 19., 3.], np.float32)]
+    return x, boxes, classes
+
+
+def f64_oracle_grads(params, operand_round=None, dtype=torch.float64):
+    x, boxes, classes = f64_case()
+    P = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in params.items()}
+    loc, conf = O.ssd300_forward(torch.from_numpy(x).to(dtype), P, operand_round=operand_round)
+    a1, a2 = O.multibox_loss_torch(loc, conf, [torch.from_numpy(b) for b in boxes], [torch.from_numpy(c) for c in classes])
+    (a1 + a2).backward()
+    return loc.detach(), conf.detach(), float(a1), float(a2), {k: v.grad.double() for k, v in P.items()}
+
+
+def rel_l2(got, ref):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    return float((got - ref).norm() / ref.norm().clamp_min(1e-30))
+
+
+def gpu_f64_case(net):
+    x, boxes, classes = f64_case()
+    return train_step(net, _t(x), [_t(c) for c in classes], [_t(b) for b in boxes])
+
+
+def golden_case(z):
+    bs = int(z["bs"])
+    x = np.random.default_rng(int(z["x_seed"])).standard_normal((bs, 3, 300, 300), dtype=np.float32)
+    boxes, classes = synth_gt(np.random.default_rng(int(z["gt_seed"])), bs)
+    return _t(x), [_t(c) for c in classes], [_t(b) for b in boxes]
+
+
+def bench_batch(bs=32, seed=1234):
+    """bench.py's synth_batch"""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(bs, 3, 300, 300, generator=g)
+    rng = np.random.default_rng(seed)
+    boxes, classes = [], []
+    for _ in range(bs):
+        n = 1 + min(int(rng.poisson(1.4)), 7)
+        x1 = rng.uniform(0, .6, n); y1 = rng.uniform(0, .6, n)
+        w = rng.uniform(.08, .6, n); h = rng.uniform(.08, .6, n)
+        b = np.stack([x1, y1, np.minimum(x1 + w, 1.), np.minimum(y1 + h, 1.)], 1).astype(np.float32)
+        boxes.append(_t(b))
+        classes.append(_t(rng.integers(0, 20, n).astype(np.float32)))
+    return x.to(DEV), classes, boxes
+
+
+def layerwise_forward_distance(net, params, conv_dtype):
+    """Relative L2 distance of every activation of the HIP forward (engine tensors, NHWC) to the oracle's activation of the same
+    name on the f64-case input, the oracle run with the same operand rounding -> ({name: rel}, loc rel-max, conf rel-max)."""
+    x, _, _ = f64_case()
+    acts = {}
+    with torch.no_grad():
+        lo, co = O.ssd300_forward(torch.from_numpy(x), params, operand_round=None if conv_dtype == "f32" else conv_dtype, acts=acts)
+    set_engine(net, "wino", conv_dtype)
+    try:
+        with torch.no_grad():
+            loc, conf, saved = net._engine.forward(_t(x), net._forward_params(), save=True)
+    finally:
+        set_engine(net, "wino", "f32")
+    out = {}
+    for name, ref in acts.items():
+        got = saved["T"].get(name)
+        if got is None or not torch.is_tensor(got):           # consumed by a fused kernel without being written (f32 Winograd + pool)
+            continue
+        out[name] = rel_l2(got.permute(0, 3, 1, 2), ref)
+    return out, float((loc.cpu() - lo).abs().max() / lo.abs().max().clamp_min(1)), float((conf.cpu() - co).abs().max() / co.abs().max().clamp_min(1))

@@ -531,6 +531,129 @@ def test_conv_adjoint_identities_at_full_batch(layer):
     assert abs(float(db.double().sum()) - float(dy.double().sum())) <= 1e-6 * float(dy.abs().double().sum())       # bias grad = column sums
 
 
+WINO_BENCH_LAYERS = [  # the Winograd layers of BASELINE configs[1] as bench.py runs them at batch 32: (H, Ci, Co, pool ceil_mode or None)
+    (300, 64, 64, False),     # conv1_2 + pool1 (fused output transform); 2 x 1.66 GB planes
+    (150, 64, 128, None),     # conv2_1
+    (150, 128, 128, False),   # conv2_2 + pool2
+    (75, 256, 256, None),     # conv3_2
+    (75, 256, 256, True),     # conv3_3 + pool3 (ceil_mode, 75 -> 38)
+    (38, 512, 512, None),     # conv4_2
+    (19, 512, 512, None),     # conv5_2
+    (38, 512, 100, None),     # head c_4 (Co = 100 -> ld 128)
+    (19, 1024, 150, None),    # head c_7
+]
+
+
+@pytest.mark.parametrize("layer", WINO_BENCH_LAYERS)
+def test_winograd_entry_points_at_bench_batch(layer):
+    """The code path bench.py times, at the size it times it (batch 32): `ssd_conv3x3_wino_fwd_keep` / `_fwd_pool` (kept planes),
+    `_wgrad_planes` with `dgrad_planes_out` (the shared dy pass), `_dgrad_planes` -- held against the DIRECT exact-f32 kernels
+    on the same operands (1e-4 of the scale, the bar of every f32 kernel here) and against each other through the adjoint
+    identities <conv(x;W), dy> == <x, dgrad(dy;W)> == <W, wgrad(x,dy)> in float64 dots.  Split-K plans, plane sizes and the
+    32-bit buffer offsets of these kernels depend on the batch, so small-batch tests do not cover them."""
+    from objectdetection_ssd_amd import ops
+    h, ci, co, pool = layer
+    n = 32
+    dev = _dev()
+    gen = torch.Generator(device=dev).manual_seed(1000 + h + co)
+    x = torch.randn(n, h, h, ci, device=dev, generator=gen)
+    w = torch.randn(co, ci, 3, 3, device=dev, generator=gen) * (2.0 / (ci * 9)) ** 0.5
+    b = torch.randn(co, device=dev, generator=gen) * 0.1
+    g = ops.make_geom(n, h, h, ci, co, 3, 1, 1, 1)
+    ld = ops.pad32(co)
+    uf, ub = ops.wino_weights(w, ld, mo=4)
+    wf, wb = ops.weight_ohwi(w, ld), ops.weight_ihwo(w, ld)
+    dy = torch.zeros(n, h, h, ld, device=dev)
+    dy[..., :co] = torch.randn(n, h, h, co, device=dev, generator=gen)
+
+    def dot(a, c):
+        return float((a.double() * c.double()).sum())
+
+    # ---- forward, planes kept --------------------------------------------------------------------------------------
+    y_d = ops.conv2d_fwd(x, wf, b, g, False, ld=ld)                       # direct exact-f32 MFMA kernel
+    y_w, planes = ops.conv2d_fwd_wino(x, uf, b, g, False, ld=ld, keep_planes=True)
+    assert tuple(planes.shape) == ops.wino_planes_shape(g)
+    _close(y_w[..., :co], y_d[..., :co], what=f"wino fwd_keep vs direct {layer}")
+    if ld != co:
+        assert float(y_w[..., co:].abs().max()) == 0.0
+    lhs = dot(y_w[..., :co] - b, dy[..., :co])                            # <conv(x;W), dy>, bias taken out
+    if pool is not None:
+        yp, am, planes_p = ops.conv2d_fwd_wino_pool(x, uf, b, g, pool, keep_planes=True)
+        assert torch.equal(planes_p, planes)                              # the same transformed input either way
+        y_r, planes_r = ops.conv2d_fwd_wino(x, uf, b, g, True, keep_planes=True)
+        yp_ref, am_ref = ops.maxpool_fwd(y_r, 2, 2, 0, pool)
+        assert torch.equal(yp, yp_ref) and torch.equal(am, am_ref)        # fused == two kernels, bit for bit
+        yp_d, _ = ops.maxpool_fwd(torch.relu(y_d), 2, 2, 0, pool)
+        _close(yp, yp_d, what=f"wino fwd_pool vs direct conv + relu + pool {layer}")
+        del yp, am, planes_p, y_r, planes_r, yp_ref, am_ref, yp_d
+    del y_d, y_w
+    # ---- weight gradient on the kept planes + the data gradient's planes from the same pass over dy --------------------
+    dw, db, dyp = ops.conv2d_wgrad_wino(None, dy, g, ld, True, mo=4, planes=planes, dgrad_planes=True)
+    dw_d, db_d = ops.conv2d_wgrad(x, dy, g, ld, True)
+    _close(dw, dw_d, what=f"wino wgrad_planes vs direct {layer}")
+    _close(db, db_d, what=f"wino bias grad vs direct {layer}")
+    dw2, db2 = ops.conv2d_wgrad_wino(x, dy, g, ld, True, mo=4)            # transforming x again gives the same bits
+    assert torch.equal(dw2, dw) and torch.equal(db2, db)
+    # every dw element is an f32 sum over N*H*W (2.9 M at conv1_2) products; its error bar is 1e-4 of max|dw| like above, so the dot
+    # with W can be off by that times ||W||_2 (independent errors) -- |lhs| itself is a random-walk sum and no yardstick for it
+    rhs_w = dot(w, dw)
+    assert abs(lhs - rhs_w) <= 1e-4 * float(w.norm()) * float(dw.abs().max()), ("wgrad adjoint", layer, lhs, rhs_w)
+    assert abs(float(db.double().sum()) - float(dy.double().sum())) <= 1e-5 * float(dy.abs().double().sum())
+    del planes, dw2, db2, dw_d, db_d
+    # ---- data gradient from those planes ------------------------------------------------------------------------------------
+    dx_w = ops.conv2d_dgrad_wino(None, ub, g, planes=dyp)
+    dx_d = ops.conv2d_dgrad(dy, wb, g)
+    _close(dx_w, dx_d, what=f"wino dgrad_planes vs direct {layer}")
+    assert torch.equal(ops.conv2d_dgrad_wino(dy, ub, g), dx_w)            # own dy transform == shared pass
+    rhs_x = dot(x, dx_w)
+    assert abs(lhs - rhs_x) <= 1e-4 * max(1.0, abs(lhs)), ("dgrad adjoint", layer, lhs, rhs_x)
+    # accumulate + ReLU mask epilogue of the planes entry (what the backward of a two-consumer tensor uses)
+    prev = torch.randn(n, h, h, ci, device=dev, generator=gen)
+    mask = torch.randn(n, h, h, ci, device=dev, generator=gen).clamp_min(0)
+    dx_a = ops.conv2d_dgrad_wino(None, ub, g, dx=prev.clone(), relu_mask=mask, accumulate=True, planes=dyp)
+    _close(dx_a, (dx_d + prev) * (mask > 0), what=f"wino dgrad_planes accumulate + mask {layer}")
+
+
+@pytest.mark.parametrize("layer", [(300, 64, 64, 3, 1, 1, 1), (38, 512, 512, 3, 1, 1, 1), (19, 512, 1024, 3, 1, 4, 4)])
+def test_bf16_operand_kernels_at_bench_batch(layer):
+    """BASELINE configs[2] at its per-GPU batch (32): conv1_2, conv4_2 and fc6 through the bf16-operand kernels the mode uses
+    (halo-tile / generic igemm forward and dgrad, fused bf16 weight gradient or the f32 one) against an f32 torch-CPU
+    convolution of the SAME bf16-rounded operands (bf16 x bf16 products are exact in f32, so only the f32 summation order
+    differs): 2e-5 of the scale for forward / dgrad, 1e-4 for the weight gradient."""
+    from objectdetection_ssd_amd import ops
+    h, ci, co, k, s, p, d = layer
+    n = 32
+    dev = _dev()
+    torch.set_num_threads(16)
+    gen = torch.Generator().manual_seed(77 + h)
+    x = torch.randn(n, ci, h, h, generator=gen)
+    wt = torch.randn(co, ci, k, k, generator=gen) * (2.0 / (ci * k * k)) ** 0.5
+    b = torch.randn(co, generator=gen) * 0.1
+    xr, wr = x.bfloat16().float().requires_grad_(True), wt.bfloat16().float().requires_grad_(True)
+    y = F.conv2d(xr, wr, b, stride=s, padding=p, dilation=d)
+    dy = torch.randn(y.shape, generator=gen)
+    dyr = dy.bfloat16().float()
+    y.backward(dyr)
+    g = ops.make_geom(n, h, h, ci, co, k, s, p, d)
+    wd = wt.to(dev)
+    wf, wb = ops.weight_ohwi(wd, co), ops.weight_ihwo(wd, co)
+    wf3, wb3 = ops.weight_split3(wf), ops.weight_split3(wb)
+    xd, dyd = _nhwc(x).to(dev), _nhwc(dy).to(dev)
+    yd = ops.conv2d_fwd(xd, wf, b.to(dev), g, False, bf16=True, w3=wf3)
+    _close(yd, _nhwc(y), tol=2e-5, what=f"bf16 fwd @32 {layer}")
+    dx = ops.conv2d_dgrad(dyd, wb, g, bf16=True, w3=wb3)
+    _close(dx, _nhwc(xr.grad), tol=2e-5, what=f"bf16 dgrad @32 {layer}")
+    dw, db = ops.conv2d_wgrad(xd, dyd, g, co, True, bf16=True)
+    if (k, s, p, d) == (3, 1, 1, 1):
+        ref_dw = wr.grad                                                   # fused bf16 kernel: both operands rounded
+    else:
+        w2 = wt.clone().requires_grad_(True)                               # f32 kernel: unrounded x and dy
+        F.conv2d(x, w2, None, stride=s, padding=p, dilation=d).backward(dy)
+        ref_dw = w2.grad
+    _close(dw, ref_dw, tol=1e-4, what=f"bf16-mode wgrad @32 {layer}")
+    _close(db, dy.sum(dim=(0, 2, 3)), tol=1e-4, what=f"bf16-mode bias grad @32 {layer}")
+
+
 WINO_CASES = [(2, 19, 19, 64, 64), (1, 38, 38, 128, 256), (2, 75, 75, 32, 64), (1, 19, 19, 512, 100), (3, 10, 7, 64, 32), (1, 5, 5, 32, 32)]
 
 
