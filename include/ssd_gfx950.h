@@ -163,6 +163,12 @@ int ssd_conv3x3_wino_wgrad_planes(const float* planes, const float* dy, int ldy,
                                   float* dgrad_planes_out, void* workspace, size_t workspace_bytes, void* stream);
 int ssd_conv3x3_wino_dgrad_planes(const float* dy_planes, const float* U_bwd, int Co_pad, float* dx, const float* relu_mask,
                                   int accumulate, const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream);
+/* Forward / dgrad of the F(4x4,3x3) entry points: 36 plane GEMMs + output transform in ONE kernel (accumulators of all planes in
+ * registers, the M planes never reach memory) where the reduction length is a multiple of 64.  -1 (default): where it is the faster
+ * form; 0: never (batched GEMM + output transform kernels); 1: wherever the geometry allows. */
+int ssd_tune_set_wino_fused(int mode);
+int ssd_tune_set_wino_fused_stagger(int cycles);   /* first-round start delay step between CUs; -1 automatic, 0 none */
+int ssd_tune_set_wino_fused_stamps(uint64_t* device_buffer);   /* diagnostic: in-kernel phase stamps of the fused kernel; NULL = off */
 int ssd_tune_set_wino_wgrad_tn(int on);   /* 1 (default): F(4x4) weight gradient on untransposed planes + TN GEMM; 0: transposed planes */
 /* Measurement aid: arm / read back per-launch timings (library-owned HIP events) of the batched Winograd GEMM kernel.
  * collect() returns the number of (milliseconds, executed FLOPs) pairs written; the caller synchronises the stream first. */

@@ -1,0 +1,348 @@
+// Winograd F(4x4,3x3): the 36 plane GEMMs AND the output transform in one kernel (forward and dgrad of the 3x3 / stride-1 layers).
+//
+//   M[xi][tile][n] = sum_k V[xi][tile][k] * U[xi][n][k]      36 GEMMs            (winograd.hip: batched igemm, M planes to HBM)
+//   y = A^T m A (+ bias, ReLU | + previous dx, ReLU mask | -> 2x2 max pool)      (winograd.hip: wino4_output*_kernel, M planes from HBM)
+//
+// In the two-kernel form the M planes (2.25x the output tensor, 1.66 GB for conv1_2 at batch 32) are written and read back; for the
+// 64 / 128 / 256-channel layers that traffic, not the MFMA, sets the time.  Here a workgroup owns 32 tiles x 64 output channels and keeps
+// ALL 36 planes of that block in accumulator registers (eight waves of 16 tiles x 16 channels: 36 x f32x4 = 144 per lane, two waves per
+// SIMD), so the output transform is lane-local and M never exists in memory.
+//
+// Loop: stages (plane xi, 64-wide K chunk): A = V[xi][32 tiles][64 k] (8 KB), B = U[xi][64 n][64 k] (16 KB), brought in by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write) into a 5-slot ring, three stages ahead, counted vmcnt + raw s_barrier
+// (cdna_hip_programming.md section 5, "Pipelining across barriers").  The ring rows are 256 B and unpadded (LDS-DMA writes 1 KB
+// contiguously per wave instruction), so the 16-byte chunks of a row are XOR-swizzled by the row number on the SOURCE address and on
+// the ds_read_b128 address alike (rule 21): the 16 rows a lane group reads land on 16 different chunks.
+// MFMA: v_mfma_f32_16x16x4_f32, wave tile 16 tiles x 16 channels; its C/D layout puts a (tile, channel) pair's 36 plane values in one
+// lane.  K is walked in the permuted order k = 16j + 4(lane>>4) + e for both operands (a sum does not care).
+// Rows beyond the last tile / beyond the filter rows are clamped to the last valid row: their results are never stored.
+#include "common.h"
+
+namespace {
+
+__device__ constexpr float F4_AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+
+struct FusedParams {
+    const float* V;            // [36][tiles][K]
+    const float* U;            // [36][Nrows][K]
+    size_t plane_v, plane_u;   // floats per plane
+    int tiles, K, Nrows, Nout; // Nout: channels produced (multiple of 4)
+    int groups, nblk_n;        // ceil(tiles / 32), ceil(Nout / 64)
+    float* out; int ldo; int Cvalid;
+    const float* bias; const float* mask; int relu, accumulate;
+    int H, W, TH, TW;
+    float* yp; uint8_t* am; int Ho, Wo;      // pooled form (yp != nullptr): conv -> ReLU -> 2x2 / stride-2 max pool
+    unsigned long long* stamps;              // diagnostic (ssd_tune_set_wino_fused_stamps): 8 shader-clock stamps per 16th block
+    int stagger;                             // start delay step (shader cycles) between the first workgroups of the CUs
+};
+
+constexpr int FG = 32, FN = 64, FK = 64;       // block tile: tiles x channels, K per stage
+#ifndef WF_NS
+#define WF_NS 5
+#define WF_PD 3
+#endif
+constexpr int NS = WF_NS, PD = WF_PD;          // ring slots; LDS-DMA of stage s+PD is issued while stage s is multiplied
+constexpr int STAGE_F = (FG + FN) * FK;        // floats per slot (24 KB)
+constexpr int LOADS = 3;                       // LDS-DMA instructions per wave per stage (24 one-KB pieces over 8 waves)
+constexpr int YS_F = FG * 16 * FN;             // epilogue image [32 tiles][16 px][64 ch] (128 KB)
+constexpr int LDS_F = NS * STAGE_F > YS_F ? NS * STAGE_F : YS_F;
+static_assert(NS - PD >= 2, "a slot is re-filled no earlier than two barriers after its last read");
+static_assert(LDS_F * 4 <= 160 * 1024, "LDS");
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// 512 threads = 8 waves, two per SIMD: wave (mb, nb) = (wave >> 2, wave & 3) owns tiles mb*16 .. +15 x channels nb*16 .. +15 for all 36
+// planes (144 accumulator registers).  Each wave has ONE dependent accumulator chain per plane (40-cycle latency against a 32-cycle
+// issue slot); the partner wave on the same SIMD takes the other slot, and fills the matrix pipe while this one issues its LDS-DMA
+// pieces and fragment reads.
+__global__ __launch_bounds__(512, 2) void wino4_gemm_out_kernel(const FusedParams p) {
+    __shared__ __attribute__((aligned(16))) float lds[LDS_F];                 // the only LDS object of the kernel
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mb = wave >> 2, nbw = wave & 3;
+    const int nblk = p.groups * p.nblk_n;
+    const int lid = xcd_swizzle(blockIdx.x, nblk);
+    const int grp = lid / p.nblk_n, nb = lid - grp * p.nblk_n;              // channel blocks of one tile group are neighbours in one L2
+    const int tile0 = grp * FG, n0 = nb * FN;
+    const int KCN = p.K / FK, S = 36 * KCN;
+    const bool stamp = p.stamps != nullptr && (blockIdx.x & 15) == 0 && tid == 0;
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (stamp) ts[0] = __builtin_readcyclecounter();
+    // The first workgroup of every CU starts together and all of them have the same length: without help the whole chip loads, multiplies
+    // and stores in lockstep and the stores of every CU hit HBM in one burst.  Delay the first round by a per-CU phase (speed only).
+    if (p.stagger > 0 && blockIdx.x < 256) {
+        const long long want = (long long)((blockIdx.x >> 3) & 7) * p.stagger;
+        const long long t0 = (long long)__builtin_readcyclecounter();
+        while ((long long)__builtin_readcyclecounter() - t0 < want) __builtin_amdgcn_s_sleep(64);
+    }
+
+    // ---- LDS-DMA pieces of this wave: piece q = 3 * wave + i of a stage's 24 (0..7: four A rows each, 8..23: four B rows each) --------
+    const int lrow = lane >> 4, pc = lane & 15;                              // row within the piece, physical 16-byte chunk
+    unsigned src_off[LOADS];
+    bool is_a[LOADS];
+    int lds_off[LOADS];
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+        const int q = 3 * wave + i;
+        is_a[i] = q < 8;
+        const int row = is_a[i] ? 4 * q + lrow : 4 * (q - 8) + lrow;
+        const int src_row = is_a[i] ? min(tile0 + row, p.tiles - 1) : min(n0 + row, p.Nrows - 1);
+        src_off[i] = (unsigned)src_row * (unsigned)p.K + (unsigned)((pc ^ (row & 15)) * 4);
+        lds_off[i] = q * 256;                                               // A pieces then B pieces, contiguous: A = rows 0..31, B = 32..95
+    }
+    const float* vsrc = p.V;                 // plane / K-chunk of the NEXT stage to issue
+    const float* usrc = p.U;
+    int kc_i = 0, slot_i = 0, issued = 0;
+    auto issue = [&]() {
+        float* base = lds + slot_i * STAGE_F;
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i)
+            __builtin_amdgcn_global_load_lds((is_a[i] ? vsrc : usrc) + src_off[i], (lds_void*)(base + lds_off[i]), 16, 0, 0);
+        ++issued;
+        slot_i = slot_i + 1 == NS ? 0 : slot_i + 1;
+        if (++kc_i == KCN) {
+            kc_i = 0;
+            vsrc += p.plane_v - (size_t)(KCN - 1) * FK;
+            usrc += p.plane_u - (size_t)(KCN - 1) * FK;
+        } else {
+            vsrc += FK;
+            usrc += FK;
+        }
+    };
+
+    f32x4 acc[36];
+#pragma unroll
+    for (int xi = 0; xi < 36; ++xi) acc[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int r15 = lane & 15, kq = lane >> 4;
+    const int a_rd = (mb * 16 + r15) * FK, b_rd = FG * FK + (nbw * 16 + r15) * FK;
+    int sw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sw[j] = ((4 * j + kq) ^ r15) * 4;
+
+    // The 8 fragment reads of stage s+1 are issued BEFORE the 16 MFMAs of stage s (two register sets, their roles fixed at compile
+    // time: K == 64 alternates with the plane, longer K with the chunk).
+    struct Frag { f32x4 a[4], b[4]; };
+    Frag F[2];
+    auto load_frags = [&](Frag& f, int slot) {
+        const float* st = lds + slot * STAGE_F;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f.a[j] = *reinterpret_cast<const f32x4*>(st + a_rd + sw[j]);
+            f.b[j] = *reinterpret_cast<const f32x4*>(st + b_rd + sw[j]);
+        }
+    };
+    int slot_c = 0, done = 0;                 // slot / index of the stage being multiplied
+    auto wait_landed = [&](int stage) {       // this wave's LDS-DMA of `stage` is complete once at most (issued - stage - 1) stages' are outstanding
+        const int ahead = issued - stage - 1;
+        if (ahead >= 4) wait_vmcnt<4 * LOADS>();
+        else if (ahead == 3) wait_vmcnt<3 * LOADS>();
+        else if (ahead == 2) wait_vmcnt<2 * LOADS>();
+        else if (ahead == 1) wait_vmcnt<LOADS>();
+        else wait_vmcnt<0>();
+    };
+    auto step = [&](f32x4& c, const Frag& cur, Frag& nxt) {
+#ifndef WF_NO_LOAD
+        if (issued < S) issue();
+#else
+        if (issued < S) ++issued;
+#endif
+        const int slot_n = slot_c + 1 == NS ? 0 : slot_c + 1;
+        if (done + 1 < S) {
+            wait_landed(done + 1);
+            __builtin_amdgcn_s_barrier();                                     // every wave's part of stage done+1 has landed; stage done-1 is fully read
+            asm volatile("" ::: "memory");
+            load_frags(nxt, slot_n);
+        }
+#ifdef WF_NO_MFMA
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c += cur.a[j] * cur.b[j];
+#else
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[j][e], cur.b[j][e], c, 0, 0, 0);
+#endif
+        slot_c = slot_n;
+        ++done;
+    };
+
+#pragma unroll
+    for (int s = 0; s < PD; ++s)
+        if (s < S) issue();
+    wait_landed(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    load_frags(F[0], 0);
+    if (stamp) ts[1] = __builtin_readcyclecounter();
+
+    if (KCN == 1) {
+#pragma unroll
+        for (int xi = 0; xi < 36; ++xi) step(acc[xi], F[xi & 1], F[(xi & 1) ^ 1]);
+    } else {                                                                   // KCN even (host checks)
+#pragma unroll
+        for (int xi = 0; xi < 36; ++xi)
+            for (int kc = 0; kc < KCN; kc += 2) {
+                step(acc[xi], F[0], F[1]);
+                step(acc[xi], F[1], F[0]);
+            }
+    }
+
+    if (stamp) ts[2] = __builtin_readcyclecounter();
+    // ---- epilogue: lane-local A^T m A, then through LDS so that a thread owns (tile, 4 channels) and moves 16 bytes at a time --------
+    // C/D layout of the 16x16 MFMA: register r is tile mb*16 + 4*(lane>>4) + r, channel nbw*16 + (lane&15)
+    float* ys = lds;                                                          // [32 tiles][16 px][64 ch]
+    const int C4 = p.Nout >> 2;
+    __builtin_amdgcn_s_barrier();                                             // the ring is no longer read
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float t[4][6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const float m0 = acc[b][r], m1 = acc[6 + b][r], m2 = acc[12 + b][r], m3 = acc[18 + b][r], m4 = acc[24 + b][r], m5 = acc[30 + b][r];
+            const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+            t[0][b] = m0 + s1 + s2;
+            t[1][b] = d1 + 2.f * d2;
+            t[2][b] = s1 + 4.f * s2;
+            t[3][b] = d1 + 8.f * d2 + m5;
+        }
+        float* dst = ys + (size_t)((mb * 16 + 4 * kq + r) * 16) * FN + nbw * 16 + r15;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float s1 = t[i][1] + t[i][2], d1 = t[i][1] - t[i][2], s2 = t[i][3] + t[i][4], d2 = t[i][3] - t[i][4];
+            dst[(i * 4 + 0) * FN] = t[i][0] + s1 + s2;
+            dst[(i * 4 + 1) * FN] = d1 + 2.f * d2;
+            dst[(i * 4 + 2) * FN] = s1 + 4.f * s2;
+            dst[(i * 4 + 3) * FN] = d1 + 8.f * d2 + t[i][5];
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (stamp) ts[3] = __builtin_readcyclecounter();
+    {
+        // thread = (tile tl of the group, channel quad c4l)
+        const int tl = tid >> 4, c4l = tid & 15;
+        const int tile = tile0 + tl, c4 = (n0 >> 2) + c4l;
+        if (tile < p.tiles && c4 < C4) {
+            const int tw = tile % p.TW, th = (tile / p.TW) % p.TH, n = tile / (p.TW * p.TH);
+            const float* src = ys + (size_t)(tl * 16) * FN + c4l * 4;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[e] = c4 * 4 + e < p.Cvalid ? p.bias[c4 * 4 + e] : 0.f;
+            }
+            if (p.yp == nullptr) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int oh = 4 * th + a;
+                    if (oh >= p.H) continue;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int ow = 4 * tw + b;
+                        if (ow >= p.W) continue;
+                        f32x4 v = *reinterpret_cast<const f32x4*>(src + (a * 4 + b) * FN) + bv;
+                        const size_t idx = (((size_t)n * p.H + oh) * p.W + ow) * p.ldo + c4 * 4;
+                        if (p.accumulate) v += *reinterpret_cast<const f32x4*>(p.out + idx);
+                        if (p.relu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
+                        }
+                        if (p.mask != nullptr) {
+                            const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + idx);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+                        }
+                        *reinterpret_cast<f32x4*>(p.out + idx) = v;
+                    }
+                }
+            } else {
+                // conv -> ReLU -> MaxPool2d(2, 2): window scan order, NaN rule and argmax codes of maxpool_fwd_kernel (elementwise.hip)
+#pragma unroll
+                for (int pa = 0; pa < 2; ++pa) {
+                    const int oh = 2 * th + pa;
+                    if (oh >= p.Ho) continue;
+#pragma unroll
+                    for (int pb = 0; pb < 2; ++pb) {
+                        const int ow = 2 * tw + pb;
+                        if (ow >= p.Wo) continue;
+                        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                        int bi[4] = {0, 0, 0, 0};
+                        bool first = true;
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            if (2 * oh + r >= p.H) continue;
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) {
+                                if (2 * ow + q >= p.W) continue;
+                                f32x4 v = *reinterpret_cast<const f32x4*>(src + ((2 * pa + r) * 4 + 2 * pb + q) * FN) + bv;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    v[e] = v[e] < 0.f ? 0.f : v[e];
+                                    if (first || v[e] > best[e] || v[e] != v[e]) {
+                                        best[e] = v[e];
+                                        bi[e] = r * 2 + q;
+                                    }
+                                }
+                                first = false;
+                            }
+                        }
+                        const size_t o = (((size_t)n * p.Ho + oh) * p.Wo + ow) * C4 + c4;
+                        *reinterpret_cast<f32x4*>(p.yp + o * 4) = best;
+                        if (p.am != nullptr)
+                            *reinterpret_cast<uint32_t*>(p.am + o * 4) =
+                                (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+                    }
+                }
+            }
+        }
+    }
+    if (stamp) {
+        ts[4] = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* o = p.stamps + (size_t)(blockIdx.x >> 4) * 8;
+        for (int i = 0; i < 5; ++i) o[i] = ts[i];
+        o[5] = __builtin_readcyclecounter();
+    }
+}
+
+unsigned long long* g_fused_stamps = nullptr;
+int g_fused_stagger = -1;         // -1: automatic; 0: none
+}  // namespace
+
+// Diagnostic: device buffer of 8 x uint64 per 16 blocks (start, main loop start, main loop end, output transformed, stores issued,
+// stores complete; shader clock) filled by every 16th block of the fused launches that follow; NULL switches it off.
+extern "C" int ssd_tune_set_wino_fused_stagger(int cycles) {
+    g_fused_stagger = cycles;
+    return SSD_OK;
+}
+extern "C" int ssd_tune_set_wino_fused_stamps(uint64_t* device_buffer) {
+    g_fused_stamps = reinterpret_cast<unsigned long long*>(device_buffer);
+    return SSD_OK;
+}
+
+// Internal (not part of the C ABI; called by winograd.hip's wino_conv): the GEMMs + output transform of one F(4x4,3x3) convolution on
+// planes V [36][tiles][K] and filters U [36][Nrows][K].  Returns SSD_ERR_BAD_SHAPE when the geometry is not the kernel's (K % 64).
+__attribute__((visibility("hidden"))) int ssd_internal_wino4_gemm_out(const float* V, const float* U, int tiles, int K, int Nrows, int Nout,
+                                                                       float* out, int ldo, int Cvalid, const float* bias, const float* mask,
+                                                                       int relu, int accumulate, int H, int W, int TH, int TW, float* yp,
+                                                                       uint8_t* am, int Ho, int Wo, hipStream_t st) {
+    if (K <= 0 || K % FK != 0 || (K / FK > 1 && (K / FK) % 2 != 0) || tiles <= 0 || Nout <= 0 || Nout % 4 != 0 || Nrows <= 0) return SSD_ERR_BAD_SHAPE;
+    if ((size_t)tiles * K >= (1ull << 32) || (size_t)Nrows * K >= (1ull << 32)) return SSD_ERR_BAD_SHAPE;
+    FusedParams p;
+    p.V = V; p.U = U;
+    p.plane_v = (size_t)tiles * K; p.plane_u = (size_t)Nrows * K;
+    p.tiles = tiles; p.K = K; p.Nrows = Nrows; p.Nout = Nout;
+    p.groups = ssd_cdiv(tiles, FG); p.nblk_n = ssd_cdiv(Nout, FN);
+    p.out = out; p.ldo = ldo; p.Cvalid = Cvalid; p.bias = bias; p.mask = mask; p.relu = relu; p.accumulate = accumulate;
+    p.H = H; p.W = W; p.TH = TH; p.TW = TW;
+    p.yp = yp; p.am = am; p.Ho = Ho; p.Wo = Wo;
+    p.stamps = g_fused_stamps;
+    p.stagger = g_fused_stagger < 0 ? (K / FK) * 36 * 160 : g_fused_stagger;      // eight phases over about one workgroup's life
+    const long long nblk = (long long)p.groups * p.nblk_n;
+    if (nblk >= (1ll << 31)) return SSD_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(wino4_gemm_out_kernel, dim3((unsigned)nblk), dim3(512), 0, st, p);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}

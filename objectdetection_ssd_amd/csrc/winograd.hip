@@ -11,6 +11,9 @@
 
 int ssd_internal_gemm_batched(const float* a, const float* w, float* out, int M, int K, int N, int n_rows, int nbatch,
                               size_t batch_a_elems, size_t batch_w_elems, int ksplit, hipStream_t st);
+int ssd_internal_wino4_gemm_out(const float* V, const float* U, int tiles, int K, int Nrows, int Nout, float* out, int ldo, int Cvalid,
+                                const float* bias, const float* mask, int relu, int accumulate, int H, int W, int TH, int TW, float* yp,
+                                uint8_t* am, int Ho, int Wo, hipStream_t st);
 
 namespace {
 
@@ -835,7 +838,15 @@ __global__ __launch_bounds__(256) void wino4_wgrad_finish_kernel(const float* __
     }
 }
 
+int g_fused = -1;                  // ssd_tune_set_wino_fused: -1 automatic, 0 never, 1 wherever K % 64 == 0
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+// GEMMs + output transform in one kernel (wino_fused.hip)?  It removes the write and the read-back of the M planes; what it costs is
+// MFMA efficiency on long reductions (one workgroup per CU, 16x16x4 MFMAs).
+inline bool use_fused(int mo, int K, int Nout) {
+    if (mo != 4 || K % 64 != 0 || (K > 64 && K % 128 != 0) || g_fused == 0) return false;
+    if (g_fused == 1) return true;
+    return K == 64;                    // measured at batch 32 (tools/wino_bench.py): conv1_2 forward 1.52 -> 1.14 ms, dgrad 1.26 -> 0.94, conv2_1 forward 0.67 -> 0.50
+}
 inline int grid_for(size_t total) { const size_t b = (total + 255) / 256; return (int)(b > 8192 ? 8192 : (b == 0 ? 1 : b)); }
 
 // one Winograd convolution, F(mo x mo, 3x3) with mo = 2 or 4: in (N,H,W,Cin) -> out (N,H,W,ldo) first Cout channels
@@ -856,6 +867,10 @@ int wino_conv(int mo, const float* in, int Cin, const float* U, int U_rows, floa
     else if (mo == 2) hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(tiles * (Cin / 4))), dim3(256), 0, st, in, V, N, H, W, Cin, TH, TW);
     else hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(tiles * (Cin / 4))), dim3(256), 0, st, in, V, N, H, W, Cin, TH, TW);
     SSD_CHECK_LAUNCH();
+    if (use_fused(mo, Cin, Cout))
+        return ssd_internal_wino4_gemm_out(V, U, (int)tiles, Cin, U_rows, Cout, out, ldo, Cvalid, bias, mask, relu, accumulate, H, W, TH, TW,
+                                           pooled ? pooled->y : nullptr, pooled ? pooled->argmax : nullptr, pooled ? pooled->Ho : 0,
+                                           pooled ? pooled->Wo : 0, st);
     if (int e = ssd_internal_gemm_batched(V, U, Mx, (int)tiles, Cin, Cout, U_rows, P, tiles * Cin, (size_t)U_rows * Cin, 1, st)) return e;
     if (pooled != nullptr)
         hipLaunchKernelGGL(wino4_output_pool_kernel, dim3(grid_for(tiles * (Cout / 4))), dim3(256), 0, st, Mx, pooled->y, pooled->argmax, N, H, W,
@@ -975,6 +990,12 @@ WinoWgradPlan wino_wgrad_plan(const ssd_conv_geom* g, int ldy, int mo) {
     return w;
 }
 }  // namespace
+
+extern "C" int ssd_tune_set_wino_fused(int mode) {
+    if (mode < -1 || mode > 1) return SSD_ERR_BAD_SHAPE;
+    g_fused = mode;
+    return SSD_OK;
+}
 
 extern "C" int ssd_tune_set_wino_wgrad_tn(int on) {
     g_wgrad_tn = on ? 1 : 0;
