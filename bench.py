@@ -434,16 +434,17 @@ def main():
         from objectdetection_ssd_amd import _lib as _l
         import ctypes as _C
         gemm_tag = "igemm_kernel<64, 64, 2, 2, 1, true"
+        fused_tag = "wino4_gemm_out_kernel"
         exec_flops = 0.0
         for _ in range(3):
             eng.prof = []
             _l.check(_l.load().ssd_prof_gemm_begin(), "prof")        # the batched Winograd GEMM launches, each by itself
             step()
             torch.cuda.synchronize()
-            ms_buf, fl_buf = (_C.c_float * 1024)(), (_C.c_double * 1024)()
-            ng = _l.load().ssd_prof_gemm_collect(ms_buf, fl_buf, 1024)
+            ms_buf, fl_buf, kind_buf = (_C.c_float * 1024)(), (_C.c_double * 1024)(), (_C.c_int * 1024)()
+            ng = _l.load().ssd_prof_gemm_collect_kinds(ms_buf, fl_buf, kind_buf, 1024)
             for i in range(max(ng, 0)):
-                a = agg.setdefault(gemm_tag, [0.0, 0.0, 0])
+                a = agg.setdefault(fused_tag if kind_buf[i] == 1 else gemm_tag, [0.0, 0.0, 0])
                 a[0] += ms_buf[i] * 1e-3; a[1] += fl_buf[i]; a[2] += 1
             for label, tag, flops, e0, e1, executed in eng.prof:
                 exec_flops += executed
@@ -472,6 +473,9 @@ def main():
             peak, peak_note = 2500.0, "bf16 MFMA dense"
         else:
             peak, peak_note = round(2500.0 / 6, 1), "bf16 MFMA dense / 6 limb products per f32 product"
+        if tag == fused_tag:
+            peak_note += ("; the fused Winograd kernel (36 plane GEMMs + output transform, all planes' accumulators in registers): `achieved` is "
+                          "its EXECUTED rate over the whole kernel, epilogue included")
         if tag == gemm_tag:
             peak_note += ("; this is the batched GEMM inside the Winograd ops, timed by itself: `achieved` is its EXECUTED rate (4/9 resp. 1/4 of "
                           "the direct convolution's FLOPs plus tile padding); the ops it serves are the `winograd_3x3` row of by_kernel, in "

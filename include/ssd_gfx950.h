@@ -159,6 +159,17 @@ int ssd_conv3x3_wino_wgrad(const float* x, const float* dy, int ldy, float* dw_o
 /* The same with the x planes a ..._fwd_keep / ..._fwd_pool call kept (F(4x4) only); workspace as ssd_conv3x3_wino_wgrad_workspace(g, ldy, 4).
  * dgrad_planes_out (may be NULL; 36 x tiles x ldy floats): the pass over dy also writes B^T dy B, the input planes of this layer's
  * data gradient, which ssd_conv3x3_wino_dgrad_planes (Co_pad = ldy) then takes instead of transforming dy again. */
+/* ReLU masks as bits.  The forward's input transform can leave, per (tile, channel quad), one 64-bit word -- bit (a*4+b)*4+e set iff
+ * x[4 th + a][4 tw + b][4 c4 + e] > 0 -- in relu_bits_out (tiles x Ci/4 words; may be NULL): the ReLU mask of the layer's INPUT on the tile
+ * grid its data gradient is written on (autograd's ReLU backward, Model.py:136-141).  ssd_conv3x3_wino_dgrad_planes_bits applies it in
+ * place of ssd_conv3x3_wino_dgrad_planes's float relu_mask, reading 1/32 of the bytes; results are identical. */
+int ssd_conv3x3_wino_fwd_keep_bits(const float* x, const float* U_fwd, const float* bias, float* y, int ldy, const ssd_conv_geom* g, int relu,
+                                   float* planes_keep, uint64_t* relu_bits_out, void* workspace, size_t workspace_bytes, void* stream);
+int ssd_conv3x3_wino_fwd_pool_bits(const float* x, const float* U_fwd, const float* bias, float* y_pooled, uint8_t* argmax,
+                                   const ssd_conv_geom* g, int ceil_mode, float* planes_keep, uint64_t* relu_bits_out, void* workspace,
+                                   size_t workspace_bytes, void* stream);
+int ssd_conv3x3_wino_dgrad_planes_bits(const float* dy_planes, const float* U_bwd, int Co_pad, float* dx, const uint64_t* relu_bits,
+                                       int accumulate, const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream);
 int ssd_conv3x3_wino_wgrad_planes(const float* planes, const float* dy, int ldy, float* dw_oihw, float* dbias, const ssd_conv_geom* g,
                                   float* dgrad_planes_out, void* workspace, size_t workspace_bytes, void* stream);
 int ssd_conv3x3_wino_dgrad_planes(const float* dy_planes, const float* U_bwd, int Co_pad, float* dx, const float* relu_mask,
@@ -173,6 +184,7 @@ int ssd_tune_set_wino_wgrad_tn(int on);   /* 1 (default): F(4x4) weight gradient
 /* Measurement aid: arm / read back per-launch timings (library-owned HIP events) of the batched Winograd GEMM kernel.
  * collect() returns the number of (milliseconds, executed FLOPs) pairs written; the caller synchronises the stream first. */
 int ssd_prof_gemm_begin(void);
+int ssd_prof_gemm_collect_kinds(float* ms_out, double* flops_out, int* kinds_out, int max);   /* kind 0: batched plane GEMMs, 1: fused GEMM + output transform */
 int ssd_prof_gemm_collect(float* ms_out, double* flops_out, int max);
 int ssd_tune_set_igemm(int tile, int nbuf);
 int ssd_tune_set_igemm_stamps(uint64_t* device_buffer);   /* diagnostic: per-block shader-clock stamps (see conv_igemm.hip) */

@@ -144,8 +144,20 @@ class _Engine:
     """Runs the op list on the current HIP stream.  Holds only caches (re-laid-out weights)."""
 
     def __init__(self, variant: int = 300):
-        self.ops = build_ops(variant)
-        self.names = param_names(self.ops)
+        ops_ = build_ops(variant)
+        self.names = param_names(ops_)            # parameter order of the autograd Function: the reference's forward order
+        # Schedule: [backbone ... seq8] then [L2-norm, c_4, c_7: big MFMA-bound head convolutions] then [c_8, seq9 ... c_11: a dozen tiny
+        # maps (10x10 ... 1x1) whose ~60 launches per direction are latency-bound].  The last group runs on a second HIP stream beside
+        # the middle one, forward and backward: it depends only on a8, and nothing but its own ops reads what it produces.
+        late = [o for o in ops_ if o["op"] == "l2norm" or (o["op"] == "head" and o["p"] in ("c_4", "c_7"))]
+        k8 = next(i for i, o in enumerate(ops_) if o["op"] == "conv" and o["y"] == "a8")
+        side = [o for i, o in enumerate(ops_) if i > k8 and o not in late]
+        early = [o for o in ops_ if o not in late and o not in side]
+        self.ops = early + late + side
+        self._side_ids = {id(o) for o in side}
+        self._late_first = id(late[0])
+        self.overlap_tail = True                  # False: everything on the caller's stream
+        self._side_stream = None
         self._wcache: Dict[str, tuple] = {}
         self.consumers: Dict[str, int] = {}
         for op in self.ops:
@@ -162,6 +174,7 @@ class _Engine:
         self.dual_dy = True       # backward: one pass over dy writes the planes of the weight gradient AND of the data gradient
         self.keep_planes = True   # training forward keeps the F(4x4) input planes of the layers whose weight gradient is Winograd
         self.fuse_pool = True     # Winograd F(4x4) layers in pool_after write the pooled map + argmax only
+        self.relu_bits = True     # training forward: the input transform also leaves the ReLU mask of its input as bits for the dgrad epilogue
         self.prof = None          # bench.py: list collecting (label, kernel tag, flops, start event, end event)
         self.bf16 = False         # True: forward / dgrad / fused-wgrad convolutions multiply bf16-rounded operands (f32 accumulate)
         self.x3 = False           # True: forward / dgrad convolutions form f32 products from three bf16 limbs per operand
@@ -256,8 +269,20 @@ class _Engine:
         T = {"x": x}
         aux = {}
         heads = []
+        main = torch.cuda.current_stream(x.device)
+        overlap = self.overlap_tail and bool(self._side_ids)
+        if overlap and self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=x.device)
+        side, side_ctx, fork = self._side_stream, None, None
         for op in self.ops:
             kind = op["op"]
+            if overlap and id(op) == self._late_first:
+                fork = main.record_event()                        # a8 (and everything before it) is enqueued
+            if overlap and side_ctx is None and id(op) in self._side_ids:
+                side.wait_event(fork)
+                T[op["x"]].record_stream(side)
+                side_ctx = torch.cuda.stream(side)
+                side_ctx.__enter__()
             if kind == "conv_first":
                 # conv1_1 as im2col (K = 27 -> 32) + the 1x1 MFMA convolution
                 col = ops.im2col_first(x)
@@ -282,19 +307,26 @@ class _Engine:
                     pl = self.pool_after.get(op["y"]) if (self.fuse_pool and self.WINO_TILE == 4) else None
                     # training: the transformed input stays for the weight gradient, which multiplies the same planes
                     keep = save and self.keep_planes and self.WINO_TILE == 4 and self._wino_wgrad_ok(g, False)
+                    # the mask is only ever applied to a post-ReLU input (deliver() below): pool outputs and the image are not gated here
+                    wb = keep and self.relu_bits and self.dual_dy and op["x"] in self.relu_out and g.Co % 32 == 0
                     if pl is not None:
                         res = self._timed("fwd " + op["p"], "winograd_3x3", ops.wino_flops(g),
-                                          lambda: ops.conv2d_fwd_wino_pool(xin, uf, bias, g, pl["ceil"], want_argmax=save, keep_planes=keep))
+                                          lambda: ops.conv2d_fwd_wino_pool(xin, uf, bias, g, pl["ceil"], want_argmax=save, keep_planes=keep,
+                                                                           want_bits=wb))
                         T[op["y"]] = _Elided((bs, g.H, g.W, op["co"]))      # never materialised: its only reader is the pool
                         T[pl["y"]], aux[pl["y"]], aux[op["y"]] = res[0], res[1], g
                         if keep:
                             aux["planes:" + op["p"]] = res[2]
+                        if wb:
+                            aux["bits:" + op["p"]] = res[3]
                         continue
                     res = self._timed("fwd " + op["p"], "winograd_3x3", ops.wino_flops(g),
-                                      lambda: ops.conv2d_fwd_wino(xin, uf, bias, g, op["relu"], keep_planes=keep))
+                                      lambda: ops.conv2d_fwd_wino(xin, uf, bias, g, op["relu"], keep_planes=keep, want_bits=wb))
                     T[op["y"]] = res[0] if keep else res
                     if keep:
                         aux["planes:" + op["p"]] = res[1]
+                    if wb:
+                        aux["bits:" + op["p"]] = res[2]
                     aux[op["y"]] = g
                     continue
                 wf, _ = self._layouts(op["p"], (P[op["p"] + ".weight"],), op["co"], False)
@@ -331,6 +363,13 @@ class _Engine:
                                      lambda: ops.conv2d_fwd_x3(xin, wf, bias, g, False, ld=ops.pad32(co)) if self.x3 else
                                      ops.conv2d_fwd(xin, wf, bias, g, False, ld=ops.pad32(co), bf16=self.bf16, w3=self._planes(pre, False)))
                 heads.append((op, packed, g))
+        if side_ctx is not None:
+            side_ctx.__exit__(None, None, None)
+            for op, packed, _ in heads:
+                if id(op) in self._side_ids:
+                    packed.record_stream(main)
+            main.wait_event(side.record_event())
+        heads.sort(key=lambda h: h[0]["scale"])                   # prior order: c_4, c_7, c_8, ... (Model.py:235)
         P_total = sum(g.Ho * g.Wo * op["a"] for op, _, g in heads)
         loc = torch.empty((bs, P_total, 4), device=x.device, dtype=torch.float32)
         conf = torch.empty((bs, P_total, N_CLASSES), device=x.device, dtype=torch.float32)
@@ -360,8 +399,27 @@ class _Engine:
             G[name] = fn(G.get(name), k > 0, mask)
             arrived[name] = k + 1
 
+        main = torch.cuda.current_stream(dloc.device)
+        overlap = self.overlap_tail and bool(self._side_ids) and self._side_stream is not None
+        side, side_ctx, joined = self._side_stream, None, not overlap
+        if overlap:                                               # the reversed list starts with the side group
+            side.wait_event(main.record_event())
+            dloc.record_stream(side)
+            dconf.record_stream(side)
+            side_ctx = torch.cuda.stream(side)
+            side_ctx.__enter__()
+        join_event = None
         for op in reversed(self.ops):
             kind = op["op"]
+            if side_ctx is not None and id(op) not in self._side_ids:      # the side group is enqueued: back to the caller's stream
+                side_ctx.__exit__(None, None, None)
+                side_ctx = None
+                join_event = side.record_event()
+                for t in list(G.values()) + list(grads.values()):
+                    t.record_stream(main)
+            if not joined and side_ctx is None and kind in ("conv", "pool", "conv_first"):      # first op that needs what the side group produced (a8's gradient)
+                main.wait_event(join_event)
+                joined = True
             if kind == "head":
                 pre = op["p"]
                 off, g = offs[pre]
@@ -414,8 +472,10 @@ class _Engine:
                     grads[op["p"] + ".weight"], grads[op["p"] + ".bias"] = dw, db
                 if self._wino_ok(g):
                     _, ub = self._wino_weights(op["p"], (P[op["p"] + ".weight"],), op["co"])
-                    deliver(op["x"], lambda dx, acc, mask: self._timed("dgrad " + op["p"], "winograd_3x3", ops.wino_flops(g),
-                                                                       lambda: ops.conv2d_dgrad_wino(dy, ub, g, dx, mask, acc, planes=dyp)))
+                    bits = aux.pop("bits:" + op["p"], None) if dyp is not None else None
+                    deliver(op["x"], lambda dx, acc, mask: self._timed(
+                        "dgrad " + op["p"], "winograd_3x3", ops.wino_flops(g),
+                        lambda: ops.conv2d_dgrad_wino(dy, ub, g, dx, mask, acc, planes=dyp, bits=bits if mask is not None else None)))
                     continue
                 _, wb = self._layouts(op["p"], (P[op["p"] + ".weight"],), op["co"], True)
                 deliver(op["x"], lambda dx, acc, mask: self._timed(
@@ -452,6 +512,8 @@ class _Engine:
                     dw, db = self._timed("wgrad " + op["p"], ops.wgrad_tile(g) if self.prof is not None else "", 2.0 * dy.numel() * 27,
                                          lambda: ops.conv2d_wgrad(col, dy, g, g.Co, True))
                     grads[op["p"] + ".weight"], grads[op["p"] + ".bias"] = ops.first_weight_grad(dw), db
+        if not joined:
+            main.wait_event(join_event)
         return grads
 
 

@@ -80,6 +80,9 @@ SIGNATURES = {
     "ssd_conv3x3_wino_fwd": (_I, [_P, _P, _P, _P, _I, _G, _I, _I, _P, _Z, _P]),
     "ssd_conv3x3_wino_fwd_pool": (_I, [_P, _P, _P, _P, _P, _G, _I, _P, _P, _Z, _P]),
     "ssd_conv3x3_wino_fwd_keep": (_I, [_P, _P, _P, _P, _I, _G, _I, _P, _P, _Z, _P]),
+    "ssd_conv3x3_wino_fwd_keep_bits": (_I, [_P, _P, _P, _P, _I, _G, _I, _P, _P, _P, _Z, _P]),
+    "ssd_conv3x3_wino_fwd_pool_bits": (_I, [_P, _P, _P, _P, _P, _G, _I, _P, _P, _P, _Z, _P]),
+    "ssd_conv3x3_wino_dgrad_planes_bits": (_I, [_P, _P, _I, _P, _P, _I, _G, _P, _Z, _P]),
     "ssd_conv3x3_wino_wgrad_planes": (_I, [_P, _P, _I, _P, _P, _G, _P, _P, _Z, _P]),
     "ssd_conv3x3_wino_dgrad_planes": (_I, [_P, _P, _I, _P, _P, _I, _G, _P, _Z, _P]),
     "ssd_conv3x3_wino_dgrad": (_I, [_P, _I, _P, _I, _P, _P, _I, _G, _I, _P, _Z, _P]),
@@ -91,6 +94,7 @@ SIGNATURES = {
     "ssd_tune_set_wino_fused_stagger": (_I, [_I]),
     "ssd_prof_gemm_begin": (_I, []),
     "ssd_prof_gemm_collect": (_I, [_P, _P, _I]),
+    "ssd_prof_gemm_collect_kinds": (_I, [_P, _P, _P, _I]),
     "ssd_tune_set_igemm": (_I, [_I, _I]),
     "ssd_tune_set_igemm_lds_pad": (_I, [_I]),
     "ssd_tune_set_igemm_stamps": (_I, [_P]),

@@ -1219,6 +1219,20 @@ static std::atomic<bool> g_prof_on{false};        // forward (caller thread) and
 static std::atomic<int> g_prof_n{0};              // slots of the recorder are claimed atomically
 static hipEvent_t g_prof_ev[2 * PROF_MAX] = {};
 static double g_prof_flops[PROF_MAX];
+static int g_prof_kind[PROF_MAX];                 // 0: batched igemm (Winograd plane GEMMs), 1: fused GEMM + output transform kernel
+
+// Internal: bracket one launch of another file's kernel with the recorder's events (kind as above).  begin returns the slot or -1.
+__attribute__((visibility("hidden"))) int ssd_internal_prof_open(double flops, int kind, hipStream_t st) {
+    const int i = g_prof_on.load(std::memory_order_acquire) ? g_prof_n.fetch_add(1, std::memory_order_relaxed) : PROF_MAX;
+    if (i >= PROF_MAX) return -1;
+    g_prof_flops[i] = flops;
+    g_prof_kind[i] = kind;
+    (void)hipEventRecord(g_prof_ev[2 * i], st);
+    return i;
+}
+__attribute__((visibility("hidden"))) void ssd_internal_prof_close(int slot, hipStream_t st) {
+    if (slot >= 0) (void)hipEventRecord(g_prof_ev[2 * slot + 1], st);
+}
 
 // Internal (not part of the C ABI): `nbatch` independent GEMMs out[b][M][N] = a[b][M][K] * w[b][N][K]^T on the 64x64 f32 kernel
 // (the sixteen planes of a Winograd F(2x2,3x3) convolution).  K % 32 == 0; rows of w beyond n_rows read as zero.
@@ -1247,6 +1261,7 @@ __attribute__((visibility("hidden"))) int ssd_internal_gemm_batched(const float*
     const int i = g_prof_on.load(std::memory_order_acquire) ? g_prof_n.fetch_add(1, std::memory_order_relaxed) : PROF_MAX;
     if (i < PROF_MAX) {                                  // measurement aid: this launch alone between two events of the library
         g_prof_flops[i] = 2.0 * M * K * N * nbatch;
+        g_prof_kind[i] = 0;
         (void)hipEventRecord(g_prof_ev[2 * i], st);
         const int e = launch_igemm<64, 64, 2, 2, 1, true>(p, st);
         (void)hipEventRecord(g_prof_ev[2 * i + 1], st);
@@ -1265,7 +1280,8 @@ extern "C" int ssd_prof_gemm_begin(void) {
     g_prof_on.store(true, std::memory_order_release);
     return SSD_OK;
 }
-extern "C" int ssd_prof_gemm_collect(float* ms_out, double* flops_out, int max) {
+extern "C" int ssd_prof_gemm_collect(float* ms_out, double* flops_out, int max) { return ssd_prof_gemm_collect_kinds(ms_out, flops_out, nullptr, max); }
+extern "C" int ssd_prof_gemm_collect_kinds(float* ms_out, double* flops_out, int* kinds_out, int max) {
     g_prof_on.store(false);
     if (!ms_out || !flops_out) return SSD_ERR_NULL;
     int n = 0;
@@ -1273,6 +1289,7 @@ extern "C" int ssd_prof_gemm_collect(float* ms_out, double* flops_out, int max) 
     for (; n < recorded && n < max; ++n) {
         if (hipEventElapsedTime(&ms_out[n], g_prof_ev[2 * n], g_prof_ev[2 * n + 1]) != hipSuccess) return -n - 100;
         flops_out[n] = g_prof_flops[n];
+        if (kinds_out) kinds_out[n] = g_prof_kind[n];
     }
     g_prof_n.store(0);
     return n;

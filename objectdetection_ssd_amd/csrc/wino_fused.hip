@@ -29,7 +29,7 @@ struct FusedParams {
     int tiles, K, Nrows, Nout; // Nout: channels produced (multiple of 4)
     int groups, nblk_n;        // ceil(tiles / 32), ceil(Nout / 64)
     float* out; int ldo; int Cvalid;
-    const float* bias; const float* mask; int relu, accumulate;
+    const float* bias; const float* mask; const unsigned long long* mask_bits; int relu, accumulate;
     int H, W, TH, TW;
     float* yp; uint8_t* am; int Ho, Wo;      // pooled form (yp != nullptr): conv -> ReLU -> 2x2 / stride-2 max pool
     unsigned long long* stamps;              // diagnostic (ssd_tune_set_wino_fused_stamps): 8 shader-clock stamps per 16th block
@@ -57,6 +57,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // planes (144 accumulator registers).  Each wave has ONE dependent accumulator chain per plane (40-cycle latency against a 32-cycle
 // issue slot); the partner wave on the same SIMD takes the other slot, and fills the matrix pipe while this one issues its LDS-DMA
 // pieces and fragment reads.
+template <int KCN>      // K / 64: the stage loop (36 planes x KCN chunks) is fully unrolled, every wait count and ring slot a constant
 __global__ __launch_bounds__(512, 2) void wino4_gemm_out_kernel(const FusedParams p) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_F];                 // the only LDS object of the kernel
     const int tid = threadIdx.x, lane = tid & 63;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_out_kernel(const FusedParam
     const int lid = xcd_swizzle(blockIdx.x, nblk);
     const int grp = lid / p.nblk_n, nb = lid - grp * p.nblk_n;              // channel blocks of one tile group are neighbours in one L2
     const int tile0 = grp * FG, n0 = nb * FN;
-    const int KCN = p.K / FK, S = 36 * KCN;
+    constexpr int S = 36 * KCN;
     const bool stamp = p.stamps != nullptr && (blockIdx.x & 15) == 0 && tid == 0;
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (stamp) ts[0] = __builtin_readcyclecounter();
@@ -92,24 +93,14 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_out_kernel(const FusedParam
         src_off[i] = (unsigned)src_row * (unsigned)p.K + (unsigned)((pc ^ (row & 15)) * 4);
         lds_off[i] = q * 256;                                               // A pieces then B pieces, contiguous: A = rows 0..31, B = 32..95
     }
-    const float* vsrc = p.V;                 // plane / K-chunk of the NEXT stage to issue
-    const float* usrc = p.U;
-    int kc_i = 0, slot_i = 0, issued = 0;
-    auto issue = [&]() {
-        float* base = lds + slot_i * STAGE_F;
+    auto issue = [&](int stage) {             // `stage` is a compile-time constant at every call
+        const int xi = stage / KCN, kc = stage % KCN, slot = stage % NS;
+        const float* vsrc = p.V + (size_t)xi * p.plane_v + kc * FK;
+        const float* usrc = p.U + (size_t)xi * p.plane_u + kc * FK;
+        float* base = lds + slot * STAGE_F;
 #pragma unroll
         for (int i = 0; i < LOADS; ++i)
             __builtin_amdgcn_global_load_lds((is_a[i] ? vsrc : usrc) + src_off[i], (lds_void*)(base + lds_off[i]), 16, 0, 0);
-        ++issued;
-        slot_i = slot_i + 1 == NS ? 0 : slot_i + 1;
-        if (++kc_i == KCN) {
-            kc_i = 0;
-            vsrc += p.plane_v - (size_t)(KCN - 1) * FK;
-            usrc += p.plane_u - (size_t)(KCN - 1) * FK;
-        } else {
-            vsrc += FK;
-            usrc += FK;
-        }
     };
 
     f32x4 acc[36];
@@ -122,8 +113,7 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_out_kernel(const FusedParam
 #pragma unroll
     for (int j = 0; j < 4; ++j) sw[j] = ((4 * j + kq) ^ r15) * 4;
 
-    // The 8 fragment reads of stage s+1 are issued BEFORE the 16 MFMAs of stage s (two register sets, their roles fixed at compile
-    // time: K == 64 alternates with the plane, longer K with the chunk).
+    // The 8 fragment reads of stage s+1 are issued during the MFMAs of stage s (two register sets, roles fixed by the stage's parity).
     struct Frag { f32x4 a[4], b[4]; };
     Frag F[2];
     auto load_frags = [&](Frag& f, int slot) {
@@ -134,60 +124,55 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_out_kernel(const FusedParam
             f.b[j] = *reinterpret_cast<const f32x4*>(st + b_rd + sw[j]);
         }
     };
-    int slot_c = 0, done = 0;                 // slot / index of the stage being multiplied
-    auto wait_landed = [&](int stage) {       // this wave's LDS-DMA of `stage` is complete once at most (issued - stage - 1) stages' are outstanding
-        const int ahead = issued - stage - 1;
-        if (ahead >= 4) wait_vmcnt<4 * LOADS>();
-        else if (ahead == 3) wait_vmcnt<3 * LOADS>();
-        else if (ahead == 2) wait_vmcnt<2 * LOADS>();
-        else if (ahead == 1) wait_vmcnt<LOADS>();
-        else wait_vmcnt<0>();
-    };
-    auto step = [&](f32x4& c, const Frag& cur, Frag& nxt) {
-#ifndef WF_NO_LOAD
-        if (issued < S) issue();
-#else
-        if (issued < S) ++issued;
-#endif
-        const int slot_n = slot_c + 1 == NS ? 0 : slot_c + 1;
-        if (done + 1 < S) {
-            wait_landed(done + 1);
-            __builtin_amdgcn_s_barrier();                                     // every wave's part of stage done+1 has landed; stage done-1 is fully read
-            asm volatile("" ::: "memory");
-            load_frags(nxt, slot_n);
-        }
+    auto mma4 = [&](f32x4& c, const Frag& f, int j) {
 #ifdef WF_NO_MFMA
-#pragma unroll
-        for (int j = 0; j < 4; ++j) c += cur.a[j] * cur.b[j];
+        c += f.a[j] * f.b[j];
 #else
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[j][e], cur.b[j][e], c, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[j][e], f.b[j][e], c, 0, 0, 0);
 #endif
-        slot_c = slot_n;
-        ++done;
     };
 
 #pragma unroll
     for (int s = 0; s < PD; ++s)
-        if (s < S) issue();
-    wait_landed(0);
+        if (s < S) issue(s);
+    wait_vmcnt<(PD < S ? PD - 1 : S - 1) * LOADS>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     load_frags(F[0], 0);
     if (stamp) ts[1] = __builtin_readcyclecounter();
 
-    if (KCN == 1) {
-#pragma unroll
-        for (int xi = 0; xi < 36; ++xi) step(acc[xi], F[xi & 1], F[(xi & 1) ^ 1]);
-    } else {                                                                   // KCN even (host checks)
-#pragma unroll
-        for (int xi = 0; xi < 36; ++xi)
-            for (int kc = 0; kc < KCN; kc += 2) {
-                step(acc[xi], F[0], F[1]);
-                step(acc[xi], F[1], F[0]);
-            }
+    // Stage s: 16 MFMAs of one dependent chain (the partner wave of the SIMD owns the other issue slots).  The stage's three LDS-DMA
+    // instructions, the wait + barrier that publish stage s+1 and the eight fragment reads of stage s+1 are spread between the four
+    // groups of MFMAs, so that an issue stall of this wave costs matrix-pipe time only while the partner is stalled too.
+#pragma clang loop unroll(full)
+    for (int s = 0; s < S; ++s) {
+        f32x4& c = acc[s / KCN];
+        const Frag& cur = F[s & 1];
+        Frag& nxt = F[(s & 1) ^ 1];
+        mma4(c, cur, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef WF_NO_LOAD
+        if (s + PD < S) issue(s + PD);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        mma4(c, cur, 1);
+        mma4(c, cur, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < S) {
+            // stage s+1 of THIS wave has landed once at most (issued - (s+1) - 1) stages' pieces are outstanding
+            const int issued = (s + PD + 1 < S ? s + PD + 1 : S);
+            const int ahead = issued - s - 2;
+            if (ahead >= 3) wait_vmcnt<3 * LOADS>();
+            else if (ahead == 2) wait_vmcnt<2 * LOADS>();
+            else if (ahead == 1) wait_vmcnt<LOADS>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();                                     // every wave's pieces of stage s+1 have landed; stage s-1 is fully read
+            asm volatile("" ::: "memory");
+            load_frags(nxt, (s + 1) % NS);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma4(c, cur, 3);
     }
 
     if (stamp) ts[2] = __builtin_readcyclecounter();
@@ -234,6 +219,7 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_out_kernel(const FusedParam
                 for (int e = 0; e < 4; ++e) bv[e] = c4 * 4 + e < p.Cvalid ? p.bias[c4 * 4 + e] : 0.f;
             }
             if (p.yp == nullptr) {
+                const unsigned long long word = p.mask_bits != nullptr ? p.mask_bits[(size_t)tile * C4 + c4] : 0ull;
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     const int oh = 4 * th + a;
@@ -249,7 +235,10 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_out_kernel(const FusedParam
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
                         }
-                        if (p.mask != nullptr) {
+                        if (p.mask_bits != nullptr) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = ((word >> ((a * 4 + b) * 4 + e)) & 1ull) ? v[e] : 0.f;
+                        } else if (p.mask != nullptr) {
                             const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + idx);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
@@ -307,6 +296,10 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_out_kernel(const FusedParam
     }
 }
 
+}  // namespace
+int ssd_internal_prof_open(double flops, int kind, hipStream_t st);
+void ssd_internal_prof_close(int slot, hipStream_t st);
+namespace {
 unsigned long long* g_fused_stamps = nullptr;
 int g_fused_stagger = -1;         // -1: automatic; 0: none
 }  // namespace
@@ -326,23 +319,30 @@ extern "C" int ssd_tune_set_wino_fused_stamps(uint64_t* device_buffer) {
 // planes V [36][tiles][K] and filters U [36][Nrows][K].  Returns SSD_ERR_BAD_SHAPE when the geometry is not the kernel's (K % 64).
 __attribute__((visibility("hidden"))) int ssd_internal_wino4_gemm_out(const float* V, const float* U, int tiles, int K, int Nrows, int Nout,
                                                                        float* out, int ldo, int Cvalid, const float* bias, const float* mask,
-                                                                       int relu, int accumulate, int H, int W, int TH, int TW, float* yp,
-                                                                       uint8_t* am, int Ho, int Wo, hipStream_t st) {
-    if (K <= 0 || K % FK != 0 || (K / FK > 1 && (K / FK) % 2 != 0) || tiles <= 0 || Nout <= 0 || Nout % 4 != 0 || Nrows <= 0) return SSD_ERR_BAD_SHAPE;
+                                                                       const unsigned long long* mask_bits, int relu, int accumulate, int H, int W,
+                                                                       int TH, int TW, float* yp, uint8_t* am, int Ho, int Wo, hipStream_t st) {
+    if ((K != 64 && K != 128 && K != 256) || tiles <= 0 || Nout <= 0 || Nout % 4 != 0 || Nrows <= 0) return SSD_ERR_BAD_SHAPE;
     if ((size_t)tiles * K >= (1ull << 32) || (size_t)Nrows * K >= (1ull << 32)) return SSD_ERR_BAD_SHAPE;
     FusedParams p;
     p.V = V; p.U = U;
     p.plane_v = (size_t)tiles * K; p.plane_u = (size_t)Nrows * K;
     p.tiles = tiles; p.K = K; p.Nrows = Nrows; p.Nout = Nout;
     p.groups = ssd_cdiv(tiles, FG); p.nblk_n = ssd_cdiv(Nout, FN);
-    p.out = out; p.ldo = ldo; p.Cvalid = Cvalid; p.bias = bias; p.mask = mask; p.relu = relu; p.accumulate = accumulate;
+    p.out = out; p.ldo = ldo; p.Cvalid = Cvalid; p.bias = bias; p.mask = mask; p.mask_bits = mask_bits; p.relu = relu; p.accumulate = accumulate;
     p.H = H; p.W = W; p.TH = TH; p.TW = TW;
     p.yp = yp; p.am = am; p.Ho = Ho; p.Wo = Wo;
     p.stamps = g_fused_stamps;
     p.stagger = g_fused_stagger < 0 ? (K / FK) * 36 * 160 : g_fused_stagger;      // eight phases over about one workgroup's life
     const long long nblk = (long long)p.groups * p.nblk_n;
     if (nblk >= (1ll << 31)) return SSD_ERR_BAD_SHAPE;
-    hipLaunchKernelGGL(wino4_gemm_out_kernel, dim3((unsigned)nblk), dim3(512), 0, st, p);
+    const int slot = ssd_internal_prof_open(2.0 * 36 * tiles * (double)K * (double)(p.nblk_n * FN), 1, st);   // FLOPs the grid executes
+    switch (K / FK) {
+        case 1: hipLaunchKernelGGL(wino4_gemm_out_kernel<1>, dim3((unsigned)nblk), dim3(512), 0, st, p); break;
+        case 2: hipLaunchKernelGGL(wino4_gemm_out_kernel<2>, dim3((unsigned)nblk), dim3(512), 0, st, p); break;
+        case 4: hipLaunchKernelGGL(wino4_gemm_out_kernel<4>, dim3((unsigned)nblk), dim3(512), 0, st, p); break;
+        default: return SSD_ERR_BAD_SHAPE;
+    }
+    ssd_internal_prof_close(slot, st);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
 }

@@ -12,8 +12,8 @@
 int ssd_internal_gemm_batched(const float* a, const float* w, float* out, int M, int K, int N, int n_rows, int nbatch,
                               size_t batch_a_elems, size_t batch_w_elems, int ksplit, hipStream_t st);
 int ssd_internal_wino4_gemm_out(const float* V, const float* U, int tiles, int K, int Nrows, int Nout, float* out, int ldo, int Cvalid,
-                                const float* bias, const float* mask, int relu, int accumulate, int H, int W, int TH, int TW, float* yp,
-                                uint8_t* am, int Ho, int Wo, hipStream_t st);
+                                const float* bias, const float* mask, const unsigned long long* mask_bits, int relu, int accumulate, int H,
+                                int W, int TH, int TW, float* yp, uint8_t* am, int Ho, int Wo, hipStream_t st);
 
 namespace {
 
@@ -358,8 +358,10 @@ __global__ void wino4_weight_kernel(const float* __restrict__ w, float* __restri
     }
 }
 
+// bits (optional): per (tile, channel quad) one 64-bit word, bit (a*4+b)*4+e = x[4th+a][4tw+b][4c4+e] > 0 -- the ReLU mask of this
+// layer's input on the tile grid its data gradient is written on: the dgrad epilogue then reads 1 bit instead of 32 per element.
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int H, int W, int C,
-                                                          int TH, int TW) {
+                                                          int TH, int TW, unsigned long long* __restrict__ bits) {
     const int C4 = C >> 2;
     const size_t tiles = (size_t)N * TH * TW, total = tiles * C4;
     const size_t plane = tiles * C;
@@ -368,6 +370,7 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
         const size_t tile = i / C4;
         const int tw = (int)(tile % TW), th = (int)((tile / TW) % TH), n = (int)(tile / ((size_t)TW * TH));
         f32x4 t[6][6];                                       // B^T d, one input row at a time
+        unsigned long long word = 0ull;
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
             f32x4 d[6];
@@ -377,6 +380,10 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
                 const int ih = 4 * th - 1 + a;
                 const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
                 d[a] = ok ? *reinterpret_cast<const f32x4*>(x + (((size_t)n * H + ih) * W + iw) * C + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (a >= 1 && a <= 4 && b >= 1 && b <= 4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) word |= (unsigned long long)(d[a][e] > 0.f) << (((a - 1) * 4 + (b - 1)) * 4 + e);
+                }
             }
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
@@ -398,12 +405,14 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
                     if (W4_BT[b][k] != 0.f) acc += W4_BT[b][k] * t[a][k];
                 *reinterpret_cast<f32x4*>(dst + (size_t)(a * 6 + b) * plane) = acc;
             }
+        if (bits != nullptr) bits[i] = word;
     }
 }
 
 __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ Mx, float* __restrict__ out, int N, int H, int W, int C,
                                                            int Cvalid, int ldo, int TH, int TW, const float* __restrict__ bias,
-                                                           const float* __restrict__ mask, int relu, int accumulate) {
+                                                           const float* __restrict__ mask, int relu, int accumulate,
+                                                           const unsigned long long* __restrict__ mask_bits) {
     const int C4 = C >> 2;
     const size_t tiles = (size_t)N * TH * TW, total = tiles * C4;
     const size_t plane = tiles * C;
@@ -427,6 +436,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
                 t[a][b] = acc;
             }
         }
+        const unsigned long long word = mask_bits != nullptr ? mask_bits[i] : 0ull;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if (bias != nullptr) {
 #pragma unroll
@@ -450,7 +460,10 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
                 }
-                if (mask != nullptr) {
+                if (mask_bits != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ((word >> ((a * 4 + b) * 4 + e)) & 1ull) ? v[e] : 0.f;
+                } else if (mask != nullptr) {
                     const f32x4 mk = *reinterpret_cast<const f32x4*>(mask + idx);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
@@ -843,9 +856,9 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 // GEMMs + output transform in one kernel (wino_fused.hip)?  It removes the write and the read-back of the M planes; what it costs is
 // MFMA efficiency on long reductions (one workgroup per CU, 16x16x4 MFMAs).
 inline bool use_fused(int mo, int K, int Nout) {
-    if (mo != 4 || K % 64 != 0 || (K > 64 && K % 128 != 0) || g_fused == 0) return false;
+    if (mo != 4 || (K != 64 && K != 128 && K != 256) || g_fused == 0) return false;
     if (g_fused == 1) return true;
-    return K == 64;                    // measured at batch 32 (tools/wino_bench.py): conv1_2 forward 1.52 -> 1.14 ms, dgrad 1.26 -> 0.94, conv2_1 forward 0.67 -> 0.50
+    return K <= 128;                   // measured at batch 32 (tools/wino_bench.py): conv1_2 forward 1.52 -> 1.14 ms, dgrad 1.26 -> 0.94, conv2_1 forward 0.67 -> 0.50
 }
 inline int grid_for(size_t total) { const size_t b = (total + 255) / 256; return (int)(b > 8192 ? 8192 : (b == 0 ? 1 : b)); }
 
@@ -853,7 +866,8 @@ inline int grid_for(size_t total) { const size_t b = (total + 255) / 256; return
 struct PooledOut { float* y; uint8_t* argmax; int Ho, Wo; };     // destination of the fused conv -> ReLU -> 2x2/s2 max pool form
 int wino_conv(int mo, const float* in, int Cin, const float* U, int U_rows, float* out, int ldo, int Cout, const float* bias,
               const float* mask, int relu, int accumulate, int N, int H, int W, void* ws, size_t ws_bytes, hipStream_t st,
-              const PooledOut* pooled = nullptr, float* V_keep = nullptr, const float* V_given = nullptr) {
+              const PooledOut* pooled = nullptr, float* V_keep = nullptr, const float* V_given = nullptr,
+              unsigned long long* bits_out = nullptr, const unsigned long long* mask_bits = nullptr) {
     const int TH = (H + mo - 1) / mo, TW = (W + mo - 1) / mo, P = (mo + 2) * (mo + 2);
     const size_t tiles = (size_t)N * TH * TW;
     const int Cvalid = Cout;
@@ -865,10 +879,11 @@ int wino_conv(int mo, const float* in, int Cin, const float* U, int U_rows, floa
     float* Mx = reinterpret_cast<float*>(static_cast<char*>(ws) + vb);
     if (V_given != nullptr) V = const_cast<float*>(V_given);                // input planes already formed (by the dy pass of the wgrad)
     else if (mo == 2) hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(tiles * (Cin / 4))), dim3(256), 0, st, in, V, N, H, W, Cin, TH, TW);
-    else hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(tiles * (Cin / 4))), dim3(256), 0, st, in, V, N, H, W, Cin, TH, TW);
+    else hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(tiles * (Cin / 4))), dim3(256), 0, st, in, V, N, H, W, Cin, TH, TW, bits_out);
     SSD_CHECK_LAUNCH();
+    if (mask_bits != nullptr && mo != 4) return SSD_ERR_BAD_SHAPE;
     if (use_fused(mo, Cin, Cout))
-        return ssd_internal_wino4_gemm_out(V, U, (int)tiles, Cin, U_rows, Cout, out, ldo, Cvalid, bias, mask, relu, accumulate, H, W, TH, TW,
+        return ssd_internal_wino4_gemm_out(V, U, (int)tiles, Cin, U_rows, Cout, out, ldo, Cvalid, bias, mask, mask_bits, relu, accumulate, H, W, TH, TW,
                                            pooled ? pooled->y : nullptr, pooled ? pooled->argmax : nullptr, pooled ? pooled->Ho : 0,
                                            pooled ? pooled->Wo : 0, st);
     if (int e = ssd_internal_gemm_batched(V, U, Mx, (int)tiles, Cin, Cout, U_rows, P, tiles * Cin, (size_t)U_rows * Cin, 1, st)) return e;
@@ -880,7 +895,7 @@ int wino_conv(int mo, const float* in, int Cin, const float* U, int U_rows, floa
                            bias, mask, relu, accumulate);
     else
         hipLaunchKernelGGL(wino4_output_kernel, dim3(grid_for(tiles * (Cout / 4))), dim3(256), 0, st, Mx, out, N, H, W, Cout, Cvalid, ldo, TH,
-                           TW, bias, mask, relu, accumulate);
+                           TW, bias, mask, relu, accumulate, mask_bits);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
 }
@@ -929,18 +944,32 @@ extern "C" int ssd_conv3x3_wino_fwd(const float* x, const float* U_fwd, const fl
 
 extern "C" int ssd_conv3x3_wino_fwd_keep(const float* x, const float* U_fwd, const float* bias, float* y, int ldy, const ssd_conv_geom* g,
                                          int relu, float* planes_keep, void* workspace, size_t workspace_bytes, void* stream) {
+    return ssd_conv3x3_wino_fwd_keep_bits(x, U_fwd, bias, y, ldy, g, relu, planes_keep, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ssd_conv3x3_wino_fwd_keep_bits(const float* x, const float* U_fwd, const float* bias, float* y, int ldy, const ssd_conv_geom* g,
+                                              int relu, float* planes_keep, uint64_t* relu_bits_out, void* workspace, size_t workspace_bytes,
+                                              void* stream) {
     if (!x || !U_fwd || !y || !workspace || !planes_keep) return SSD_ERR_NULL;
+    if (relu_bits_out && ((uintptr_t)relu_bits_out & 7)) return SSD_ERR_ALIGN;
     if (!wino_geom_ok(g) || g->Ci % 32 != 0 || ldy < (g->Co + 3) / 4 * 4) return SSD_ERR_BAD_SHAPE;
     if (!ssd_aligned16(x) || !ssd_aligned16(y) || !ssd_aligned16(workspace) || !ssd_aligned16(U_fwd) || !ssd_aligned16(planes_keep) || ldy % 4 != 0)
         return SSD_ERR_ALIGN;
     return wino_conv(4, x, g->Ci, U_fwd, g->Co, y, ldy, g->Co, bias, nullptr, relu, 0, g->N, g->H, g->W, workspace, workspace_bytes,
-                     (hipStream_t)stream, nullptr, planes_keep);
+                     (hipStream_t)stream, nullptr, planes_keep, nullptr, reinterpret_cast<unsigned long long*>(relu_bits_out));
 }
 
 extern "C" int ssd_conv3x3_wino_fwd_pool(const float* x, const float* U_fwd, const float* bias, float* y_pooled, uint8_t* argmax,
                                          const ssd_conv_geom* g, int ceil_mode, float* planes_keep, void* workspace, size_t workspace_bytes,
                                          void* stream) {
+    return ssd_conv3x3_wino_fwd_pool_bits(x, U_fwd, bias, y_pooled, argmax, g, ceil_mode, planes_keep, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ssd_conv3x3_wino_fwd_pool_bits(const float* x, const float* U_fwd, const float* bias, float* y_pooled, uint8_t* argmax,
+                                              const ssd_conv_geom* g, int ceil_mode, float* planes_keep, uint64_t* relu_bits_out,
+                                              void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !U_fwd || !y_pooled || !workspace) return SSD_ERR_NULL;
+    if (relu_bits_out && ((uintptr_t)relu_bits_out & 7)) return SSD_ERR_ALIGN;
     if (!wino_geom_ok(g) || g->Ci % 32 != 0 || g->Co % 4 != 0) return SSD_ERR_BAD_SHAPE;
     if (!ssd_aligned16(x) || !ssd_aligned16(y_pooled) || !ssd_aligned16(workspace) || !ssd_aligned16(U_fwd) || (bias && !ssd_aligned16(bias)) ||
         (argmax && ((uintptr_t)argmax & 3)) || (planes_keep && !ssd_aligned16(planes_keep)))
@@ -948,7 +977,7 @@ extern "C" int ssd_conv3x3_wino_fwd_pool(const float* x, const float* U_fwd, con
     const PooledOut po = {y_pooled, argmax, ceil_mode ? (g->H + 1) / 2 : g->H / 2, ceil_mode ? (g->W + 1) / 2 : g->W / 2};
     if (po.Ho <= 0 || po.Wo <= 0) return SSD_ERR_BAD_SHAPE;
     return wino_conv(4, x, g->Ci, U_fwd, g->Co, nullptr, g->Co, g->Co, bias, nullptr, 1, 0, g->N, g->H, g->W, workspace, workspace_bytes,
-                     (hipStream_t)stream, &po, planes_keep);
+                     (hipStream_t)stream, &po, planes_keep, nullptr, reinterpret_cast<unsigned long long*>(relu_bits_out));
 }
 
 extern "C" int ssd_conv3x3_wino_dgrad(const float* dy, int ldy, const float* U_bwd, int Co_pad, float* dx, const float* relu_mask,
@@ -1026,6 +1055,17 @@ extern "C" int ssd_conv3x3_wino_wgrad_planes(const float* planes, const float* d
     if (!ssd_aligned16(planes) || (dgrad_planes_out && !ssd_aligned16(dgrad_planes_out))) return SSD_ERR_ALIGN;
     return wino_wgrad(nullptr, planes, dy, ldy, dw_oihw, dbias, g, 4, dgrad_planes_out, workspace, workspace_bytes, stream);
 }
+extern "C" int ssd_conv3x3_wino_dgrad_planes_bits(const float* dy_planes, const float* U_bwd, int Co_pad, float* dx, const uint64_t* relu_bits,
+                                                  int accumulate, const ssd_conv_geom* g, void* workspace, size_t workspace_bytes,
+                                                  void* stream) {
+    if (!dy_planes || !U_bwd || !dx || !workspace || !relu_bits) return SSD_ERR_NULL;
+    if (!wino_geom_ok(g) || Co_pad % 32 != 0 || Co_pad < g->Co || g->Ci % 4 != 0) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(dy_planes) || !ssd_aligned16(dx) || !ssd_aligned16(workspace) || !ssd_aligned16(U_bwd) || ((uintptr_t)relu_bits & 7))
+        return SSD_ERR_ALIGN;
+    return wino_conv(4, nullptr, Co_pad, U_bwd, g->Ci, dx, g->Ci, g->Ci, nullptr, nullptr, 0, accumulate, g->N, g->H, g->W, workspace,
+                     workspace_bytes, (hipStream_t)stream, nullptr, nullptr, dy_planes, nullptr,
+                     reinterpret_cast<const unsigned long long*>(relu_bits));
+}
 extern "C" int ssd_conv3x3_wino_dgrad_planes(const float* dy_planes, const float* U_bwd, int Co_pad, float* dx, const float* relu_mask,
                                              int accumulate, const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream) {
     if (!dy_planes || !U_bwd || !dx || !workspace) return SSD_ERR_NULL;
@@ -1075,7 +1115,7 @@ int wino_wgrad(const float* x, const float* planes, const float* dy, int ldy, fl
                                static_cast<float*>(nullptr), 0, dgrad_planes);
         if (planes == nullptr)
             hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(w.tiles * (g->Ci / 4))), dim3(256), 0, st, x, Vt, g->N, g->H, g->W, g->Ci, w.TH,
-                               w.TW);
+                               w.TW, static_cast<unsigned long long*>(nullptr));
         SSD_CHECK_LAUNCH();
         TnParams q;
         q.a = Yt; q.b = planes != nullptr ? planes : Vt; q.out = Zs;

@@ -633,9 +633,17 @@ def wino_planes(g: ConvGeom, device) -> torch.Tensor:
     return torch.empty((36, tiles, g.Ci), device=device, dtype=torch.float32)
 
 
+def wino_relu_bits(g: ConvGeom, device) -> torch.Tensor:
+    """Buffer for the ReLU mask of a convolution's INPUT as bits: one int64 word per (tile, channel quad) (include/ssd_gfx950.h
+    ssd_conv3x3_wino_fwd_keep_bits)."""
+    tiles = g.N * ((g.H + 3) // 4) * ((g.W + 3) // 4)
+    return torch.empty((tiles, g.Ci // 4), device=device, dtype=torch.int64)
+
+
 def conv2d_fwd_wino(x: torch.Tensor, u_fwd: torch.Tensor, bias: Optional[torch.Tensor], g: ConvGeom, relu: bool,
-                    ld: Optional[int] = None, keep_planes: bool = False):
-    """keep_planes: also return the transformed input (F(4x4) only) for `conv2d_wgrad_wino(..., planes=)` -> (y, planes)."""
+                    ld: Optional[int] = None, keep_planes: bool = False, want_bits: bool = False):
+    """keep_planes: also return the transformed input (F(4x4) only) for `conv2d_wgrad_wino(..., planes=)` -> (y, planes);
+    want_bits (with keep_planes): also the bit mask x > 0 for `conv2d_dgrad_wino(..., bits=)` -> (y, planes, bits)."""
     _req(x, "x"); _req(u_fwd, "u_fwd")
     mo = _wino_mo(u_fwd)
     if tuple(x.shape) != (g.N, g.H, g.W, g.Ci) or tuple(u_fwd.shape[1:]) != (g.Co, g.Ci):
@@ -654,16 +662,19 @@ def conv2d_fwd_wino(x: torch.Tensor, u_fwd: torch.Tensor, bias: Optional[torch.T
         if mo != 4:
             raise ValueError("conv2d_fwd_wino: keep_planes needs F(4x4,3x3) filters")
         planes = wino_planes(g, x.device)
-        check(lib.ssd_conv3x3_wino_fwd_keep(x.data_ptr(), u_fwd.data_ptr(), _ptr(bias), out.data_ptr(), ld, C.byref(g), int(relu),
-                                            planes.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "conv2d_fwd_wino")
-        return out, planes
+        bits = wino_relu_bits(g, x.device) if want_bits else None
+        check(lib.ssd_conv3x3_wino_fwd_keep_bits(x.data_ptr(), u_fwd.data_ptr(), _ptr(bias), out.data_ptr(), ld, C.byref(g), int(relu),
+                                                 planes.data_ptr(), _ptr(bits), ws.data_ptr(), ws.numel(), _stream()), "conv2d_fwd_wino")
+        return (out, planes, bits) if want_bits else (out, planes)
+    if want_bits:
+        raise ValueError("conv2d_fwd_wino: want_bits needs keep_planes")
     check(lib.ssd_conv3x3_wino_fwd(x.data_ptr(), u_fwd.data_ptr(), _ptr(bias), out.data_ptr(), ld, C.byref(g), int(relu), mo, ws.data_ptr(),
                                    ws.numel(), _stream()), "conv2d_fwd_wino")
     return out
 
 
 def conv2d_fwd_wino_pool(x: torch.Tensor, u_fwd: torch.Tensor, bias: Optional[torch.Tensor], g: ConvGeom, ceil_mode: bool,
-                         want_argmax: bool = True, keep_planes: bool = False):
+                         want_argmax: bool = True, keep_planes: bool = False, want_bits: bool = False):
     """conv3x3 -> ReLU -> max pool 2x2 / stride 2 in one pass (F(4x4,3x3) filters): (pooled y, argmax or None), the pair
     `conv2d_fwd_wino(relu=True)` + `maxpool_fwd(2, 2, 0)` returns, without the full-resolution activation in between."""
     _req(x, "x"); _req(u_fwd, "u_fwd")
@@ -682,15 +693,20 @@ def conv2d_fwd_wino_pool(x: torch.Tensor, u_fwd: torch.Tensor, bias: Optional[to
         raise ValueError("conv2d_fwd_wino_pool: not a 3x3 / stride 1 / pad 1 geometry")
     ws = workspace(nbytes, x.device, "wino")
     planes = wino_planes(g, x.device) if keep_planes else None
-    check(lib.ssd_conv3x3_wino_fwd_pool(x.data_ptr(), u_fwd.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(am), C.byref(g), int(ceil_mode),
-                                        _ptr(planes), ws.data_ptr(), ws.numel(), _stream()), "conv2d_fwd_wino_pool")
+    bits = wino_relu_bits(g, x.device) if want_bits else None
+    check(lib.ssd_conv3x3_wino_fwd_pool_bits(x.data_ptr(), u_fwd.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(am), C.byref(g), int(ceil_mode),
+                                             _ptr(planes), _ptr(bits), ws.data_ptr(), ws.numel(), _stream()), "conv2d_fwd_wino_pool")
+    if want_bits:
+        return y, am, planes, bits
     return (y, am, planes) if keep_planes else (y, am)
 
 
 def conv2d_dgrad_wino(dy: Optional[torch.Tensor], u_bwd: torch.Tensor, g: ConvGeom, dx: Optional[torch.Tensor] = None,
                       relu_mask: Optional[torch.Tensor] = None, accumulate: bool = False,
-                      planes: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """planes: B^T dy B as `conv2d_wgrad_wino(..., dgrad_planes=True)` left it ((36, tiles, Co_pad), F(4x4)); dy is then not read."""
+                      planes: Optional[torch.Tensor] = None, bits: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """planes: B^T dy B as `conv2d_wgrad_wino(..., dgrad_planes=True)` left it ((36, tiles, Co_pad), F(4x4)); dy is then not read.
+    bits (with planes): the ReLU mask as the forward's input transform left it (`conv2d_fwd_wino(..., want_bits=True)`), applied
+    instead of relu_mask."""
     _req(u_bwd, "u_bwd")
     mo = _wino_mo(u_bwd)
     co_pad = u_bwd.shape[2]
@@ -712,6 +728,13 @@ def conv2d_dgrad_wino(dy: Optional[torch.Tensor], u_bwd: torch.Tensor, g: ConvGe
         _req(relu_mask, "relu_mask")
     lib = _lib.load()
     ws = workspace(lib.ssd_conv3x3_wino_workspace(C.byref(g), 1, mo), dev, "wino")
+    if bits is not None:
+        _req(bits, "bits", torch.int64)
+        if planes is None or tuple(bits.shape) != (wino_planes_shape(g)[1], g.Ci // 4) or g.Ci % 4 != 0:
+            raise ValueError("conv2d_dgrad_wino: bits need the planes form and one word per (tile, channel quad)")
+        check(lib.ssd_conv3x3_wino_dgrad_planes_bits(planes.data_ptr(), u_bwd.data_ptr(), co_pad, dx.data_ptr(), bits.data_ptr(), int(accumulate),
+                                                     C.byref(g), ws.data_ptr(), ws.numel(), _stream()), "conv2d_dgrad_wino")
+        return dx
     if planes is not None:
         check(lib.ssd_conv3x3_wino_dgrad_planes(planes.data_ptr(), u_bwd.data_ptr(), co_pad, dx.data_ptr(), _ptr(relu_mask), int(accumulate),
                                                 C.byref(g), ws.data_ptr(), ws.numel(), _stream()), "conv2d_dgrad_wino")

@@ -612,6 +612,25 @@ def test_winograd_entry_points_at_bench_batch(layer):
     mask = torch.randn(n, h, h, ci, device=dev, generator=gen).clamp_min(0)
     dx_a = ops.conv2d_dgrad_wino(None, ub, g, dx=prev.clone(), relu_mask=mask, accumulate=True, planes=dyp)
     _close(dx_a, (dx_d + prev) * (mask > 0), what=f"wino dgrad_planes accumulate + mask {layer}")
+    # the ReLU mask as bits: the forward's input transform leaves x > 0 per (tile, channel quad) word; the dgrad epilogue applying
+    # those bits must equal, bit for bit, the one reading x itself as the float mask
+    xm = x * (torch.rand(x.shape, device=dev, generator=gen) > 0.5)        # a post-ReLU-like input: half of it exact zeros
+    res = ops.conv2d_fwd_wino_pool(xm, uf, b, g, pool, keep_planes=True, want_bits=True) if pool is not None else \
+        ops.conv2d_fwd_wino(xm, uf, b, g, True, ld=ld, keep_planes=True, want_bits=True)
+    bits = res[-1]
+    assert bits.dtype == torch.int64 and tuple(bits.shape) == (ops.wino_planes_shape(g)[1], ci // 4)
+    tiles_side = (h + 3) // 4
+    pth, ptw = min(5, tiles_side - 1), min(7, tiles_side - 1)              # a tile of image 1 (the last one on small maps: cut by the edge)
+    t_probe = tiles_side * tiles_side + pth * tiles_side + ptw
+    word = int(bits[t_probe, 3].item()) & ((1 << 64) - 1)
+    for a_, b_, e_ in ((0, 0, 0), (1, 2, 3), (3, 3, 1), (2, 0, 2)):
+        want = bool(xm[1, 4 * pth + a_, 4 * ptw + b_, 12 + e_] > 0) if (4 * pth + a_ < h and 4 * ptw + b_ < h) else False
+        assert bool((word >> ((a_ * 4 + b_) * 4 + e_)) & 1) == want, (layer, a_, b_, e_)
+    dx_m = ops.conv2d_dgrad_wino(None, ub, g, relu_mask=xm, planes=dyp)
+    dx_b = ops.conv2d_dgrad_wino(None, ub, g, planes=dyp, bits=bits)
+    assert torch.equal(dx_b, dx_m), f"bit mask != float mask {layer}"
+    dx_ba = ops.conv2d_dgrad_wino(None, ub, g, dx=prev.clone(), accumulate=True, planes=dyp, bits=bits)
+    assert torch.equal(dx_ba, ops.conv2d_dgrad_wino(None, ub, g, dx=prev.clone(), relu_mask=xm, accumulate=True, planes=dyp))
 
 
 @pytest.mark.parametrize("layer", [(300, 64, 64, 3, 1, 1, 1), (38, 512, 512, 3, 1, 1, 1), (19, 512, 1024, 3, 1, 4, 4)])
@@ -652,6 +671,83 @@ def test_bf16_operand_kernels_at_bench_batch(layer):
         ref_dw = w2.grad
     _close(dw, ref_dw, tol=1e-4, what=f"bf16-mode wgrad @32 {layer}")
     _close(db, dy.sum(dim=(0, 2, 3)), tol=1e-4, what=f"bf16-mode bias grad @32 {layer}")
+
+
+FUSED_CASES = [  # n, h, w, ci, co: K = 64 / 128 / 256, ragged tile groups (tiles % 32 != 0), partial channel blocks (co % 64 != 0), cut tiles
+    (1, 19, 19, 64, 64), (2, 30, 26, 128, 100), (1, 75, 75, 256, 32), (3, 10, 7, 64, 32), (1, 38, 38, 128, 256), (2, 13, 21, 64, 132),
+]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_winograd_fused_gemm_output_kernel_equals_two_kernel_form(case):
+    """csrc/wino_fused.hip (36 plane GEMMs + output transform in one kernel, accumulators of all planes in registers) against the
+    batched-GEMM + output-transform kernels it replaces, and against an f64 convolution: forward with bias / ReLU, forward fused with
+    the 2x2 pool in both rounding modes (pooled values and argmax codes), dgrad from planes with float mask, bit mask, accumulate.
+    Same sums in another order: 2e-5 of the scale between the two forms, 1e-4 against f64."""
+    from objectdetection_ssd_amd import _lib, ops
+    lib = _lib.load()
+    n, h, w, ci, co = case
+    dev = _dev()
+    full = (n, h, w, ci, co, 3, 1, 1, 1)
+    x, wt, b = _conv_data(full, seed=101)
+    x = F.relu(x)                                                          # post-ReLU input: the bit mask has something to say
+    x64 = x.double().requires_grad_(True)
+    y64 = F.conv2d(x64, wt.double(), b.double(), padding=1)
+    dy = torch.randn(y64.shape, generator=torch.Generator().manual_seed(102))
+    y64.backward(dy.double())
+    g = ops.make_geom(*full)
+    ld = ops.pad32(co)
+    uf, ub = ops.wino_weights(wt.to(dev), ld, mo=4)
+    xd = _nhwc(x).to(dev)
+    dy_p = torch.zeros(n, h, w, ld)
+    dy_p[..., :co] = _nhwc(dy)
+    dy_p = dy_p.to(dev)
+    prev = torch.randn(n, h, w, ci, generator=torch.Generator().manual_seed(103)).to(dev)
+    out = {}
+    try:
+        for mode in (0, 1):
+            _lib.check(lib.ssd_tune_set_wino_fused(mode), "tune")
+            r = {}
+            r["y"], planes, bits = ops.conv2d_fwd_wino(xd, uf, b.to(dev), g, False, ld=ld, keep_planes=True, want_bits=True)
+            r["y_relu"] = ops.conv2d_fwd_wino(xd, uf, b.to(dev), g, True, ld=ld)
+            if co % 4 == 0:
+                for ceil in (False, True):
+                    r[f"pool{ceil}"], r[f"am{ceil}"] = ops.conv2d_fwd_wino_pool(xd, uf, b.to(dev), g, ceil)
+            _, _, dyp = ops.conv2d_wgrad_wino(None, dy_p, g, ld, True, mo=4, planes=planes, dgrad_planes=True)
+            r["dx"] = ops.conv2d_dgrad_wino(None, ub, g, planes=dyp)
+            r["dx_mask"] = ops.conv2d_dgrad_wino(None, ub, g, relu_mask=xd, planes=dyp)
+            r["dx_bits"] = ops.conv2d_dgrad_wino(None, ub, g, planes=dyp, bits=bits)
+            r["dx_acc"] = ops.conv2d_dgrad_wino(None, ub, g, dx=prev.clone(), relu_mask=xd, accumulate=True, planes=dyp)
+            r["dx_own"] = ops.conv2d_dgrad_wino(dy_p, ub, g)
+            out[mode] = r
+    finally:
+        _lib.check(lib.ssd_tune_set_wino_fused(-1), "tune")
+    a, f_ = out[0], out[1]
+    for k in a:
+        if k.startswith("am"):
+            continue
+        _close(f_[k], a[k], tol=2e-5, what=f"fused vs two-kernel: {k} {case}")
+    for r in (a, f_):
+        _close(r["y"][..., :co], _nhwc(y64.detach()), what=f"fwd vs f64 {case}")
+        _close(r["y_relu"][..., :co], _nhwc(F.relu(y64.detach())), what=f"fwd relu vs f64 {case}")
+        if ld != co:
+            assert float(r["y"][..., co:].abs().max()) == 0.0
+        _close(r["dx"], _nhwc(x64.grad), what=f"dgrad vs f64 {case}")
+        assert torch.equal(r["dx_bits"], r["dx_mask"]) and torch.equal(r["dx_own"], r["dx"])
+        _close(r["dx_mask"], _nhwc(x64.grad) * (xd.cpu() > 0), what=f"dgrad mask vs f64 {case}")
+        _close(r["dx_acc"], (_nhwc(x64.grad) + prev.cpu()) * (xd.cpu() > 0), what=f"dgrad accumulate + mask vs f64 {case}")
+        if co % 4 == 0:
+            for ceil in (False, True):
+                p64 = F.max_pool2d(F.relu(y64.detach()), 2, 2, 0, ceil_mode=ceil)
+                _close(r[f"pool{ceil}"], _nhwc(p64), what=f"fused pool vs f64 {case}")
+                # the argmax code must point at a window element that carries the pooled value
+                yfull = r["y_relu"][..., :co]
+                code = r[f"am{ceil}"].long()
+                oh = torch.arange(code.shape[1], device=dev).view(1, -1, 1, 1) * 2 + (code >> 1)
+                ow = torch.arange(code.shape[2], device=dev).view(1, 1, -1, 1) * 2 + (code & 1)
+                assert int(oh.max()) < h and int(ow.max()) < w
+                picked = yfull[torch.arange(n, device=dev).view(-1, 1, 1, 1), oh, ow, torch.arange(co, device=dev).view(1, 1, 1, -1)]
+                assert torch.equal(picked, r[f"pool{ceil}"]), f"argmax code does not select the maximum {case} ceil={ceil} mode"
 
 
 WINO_CASES = [(2, 19, 19, 64, 64), (1, 38, 38, 128, 256), (2, 75, 75, 32, 64), (1, 19, 19, 512, 100), (3, 10, 7, 64, 32), (1, 5, 5, 32, 32)]

@@ -332,10 +332,16 @@ def _sgd_groups(named):
     return biases, others
 
 
-def test_training_loop_as_train_function_vs_cpu_oracle(gold_dir):
+@pytest.mark.parametrize("engine", ["direct", "wino"])
+def test_training_loop_as_train_function_vs_cpu_oracle(gold_dir, engine):
     """The caller's loop (train_function.py:59-95: zero_grad, cnn(inputs), ssd(...), loss1+loss2, .item(),
     backward, optimizer.step with train.py's SGD groups) for three iterations on the GPU path against the same
-    loop on the CPU oracle: the loss trajectory must agree step by step."""
+    loop on the CPU oracle: the loss trajectory must agree step by step.  Bars: the first step (same weights) 1e-4 for both
+    engines.  After an update every last-bit difference of a gradient moves the weights, and a handful of ReLU / max-pool decisions
+    out of ~1e8 flip in the next forward -- each flip a discrete change of one path.  Measured (loc / conf): direct engine
+    (plain f32 fma chains, other summation order than the CPU's) 1.4e-5 / 7e-6 at step 2, 1.2e-5 / 4.9e-5 at step 3, bar 1e-4;
+    Winograd engine (re-associated sums) 1.4e-5 / 3.4e-5 at step 2, 3.4e-4 / 8e-5 at step 3, bar 1e-3.  (The gradients themselves
+    are held per tensor against f64 in test_train_step_gradients_vs_f64_oracle.)"""
     from objectdetection_ssd_amd import Losses, Model
     lr = 1e-4                                   # train.py:53
     bs = 2
@@ -358,6 +364,7 @@ def test_training_loop_as_train_function_vs_cpu_oracle(gold_dir):
     cnn = Model.SSD_300()
     _load_params(cnn, params)
     cnn = cnn.to(DEV)
+    cnn.winograd = engine == "wino"
     biases, not_biases = _sgd_groups(cnn.named_parameters())
     assert len(biases) == 38
     optimizer = torch.optim.SGD(params=[{"params": biases, "lr": 2 * lr}, {"params": not_biases}], lr=lr, momentum=0.9, weight_decay=5e-4)
@@ -375,9 +382,10 @@ def test_training_loop_as_train_function_vs_cpu_oracle(gold_dir):
             got.append((loss1.item(), loss2.item()))
             loss.backward()
             optimizer.step()
-    for (a1, a2), (b1, b2) in zip(got, ref):
-        assert abs(a1 - b1) <= 2e-4 * max(1, abs(b1)), (got, ref)
-        assert abs(a2 - b2) <= 2e-4 * max(1, abs(b2)), (got, ref)
+    for it, ((a1, a2), (b1, b2)) in enumerate(zip(got, ref)):
+        tol = 1e-4 if (it == 0 or engine == "direct") else 1e-3
+        assert abs(a1 - b1) <= tol * max(1, abs(b1)), (it, got, ref)
+        assert abs(a2 - b2) <= tol * max(1, abs(b2)), (it, got, ref)
     assert len(not_biases) == 39          # 77 named parameters - 38 biases (incl. the dead VGG classifier)
     assert got[2][0] + got[2][1] < got[0][0] + got[0][1]            # it trains
     # eval / no_grad path gives the same outputs as the autograd path
@@ -1246,3 +1254,35 @@ def test_two_rank_data_parallel_step_of_the_real_engine_equals_the_global_batch_
     got, want = torch.from_numpy(out[0][1]), probe.flat_param.cpu()
     err = float((got - want).abs().max())
     assert err <= 2e-5 * max(1.0, float(want.abs().max())), err
+
+
+def test_second_stream_schedule_is_bitwise_the_single_stream_step():
+    """The engine runs the tiny-map group (c_8, seq9 ... c_11: ~60 latency-bound launches per direction) on a second HIP stream beside
+    the c_4 / c_7 head convolutions, forward and backward.  Same kernels, same operands, only the stream differs: outputs, losses and
+    every gradient must be bit-identical to the single-stream schedule, three steps in a row (events order every cross-stream use)."""
+    import grad_measure as M
+    from objectdetection_ssd_amd import Model
+    torch.manual_seed(11)
+    net = Model.SSD_300().to(DEV)
+    x, cl, bx = M.bench_batch(bs=4, seed=77)
+    res = {}
+    for overlap in (True, False, True):
+        net._engine.overlap_tail = overlap
+        steps = [M.train_step(net, x, cl, bx) for _ in range(3)]
+        for a in steps[1:]:
+            assert torch.equal(a[0], steps[0][0]) and torch.equal(a[1], steps[0][1])
+            assert all(torch.equal(a[4][k], steps[0][4][k]) for k in steps[0][4])
+        res.setdefault(overlap, steps[0])
+    net._engine.overlap_tail = True
+    a, b = res[True], res[False]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3]
+    assert set(a[4]) == set(b[4]) and len(a[4]) == 71
+    for k in a[4]:
+        assert torch.equal(a[4][k], b[4][k]), k
+    net.eval()
+    with torch.no_grad():
+        net._engine.overlap_tail = False
+        l0, c0 = net(x)
+        net._engine.overlap_tail = True
+        l1, c1 = net(x)
+    assert torch.equal(l0, l1) and torch.equal(c0, c1)

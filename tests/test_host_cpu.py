@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ssd_abi_version() == 1
+    assert lib.ssd_abi_version() == 1      # entry points were added since round 1, none changed
     assert lib.ssd_status_string(-2) == b"workspace too small"
 
 

@@ -39,3 +39,13 @@ for name, h, ci, co, pool, dgrad in (("conv1_2 fwd+pool", 300, 64, 64, False, Fa
     med = np.median(d, axis=0)
     print(f"{name:18s} blocks {nblk:5d}  total/WG {np.median(t[:, 5] - t[:, 0]):8.0f} cyc: " + "  ".join(f"{k} {v:.0f}" for k, v in zip(names, med)))
     _lib.check(lib.ssd_tune_set_wino_fused(-1))
+    if name.startswith("conv1_2"):                     # effect of the first-round start stagger on the same launch
+        _lib.check(lib.ssd_tune_set_wino_fused(1))
+        for stg in (0, 2000, 8000, 20000):
+            _lib.check(lib.ssd_tune_set_wino_fused_stagger(stg))
+            run(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); run(); e1.record(); torch.cuda.synchronize()
+            print(f"    stagger step {stg:6d} cycles: {e0.elapsed_time(e1):.3f} ms")
+        _lib.check(lib.ssd_tune_set_wino_fused_stagger(-1))
+        _lib.check(lib.ssd_tune_set_wino_fused(-1))
