@@ -255,6 +255,9 @@ def main():
     ap.add_argument("--wino-tile", type=int, default=-1, choices=(-1, 2, 4), help="tuning aid: Winograd output tile of forward / dgrad")
     ap.add_argument("--wino-wgrad-min-ci", type=int, default=-1, help="tuning aid: Winograd weight gradient from this many input channels")
     ap.add_argument("--wino-wgrad-max-hw", type=int, default=-1, help="tuning aid: Winograd weight gradient on maps up to this size (0 = off)")
+    ap.add_argument("--wino-min-hw", type=int, default=-1, help="tuning aid: Winograd only on maps of at least this size")
+    ap.add_argument("--no-overlap-tail", action="store_true", help="tuning aid: everything on one stream")
+    ap.add_argument("--no-overlap-wgrad", action="store_true", help="tuning aid: Winograd weight-gradient GEMMs on the main stream")
     ap.add_argument("--no-fuse-pool", action="store_true", help="tuning aid: conv -> ReLU -> 2x2 pool as separate kernels")
     ap.add_argument("--wino-wgrad-nt", action="store_true", help="tuning aid: Winograd weight gradient on transposed planes (NT GEMM)")
     ap.add_argument("--no-keep-planes", action="store_true", help="tuning aid: the Winograd weight gradient transforms x again")
@@ -343,6 +346,12 @@ def main():
         net._engine.WINO_WGRAD_MIN_CI = args.wino_wgrad_min_ci
     if args.wino_wgrad_max_hw >= 0:
         net._engine.WINO_WGRAD_MAX_HW = args.wino_wgrad_max_hw
+    if args.wino_min_hw >= 0:
+        net._engine.WINO_MIN_HW = args.wino_min_hw
+    if args.no_overlap_tail:
+        net._engine.overlap_tail = False
+    if args.no_overlap_wgrad:
+        net._engine.overlap_wgrad = False
     if args.no_fuse_pool:
         net._engine.fuse_pool = False
     if args.no_keep_planes:

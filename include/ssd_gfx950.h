@@ -159,6 +159,18 @@ int ssd_conv3x3_wino_wgrad(const float* x, const float* dy, int ldy, float* dw_o
 /* The same with the x planes a ..._fwd_keep / ..._fwd_pool call kept (F(4x4) only); workspace as ssd_conv3x3_wino_wgrad_workspace(g, ldy, 4).
  * dgrad_planes_out (may be NULL; 36 x tiles x ldy floats): the pass over dy also writes B^T dy B, the input planes of this layer's
  * data gradient, which ssd_conv3x3_wino_dgrad_planes (Co_pad = ldy) then takes instead of transforming dy again. */
+/* The F(4x4) weight gradient on kept planes as two calls, so that the caller can put the second on another stream: nothing in the
+ * backward pass waits for dw, while the data gradient waits for dgrad_planes_out.  (1) ssd_wino4_dy_transform: one pass over dy ->
+ * wgrad_planes (36 x tiles x ldy: A dy A^T), optionally dgrad_planes_out (36 x tiles x ldy: B^T dy B, for ssd_conv3x3_wino_dgrad_planes)
+ * and bias_partial (ssd_wino4_bias_partial_floats(g, ldy) floats: per-block column sums of dy; needs ldy <= 1024).
+ * (2) ssd_wino4_wgrad_gemm: the 36 split-K TN GEMMs wgrad_planes^T x x_planes, inverse transform to OIHW, and dbias from bias_partial;
+ * workspace ssd_wino4_wgrad_gemm_workspace(g, ldy) bytes.  Together they equal ssd_conv3x3_wino_wgrad_planes bit for bit. */
+size_t ssd_wino4_bias_partial_floats(const ssd_conv_geom* g, int ldy);
+int ssd_wino4_dy_transform(const float* dy, int ldy, const ssd_conv_geom* g, float* wgrad_planes, float* dgrad_planes_out,
+                           float* bias_partial, void* stream);
+size_t ssd_wino4_wgrad_gemm_workspace(const ssd_conv_geom* g, int ldy);
+int ssd_wino4_wgrad_gemm(const float* wgrad_planes, const float* x_planes, int ldy, const float* bias_partial, float* dw_oihw, float* dbias,
+                         const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream);
 /* ReLU masks as bits.  The forward's input transform can leave, per (tile, channel quad), one 64-bit word -- bit (a*4+b)*4+e set iff
  * x[4 th + a][4 tw + b][4 c4 + e] > 0 -- in relu_bits_out (tiles x Ci/4 words; may be NULL): the ReLU mask of the layer's INPUT on the tile
  * grid its data gradient is written on (autograd's ReLU backward, Model.py:136-141).  ssd_conv3x3_wino_dgrad_planes_bits applies it in

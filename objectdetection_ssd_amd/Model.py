@@ -158,6 +158,10 @@ class _Engine:
         self._late_first = id(late[0])
         self.overlap_tail = True                  # False: everything on the caller's stream
         self._side_stream = None
+        # Backward: the Winograd weight-gradient GEMMs (MFMA-bound, nothing waits for them) on their own stream beside the chain
+        # dy transform -> dgrad GEMM -> output transform -> next layer's dy transform, whose transforms are HBM-bound.
+        self.overlap_wgrad = True
+        self._wgrad_stream = None
         self._wcache: Dict[str, tuple] = {}
         self.consumers: Dict[str, int] = {}
         for op in self.ops:
@@ -221,11 +225,12 @@ class _Engine:
     WINO_WGRAD_MAX_HW = 512       # Winograd weight gradient on maps up to this size and from this many input channels.  Steps measured in
     WINO_WGRAD_MIN_CI = 64        # the train step: (80, 256) 985 -> (150, 128) 1018 images/s; once the forward planes were kept and one pass
                                   # over dy fed both gradients, the 64-channel layers paid too: + conv2_1 +0.7 %, + conv1_2 +3.8 %
+    WINO_MIN_HW = 8               # maps below this (heads c_9 .. c_11: 5x5, 3x3, 1x1) take the direct kernel: one launch instead of five
     WINO_MIN_CI = 64              # measured in the step with F(4x4): 256 -> 836, 128 -> 872, 64 -> 879 images/s (F(2x2): only >= 256 paid)
 
     def _wino_ok(self, g) -> bool:
         return (self.wino and not self.bf16 and not self.x3 and g.R == 3 and g.S == 3 and g.stride == 1 and g.dil == 1 and g.pad == 1
-                and g.Ci % 32 == 0 and g.Ci >= self.WINO_MIN_CI)
+                and g.Ci % 32 == 0 and g.Ci >= self.WINO_MIN_CI and g.H >= self.WINO_MIN_HW)
 
     def _wino_wgrad_ok(self, g, head: bool) -> bool:
         """Weight gradient of this layer in the Winograd domain (else: the fused direct kernels)."""
@@ -382,6 +387,19 @@ class _Engine:
         saved = dict(T=T, aux=aux, offs=offs, bs=bs) if save else None
         return loc, conf, saved
 
+    def _wgrad_gemm_async(self, main, Y, kept, part, g, ldy, assign):
+        """Second half of a Winograd weight gradient on the weight-gradient stream: waits for what `main` has enqueued so far (the dy
+        transform), multiplies, and hands (dw, db) to `assign` inside the stream context."""
+        ws = self._wgrad_stream
+        ws.wait_event(main.record_event())
+        for t in (Y, kept, part):
+            t.record_stream(ws)
+        with torch.cuda.stream(ws):
+            dw, db = ops.wino_wgrad_gemm(Y, kept, part, g, ldy)
+            dw.record_stream(main)
+            db.record_stream(main)
+            assign(dw, db)
+
     # -- backward ---------------------------------------------------------------------------
     def backward(self, saved, dloc: torch.Tensor, dconf: torch.Tensor, P: Dict[str, torch.Tensor], need: Dict[str, bool]):
         T, aux, offs, bs = saved["T"], saved["aux"], saved["offs"], saved["bs"]
@@ -400,6 +418,10 @@ class _Engine:
             arrived[name] = k + 1
 
         main = torch.cuda.current_stream(dloc.device)
+        async_wgrad = self.overlap_wgrad and self.prof is None and self.dual_dy and self.WINO_TILE == 4
+        if async_wgrad and self._wgrad_stream is None:
+            self._wgrad_stream = torch.cuda.Stream(device=dloc.device)
+        wgrad_used = False
         overlap = self.overlap_tail and bool(self._side_ids) and self._side_stream is not None
         side, side_ctx, joined = self._side_stream, None, not overlap
         if overlap:                                               # the reversed list starts with the side group
@@ -428,8 +450,19 @@ class _Engine:
                 xin = T[op["x"]]
                 a4 = 4 * op["a"]
                 dyp = None
+                dw = db = None
                 if any(need[pre + s] for s in ("_bb.weight", "_bb.bias", "_cl.weight", "_cl.bias")):
-                    if self._wino_wgrad_ok(g, True):
+                    if self._wino_wgrad_ok(g, True) and async_wgrad and side_ctx is None and aux.get("planes:" + pre) is not None \
+                            and co_pad <= 1024:
+                        kept = aux.pop("planes:" + pre)
+                        Y, dyp, part = ops.wino_dy_transform(dy, g, co_pad, True, True)
+
+                        def put(dw, db, pre=pre, a4=a4):
+                            grads[pre + "_bb.weight"], grads[pre + "_cl.weight"] = dw[:a4], dw[a4:]
+                            grads[pre + "_bb.bias"], grads[pre + "_cl.bias"] = db[:a4], db[a4:]
+                        self._wgrad_gemm_async(main, Y, kept, part, g, co_pad, put)
+                        wgrad_used = True
+                    elif self._wino_wgrad_ok(g, True):
                         kept = aux.pop("planes:" + pre, None)
                         dual = kept is not None and self.dual_dy        # one pass over dy feeds the weight and the data gradient
                         res = self._timed("wgrad " + pre, "winograd_3x3", ops.wino_flops(g),
@@ -440,8 +473,9 @@ class _Engine:
                     else:
                         dw, db = self._timed("wgrad " + pre, ops.wgrad_tile(g) if self.prof is not None else "", ops.conv_flops(g),
                                              lambda: ops.conv2d_wgrad(xin, dy, g, co_pad, True, bf16=self.bf16))
-                    grads[pre + "_bb.weight"], grads[pre + "_cl.weight"] = dw[:a4], dw[a4:]
-                    grads[pre + "_bb.bias"], grads[pre + "_cl.bias"] = db[:a4], db[a4:]
+                    if dw is not None:
+                        grads[pre + "_bb.weight"], grads[pre + "_cl.weight"] = dw[:a4], dw[a4:]
+                        grads[pre + "_bb.bias"], grads[pre + "_cl.bias"] = db[:a4], db[a4:]
                 if self._wino_ok(g):
                     _, ub = self._wino_weights(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]), co_pad)
                     deliver(op["x"], lambda dx, acc, mask: self._timed("dgrad " + pre, "winograd_3x3", ops.wino_flops(g),
@@ -458,7 +492,17 @@ class _Engine:
                 xin = T[op["x"]]
                 dyp = None
                 if need[op["p"] + ".weight"] or need[op["p"] + ".bias"]:
-                    if self._wino_wgrad_ok(g, False):
+                    if self._wino_wgrad_ok(g, False) and async_wgrad and side_ctx is None and aux.get("planes:" + op["p"]) is not None \
+                            and g.Co % 32 == 0 and g.Co <= 1024:
+                        kept = aux.pop("planes:" + op["p"])
+                        Y, dyp, part = ops.wino_dy_transform(dy, g, g.Co, True, True)
+
+                        def put(dw, db, name=op["p"]):
+                            grads[name + ".weight"], grads[name + ".bias"] = dw, db
+                        self._wgrad_gemm_async(main, Y, kept, part, g, g.Co, put)
+                        wgrad_used = True
+                        dw = None
+                    elif self._wino_wgrad_ok(g, False):
                         kept = aux.pop("planes:" + op["p"], None)
                         dual = kept is not None and self.dual_dy and g.Co % 32 == 0
                         res = self._timed("wgrad " + op["p"], "winograd_3x3", ops.wino_flops(g),
@@ -469,7 +513,8 @@ class _Engine:
                     else:
                         dw, db = self._timed("wgrad " + op["p"], ops.wgrad_tile(g) if self.prof is not None else "", ops.conv_flops(g),
                                              lambda: ops.conv2d_wgrad(xin, dy, g, g.Co, True, bf16=self.bf16))
-                    grads[op["p"] + ".weight"], grads[op["p"] + ".bias"] = dw, db
+                    if dw is not None:
+                        grads[op["p"] + ".weight"], grads[op["p"] + ".bias"] = dw, db
                 if self._wino_ok(g):
                     _, ub = self._wino_weights(op["p"], (P[op["p"] + ".weight"],), op["co"])
                     bits = aux.pop("bits:" + op["p"], None) if dyp is not None else None
@@ -514,6 +559,8 @@ class _Engine:
                     grads[op["p"] + ".weight"], grads[op["p"] + ".bias"] = ops.first_weight_grad(dw), db
         if not joined:
             main.wait_event(join_event)
+        if wgrad_used:
+            main.wait_event(self._wgrad_stream.record_event())
         return grads
 
 

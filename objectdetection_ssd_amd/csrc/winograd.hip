@@ -1171,3 +1171,95 @@ int wino_wgrad(const float* x, const float* planes, const float* dy, int ldy, fl
     return SSD_OK;
 }
 }  // namespace
+
+
+// ---- the weight gradient in two calls: the pass over dy (the data gradient waits for its planes) and the GEMMs + inverse transform
+// (nothing in the backward pass waits for them: the caller may enqueue them on another stream) -----------------------------------------
+namespace {
+int dy_bias_blocks_for(const ssd_conv_geom* g, int ldy, size_t tiles) {
+    const int c4 = ldy / 4;
+    if (c4 > 256) return 0;
+    int gcd = 256, r = c4;
+    while (r) { const int tmp = gcd % r; gcd = r; r = tmp; }
+    const int unit = c4 / gcd;
+    int blocks = grid_for(tiles * c4);
+    if (blocks > DY_BIAS_BLOCKS) blocks = DY_BIAS_BLOCKS;
+    blocks = (blocks + unit - 1) / unit * unit;
+    if (blocks > DY_BIAS_BLOCKS) blocks -= unit;
+    return blocks;
+}
+}  // namespace
+
+extern "C" size_t ssd_wino4_bias_partial_floats(const ssd_conv_geom* g, int ldy) {
+    if (!wino_geom_ok(g) || ldy < g->Co || ldy % 4 != 0) return 0;
+    return (size_t)DY_BIAS_BLOCKS * ldy;
+}
+
+extern "C" int ssd_wino4_dy_transform(const float* dy, int ldy, const ssd_conv_geom* g, float* wgrad_planes, float* dgrad_planes_out,
+                                      float* bias_partial, void* stream) {
+    if (!dy || !wgrad_planes) return SSD_ERR_NULL;
+    if (!wino_geom_ok(g) || ldy % 4 != 0 || ldy < g->Co) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(dy) || !ssd_aligned16(wgrad_planes) || (dgrad_planes_out && !ssd_aligned16(dgrad_planes_out)) ||
+        (bias_partial && !ssd_aligned16(bias_partial)))
+        return SSD_ERR_ALIGN;
+    const int TH = (g->H + 3) / 4, TW = (g->W + 3) / 4;
+    const size_t tiles = (size_t)g->N * TH * TW;
+    if (tiles >= (1ull << 31)) return SSD_ERR_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = bias_partial ? dy_bias_blocks_for(g, ldy, tiles) : 0;
+    if (bias_partial && blocks == 0) return SSD_ERR_BAD_SHAPE;             // more than 1024 channels: use ssd_conv3x3_wino_wgrad_planes
+    if (blocks > 0)
+        hipLaunchKernelGGL(wino4_dy_kernel<true>, dim3(blocks), dim3(256), 0, st, dy, wgrad_planes, g->N, g->H, g->W, ldy, TH, TW, bias_partial,
+                           g->Co, dgrad_planes_out);
+    else
+        hipLaunchKernelGGL(wino4_dy_kernel<false>, dim3(grid_for(tiles * (ldy / 4))), dim3(256), 0, st, dy, wgrad_planes, g->N, g->H, g->W, ldy,
+                           TH, TW, static_cast<float*>(nullptr), 0, dgrad_planes_out);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
+extern "C" size_t ssd_wino4_wgrad_gemm_workspace(const ssd_conv_geom* g, int ldy) {
+    if (!wino_geom_ok(g) || ldy < g->Co) return 0;
+    return wino_wgrad_plan(g, ldy, 4).zb;
+}
+
+extern "C" int ssd_wino4_wgrad_gemm(const float* wgrad_planes, const float* x_planes, int ldy, const float* bias_partial, float* dw_oihw,
+                                    float* dbias, const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!wgrad_planes || !x_planes || !dw_oihw || !workspace) return SSD_ERR_NULL;
+    if (!wino_geom_ok(g) || g->Ci % 4 != 0 || ldy % 4 != 0 || ldy < g->Co) return SSD_ERR_BAD_SHAPE;
+    if (dbias && !bias_partial) return SSD_ERR_NULL;
+    if (!ssd_aligned16(wgrad_planes) || !ssd_aligned16(x_planes) || !ssd_aligned16(dw_oihw) || !ssd_aligned16(workspace)) return SSD_ERR_ALIGN;
+    const WinoWgradPlan w = wino_wgrad_plan(g, ldy, 4);
+    if (workspace_bytes < w.zb) return SSD_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* Zs = static_cast<float*>(workspace);
+    TnParams q;
+    q.a = wgrad_planes; q.b = x_planes; q.out = Zs;
+    q.M = g->Co; q.N = g->Ci; q.K = (int)w.tiles; q.lda = ldy; q.ldb = g->Ci;
+    q.tiles_m = (g->Co + 63) / 64; q.tiles_n = (g->Ci + 63) / 64;
+    const int ksteps = (q.K + 31) / 32;
+    q.ksplit = w.ks;
+    q.ksteps_per_split = (ksteps + w.ks - 1) / w.ks;
+    q.batch_a = w.tiles * ldy; q.batch_b = w.tiles * g->Ci;
+    if (q.batch_a * 4 >= 0xFFFFFFF0ull || q.batch_b * 4 >= 0xFFFFFFF0ull) return SSD_ERR_BAD_SHAPE;
+    q.a_bytes = (unsigned)(q.batch_a * 4); q.b_bytes = (unsigned)(q.batch_b * 4);
+    hipLaunchKernelGGL(wino_gemm_tn_kernel, dim3(q.tiles_m * q.tiles_n, w.ks, w.P), dim3(256), 0, st, q);
+    SSD_CHECK_LAUNCH();
+    const size_t total = (size_t)g->Co * g->Ci;
+    int ks_left = w.ks;
+    if (w.ks > 1 && total / 4 < 65536) {
+        hipLaunchKernelGGL(wino_splitk_sum_kernel, dim3(grid_for(total / 4 * w.P)), dim3(256), 0, st, Zs, total, w.P, w.ks);
+        SSD_CHECK_LAUNCH();
+        ks_left = 1;
+    }
+    hipLaunchKernelGGL(wino4_wgrad_finish_kernel, dim3(grid_for(total / 4)), dim3(256), 0, st, Zs, dw_oihw, g->Co, g->Ci, ks_left, (size_t)w.ks * total);
+    SSD_CHECK_LAUNCH();
+    if (dbias) {
+        const int blocks = dy_bias_blocks_for(g, ldy, w.tiles);
+        if (blocks == 0) return SSD_ERR_BAD_SHAPE;
+        const int ldp = (g->Co + 3) / 4 * 4;
+        hipLaunchKernelGGL(colsum_final4_kernel, dim3((ldp + 15) / 16), dim3(256), 0, st, bias_partial, dbias, blocks, g->Co, ldp);
+        SSD_CHECK_LAUNCH();
+    }
+    return SSD_OK;
+}

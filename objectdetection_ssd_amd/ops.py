@@ -779,3 +779,35 @@ def conv2d_wgrad_wino(x: Optional[torch.Tensor], dy: torch.Tensor, g: ConvGeom, 
     check(lib.ssd_conv3x3_wino_wgrad(x.data_ptr(), dy.data_ptr(), ldy, dw.data_ptr(), _ptr(db), C.byref(g), mo, ws.data_ptr(), ws.numel(),
                                      _stream()), "conv2d_wgrad_wino")
     return dw, db
+
+
+def wino_dy_transform(dy: torch.Tensor, g: ConvGeom, ldy: int, dgrad_planes: bool = True, want_bias: bool = True):
+    """First half of the F(4x4) weight gradient on kept planes: one pass over dy -> (wgrad_planes (36, tiles, ldy),
+    dgrad_planes (36, tiles, ldy) or None, bias_partial or None).  The data gradient only needs dgrad_planes."""
+    _req(dy, "dy")
+    tiles = wino_planes_shape(g)[1]
+    if dy.numel() != g.N * g.H * g.W * ldy or ldy % 4 != 0 or ldy < g.Co:
+        raise ValueError("wino_dy_transform: shapes do not match the geometry")
+    lib = _lib.load()
+    Y = torch.empty((36, tiles, ldy), device=dy.device, dtype=torch.float32)
+    Vd = torch.empty((36, tiles, ldy), device=dy.device, dtype=torch.float32) if dgrad_planes else None
+    part = torch.empty((lib.ssd_wino4_bias_partial_floats(C.byref(g), ldy),), device=dy.device, dtype=torch.float32) if want_bias else None
+    check(lib.ssd_wino4_dy_transform(dy.data_ptr(), ldy, C.byref(g), Y.data_ptr(), _ptr(Vd), _ptr(part), _stream()), "wino_dy_transform")
+    return Y, Vd, part
+
+
+def wino_wgrad_gemm(wgrad_planes: torch.Tensor, x_planes: torch.Tensor, bias_partial: Optional[torch.Tensor], g: ConvGeom, ldy: int):
+    """Second half: the TN GEMMs over the tiles, the inverse transform and the bias gradient -> (dw (Co,Ci,3,3), dbias or None).
+    Runs on the CURRENT stream, which may differ from the one `wino_dy_transform` ran on (the caller orders them with an event)."""
+    _req(wgrad_planes, "wgrad_planes"); _req(x_planes, "x_planes")
+    tiles = wino_planes_shape(g)[1]
+    if tuple(wgrad_planes.shape) != (36, tiles, ldy) or tuple(x_planes.shape) != (36, tiles, g.Ci):
+        raise ValueError("wino_wgrad_gemm: planes do not match the geometry")
+    lib = _lib.load()
+    dev = x_planes.device
+    ws = workspace(lib.ssd_wino4_wgrad_gemm_workspace(C.byref(g), ldy), dev, "wino_wgrad")
+    dw = torch.empty((g.Co, g.Ci, 3, 3), device=dev, dtype=torch.float32)
+    db = torch.empty((g.Co,), device=dev, dtype=torch.float32) if bias_partial is not None else None
+    check(lib.ssd_wino4_wgrad_gemm(wgrad_planes.data_ptr(), x_planes.data_ptr(), ldy, _ptr(bias_partial), dw.data_ptr(), _ptr(db), C.byref(g),
+                                   ws.data_ptr(), ws.numel(), _stream()), "wino_wgrad_gemm")
+    return dw, db

@@ -1258,7 +1258,8 @@ def test_two_rank_data_parallel_step_of_the_real_engine_equals_the_global_batch_
 
 def test_second_stream_schedule_is_bitwise_the_single_stream_step():
     """The engine runs the tiny-map group (c_8, seq9 ... c_11: ~60 latency-bound launches per direction) on a second HIP stream beside
-    the c_4 / c_7 head convolutions, forward and backward.  Same kernels, same operands, only the stream differs: outputs, losses and
+    the c_4 / c_7 head convolutions, forward and backward, and the Winograd weight-gradient GEMMs (which nothing in the backward pass
+    waits for) on a third beside the data-gradient chain.  Same kernels, same operands, only the stream differs: outputs, losses and
     every gradient must be bit-identical to the single-stream schedule, three steps in a row (events order every cross-stream use)."""
     import grad_measure as M
     from objectdetection_ssd_amd import Model
@@ -1268,12 +1269,13 @@ def test_second_stream_schedule_is_bitwise_the_single_stream_step():
     res = {}
     for overlap in (True, False, True):
         net._engine.overlap_tail = overlap
+        net._engine.overlap_wgrad = overlap                  # ... and the Winograd weight-gradient GEMMs on a third one
         steps = [M.train_step(net, x, cl, bx) for _ in range(3)]
         for a in steps[1:]:
             assert torch.equal(a[0], steps[0][0]) and torch.equal(a[1], steps[0][1])
             assert all(torch.equal(a[4][k], steps[0][4][k]) for k in steps[0][4])
         res.setdefault(overlap, steps[0])
-    net._engine.overlap_tail = True
+    net._engine.overlap_tail = net._engine.overlap_wgrad = True
     a, b = res[True], res[False]
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3]
     assert set(a[4]) == set(b[4]) and len(a[4]) == 71
@@ -1286,3 +1288,56 @@ def test_second_stream_schedule_is_bitwise_the_single_stream_step():
         net._engine.overlap_tail = True
         l1, c1 = net(x)
     assert torch.equal(l0, l1) and torch.equal(c0, c1)
+
+
+def test_ssd512_at_its_per_gpu_batch_vs_oracle_and_direct_engine():
+    """BASELINE configs[3] (build-defined SSD512, 16 images per GPU) at that batch: the forward + loss of the default engine against the
+    oracle's restatement on the CPU (loc / conf / both losses 1e-4, per-prior classes bit-exact; parity UNPINNED by the reference,
+    which has no SSD512) and one full train step against the direct exact-f32 engine (outputs 1e-4, every gradient within 5e-3
+    relative L2 -- no per-tensor table exists for this geometry)."""
+    import grad_measure as M
+    from objectdetection_ssd_amd import Losses, Model
+    bs = 16
+    params = O.ssd300_random_params(8, variant=512)
+    net = Model.SSD_512()
+    _load_params(net, params)
+    net = net.to(DEV)
+    g = torch.Generator().manual_seed(512)
+    x = torch.randn(bs, 3, 512, 512, generator=g)
+    boxes, classes = synth_gt(np.random.default_rng(513), bs)
+    pri = O.create_priors_ssd512()
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        lo, co = O.ssd300_forward(x, params, variant=512)
+    ref = O.multibox_loss(lo.numpy(), co.numpy(), boxes, classes, pri_cxcywh=pri, want_grads=False)
+    cl, bx = [_t(c) for c in classes], [_t(b) for b in boxes]
+    res = {}
+    for eng in M.ENGINES:
+        M.set_engine(net, eng)
+        res[eng] = M.train_step(net, x.to(DEV), cl, bx) + (Losses.last_match["cls"].cpu().numpy(),)
+    M.set_engine(net, "wino")
+    for eng in M.ENGINES:
+        loc, conf, l1, l2, _, cls = res[eng]
+        assert tuple(loc.shape) == (bs, 24564, 4)
+        assert float((loc.cpu() - lo).abs().max()) <= 1e-4 * max(1, float(lo.abs().max())), eng
+        assert float((conf.cpu() - co).abs().max()) <= 1e-4 * max(1, float(co.abs().max())), eng
+        assert abs(l1 - float(ref["loc_loss"])) <= 1e-4 * max(1, float(ref["loc_loss"])), eng
+        assert abs(l2 - float(ref["conf_loss"])) <= 1e-4 * max(1, float(ref["conf_loss"])), eng
+        assert np.array_equal(cls, ref["cls"])
+    ga, gb = res["wino"][4], res["direct"][4]
+    assert set(ga) == set(gb) and len(ga) == 79
+    bad = [(k, M.rel_l2(ga[k], gb[k])) for k in ga if M.rel_l2(ga[k], gb[k]) > 5e-3]
+    assert not bad, bad
+
+
+def test_resnet34_eval_forward_at_its_per_gpu_batch_vs_oracle():
+    """BASELINE configs[4] first half (SSD_resnet34, 32 images per GPU, eval mode as section 8 A16 scopes it) against the oracle, 1e-4."""
+    net, state = _resnet34_with_state(9)
+    x = torch.randn(32, 3, 224, 224, generator=torch.Generator().manual_seed(10))
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        rl, rc = O.ssd_resnet34_forward(x, state)
+        loc, conf = net(x.to(DEV))
+    assert tuple(loc.shape) == (32, 63, 4) and tuple(conf.shape) == (32, 63, 21)
+    for got, ref in ((loc, rl), (conf, rc)):
+        assert float((got.cpu() - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
