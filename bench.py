@@ -256,6 +256,7 @@ def main():
     ap.add_argument("--wino-wgrad-min-ci", type=int, default=-1, help="tuning aid: Winograd weight gradient from this many input channels")
     ap.add_argument("--wino-wgrad-max-hw", type=int, default=-1, help="tuning aid: Winograd weight gradient on maps up to this size (0 = off)")
     ap.add_argument("--wino-min-hw", type=int, default=-1, help="tuning aid: Winograd only on maps of at least this size")
+    ap.add_argument("--xform-blocks", type=int, default=-1, help="tuning aid: grid cap of the Winograd transform kernels")
     ap.add_argument("--no-overlap-tail", action="store_true", help="tuning aid: everything on one stream")
     ap.add_argument("--no-overlap-wgrad", action="store_true", help="tuning aid: Winograd weight-gradient GEMMs on the main stream")
     ap.add_argument("--no-fuse-pool", action="store_true", help="tuning aid: conv -> ReLU -> 2x2 pool as separate kernels")
@@ -331,6 +332,9 @@ def main():
     if args.wino_wgrad_nt:
         from objectdetection_ssd_amd import _lib
         _lib.check(_lib.load().ssd_tune_set_wino_wgrad_tn(0), "tune")
+    if args.xform_blocks > 0:
+        from objectdetection_ssd_amd import _lib
+        _lib.check(_lib.load().ssd_tune_set_wino_xform_blocks(args.xform_blocks), "tune")
     if args.igemm_lds_pad >= 0:
         from objectdetection_ssd_amd import _lib
         _lib.check(_lib.load().ssd_tune_set_igemm_lds_pad(args.igemm_lds_pad), "tune")
@@ -468,7 +472,7 @@ def main():
         ach = fsum / tsum / 1e12
         traffic = None            # HBM bytes per launch from the committed PMC passes (cannot be collected live)
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
             if tj["kernel"] == tag:
                 traffic = tj["bytes_per_launch"]
         except Exception:
@@ -494,7 +498,7 @@ def main():
                           "GEMMs + output transform): `achieved` counts the direct convolution's FLOPs, the GEMMs execute 2.25x fewer")
         out["roofline"] = {"bound": "mfma", "kernel": tag + ", ...>", "achieved": round(ach, 2),
                            "peak": peak, "peak_note": peak_note, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                           "traffic": traffic, "traffic_unit": "bytes per launch (profiles/r01_traffic.json)", "launches_timed": n, "avg_launch_ms": round(tsum / n * 1e3, 4),
+                           "traffic": traffic, "traffic_unit": "bytes per launch (profiles/r02_traffic.json)", "launches_timed": n, "avg_launch_ms": round(tsum / n * 1e3, 4),
                            "avg_launch_gflop": round(fsum / n / 1e9, 3),
                            "step_executed_gflop": round(exec_flops / 3 / 1e9, 1),
                            "step_executed_frac": round(exec_flops / 3 / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),

@@ -860,7 +860,11 @@ inline bool use_fused(int mo, int K, int Nout) {
     if (g_fused == 1) return true;
     return K <= 128;                   // measured at batch 32 (tools/wino_bench.py): conv1_2 forward 1.52 -> 1.14 ms, dgrad 1.26 -> 0.94, conv2_1 forward 0.67 -> 0.50
 }
-inline int grid_for(size_t total) { const size_t b = (total + 255) / 256; return (int)(b > 8192 ? 8192 : (b == 0 ? 1 : b)); }
+int g_xform_cap = 8192;            // ssd_tune_set_wino_xform_blocks: most blocks a transform kernel is launched with (grid-stride loops do the rest)
+inline int grid_for(size_t total) {
+    const size_t b = (total + 255) / 256, cap = (size_t)g_xform_cap;
+    return (int)(b > cap ? cap : (b == 0 ? 1 : b));
+}
 
 // one Winograd convolution, F(mo x mo, 3x3) with mo = 2 or 4: in (N,H,W,Cin) -> out (N,H,W,ldo) first Cout channels
 struct PooledOut { float* y; uint8_t* argmax; int Ho, Wo; };     // destination of the fused conv -> ReLU -> 2x2/s2 max pool form
@@ -1019,6 +1023,12 @@ WinoWgradPlan wino_wgrad_plan(const ssd_conv_geom* g, int ldy, int mo) {
     return w;
 }
 }  // namespace
+
+extern "C" int ssd_tune_set_wino_xform_blocks(int blocks) {
+    if (blocks < 64 || blocks > 65535) return SSD_ERR_BAD_SHAPE;
+    g_xform_cap = blocks;
+    return SSD_OK;
+}
 
 extern "C" int ssd_tune_set_wino_fused(int mode) {
     if (mode < -1 || mode > 1) return SSD_ERR_BAD_SHAPE;
@@ -1186,6 +1196,7 @@ int dy_bias_blocks_for(const ssd_conv_geom* g, int ldy, size_t tiles) {
     if (blocks > DY_BIAS_BLOCKS) blocks = DY_BIAS_BLOCKS;
     blocks = (blocks + unit - 1) / unit * unit;
     if (blocks > DY_BIAS_BLOCKS) blocks -= unit;
+    if (blocks < unit) blocks = unit;
     return blocks;
 }
 }  // namespace
