@@ -180,6 +180,8 @@ int ssd_conv3x3_wino_fwd_keep_bits(const float* x, const float* U_fwd, const flo
 int ssd_conv3x3_wino_fwd_pool_bits(const float* x, const float* U_fwd, const float* bias, float* y_pooled, uint8_t* argmax,
                                    const ssd_conv_geom* g, int ceil_mode, float* planes_keep, uint64_t* relu_bits_out, void* workspace,
                                    size_t workspace_bytes, void* stream);
+int ssd_conv3x3_wino_dgrad_bits(const float* dy, int ldy, const float* U_bwd, int Co_pad, float* dx, const uint64_t* relu_bits, int accumulate,
+                                const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream);
 int ssd_conv3x3_wino_dgrad_planes_bits(const float* dy_planes, const float* U_bwd, int Co_pad, float* dx, const uint64_t* relu_bits,
                                        int accumulate, const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream);
 int ssd_conv3x3_wino_wgrad_planes(const float* planes, const float* dy, int ldy, float* dw_oihw, float* dbias, const ssd_conv_geom* g,
@@ -191,6 +193,11 @@ int ssd_conv3x3_wino_dgrad_planes(const float* dy_planes, const float* U_bwd, in
  * form; 0: never (batched GEMM + output transform kernels); 1: wherever the geometry allows. */
 int ssd_tune_set_wino_xform_blocks(int blocks);   /* grid cap of the Winograd transform kernels (default 8192; 64 .. 65535) */
 int ssd_tune_set_wino_fused(int mode);
+/* The whole convolution (input transform too) in one kernel where the reduction length is 64 (128 when forced): -1 automatic, 0 never, 1 force.
+ * ssd_conv3x3_wino_uses_full tells the caller whether a geometry's forward (0) / data gradient from dy (1) takes that kernel -- it then
+ * needs no dgrad planes from ssd_wino4_dy_transform. */
+int ssd_tune_set_wino_full(int mode);
+int ssd_conv3x3_wino_uses_full(const ssd_conv_geom* g, int direction);
 int ssd_tune_set_wino_fused_stagger(int cycles);   /* first-round start delay step between CUs; -1 automatic, 0 none */
 int ssd_tune_set_wino_fused_stamps(uint64_t* device_buffer);   /* diagnostic: in-kernel phase stamps of the fused kernel; NULL = off */
 int ssd_tune_set_wino_wgrad_tn(int on);   /* 1 (default): F(4x4) weight gradient on untransposed planes + TN GEMM; 0: transposed planes */

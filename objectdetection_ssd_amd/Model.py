@@ -495,7 +495,8 @@ class _Engine:
                     if self._wino_wgrad_ok(g, False) and async_wgrad and side_ctx is None and aux.get("planes:" + op["p"]) is not None \
                             and g.Co % 32 == 0 and g.Co <= 1024:
                         kept = aux.pop("planes:" + op["p"])
-                        Y, dyp, part = ops.wino_dy_transform(dy, g, g.Co, True, True)
+                        # the one-kernel data gradient reads dy itself: no B^T dy B planes to write
+                        Y, dyp, part = ops.wino_dy_transform(dy, g, g.Co, not ops.wino_uses_full(g, 1), True)
 
                         def put(dw, db, name=op["p"]):
                             grads[name + ".weight"], grads[name + ".bias"] = dw, db
@@ -504,7 +505,7 @@ class _Engine:
                         dw = None
                     elif self._wino_wgrad_ok(g, False):
                         kept = aux.pop("planes:" + op["p"], None)
-                        dual = kept is not None and self.dual_dy and g.Co % 32 == 0
+                        dual = kept is not None and self.dual_dy and g.Co % 32 == 0 and not ops.wino_uses_full(g, 1)
                         res = self._timed("wgrad " + op["p"], "winograd_3x3", ops.wino_flops(g),
                                           lambda: ops.conv2d_wgrad_wino(xin, dy, g, g.Co, True, mo=self.WINO_TILE, planes=kept,
                                                                         dgrad_planes=dual))
@@ -517,7 +518,7 @@ class _Engine:
                         grads[op["p"] + ".weight"], grads[op["p"] + ".bias"] = dw, db
                 if self._wino_ok(g):
                     _, ub = self._wino_weights(op["p"], (P[op["p"] + ".weight"],), op["co"])
-                    bits = aux.pop("bits:" + op["p"], None) if dyp is not None else None
+                    bits = aux.pop("bits:" + op["p"], None) if (dyp is not None or ops.wino_uses_full(g, 1)) else None
                     deliver(op["x"], lambda dx, acc, mask: self._timed(
                         "dgrad " + op["p"], "winograd_3x3", ops.wino_flops(g),
                         lambda: ops.conv2d_dgrad_wino(dy, ub, g, dx, mask, acc, planes=dyp, bits=bits if mask is not None else None)))

@@ -15,6 +15,10 @@ int ssd_internal_wino4_gemm_out(const float* V, const float* U, int tiles, int K
                                 const float* bias, const float* mask, const unsigned long long* mask_bits, int relu, int accumulate, int H,
                                 int W, int TH, int TW, float* yp, uint8_t* am, int Ho, int Wo, hipStream_t st);
 
+int ssd_internal_wino4_full(const float* x, const float* U, int tiles, int K, int Nrows, int Nout, float* out, int ldo, int Cvalid,
+                            const float* bias, const float* mask, const unsigned long long* mask_bits, int relu, int accumulate, int H, int W,
+                            int TH, int TW, float* yp, uint8_t* am, int Ho, int Wo, float* V_keep, unsigned long long* bits_out, hipStream_t st);
+
 namespace {
 
 // U[xi][n][k]: rows n = output channels of the GEMM, k = its reduction channels.
@@ -852,6 +856,16 @@ __global__ __launch_bounds__(256) void wino4_wgrad_finish_kernel(const float* __
 }
 
 int g_fused = -1;                  // ssd_tune_set_wino_fused: -1 automatic, 0 never, 1 wherever K % 64 == 0
+int g_full = -1;                   // ssd_tune_set_wino_full: -1 automatic, 0 never, 1 wherever K is 64 or 128
+// input transform + GEMMs + output transform in one kernel (wino_fused.hip: wino4_full_kernel)?
+inline bool use_full(int mo, int K, int Nout) {
+    if (mo != 4 || (K != 64 && K != 128) || g_full == 0 || g_fused == 0) return false;
+    // Measured at batch 32 (tools/wino_bench.py, wf_stamps.py full): conv1_2 forward 1.62 ms against 1.16 for input transform + fused
+    // kernel.  Its B fragments come straight from L2 (the V pass fills the LDS): 16 tiles per workgroup need 32 B/cycle/CU of filter
+    // stream and run L2-bound at half the MFMA rate; 32 tiles need the K passes, whose transform registers push the 144 accumulators
+    // to scratch.  Off unless forced; kept as the correct, tested starting point for an LDS-DMA filter ring beside a 16-channel V pass.
+    return g_full == 1;
+}
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 // GEMMs + output transform in one kernel (wino_fused.hip)?  It removes the write and the read-back of the M planes; what it costs is
 // MFMA efficiency on long reductions (one workgroup per CU, 16x16x4 MFMAs).
@@ -881,6 +895,10 @@ int wino_conv(int mo, const float* in, int Cin, const float* U, int U_rows, floa
     if (ws_bytes < vb + mb) return SSD_ERR_WORKSPACE;
     float* V = V_keep != nullptr ? V_keep : static_cast<float*>(ws);       // kept planes: the weight gradient multiplies them again
     float* Mx = reinterpret_cast<float*>(static_cast<char*>(ws) + vb);
+    if (V_given == nullptr && use_full(mo, Cin, Cout))                      // one kernel from the activation to the output
+        return ssd_internal_wino4_full(in, U, (int)tiles, Cin, U_rows, Cout, out, ldo, Cvalid, bias, mask, mask_bits, relu, accumulate, H, W, TH,
+                                       TW, pooled ? pooled->y : nullptr, pooled ? pooled->argmax : nullptr, pooled ? pooled->Ho : 0,
+                                       pooled ? pooled->Wo : 0, V_keep, bits_out, st);
     if (V_given != nullptr) V = const_cast<float*>(V_given);                // input planes already formed (by the dy pass of the wgrad)
     else if (mo == 2) hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(tiles * (Cin / 4))), dim3(256), 0, st, in, V, N, H, W, Cin, TH, TW);
     else hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(tiles * (Cin / 4))), dim3(256), 0, st, in, V, N, H, W, Cin, TH, TW, bits_out);
@@ -1030,6 +1048,19 @@ extern "C" int ssd_tune_set_wino_xform_blocks(int blocks) {
     return SSD_OK;
 }
 
+extern "C" int ssd_tune_set_wino_full(int mode) {
+    if (mode < -1 || mode > 1) return SSD_ERR_BAD_SHAPE;
+    g_full = mode;
+    return SSD_OK;
+}
+
+// 1 if the forward (direction 0) / data gradient from dy (direction 1) of this geometry runs as ONE kernel from the activation (no planes read)
+extern "C" int ssd_conv3x3_wino_uses_full(const ssd_conv_geom* g, int direction) {
+    if (!wino_geom_ok(g)) return 0;
+    const int co_pad = (g->Co + 31) / 32 * 32;
+    return direction == 0 ? use_full(4, g->Ci, (g->Co + 3) / 4 * 4) : use_full(4, co_pad, g->Ci);
+}
+
 extern "C" int ssd_tune_set_wino_fused(int mode) {
     if (mode < -1 || mode > 1) return SSD_ERR_BAD_SHAPE;
     g_fused = mode;
@@ -1064,6 +1095,15 @@ extern "C" int ssd_conv3x3_wino_wgrad_planes(const float* planes, const float* d
     if (!planes) return SSD_ERR_NULL;
     if (!ssd_aligned16(planes) || (dgrad_planes_out && !ssd_aligned16(dgrad_planes_out))) return SSD_ERR_ALIGN;
     return wino_wgrad(nullptr, planes, dy, ldy, dw_oihw, dbias, g, 4, dgrad_planes_out, workspace, workspace_bytes, stream);
+}
+extern "C" int ssd_conv3x3_wino_dgrad_bits(const float* dy, int ldy, const float* U_bwd, int Co_pad, float* dx, const uint64_t* relu_bits,
+                                           int accumulate, const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dy || !U_bwd || !dx || !workspace || !relu_bits) return SSD_ERR_NULL;
+    if (!wino_geom_ok(g) || Co_pad % 32 != 0 || Co_pad < g->Co || ldy != Co_pad || g->Ci % 4 != 0) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(dy) || !ssd_aligned16(dx) || !ssd_aligned16(workspace) || !ssd_aligned16(U_bwd) || ((uintptr_t)relu_bits & 7))
+        return SSD_ERR_ALIGN;
+    return wino_conv(4, dy, Co_pad, U_bwd, g->Ci, dx, g->Ci, g->Ci, nullptr, nullptr, 0, accumulate, g->N, g->H, g->W, workspace, workspace_bytes,
+                     (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<const unsigned long long*>(relu_bits));
 }
 extern "C" int ssd_conv3x3_wino_dgrad_planes_bits(const float* dy_planes, const float* U_bwd, int Co_pad, float* dx, const uint64_t* relu_bits,
                                                   int accumulate, const ssd_conv_geom* g, void* workspace, size_t workspace_bytes,

@@ -633,6 +633,11 @@ def wino_planes(g: ConvGeom, device) -> torch.Tensor:
     return torch.empty((36, tiles, g.Ci), device=device, dtype=torch.float32)
 
 
+def wino_uses_full(g: ConvGeom, direction: int) -> bool:
+    """True if the library runs this geometry's F(4x4) forward (0) / data gradient from dy (1) as one kernel from the activation."""
+    return bool(_lib.load().ssd_conv3x3_wino_uses_full(C.byref(g), direction))
+
+
 def wino_relu_bits(g: ConvGeom, device) -> torch.Tensor:
     """Buffer for the ReLU mask of a convolution's INPUT as bits: one int64 word per (tile, channel quad) (include/ssd_gfx950.h
     ssd_conv3x3_wino_fwd_keep_bits)."""
@@ -730,8 +735,12 @@ def conv2d_dgrad_wino(dy: Optional[torch.Tensor], u_bwd: torch.Tensor, g: ConvGe
     ws = workspace(lib.ssd_conv3x3_wino_workspace(C.byref(g), 1, mo), dev, "wino")
     if bits is not None:
         _req(bits, "bits", torch.int64)
-        if planes is None or tuple(bits.shape) != (wino_planes_shape(g)[1], g.Ci // 4) or g.Ci % 4 != 0:
-            raise ValueError("conv2d_dgrad_wino: bits need the planes form and one word per (tile, channel quad)")
+        if mo != 4 or tuple(bits.shape) != (wino_planes_shape(g)[1], g.Ci // 4) or g.Ci % 4 != 0:
+            raise ValueError("conv2d_dgrad_wino: bits need F(4x4) filters and one word per (tile, channel quad)")
+        if planes is None:
+            check(lib.ssd_conv3x3_wino_dgrad_bits(dy.data_ptr(), co_pad, u_bwd.data_ptr(), co_pad, dx.data_ptr(), bits.data_ptr(), int(accumulate),
+                                                  C.byref(g), ws.data_ptr(), ws.numel(), _stream()), "conv2d_dgrad_wino")
+            return dx
         check(lib.ssd_conv3x3_wino_dgrad_planes_bits(planes.data_ptr(), u_bwd.data_ptr(), co_pad, dx.data_ptr(), bits.data_ptr(), int(accumulate),
                                                      C.byref(g), ws.data_ptr(), ws.numel(), _stream()), "conv2d_dgrad_wino")
         return dx

@@ -705,8 +705,11 @@ def test_winograd_fused_gemm_output_kernel_equals_two_kernel_form(case):
     prev = torch.randn(n, h, w, ci, generator=torch.Generator().manual_seed(103)).to(dev)
     out = {}
     try:
-        for mode in (0, 1):
-            _lib.check(lib.ssd_tune_set_wino_fused(mode), "tune")
+        for mode in (0, 1, 2):                                             # two-kernel form, fused GEMMs + output, the whole convolution in one kernel
+            _lib.check(lib.ssd_tune_set_wino_fused(min(mode, 1)), "tune")
+            _lib.check(lib.ssd_tune_set_wino_full(1 if mode == 2 else 0), "tune")
+            if mode == 2 and not (ops.wino_uses_full(g, 0) or ops.wino_uses_full(g, 1)):
+                continue
             r = {}
             r["y"], planes, bits = ops.conv2d_fwd_wino(xd, uf, b.to(dev), g, False, ld=ld, keep_planes=True, want_bits=True)
             r["y_relu"] = ops.conv2d_fwd_wino(xd, uf, b.to(dev), g, True, ld=ld)
@@ -719,21 +722,29 @@ def test_winograd_fused_gemm_output_kernel_equals_two_kernel_form(case):
             r["dx_bits"] = ops.conv2d_dgrad_wino(None, ub, g, planes=dyp, bits=bits)
             r["dx_acc"] = ops.conv2d_dgrad_wino(None, ub, g, dx=prev.clone(), relu_mask=xd, accumulate=True, planes=dyp)
             r["dx_own"] = ops.conv2d_dgrad_wino(dy_p, ub, g)
+            r["dx_own_bits"] = ops.conv2d_dgrad_wino(dy_p, ub, g, bits=bits)
+            r["planes"], r["bits"] = planes, bits
             out[mode] = r
     finally:
         _lib.check(lib.ssd_tune_set_wino_fused(-1), "tune")
-    a, f_ = out[0], out[1]
-    for k in a:
-        if k.startswith("am"):
+        _lib.check(lib.ssd_tune_set_wino_full(-1), "tune")
+    a = out[0]
+    for mode in out:
+        if mode == 0:
             continue
-        _close(f_[k], a[k], tol=2e-5, what=f"fused vs two-kernel: {k} {case}")
-    for r in (a, f_):
+        for k in a:
+            if k.startswith("am") or k in ("planes", "bits"):
+                continue
+            _close(out[mode][k], a[k], tol=2e-5, what=f"mode {mode} vs two-kernel: {k} {case}")
+        assert torch.equal(out[mode]["planes"], a["planes"]) and torch.equal(out[mode]["bits"], a["bits"]), f"kept planes / bits differ, mode {mode}"
+    for r in out.values():
         _close(r["y"][..., :co], _nhwc(y64.detach()), what=f"fwd vs f64 {case}")
         _close(r["y_relu"][..., :co], _nhwc(F.relu(y64.detach())), what=f"fwd relu vs f64 {case}")
         if ld != co:
             assert float(r["y"][..., co:].abs().max()) == 0.0
         _close(r["dx"], _nhwc(x64.grad), what=f"dgrad vs f64 {case}")
-        assert torch.equal(r["dx_bits"], r["dx_mask"]) and torch.equal(r["dx_own"], r["dx"])
+        assert torch.equal(r["dx_bits"], r["dx_mask"]) and torch.equal(r["dx_own_bits"] * 1.0, r["dx_own"] * (xd > 0))
+        _close(r["dx_own"], r["dx"], tol=2e-5, what=f"dgrad from dy vs from planes {case}")
         _close(r["dx_mask"], _nhwc(x64.grad) * (xd.cpu() > 0), what=f"dgrad mask vs f64 {case}")
         _close(r["dx_acc"], (_nhwc(x64.grad) + prev.cpu()) * (xd.cpu() > 0), what=f"dgrad accumulate + mask vs f64 {case}")
         if co % 4 == 0:

@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT)
 from objectdetection_ssd_amd import _lib, ops
 lib = _lib.load()
 dev = torch.device("cuda:0")
+FULL = len(sys.argv) > 1 and sys.argv[1] == "full"
 for name, h, ci, co, pool, dgrad in (("conv1_2 fwd+pool", 300, 64, 64, False, False), ("conv1_2 dgrad", 300, 64, 64, None, True),
                                      ("conv2_2 fwd+pool", 150, 128, 128, False, False), ("conv3_2 fwd", 75, 256, 256, None, False),
                                      ("conv4_2 fwd", 38, 512, 512, None, False)):
@@ -18,6 +19,9 @@ for name, h, ci, co, pool, dgrad in (("conv1_2 fwd+pool", 300, 64, 64, False, Fa
     uf, ub = ops.wino_weights(w, co, mo=4)
     mask = torch.randn(n, h, h, ci, device=dev).clamp_min(0)
     _lib.check(lib.ssd_tune_set_wino_fused(1))
+    _lib.check(lib.ssd_tune_set_wino_full(1 if FULL else 0))
+    if FULL and ci > 128:
+        continue
     tiles = n * ((h + 3) // 4) ** 2
     nblk = ((tiles + 31) // 32) * ((co + 63) // 64)
     buf = torch.zeros((nblk // 16 + 2, 8), dtype=torch.int64, device=dev)
@@ -25,8 +29,8 @@ for name, h, ci, co, pool, dgrad in (("conv1_2 fwd+pool", 300, 64, 64, False, Fa
         if dgrad:
             return ops.conv2d_dgrad_wino(x if ci == co else None, ub, g, relu_mask=mask)
         if pool is not None:
-            return ops.conv2d_fwd_wino_pool(x, uf, b, g, pool)
-        return ops.conv2d_fwd_wino(x, uf, b, g, True)
+            return ops.conv2d_fwd_wino_pool(x, uf, b, g, pool, keep_planes=FULL)
+        return ops.conv2d_fwd_wino(x, uf, b, g, True, keep_planes=FULL)
     run(); torch.cuda.synchronize()
     _lib.check(lib.ssd_tune_set_wino_fused_stamps(buf.data_ptr()))
     run(); torch.cuda.synchronize()
@@ -35,7 +39,7 @@ for name, h, ci, co, pool, dgrad in (("conv1_2 fwd+pool", 300, 64, 64, False, Fa
     t = t[t[:, 0] > 0]
     t = t[:, :6]
     d = np.diff(t, axis=1).astype(np.float64)
-    names = ["prologue", "main loop", "transform", "phase 2 issue", "store drain"]
+    names = ["T (input transform)", "M (MFMA)", "E transform", "phase 2", "store drain"] if FULL else ["prologue", "main loop", "transform", "phase 2 issue", "store drain"]
     med = np.median(d, axis=0)
     print(f"{name:18s} blocks {nblk:5d}  total/WG {np.median(t[:, 5] - t[:, 0]):8.0f} cyc: " + "  ".join(f"{k} {v:.0f}" for k, v in zip(names, med)))
     _lib.check(lib.ssd_tune_set_wino_fused(-1))

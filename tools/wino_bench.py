@@ -52,25 +52,33 @@ def main():
             return ops.conv2d_fwd_wino(x, uf, b, g, True, ld=ld, keep_planes=True)[0]
 
         def dgrad():
+            if _lib.load().ssd_conv3x3_wino_uses_full(__import__("ctypes").byref(g), 1):
+                return ops.conv2d_dgrad_wino(dy, ub, g, relu_mask=mask)            # one kernel, from dy (no planes to read)
             return ops.conv2d_dgrad_wino(None, ub, g, relu_mask=mask, planes=dyp)
         res = {}
         for what, fn in (("fwd", fwd), ("dgrad", dgrad)):
             outs = {}
-            for mode in (0, 1):
-                _lib.check(lib.ssd_tune_set_wino_fused(mode), "tune")
+            modes = (0, 1, 2) if (ci in (64, 128) if what == "fwd" else ld in (64, 128)) else (0, 1)
+
+            def setmode(mode):
+                _lib.check(lib.ssd_tune_set_wino_fused(min(mode, 1)), "tune")
+                _lib.check(lib.ssd_tune_set_wino_full(1 if mode == 2 else 0), "tune")
+            for mode in modes:
+                setmode(mode)
                 outs[mode] = fn().clone()
-            err = float((outs[1] - outs[0]).abs().max() / outs[0].abs().max().clamp_min(1e-30))
-            t = {}
+            err = max(float((outs[m] - outs[0]).abs().max() / outs[0].abs().max().clamp_min(1e-30)) for m in modes[1:])
+            t = {2: (float("nan"), 0)}
             for rep in range(2):                          # interleaved
-                for mode in (0, 1):
-                    _lib.check(lib.ssd_tune_set_wino_fused(mode), "tune")
+                for mode in modes:
+                    setmode(mode)
                     fn()
                     t[mode] = timed(fn, rounds)
-            res[what] = (t[0][0], t[1][0], err)
+            res[what] = (t[0][0], t[1][0], err, t[2][0])
         _lib.check(lib.ssd_tune_set_wino_fused(-1), "tune")
+        _lib.check(lib.ssd_tune_set_wino_full(-1), "tune")
         ex = ops.wino_flops(g)[1] / 1e9
-        print(f"{name:8s} {h:3d} {ci:4d}->{co:4d}  fwd  two-kernel {res['fwd'][0]:.3f} ms  fused {res['fwd'][1]:.3f} ms  (max rel diff {res['fwd'][2]:.1e})"
-              f" | dgrad {res['dgrad'][0]:.3f} -> {res['dgrad'][1]:.3f} ms ({res['dgrad'][2]:.1e}) | executed {ex:.1f} GF", flush=True)
+        print(f"{name:8s} {h:3d} {ci:4d}->{co:4d}  fwd  two-kernel {res['fwd'][0]:.3f}  fused {res['fwd'][1]:.3f}  one-kernel {res['fwd'][3]:.3f} ms (max rel diff {res['fwd'][2]:.1e})"
+              f" | dgrad {res['dgrad'][0]:.3f} -> {res['dgrad'][1]:.3f} -> {res['dgrad'][3]:.3f} ms ({res['dgrad'][2]:.1e}) | executed {ex:.1f} GF", flush=True)
         del x, dy, dyp, mask
         torch.cuda.empty_cache()
 
