@@ -258,7 +258,8 @@ def main():
     ap.add_argument("--wino-min-hw", type=int, default=-1, help="tuning aid: Winograd only on maps of at least this size")
     ap.add_argument("--xform-blocks", type=int, default=-1, help="tuning aid: grid cap of the Winograd transform kernels")
     ap.add_argument("--no-overlap-tail", action="store_true", help="tuning aid: everything on one stream")
-    ap.add_argument("--no-overlap-wgrad", action="store_true", help="tuning aid: Winograd weight-gradient GEMMs on the main stream")
+    ap.add_argument("--overlap-wgrad", action="store_true", help="tuning aid: Winograd weight-gradient GEMMs on their own stream")
+    ap.add_argument("--no-batch-weights", action="store_true", help="tuning aid: filter transforms / re-layouts layer by layer")
     ap.add_argument("--no-fuse-pool", action="store_true", help="tuning aid: conv -> ReLU -> 2x2 pool as separate kernels")
     ap.add_argument("--wino-wgrad-nt", action="store_true", help="tuning aid: Winograd weight gradient on transposed planes (NT GEMM)")
     ap.add_argument("--no-keep-planes", action="store_true", help="tuning aid: the Winograd weight gradient transforms x again")
@@ -352,10 +353,10 @@ def main():
         net._engine.WINO_WGRAD_MAX_HW = args.wino_wgrad_max_hw
     if args.wino_min_hw >= 0:
         net._engine.WINO_MIN_HW = args.wino_min_hw
-    if args.no_overlap_tail:
-        net._engine.overlap_tail = False
-    if args.no_overlap_wgrad:
-        net._engine.overlap_wgrad = False
+    net._engine.overlap_tail = not args.no_overlap_tail
+    net._engine.overlap_wgrad = args.overlap_wgrad
+    if args.no_batch_weights:
+        net._engine.batch_weights = False
     if args.no_fuse_pool:
         net._engine.fuse_pool = False
     if args.no_keep_planes:

@@ -159,6 +159,18 @@ int ssd_conv3x3_wino_wgrad(const float* x, const float* dy, int ldy, float* dw_o
 /* The same with the x planes a ..._fwd_keep / ..._fwd_pool call kept (F(4x4) only); workspace as ssd_conv3x3_wino_wgrad_workspace(g, ldy, 4).
  * dgrad_planes_out (may be NULL; 36 x tiles x ldy floats): the pass over dy also writes B^T dy B, the input planes of this layer's
  * data gradient, which ssd_conv3x3_wino_dgrad_planes (Co_pad = ldy) then takes instead of transforming dy again. */
+/* Every filter transform / re-layout of a training step in one launch.  A job: kind 0 = Winograd F(4x4,3x3) filters (out_fwd [36][co][ci],
+ * out_bwd [36][ci][co_pad]: the transposed, rotated filter of the data gradient), kind 1 = the direct kernels' copies (out_fwd OHWI
+ * [co_pad][taps][ci], out_bwd IHWO [ci][taps][co_pad]), kind 2 = conv1_1's rows for the im2col GEMM (out_fwd [co][32]).  The OIHW source
+ * may come in two pieces (rows 0..co0-1 from w0, the rest from w1: a head's loc and conf filters); out_bwd may be NULL.  The caller
+ * uploads the job array and the exclusive prefix sum of ssd_weight_job_blocks(job) (block_start, njobs entries) to the device once. */
+typedef struct ssd_weight_job {
+    const float* w0; const float* w1;
+    float* out_fwd; float* out_bwd;
+    int co0, co, ci, taps, co_pad, kind, pad0, pad1;
+} ssd_weight_job;
+int ssd_weight_job_blocks(const ssd_weight_job* job);
+int ssd_weights_prepare(const ssd_weight_job* jobs_device, const int* block_start_device, int njobs, int total_blocks, void* stream);
 /* The F(4x4) weight gradient on kept planes as two calls, so that the caller can put the second on another stream: nothing in the
  * backward pass waits for dw, while the data gradient waits for dgrad_planes_out.  (1) ssd_wino4_dy_transform: one pass over dy ->
  * wgrad_planes (36 x tiles x ldy: A dy A^T), optionally dgrad_planes_out (36 x tiles x ldy: B^T dy B, for ssd_conv3x3_wino_dgrad_planes)

@@ -156,12 +156,17 @@ class _Engine:
         self.ops = early + late + side
         self._side_ids = {id(o) for o in side}
         self._late_first = id(late[0])
-        self.overlap_tail = True                  # False: everything on the caller's stream
+        self.overlap_tail = True                  # False: everything on the caller's stream (bit-identical; interleaved A/B: 26.09 -> 25.85 ms)
         self._side_stream = None
         # Backward: the Winograd weight-gradient GEMMs (MFMA-bound, nothing waits for them) on their own stream beside the chain
-        # dy transform -> dgrad GEMM -> output transform -> next layer's dy transform, whose transforms are HBM-bound.
-        self.overlap_wgrad = True
+        # dy transform -> dgrad GEMM -> output transform -> next layer's dy transform, whose transforms are HBM-bound.  Opt-in: measured
+        # +-0.2 ms (the GEMMs end up beside other GEMMs, the transform kernels leave no room on the CUs), and the planes that cross the
+        # streams (GBs per layer, held by record_stream until the other stream has passed) make torch's caching allocator reserve
+        # 180 GB instead of 19.
+        self.overlap_wgrad = False
         self._wgrad_stream = None
+        self.batch_weights = True     # training forward: all ~56 filter transforms / re-layouts of the step in ONE launch (ops.WeightTable)
+        self._wtable = None           # (signature, WeightTable, [(cache key, kind, layer signature fn, buffers)])
         self._wcache: Dict[str, tuple] = {}
         self.consumers: Dict[str, int] = {}
         for op in self.ops:
@@ -255,6 +260,64 @@ class _Engine:
         ent = self._wcache.get(key)
         return None if ent is None or len(ent) < 6 else ent[5 if bwd else 4]
 
+    def _prepare_weights_batched(self, x: torch.Tensor, P: Dict[str, torch.Tensor]) -> None:
+        """Fill the weight cache for a training step with one launch.  The output buffers persist across steps (rewritten in place, on the
+        caller's stream, after the previous step's last use); the job table is rebuilt only when a parameter's storage or the input
+        size changes."""
+        sig = (x.shape[2], x.shape[3], self.wino, self.WINO_TILE, self.WINO_MIN_CI, self.WINO_MIN_HW) + tuple(P[n].data_ptr() for n in self.names)
+        if self._wtable is None or self._wtable[0] != sig:
+            jobs, entries = [], []
+            bs, hw, dev = x.shape[0], {"x": (x.shape[2], x.shape[3])}, x.device
+            for op in self.ops:
+                kind = op["op"]
+                if kind == "conv_first":
+                    hw[op["y"]] = hw[op["x"]]
+                    w = P[op["p"] + ".weight"]
+                    rows = torch.empty((64, 1, 32), device=dev, dtype=torch.float32)
+                    jobs.append(dict(kind=2, w0=w.detach(), co0=64, co=64, ci=3, taps=9, co_pad=64, out_fwd=rows))
+                    entries.append((op["p"], "first", (w,), (rows,)))
+                elif kind == "pool":
+                    h, w_ = hw[op["x"]]
+                    hw[op["y"]] = (ops.pool_out(h, op["k"], op["s"], op["pad"], op["ceil"]), ops.pool_out(w_, op["k"], op["s"], op["pad"], op["ceil"]))
+                elif kind == "l2norm":
+                    hw[op["y"]] = hw[op["x"]]
+                elif kind in ("conv", "head"):
+                    h, w_ = hw[op["x"]]
+                    if kind == "conv":
+                        g = ops.make_geom(bs, h, w_, op["ci"], op["co"], op["k"], op["s"], op["pad"], op["dil"])
+                        hw[op["y"]] = (g.Ho, g.Wo)
+                        tensors, co_pad = (P[op["p"] + ".weight"],), op["co"]
+                    else:
+                        co = op["a"] * (4 + N_CLASSES)
+                        g = ops.make_geom(bs, h, w_, op["ci"], co, 3, 1, 1, 1)
+                        tensors, co_pad = (P[op["p"] + "_bb.weight"], P[op["p"] + "_cl.weight"]), ops.pad32(co)
+                    co_all = sum(t.shape[0] for t in tensors)
+                    job = dict(w0=tensors[0].detach(), w1=tensors[1].detach() if len(tensors) > 1 else None, co0=tensors[0].shape[0], co=co_all,
+                               ci=g.Ci, taps=g.R * g.S, co_pad=co_pad)
+                    if self._wino_ok(g) and self.WINO_TILE == 4:
+                        uf = torch.empty((36, co_all, g.Ci), device=dev, dtype=torch.float32)
+                        ub = torch.empty((36, g.Ci, co_pad), device=dev, dtype=torch.float32)
+                        jobs.append(dict(job, kind=0, out_fwd=uf, out_bwd=ub))
+                        entries.append((op["p"], "wino", tensors, (uf, ub)))
+                    elif self._wino_ok(g):
+                        continue                               # F(2x2) (a tuning aid): transformed per layer as before
+                    else:
+                        wf = torch.empty((co_pad, g.R * g.S, g.Ci), device=dev, dtype=torch.float32)
+                        wb = torch.empty((g.Ci, g.R * g.S, co_pad), device=dev, dtype=torch.float32)
+                        jobs.append(dict(job, kind=1, out_fwd=wf, out_bwd=wb))
+                        entries.append((op["p"], "layout", tensors, (wf, wb)))
+            self._wtable = (sig, ops.WeightTable(jobs, dev), entries)
+        _, table, entries = self._wtable
+        table.run()
+        for key, what, tensors, bufs in entries:
+            lsig = tuple((t.data_ptr(), t._version) for t in tensors)
+            if what == "wino":
+                self._wcache["wino:" + key] = (lsig, bufs[0], bufs[1])
+            elif what == "layout":
+                self._wcache[key] = [lsig, None, bufs[0], bufs[1]]
+            else:
+                self._wcache[key] = [lsig[0], None, bufs[0], None]
+
     # -- forward ----------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, P: Dict[str, torch.Tensor], save: bool):
         if x.dim() != 4 or x.shape[1] != 3:
@@ -271,6 +334,8 @@ class _Engine:
             # (data_ptr, _version) cannot see writes through `.data` (p.data.mul_(), dist.broadcast(p.data), EMA swaps).
             # The backward of this step reads what this forward stored.
             self._wcache.clear()
+            if self.batch_weights and not self.bf16 and not self.x3:
+                self._prepare_weights_batched(x, P)
         T = {"x": x}
         aux = {}
         heads = []

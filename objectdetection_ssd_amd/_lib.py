@@ -26,6 +26,12 @@ class ImageDesc(C.Structure):
         "flip", "reserved")]
 
 
+class WeightJob(C.Structure):
+    """struct ssd_weight_job"""
+    _fields_ = [("w0", C.c_void_p), ("w1", C.c_void_p), ("out_fwd", C.c_void_p), ("out_bwd", C.c_void_p)] + [(n, C.c_int32) for n in (
+        "co0", "co", "ci", "taps", "co_pad", "kind", "pad0", "pad1")]
+
+
 class PhotoDesc(C.Structure):
     """struct ssd_photo_desc"""
     _fields_ = [("n_ops", C.c_int32), ("kind", C.c_int32 * 4), ("alpha", C.c_float * 4), ("hue_delta", C.c_int32 * 4)]
@@ -80,6 +86,8 @@ SIGNATURES = {
     "ssd_conv3x3_wino_fwd": (_I, [_P, _P, _P, _P, _I, _G, _I, _I, _P, _Z, _P]),
     "ssd_conv3x3_wino_fwd_pool": (_I, [_P, _P, _P, _P, _P, _G, _I, _P, _P, _Z, _P]),
     "ssd_conv3x3_wino_fwd_keep": (_I, [_P, _P, _P, _P, _I, _G, _I, _P, _P, _Z, _P]),
+    "ssd_weight_job_blocks": (_I, [_P]),
+    "ssd_weights_prepare": (_I, [_P, _P, _I, _I, _P]),
     "ssd_wino4_bias_partial_floats": (_Z, [_G, _I]),
     "ssd_wino4_dy_transform": (_I, [_P, _I, _G, _P, _P, _P, _P]),
     "ssd_wino4_wgrad_gemm_workspace": (_Z, [_G, _I]),

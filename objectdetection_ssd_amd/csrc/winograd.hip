@@ -1314,3 +1314,88 @@ extern "C" int ssd_wino4_wgrad_gemm(const float* wgrad_planes, const float* x_pl
     }
     return SSD_OK;
 }
+
+// ---- every filter transform / re-layout of a training step in ONE launch ---------------------------------------------------------------
+// A step re-lays ~30 weight tensors (Winograd-domain filters for forward and dgrad, or the OHWI / IHWO copies of the direct kernels):
+// 56 launches of ~9 microseconds in a row.  Here a job table (device memory, built once by the caller while the pointers stay the same)
+// describes them all; a block finds its job by its index and works on a 256-element chunk of it.
+namespace {
+__global__ __launch_bounds__(256) void weight_jobs_kernel(const ssd_weight_job* __restrict__ jobs, const int* __restrict__ block_start, int njobs) {
+    int lo = 0, hi = njobs - 1;                      // the job whose block range holds blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (block_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const ssd_weight_job j = jobs[lo];
+    const size_t i = (size_t)((int)blockIdx.x - block_start[lo]) * 256 + threadIdx.x;
+    const int Co = j.co, Ci = j.ci, T = j.taps;
+    auto src = [&](int co, int ci, int t) -> float {  // rows co < co0 come from w0, the rest from w1 (a head's bb and cl filters)
+        return co < j.co0 ? j.w0[((size_t)co * Ci + ci) * T + t] : j.w1[((size_t)(co - j.co0) * Ci + ci) * T + t];
+    };
+    if (j.kind == 0) {                               // Winograd F(4x4,3x3): thread = (n, k) of U_fwd [36][Co][Ci] or of U_bwd [36][Ci][co_pad]
+        const size_t nf = (size_t)Co * Ci, nb = (size_t)Ci * j.co_pad;
+        const bool fwd = i < nf;
+        if (!fwd && (j.out_bwd == nullptr || i - nf >= nb)) return;
+        const size_t e = fwd ? i : i - nf;
+        const int Nrows = fwd ? Co : Ci, K = fwd ? Ci : j.co_pad;
+        const int k = (int)(e % K), n = (int)(e / K);
+        const int co = fwd ? n : k, ci = fwd ? k : n;
+        float g[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) g[r][s] = co < Co ? src(co, ci, fwd ? r * 3 + s : (2 - r) * 3 + (2 - s)) : 0.f;
+        float t[6][3];
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) t[a][s] = W4_G[a][0] * g[0][s] + W4_G[a][1] * g[1][s] + W4_G[a][2] * g[2][s];
+        float* U = fwd ? j.out_fwd : j.out_bwd;
+        if (fwd && j.out_fwd == nullptr) return;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b)
+                U[((size_t)(a * 6 + b) * Nrows + n) * K + k] = W4_G[b][0] * t[a][0] + W4_G[b][1] * t[a][1] + W4_G[b][2] * t[a][2];
+    } else if (j.kind == 1) {                        // OHWI [co_pad][T][Ci] and IHWO [Ci][T][co_pad]
+        const size_t total = (size_t)j.co_pad * T * Ci;
+        if (i < total) {
+            const int ci = (int)(i % Ci);
+            const size_t rest = i / Ci;
+            const int t = (int)(rest % T), co = (int)(rest / T);
+            if (j.out_fwd != nullptr) j.out_fwd[i] = co < Co ? src(co, ci, t) : 0.f;
+        } else if (i < 2 * total && j.out_bwd != nullptr) {
+            const size_t e = i - total;
+            const int co = (int)(e % j.co_pad);
+            const size_t rest = e / j.co_pad;
+            const int t = (int)(rest % T), ci = (int)(rest / T);
+            j.out_bwd[e] = co < Co ? src(co, ci, t) : 0.f;
+        }
+    } else {                                         // conv1_1 rows for the im2col GEMM: [Co][32], k = (r*3+s)*3 + c, zero padded
+        const size_t total = (size_t)Co * 32;
+        if (i < total) {
+            const int k = (int)(i % 32), co = (int)(i / 32);
+            j.out_fwd[i] = k < 27 ? j.w0[((size_t)co * 3 + (k % 3)) * 9 + (k / 3)] : 0.f;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int ssd_weight_job_blocks(const ssd_weight_job* job) {
+    if (!job || job->co <= 0 || job->ci <= 0) return -1;
+    size_t elems;
+    if (job->kind == 0) elems = (size_t)job->co * job->ci + (job->out_bwd ? (size_t)job->ci * job->co_pad : 0);
+    else if (job->kind == 1) elems = (size_t)job->co_pad * job->taps * job->ci * (job->out_bwd ? 2 : 1);
+    else if (job->kind == 2) elems = (size_t)job->co * 32;
+    else return -1;
+    const size_t b = (elems + 255) / 256;
+    return b >= (1u << 30) ? -1 : (int)b;
+}
+
+extern "C" int ssd_weights_prepare(const ssd_weight_job* jobs_device, const int* block_start_device, int njobs, int total_blocks, void* stream) {
+    if (!jobs_device || !block_start_device) return SSD_ERR_NULL;
+    if (njobs <= 0 || total_blocks <= 0) return SSD_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(weight_jobs_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_device, block_start_device, njobs);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}

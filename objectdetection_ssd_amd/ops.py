@@ -820,3 +820,38 @@ def wino_wgrad_gemm(wgrad_planes: torch.Tensor, x_planes: torch.Tensor, bias_par
     check(lib.ssd_wino4_wgrad_gemm(wgrad_planes.data_ptr(), x_planes.data_ptr(), ldy, _ptr(bias_partial), dw.data_ptr(), _ptr(db), C.byref(g),
                                    ws.data_ptr(), ws.numel(), _stream()), "wino_wgrad_gemm")
     return dw, db
+
+
+class WeightTable:
+    """Job table of `ssd_weights_prepare`: every filter transform / re-layout of a training step in one launch.  `jobs` is a list of
+    dicts(kind, w0, w1 or None, co0, co, ci, taps, co_pad, out_fwd, out_bwd or None) holding tensors; the table keeps them alive and is
+    valid while their storage does not move."""
+
+    def __init__(self, jobs, device):
+        import numpy as np
+        lib = _lib.load()
+        arr = (_lib.WeightJob * len(jobs))()
+        starts, total = [], 0
+        self.keep = []
+        for a, j in zip(arr, jobs):
+            for t in (j["w0"], j.get("w1"), j.get("out_fwd"), j.get("out_bwd")):
+                if t is not None:
+                    _req(t, "weight job tensor")
+                    self.keep.append(t)
+            a.w0 = j["w0"].data_ptr()
+            a.w1 = j["w1"].data_ptr() if j.get("w1") is not None else j["w0"].data_ptr()
+            a.out_fwd = _ptr(j.get("out_fwd"))
+            a.out_bwd = _ptr(j.get("out_bwd"))
+            a.co0, a.co, a.ci, a.taps, a.co_pad, a.kind = j["co0"], j["co"], j["ci"], j["taps"], j["co_pad"], j["kind"]
+            nb = lib.ssd_weight_job_blocks(C.byref(a))
+            if nb <= 0:
+                raise ValueError("bad weight job")
+            starts.append(total)
+            total += nb
+        self.njobs, self.total_blocks = len(jobs), total
+        self.jobs_dev = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(device)
+        self.starts_dev = torch.tensor(starts, dtype=torch.int32).to(device)
+
+    def run(self) -> None:
+        check(_lib.load().ssd_weights_prepare(self.jobs_dev.data_ptr(), self.starts_dev.data_ptr(), self.njobs, self.total_blocks, _stream()),
+              "weights_prepare")

@@ -881,3 +881,47 @@ def test_winograd_f2x2_3x3_forward_and_dgrad(case):
     _close(dw, wt2.grad, tol=2e-4, what=f"winograd wgrad {case}")
     _close(db, b2.grad, tol=2e-4, what=f"winograd bias grad {case}")
     assert torch.equal(dw, dw_b) and torch.equal(db, db_b)
+
+
+def test_weight_job_table_equals_the_per_layer_transforms_bit_for_bit():
+    """ssd_weights_prepare (one launch for every filter transform / re-layout of a training step) against the per-layer entry points it
+    replaces: Winograd F(4x4) filters forward + rotated/transposed backward, OHWI / IHWO copies with padded output channels (a head's
+    loc and conf filters come as two OIHW pieces; a 1x1 layer; fc6's dilated 3x3), conv1_1's im2col rows.  Pure data movement and the
+    same G g G^T arithmetic: bit-exact."""
+    from objectdetection_ssd_amd import ops
+    dev = _dev()
+    g_ = torch.Generator().manual_seed(21)
+    rnd = lambda *s: torch.randn(*s, generator=g_).to(dev)
+    w_wino, w_bb, w_cl = rnd(128, 64, 3, 3), rnd(16, 256, 3, 3), rnd(84, 256, 3, 3)
+    w_hb, w_hc = rnd(24, 64, 3, 3), rnd(126, 64, 3, 3)
+    w_1x1, w_fc6, w_first = rnd(96, 160, 1, 1), rnd(64, 32, 3, 3), rnd(64, 3, 3, 3)
+    e = lambda *s: torch.full(s, float("nan"), device=dev)
+    head = torch.cat([w_bb, w_cl])
+    headw = torch.cat([w_hb, w_hc])                                   # 150 filters -> co_pad 160
+    jobs = [
+        dict(kind=0, w0=w_wino, co0=128, co=128, ci=64, taps=9, co_pad=128, out_fwd=e(36, 128, 64), out_bwd=e(36, 64, 128)),
+        dict(kind=0, w0=w_hb, w1=w_hc, co0=24, co=150, ci=64, taps=9, co_pad=160, out_fwd=e(36, 150, 64), out_bwd=e(36, 64, 160)),
+        dict(kind=1, w0=w_bb, w1=w_cl, co0=16, co=100, ci=256, taps=9, co_pad=128, out_fwd=e(128, 9, 256), out_bwd=e(256, 9, 128)),
+        dict(kind=1, w0=w_1x1, co0=96, co=96, ci=160, taps=1, co_pad=96, out_fwd=e(96, 1, 160), out_bwd=e(160, 1, 96)),
+        dict(kind=1, w0=w_fc6, co0=64, co=64, ci=32, taps=9, co_pad=64, out_fwd=e(64, 9, 32), out_bwd=None),
+        dict(kind=2, w0=w_first, co0=64, co=64, ci=3, taps=9, co_pad=64, out_fwd=e(64, 1, 32)),
+    ]
+    table = ops.WeightTable(jobs, dev)
+    assert table.njobs == 6 and table.total_blocks > 6
+    table.run()
+    torch.cuda.synchronize()
+    uf, ub = ops.wino_weights(w_wino, co_pad=128, mo=4)
+    assert torch.equal(jobs[0]["out_fwd"], uf) and torch.equal(jobs[0]["out_bwd"], ub)
+    uf, ub = ops.wino_weights(headw, co_pad=160, mo=4)
+    assert torch.equal(jobs[1]["out_fwd"], uf) and torch.equal(jobs[1]["out_bwd"], ub)
+    assert torch.equal(jobs[2]["out_fwd"], ops.weight_ohwi(head, 128)) and torch.equal(jobs[2]["out_bwd"], ops.weight_ihwo(head, 128))
+    assert float(jobs[2]["out_fwd"][100:].abs().max()) == 0.0
+    assert torch.equal(jobs[3]["out_fwd"], ops.weight_ohwi(w_1x1, 96)) and torch.equal(jobs[3]["out_bwd"], ops.weight_ihwo(w_1x1, 96))
+    assert torch.equal(jobs[4]["out_fwd"], ops.weight_ohwi(w_fc6, 64))
+    assert torch.equal(jobs[5]["out_fwd"], ops.first_weight_rows(w_first))
+    # the table reads the live storage: a second run after an in-place update follows it
+    w_wino.mul_(0.5)
+    table.run()
+    assert torch.equal(jobs[0]["out_fwd"], ops.wino_weights(w_wino, co_pad=128, mo=4)[0])
+    with pytest.raises(ValueError):
+        ops.WeightTable([dict(kind=7, w0=w_wino, co0=128, co=128, ci=64, taps=9, co_pad=128, out_fwd=e(4))], dev)

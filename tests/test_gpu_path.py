@@ -1270,12 +1270,14 @@ def test_second_stream_schedule_is_bitwise_the_single_stream_step():
     for overlap in (True, False, True):
         net._engine.overlap_tail = overlap
         net._engine.overlap_wgrad = overlap                  # ... and the Winograd weight-gradient GEMMs on a third one
+        net._engine.batch_weights = overlap                  # ... and all filter transforms of the step in one launch vs layer by layer
         steps = [M.train_step(net, x, cl, bx) for _ in range(3)]
         for a in steps[1:]:
             assert torch.equal(a[0], steps[0][0]) and torch.equal(a[1], steps[0][1])
             assert all(torch.equal(a[4][k], steps[0][4][k]) for k in steps[0][4])
         res.setdefault(overlap, steps[0])
-    net._engine.overlap_tail = net._engine.overlap_wgrad = True
+    net._engine.overlap_tail = net._engine.batch_weights = True
+    net._engine.overlap_wgrad = False
     a, b = res[True], res[False]
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3]
     assert set(a[4]) == set(b[4]) and len(a[4]) == 71
