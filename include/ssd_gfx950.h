@@ -183,6 +183,15 @@ int ssd_wino4_dy_transform(const float* dy, int ldy, const ssd_conv_geom* g, flo
 size_t ssd_wino4_wgrad_gemm_workspace(const ssd_conv_geom* g, int ldy);
 int ssd_wino4_wgrad_gemm(const float* wgrad_planes, const float* x_planes, int ldy, const float* bias_partial, float* dw_oihw, float* dbias,
                          const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream);
+/* The same two passes when dy is the gradient of the 2x2 / stride-2 / no-pad max pool that is the only reader of this layer's ReLU output
+ * (ssd_conv3x3_wino_fwd_pool): dy is never written to memory.  The pass takes the pooled gradient dpool (N x Hp x Wp x Co), the argmax
+ * codes and the pooled forward output of that pool (its ReLU gate) and forms dy(h, w) on the fly -- what ssd_maxpool_bwd_gated would
+ * have scattered (reference: autograd of MaxPool2d(ReLU(conv)), Model.py:135-137).  ldy must equal Co; Hp = H/2 or (H+1)/2. */
+int ssd_wino4_dy_transform_pooled(const float* dpool, const unsigned char* argmax, const float* y_pooled, int Hp, int Wp, int ldy,
+                                  const ssd_conv_geom* g, float* wgrad_planes, float* dgrad_planes_out, float* bias_partial, void* stream);
+int ssd_conv3x3_wino_wgrad_planes_pooled(const float* planes, const float* dpool, const unsigned char* argmax, const float* y_pooled,
+                                         int Hp, int Wp, int ldy, float* dw_oihw, float* dbias, const ssd_conv_geom* g,
+                                         float* dgrad_planes_out, void* workspace, size_t workspace_bytes, void* stream);
 /* ReLU masks as bits.  The forward's input transform can leave, per (tile, channel quad), one 64-bit word -- bit (a*4+b)*4+e set iff
  * x[4 th + a][4 tw + b][4 c4 + e] > 0 -- in relu_bits_out (tiles x Ci/4 words; may be NULL): the ReLU mask of the layer's INPUT on the tile
  * grid its data gradient is written on (autograd's ReLU backward, Model.py:136-141).  ssd_conv3x3_wino_dgrad_planes_bits applies it in

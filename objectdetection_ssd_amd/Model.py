@@ -183,6 +183,7 @@ class _Engine:
         self.dual_dy = True       # backward: one pass over dy writes the planes of the weight gradient AND of the data gradient
         self.keep_planes = True   # training forward keeps the F(4x4) input planes of the layers whose weight gradient is Winograd
         self.fuse_pool = True     # Winograd F(4x4) layers in pool_after write the pooled map + argmax only
+        self.lazy_pool_grad = True     # ... and in the backward their dy pass reads the pooled gradient: the pool's dx is never written
         self.relu_bits = True     # training forward: the input transform also leaves the ReLU mask of its input as bits for the dgrad epilogue
         self.prof = None          # bench.py: list collecting (label, kernel tag, flops, start event, end event)
         self.bf16 = False         # True: forward / dgrad / fused-wgrad convolutions multiply bf16-rounded operands (f32 accumulate)
@@ -556,6 +557,13 @@ class _Engine:
                 g = aux[op["y"]]
                 xin = T[op["x"]]
                 dyp = None
+                if isinstance(dy, ops.PooledGrad):
+                    # dy exists only behind its pool; the Winograd dy pass of this layer can form it on the fly when that pass feeds
+                    # both the weight gradient and the data gradient -- otherwise it is scattered to memory after all
+                    if not ((need[op["p"] + ".weight"] or need[op["p"] + ".bias"]) and self._wino_wgrad_ok(g, False) and self.WINO_TILE == 4
+                            and self.dual_dy and aux.get("planes:" + op["p"]) is not None and g.Co % 32 == 0 and g.Co <= 1024
+                            and not ops.wino_uses_full(g, 1) and self._wino_ok(g)):
+                        dy = dy.materialize()
                 if need[op["p"] + ".weight"] or need[op["p"] + ".bias"]:
                     if self._wino_wgrad_ok(g, False) and async_wgrad and side_ctx is None and aux.get("planes:" + op["p"]) is not None \
                             and g.Co % 32 == 0 and g.Co <= 1024:
@@ -586,7 +594,8 @@ class _Engine:
                     bits = aux.pop("bits:" + op["p"], None) if (dyp is not None or ops.wino_uses_full(g, 1)) else None
                     deliver(op["x"], lambda dx, acc, mask: self._timed(
                         "dgrad " + op["p"], "winograd_3x3", ops.wino_flops(g),
-                        lambda: ops.conv2d_dgrad_wino(dy, ub, g, dx, mask, acc, planes=dyp, bits=bits if mask is not None else None)))
+                        lambda: ops.conv2d_dgrad_wino(None if isinstance(dy, ops.PooledGrad) else dy, ub, g, dx, mask, acc, planes=dyp,
+                                                      bits=bits if mask is not None else None)))
                     continue
                 _, wb = self._layouts(op["p"], (P[op["p"] + ".weight"],), op["co"], True)
                 deliver(op["x"], lambda dx, acc, mask: self._timed(
@@ -599,6 +608,10 @@ class _Engine:
                 am = aux[op["y"]]
                 yout = T[op["y"]]
                 deliver(op["x"], lambda dx, acc, mask: (
+                    # behind a fused conv -> ReLU -> pool layer: that layer's dy pass reads (dy, argmax, gate) itself
+                    ops.PooledGrad(dy, am, yout, xin.shape)
+                    if (self.lazy_pool_grad and isinstance(xin, _Elided) and mask is not None and not acc and dx is None
+                        and (op["k"], op["s"], op["pad"]) == (2, 2, 0)) else
                     ops.maxpool_bwd(dy, am, tuple(xin.shape), op["k"], op["s"], op["pad"], dx, y_gate=yout)
                     if (mask is not None and not acc) else          # sole consumer of a ReLU output: gate by the pooled output
                     ops.maxpool_bwd(dy, am, tuple(xin.shape), op["k"], op["s"], op["pad"], dx, mask, acc)))

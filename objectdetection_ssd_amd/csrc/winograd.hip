@@ -628,9 +628,15 @@ __global__ __launch_bounds__(256) void wino4_xform_t_kernel(const float* __restr
 // count a multiple of C/4, so a thread keeps its channel quad over the grid-stride loop, and a block combines its threads in a fixed order.
 // Vd (optional): the same pass also writes B^T dy B of the 6x6 patch around each block -- the input planes of this layer's dgrad
 // (wino4_input_kernel's output) -- so dy is read from HBM once for both; the 4x4 block is the patch's interior and comes from cache.
-template <bool BIAS>
+// POOLED: dy is not in memory.  It is the gradient of a 2x2 / stride-2 max pool of this layer's ReLU output, given as the pooled
+// gradient dpool (Hp x Wp), the window argmax codes (byte = 2 * row + column inside the window, as the pool kernels write them) and the
+// pooled forward output (the ReLU gate: > 0).  The 4x4 pooled cells under a 6x6 patch are read once, and dy(ih, iw) = the gated dpool
+// of the cell where the code names (ih & 1, iw & 1), else 0 -- exactly what ssd_maxpool_bwd_gated would have scattered to memory.
+struct PoolSrc { const uint8_t* am; const float* gate; int Hp, Wp; };
+template <bool BIAS, bool POOLED = false>
 __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__ dy, float* __restrict__ Y, int N, int H, int W, int C,
-                                                       int TH, int TW, float* __restrict__ part, int Cvalid, float* __restrict__ Vd) {
+                                                       int TH, int TW, float* __restrict__ part, int Cvalid, float* __restrict__ Vd,
+                                                       const PoolSrc ps = PoolSrc{nullptr, nullptr, 0, 0}) {
     const int C4 = C >> 2;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     const size_t tiles = (size_t)N * TH * TW, total = tiles * C4;
@@ -639,18 +645,50 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
         const int c4 = (int)(i % C4);
         const size_t tile = i / C4;
         const int tw = (int)(tile % TW), th = (int)((tile / TW) % TH), n = (int)(tile / ((size_t)TW * TH));
+        f32x4 pg[4][4];                                      // POOLED: gated pooled gradient and codes of cells (2th-1+r, 2tw-1+q)
+        uint32_t pc[4][4];
+        if (POOLED) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool inner = (r == 1 || r == 2) && (q == 1 || q == 2);
+                    const int ph = 2 * th - 1 + r, pw = 2 * tw - 1 + q;
+                    const bool ok = (inner || Vd != nullptr) && (unsigned)ph < (unsigned)ps.Hp && (unsigned)pw < (unsigned)ps.Wp;
+                    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+                    uint32_t a = 0xffffffffu;
+                    if (ok) {
+                        const size_t idx = (((size_t)n * ps.Hp + ph) * ps.Wp + pw) * C4 + c4;
+                        d = *reinterpret_cast<const f32x4*>(dy + idx * 4);
+                        const f32x4 yv = *reinterpret_cast<const f32x4*>(ps.gate + idx * 4);
+                        a = *reinterpret_cast<const uint32_t*>(ps.am + idx * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) d[e] = yv[e] > 0.f ? d[e] : 0.f;
+                    }
+                    pg[r][q] = d;
+                    pc[r][q] = a;
+                }
+        }
+        // element (a, b) of the 6x6 patch whose corner is (4th-1, 4tw-1); a, b are compile-time after unrolling
+        auto patch = [&](int a, int b) -> f32x4 {
+            const int ih = 4 * th - 1 + a, iw = 4 * tw - 1 + b;
+            const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+            if (!POOLED)
+                return ok ? *reinterpret_cast<const f32x4*>(dy + (((size_t)n * H + ih) * W + iw) * C + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int r = (a + 1) >> 1, q = (b + 1) >> 1;
+            const uint32_t code = (uint32_t)(((a + 1) & 1) * 2 + ((b + 1) & 1));
+            f32x4 g;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = (ok && ((pc[r][q] >> (8 * e)) & 0xffu) == code) ? pg[r][q][e] : 0.f;
+            return g;
+        };
         if (Vd != nullptr) {                                 // uniform: the dgrad planes, as wino4_input_kernel forms them
             f32x4 u[6][6];
 #pragma unroll
             for (int b = 0; b < 6; ++b) {
                 f32x4 d[6];
-                const int iw = 4 * tw - 1 + b;
 #pragma unroll
-                for (int a = 0; a < 6; ++a) {
-                    const int ih = 4 * th - 1 + a;
-                    const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-                    d[a] = ok ? *reinterpret_cast<const f32x4*>(dy + (((size_t)n * H + ih) * W + iw) * C + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+                for (int a = 0; a < 6; ++a) d[a] = patch(a, b);
 #pragma unroll
                 for (int a = 0; a < 6; ++a) {
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -676,13 +714,8 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             f32x4 d[4];
-            const int iw = 4 * tw + b;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const int ih = 4 * th + a;
-                d[a] = (ih < H && iw < W) ? *reinterpret_cast<const f32x4*>(dy + (((size_t)n * H + ih) * W + iw) * C + c4 * 4)
-                                          : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int a = 0; a < 4; ++a) d[a] = patch(a + 1, b + 1);      // the 4x4 block is the patch's interior (from cache / registers)
             if (BIAS) bsum += (d[0] + d[1]) + (d[2] + d[3]);
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
@@ -727,7 +760,7 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
 // split-K over blockIdx.y into out[batch][split][M][N].  Rows beyond K and columns beyond lda / ldb read as zero (buffer range check).
 struct TnParams {
     const float* a; const float* b; float* out;
-    int M, N, K, lda, ldb, tiles_m, tiles_n, ksplit, ksteps_per_split;
+    int M, N, K, lda, ldb, tiles_m, tiles_n, ksplit, ksteps_per_split, groups;      // groups = planes x ksplit
     size_t batch_a, batch_b;
     unsigned a_bytes, b_bytes;
 };
@@ -741,10 +774,14 @@ __global__ __launch_bounds__(256) void wino_gemm_tn_kernel(const TnParams p) {
     float* Bs = lds + 32 * TN_LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    // Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  All output tiles of one (plane, K slice) --
+    // the only blocks that share operand panels -- are therefore given ids with the same residue mod 8: they run on ONE XCD, next to
+    // each other in time, and every panel leaves HBM / the fabric once instead of once per XCD that holds one of its tiles.
     const int nblk = p.tiles_m * p.tiles_n;
-    const int lid = xcd_swizzle(blockIdx.x, nblk);
+    const int idx = (int)(blockIdx.x >> 3), grp = (idx / nblk) * 8 + (int)(blockIdx.x & 7), lid = idx % nblk;
+    if (grp >= p.groups) return;                                     // uniform: the grid is padded to 8 x ceil(groups / 8) groups
     const int m0 = (lid / p.tiles_n) * 64, n0 = (lid % p.tiles_n) * 64;
-    const int by = blockIdx.y, bz = blockIdx.z;
+    const int by = grp % p.ksplit, bz = grp / p.ksplit;
     const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a + (size_t)bz * p.batch_a), 0, (int)p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t srd_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b + (size_t)bz * p.batch_b), 0, (int)p.b_bytes, 0x00020000);
     const int mchunk = tid & 15, krow = tid >> 4;
@@ -878,6 +915,21 @@ int g_xform_cap = 8192;            // ssd_tune_set_wino_xform_blocks: most block
 inline int grid_for(size_t total) {
     const size_t b = (total + 255) / 256, cap = (size_t)g_xform_cap;
     return (int)(b > cap ? cap : (b == 0 ? 1 : b));
+}
+
+// one launch of the dy pass: bias_blocks > 0 = with the bias partial sums on a grid of exactly that many blocks; ps = pooled source or NULL
+void launch_dy_pass(const float* dy, float* Y, const ssd_conv_geom* g, int ldy, int TH, int TW, float* part, int bias_blocks, float* Vd,
+                    const PoolSrc* ps, hipStream_t st) {
+    const size_t tiles = (size_t)g->N * TH * TW;
+    const PoolSrc none{nullptr, nullptr, 0, 0};
+    if (bias_blocks > 0) {
+        if (ps) hipLaunchKernelGGL((wino4_dy_kernel<true, true>), dim3(bias_blocks), dim3(256), 0, st, dy, Y, g->N, g->H, g->W, ldy, TH, TW, part, g->Co, Vd, *ps);
+        else hipLaunchKernelGGL((wino4_dy_kernel<true, false>), dim3(bias_blocks), dim3(256), 0, st, dy, Y, g->N, g->H, g->W, ldy, TH, TW, part, g->Co, Vd, none);
+    } else {
+        const dim3 grid(grid_for(tiles * (ldy / 4)));
+        if (ps) hipLaunchKernelGGL((wino4_dy_kernel<false, true>), grid, dim3(256), 0, st, dy, Y, g->N, g->H, g->W, ldy, TH, TW, static_cast<float*>(nullptr), 0, Vd, *ps);
+        else hipLaunchKernelGGL((wino4_dy_kernel<false, false>), grid, dim3(256), 0, st, dy, Y, g->N, g->H, g->W, ldy, TH, TW, static_cast<float*>(nullptr), 0, Vd, none);
+    }
 }
 
 // one Winograd convolution, F(mo x mo, 3x3) with mo = 2 or 4: in (N,H,W,Cin) -> out (N,H,W,ldo) first Cout channels
@@ -1032,8 +1084,15 @@ WinoWgradPlan wino_wgrad_plan(const ssd_conv_geom* g, int ldy, int mo) {
     const int ksteps = w.Tpad / 32;
     if (ks > ksteps / 8) ks = ksteps / 8;
     if (ks < 1) ks = 1;
-    const int per = (ksteps + ks - 1) / ks;
+    int per = (ksteps + ks - 1) / ks;
     w.ks = (ksteps + per - 1) / per;
+    // Output tiles that share panels run as one group per XCD (wino_gemm_tn_kernel): keep planes x slices a multiple of 8 (36 planes:
+    // an even slice count) so that every XCD gets the same number of groups.
+    if (bp > w.P && mo == 4 && (w.ks & 1) && ksteps >= 2 * (w.ks + 1)) {
+        per = (ksteps + w.ks) / (w.ks + 1);
+        const int k2 = (ksteps + per - 1) / per;
+        if ((k2 & 1) == 0) w.ks = k2;
+    }
     w.yb = align256((size_t)w.P * ldy * w.Tpad * 4);
     w.vb = align256((size_t)w.P * g->Ci * w.Tpad * 4);
     w.zb = align256((size_t)w.P * w.ks * g->Co * g->Ci * 4);
@@ -1081,7 +1140,7 @@ extern "C" size_t ssd_conv3x3_wino_wgrad_workspace(const ssd_conv_geom* g, int l
 // dw (Co,Ci,3,3) OIHW and, if asked, dbias (Co) from x (N,H,W,Ci) and dy (N,H,W,ldy; columns >= Co zero); mo = 2 or 4
 namespace {
 int wino_wgrad(const float* x, const float* planes, const float* dy, int ldy, float* dw_oihw, float* dbias, const ssd_conv_geom* g, int mo,
-               float* dgrad_planes, void* workspace, size_t workspace_bytes, void* stream);
+               float* dgrad_planes, void* workspace, size_t workspace_bytes, void* stream, const PoolSrc* pool = nullptr);
 }
 extern "C" int ssd_conv3x3_wino_wgrad(const float* x, const float* dy, int ldy, float* dw_oihw, float* dbias, const ssd_conv_geom* g,
                                       int mo, void* workspace, size_t workspace_bytes, void* stream) {
@@ -1128,7 +1187,7 @@ extern "C" int ssd_conv3x3_wino_dgrad_planes(const float* dy_planes, const float
 }
 namespace {
 int wino_wgrad(const float* x, const float* planes, const float* dy, int ldy, float* dw_oihw, float* dbias, const ssd_conv_geom* g, int mo,
-               float* dgrad_planes, void* workspace, size_t workspace_bytes, void* stream) {
+               float* dgrad_planes, void* workspace, size_t workspace_bytes, void* stream, const PoolSrc* pool) {
     if (!dy || !dw_oihw || !workspace) return SSD_ERR_NULL;
     if (!wino_geom_ok(g) || g->Ci % 4 != 0 || ldy % 4 != 0 || ldy < g->Co || (mo != 2 && mo != 4)) return SSD_ERR_BAD_SHAPE;
     if (!ssd_aligned16(dy) || !ssd_aligned16(workspace) || !ssd_aligned16(dw_oihw)) return SSD_ERR_ALIGN;
@@ -1158,11 +1217,9 @@ int wino_wgrad(const float* x, const float* planes, const float* dy, int ldy, fl
             blocks = (blocks + unit - 1) / unit * unit;
             if (blocks > DY_BIAS_BLOCKS) blocks -= unit;
             dy_bias_blocks = blocks;
-            hipLaunchKernelGGL(wino4_dy_kernel<true>, dim3(blocks), dim3(256), 0, st, dy, Yt, g->N, g->H, g->W, ldy, w.TH, w.TW, part, g->Co,
-                               dgrad_planes);
+            launch_dy_pass(dy, Yt, g, ldy, w.TH, w.TW, part, blocks, dgrad_planes, pool, st);
         } else
-            hipLaunchKernelGGL(wino4_dy_kernel<false>, dim3(grid_for(w.tiles * c4)), dim3(256), 0, st, dy, Yt, g->N, g->H, g->W, ldy, w.TH, w.TW,
-                               static_cast<float*>(nullptr), 0, dgrad_planes);
+            launch_dy_pass(dy, Yt, g, ldy, w.TH, w.TW, nullptr, 0, dgrad_planes, pool, st);
         if (planes == nullptr)
             hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(w.tiles * (g->Ci / 4))), dim3(256), 0, st, x, Vt, g->N, g->H, g->W, g->Ci, w.TH,
                                w.TW, static_cast<unsigned long long*>(nullptr));
@@ -1177,7 +1234,8 @@ int wino_wgrad(const float* x, const float* planes, const float* dy, int ldy, fl
         q.batch_a = w.tiles * ldy; q.batch_b = w.tiles * g->Ci;
         if (q.batch_a * 4 >= 0xFFFFFFF0ull || q.batch_b * 4 >= 0xFFFFFFF0ull) return SSD_ERR_BAD_SHAPE;
         q.a_bytes = (unsigned)(q.batch_a * 4); q.b_bytes = (unsigned)(q.batch_b * 4);
-        hipLaunchKernelGGL(wino_gemm_tn_kernel, dim3(q.tiles_m * q.tiles_n, w.ks, w.P), dim3(256), 0, st, q);
+        q.groups = w.P * w.ks;
+        hipLaunchKernelGGL(wino_gemm_tn_kernel, dim3((unsigned)(q.tiles_m * q.tiles_n * ((q.groups + 7) / 8) * 8)), dim3(256), 0, st, q);
         SSD_CHECK_LAUNCH();
     } else if (mo == 2) {
         hipLaunchKernelGGL(wino_xform_t_kernel<1>, gyd, dim3(256), 0, st, dy, Yt, g->N, g->H, g->W, ldy, w.TH, w.TW, w.Tpad);
@@ -1246,8 +1304,9 @@ extern "C" size_t ssd_wino4_bias_partial_floats(const ssd_conv_geom* g, int ldy)
     return (size_t)DY_BIAS_BLOCKS * ldy;
 }
 
-extern "C" int ssd_wino4_dy_transform(const float* dy, int ldy, const ssd_conv_geom* g, float* wgrad_planes, float* dgrad_planes_out,
-                                      float* bias_partial, void* stream) {
+namespace {
+int dy_transform(const float* dy, int ldy, const ssd_conv_geom* g, float* wgrad_planes, float* dgrad_planes_out, float* bias_partial,
+                 const PoolSrc* pool, void* stream) {
     if (!dy || !wgrad_planes) return SSD_ERR_NULL;
     if (!wino_geom_ok(g) || ldy % 4 != 0 || ldy < g->Co) return SSD_ERR_BAD_SHAPE;
     if (!ssd_aligned16(dy) || !ssd_aligned16(wgrad_planes) || (dgrad_planes_out && !ssd_aligned16(dgrad_planes_out)) ||
@@ -1259,14 +1318,46 @@ extern "C" int ssd_wino4_dy_transform(const float* dy, int ldy, const ssd_conv_g
     hipStream_t st = (hipStream_t)stream;
     const int blocks = bias_partial ? dy_bias_blocks_for(g, ldy, tiles) : 0;
     if (bias_partial && blocks == 0) return SSD_ERR_BAD_SHAPE;             // more than 1024 channels: use ssd_conv3x3_wino_wgrad_planes
-    if (blocks > 0)
-        hipLaunchKernelGGL(wino4_dy_kernel<true>, dim3(blocks), dim3(256), 0, st, dy, wgrad_planes, g->N, g->H, g->W, ldy, TH, TW, bias_partial,
-                           g->Co, dgrad_planes_out);
-    else
-        hipLaunchKernelGGL(wino4_dy_kernel<false>, dim3(grid_for(tiles * (ldy / 4))), dim3(256), 0, st, dy, wgrad_planes, g->N, g->H, g->W, ldy,
-                           TH, TW, static_cast<float*>(nullptr), 0, dgrad_planes_out);
+    launch_dy_pass(dy, wgrad_planes, g, ldy, TH, TW, bias_partial, blocks, dgrad_planes_out, pool, st);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
+}
+}  // namespace
+
+extern "C" int ssd_wino4_dy_transform(const float* dy, int ldy, const ssd_conv_geom* g, float* wgrad_planes, float* dgrad_planes_out,
+                                      float* bias_partial, void* stream) {
+    return dy_transform(dy, ldy, g, wgrad_planes, dgrad_planes_out, bias_partial, nullptr, stream);
+}
+
+namespace {
+// the pooled gradient source of the two ..._pooled entry points, checked: the pool must be the 2x2 / stride-2 / no-pad one over this layer's output
+int pool_src(const ssd_conv_geom* g, int ldy, const float* dpool, const unsigned char* argmax, const float* y_pooled, int Hp, int Wp, PoolSrc* ps) {
+    if (!dpool || !argmax || !y_pooled) return SSD_ERR_NULL;
+    if (!wino_geom_ok(g) || ldy != g->Co || Hp < g->H / 2 || Wp < g->W / 2 || Hp <= 0 || Wp <= 0 || 2 * Hp > g->H + 1 || 2 * Wp > g->W + 1)
+        return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(y_pooled) || ((uintptr_t)argmax & 3) != 0) return SSD_ERR_ALIGN;
+    ps->am = argmax; ps->gate = y_pooled; ps->Hp = Hp; ps->Wp = Wp;
+    return SSD_OK;
+}
+}  // namespace
+
+extern "C" int ssd_wino4_dy_transform_pooled(const float* dpool, const unsigned char* argmax, const float* y_pooled, int Hp, int Wp, int ldy,
+                                             const ssd_conv_geom* g, float* wgrad_planes, float* dgrad_planes_out, float* bias_partial,
+                                             void* stream) {
+    if (!g) return SSD_ERR_NULL;
+    PoolSrc ps;
+    const int e = pool_src(g, ldy, dpool, argmax, y_pooled, Hp, Wp, &ps);
+    return e != SSD_OK ? e : dy_transform(dpool, ldy, g, wgrad_planes, dgrad_planes_out, bias_partial, &ps, stream);
+}
+
+extern "C" int ssd_conv3x3_wino_wgrad_planes_pooled(const float* planes, const float* dpool, const unsigned char* argmax, const float* y_pooled,
+                                                    int Hp, int Wp, int ldy, float* dw_oihw, float* dbias, const ssd_conv_geom* g,
+                                                    float* dgrad_planes_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!planes || !g) return SSD_ERR_NULL;
+    if (!ssd_aligned16(planes) || (dgrad_planes_out && !ssd_aligned16(dgrad_planes_out))) return SSD_ERR_ALIGN;
+    PoolSrc ps;
+    const int e = pool_src(g, ldy, dpool, argmax, y_pooled, Hp, Wp, &ps);
+    return e != SSD_OK ? e : wino_wgrad(nullptr, planes, dpool, ldy, dw_oihw, dbias, g, 4, dgrad_planes_out, workspace, workspace_bytes, stream, &ps);
 }
 
 extern "C" size_t ssd_wino4_wgrad_gemm_workspace(const ssd_conv_geom* g, int ldy) {
@@ -1294,7 +1385,8 @@ extern "C" int ssd_wino4_wgrad_gemm(const float* wgrad_planes, const float* x_pl
     q.batch_a = w.tiles * ldy; q.batch_b = w.tiles * g->Ci;
     if (q.batch_a * 4 >= 0xFFFFFFF0ull || q.batch_b * 4 >= 0xFFFFFFF0ull) return SSD_ERR_BAD_SHAPE;
     q.a_bytes = (unsigned)(q.batch_a * 4); q.b_bytes = (unsigned)(q.batch_b * 4);
-    hipLaunchKernelGGL(wino_gemm_tn_kernel, dim3(q.tiles_m * q.tiles_n, w.ks, w.P), dim3(256), 0, st, q);
+    q.groups = w.P * w.ks;
+    hipLaunchKernelGGL(wino_gemm_tn_kernel, dim3((unsigned)(q.tiles_m * q.tiles_n * ((q.groups + 7) / 8) * 8)), dim3(256), 0, st, q);
     SSD_CHECK_LAUNCH();
     const size_t total = (size_t)g->Co * g->Ci;
     int ks_left = w.ks;

@@ -759,7 +759,11 @@ def conv2d_wgrad_wino(x: Optional[torch.Tensor], dy: torch.Tensor, g: ConvGeom, 
     planes: the transformed input the forward kept (`conv2d_fwd_wino(..., keep_planes=True)`); x is then not read.
     dgrad_planes (needs planes): the pass over dy also forms this layer's dgrad input planes -> (dw, dbias, planes_dy (36, tiles, ldy))
     for `conv2d_dgrad_wino(None, ..., planes=planes_dy)`."""
-    _req(dy, "dy")
+    pooled = isinstance(dy, PooledGrad)
+    if pooled and planes is None:
+        raise ValueError("conv2d_wgrad_wino: a pooled gradient needs the kept forward planes")
+    if not pooled:
+        _req(dy, "dy")
     if planes is not None:
         _req(planes, "planes")
         if mo != 4 or tuple(planes.shape) != tuple(wino_planes_shape(g)):
@@ -768,13 +772,13 @@ def conv2d_wgrad_wino(x: Optional[torch.Tensor], dy: torch.Tensor, g: ConvGeom, 
         _req(x, "x")
         if tuple(x.shape) != (g.N, g.H, g.W, g.Ci):
             raise ValueError("conv2d_wgrad_wino: shapes do not match the geometry")
-    if dy.numel() != g.N * g.H * g.W * ldy:
+    if not pooled and dy.numel() != g.N * g.H * g.W * ldy:
         raise ValueError("conv2d_wgrad_wino: shapes do not match the geometry")
     lib = _lib.load()
     nbytes = lib.ssd_conv3x3_wino_wgrad_workspace(C.byref(g), ldy, mo)
     if nbytes == 0:
         raise ValueError("conv2d_wgrad_wino: not a 3x3 / stride 1 / pad 1 geometry")
-    dev = dy.device
+    dev = planes.device if pooled else dy.device
     ws = workspace(nbytes, dev, "wino")
     dw = torch.empty((g.Co, g.Ci, 3, 3), device=dev, dtype=torch.float32)
     db = torch.empty((g.Co,), device=dev, dtype=torch.float32) if want_bias else None
@@ -782,6 +786,10 @@ def conv2d_wgrad_wino(x: Optional[torch.Tensor], dy: torch.Tensor, g: ConvGeom, 
         raise ValueError("conv2d_wgrad_wino: dgrad_planes needs the kept forward planes")
     if planes is not None:
         pd = torch.empty((36, planes.shape[1], ldy), device=dev, dtype=torch.float32) if dgrad_planes else None
+        if pooled:
+            check(lib.ssd_conv3x3_wino_wgrad_planes_pooled(planes.data_ptr(), *_pooled_args(dy, g, ldy), ldy, dw.data_ptr(), _ptr(db), C.byref(g),
+                                                           _ptr(pd), ws.data_ptr(), ws.numel(), _stream()), "conv2d_wgrad_wino_pooled")
+            return (dw, db, pd) if dgrad_planes else (dw, db)
         check(lib.ssd_conv3x3_wino_wgrad_planes(planes.data_ptr(), dy.data_ptr(), ldy, dw.data_ptr(), _ptr(db), C.byref(g), _ptr(pd),
                                                 ws.data_ptr(), ws.numel(), _stream()), "conv2d_wgrad_wino")
         return (dw, db, pd) if dgrad_planes else (dw, db)
@@ -793,16 +801,41 @@ def conv2d_wgrad_wino(x: Optional[torch.Tensor], dy: torch.Tensor, g: ConvGeom, 
 def wino_dy_transform(dy: torch.Tensor, g: ConvGeom, ldy: int, dgrad_planes: bool = True, want_bias: bool = True):
     """First half of the F(4x4) weight gradient on kept planes: one pass over dy -> (wgrad_planes (36, tiles, ldy),
     dgrad_planes (36, tiles, ldy) or None, bias_partial or None).  The data gradient only needs dgrad_planes."""
-    _req(dy, "dy")
+    pooled = isinstance(dy, PooledGrad)
+    dev = dy.dpool.device if pooled else _req(dy, "dy").device
     tiles = wino_planes_shape(g)[1]
-    if dy.numel() != g.N * g.H * g.W * ldy or ldy % 4 != 0 or ldy < g.Co:
+    if (not pooled and dy.numel() != g.N * g.H * g.W * ldy) or ldy % 4 != 0 or ldy < g.Co:
         raise ValueError("wino_dy_transform: shapes do not match the geometry")
     lib = _lib.load()
-    Y = torch.empty((36, tiles, ldy), device=dy.device, dtype=torch.float32)
-    Vd = torch.empty((36, tiles, ldy), device=dy.device, dtype=torch.float32) if dgrad_planes else None
-    part = torch.empty((lib.ssd_wino4_bias_partial_floats(C.byref(g), ldy),), device=dy.device, dtype=torch.float32) if want_bias else None
-    check(lib.ssd_wino4_dy_transform(dy.data_ptr(), ldy, C.byref(g), Y.data_ptr(), _ptr(Vd), _ptr(part), _stream()), "wino_dy_transform")
+    Y = torch.empty((36, tiles, ldy), device=dev, dtype=torch.float32)
+    Vd = torch.empty((36, tiles, ldy), device=dev, dtype=torch.float32) if dgrad_planes else None
+    part = torch.empty((lib.ssd_wino4_bias_partial_floats(C.byref(g), ldy),), device=dev, dtype=torch.float32) if want_bias else None
+    if pooled:
+        check(lib.ssd_wino4_dy_transform_pooled(*_pooled_args(dy, g, ldy), ldy, C.byref(g), Y.data_ptr(), _ptr(Vd), _ptr(part), _stream()),
+              "wino_dy_transform_pooled")
+    else:
+        check(lib.ssd_wino4_dy_transform(dy.data_ptr(), ldy, C.byref(g), Y.data_ptr(), _ptr(Vd), _ptr(part), _stream()), "wino_dy_transform")
     return Y, Vd, part
+
+
+class PooledGrad:
+    """A gradient that exists only as the gradient of the 2x2 / stride-2 max pool behind it: (dpool (N,Hp,Wp,C), argmax codes, pooled forward
+    output = the ReLU gate).  `wino_dy_transform` / `conv2d_wgrad_wino` take it in place of dy; `materialize()` is the scatter to memory."""
+
+    def __init__(self, dpool: torch.Tensor, argmax: torch.Tensor, y_pooled: torch.Tensor, in_shape):
+        _req(dpool, "dpool"); _req(y_pooled, "y_pooled"); _req(argmax, "argmax", torch.uint8)
+        if tuple(dpool.shape) != tuple(y_pooled.shape) or tuple(argmax.shape) != tuple(dpool.shape) or dpool.shape[3] != in_shape[3]:
+            raise ValueError("PooledGrad: dpool, argmax and the pooled output must have one shape, and the channels of the pool's input")
+        self.dpool, self.argmax, self.y_pooled, self.in_shape = dpool, argmax, y_pooled, tuple(in_shape)
+
+    def materialize(self, dx: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return maxpool_bwd(self.dpool, self.argmax, self.in_shape, 2, 2, 0, dx, y_gate=self.y_pooled)
+
+
+def _pooled_args(dy: "PooledGrad", g: ConvGeom, ldy: int):
+    if dy.in_shape != (g.N, g.H, g.W, g.Co) or ldy != g.Co:
+        raise ValueError("pooled gradient does not match the geometry")
+    return dy.dpool.data_ptr(), dy.argmax.data_ptr(), dy.y_pooled.data_ptr(), dy.dpool.shape[1], dy.dpool.shape[2]
 
 
 def wino_wgrad_gemm(wgrad_planes: torch.Tensor, x_planes: torch.Tensor, bias_partial: Optional[torch.Tensor], g: ConvGeom, ldy: int):

@@ -925,3 +925,40 @@ def test_weight_job_table_equals_the_per_layer_transforms_bit_for_bit():
     assert torch.equal(jobs[0]["out_fwd"], ops.wino_weights(w_wino, co_pad=128, mo=4)[0])
     with pytest.raises(ValueError):
         ops.WeightTable([dict(kind=7, w0=w_wino, co0=128, co=128, ci=64, taps=9, co_pad=128, out_fwd=e(4))], dev)
+
+
+@pytest.mark.parametrize("case", [(2, 22, 22, 32, 64, False), (1, 75, 75, 32, 32, True), (2, 9, 13, 64, 64, False), (1, 15, 11, 32, 96, True),
+                                  (32, 300, 300, 64, 64, False), (32, 75, 75, 256, 256, True)])
+def test_winograd_dy_pass_from_the_pooled_gradient_equals_scatter_then_transform(case):
+    """The backward of conv -> ReLU -> MaxPool2d(2, 2[, ceil]) (Model.py:135-137) without ever writing the pool's input gradient: the dy
+    pass of the Winograd weight / data gradient reads (pooled gradient, argmax codes, pooled output as the ReLU gate) and forms dy on the
+    fly.  Selection and gating move no bits, and the transform arithmetic is the same code: every output -- both plane sets, dw, dbias --
+    must EQUAL the two-step form (ssd_maxpool_bwd_gated to memory, then the dy pass over it), odd sizes and ceil-mode edges included."""
+    from objectdetection_ssd_amd import ops
+    dev = _dev()
+    n, h, w, ci, co, ceil = case
+    g_ = torch.Generator().manual_seed(h * 131 + w)
+    act = torch.relu(torch.randn(n, h, w, co, generator=g_)).to(dev)           # ~half the windows gate to zero somewhere
+    y, am = ops.maxpool_fwd(act, 2, 2, 0, ceil)
+    assert float((y == 0).float().mean()) > 0.01
+    dpool = torch.randn(y.shape, generator=g_).to(dev)
+    g = ops.make_geom(n, h, w, ci, co, 3, 1, 1, 1)
+    dy_full = ops.maxpool_bwd(dpool, am, (n, h, w, co), 2, 2, 0, y_gate=y)
+    lazy = ops.PooledGrad(dpool, am, y, (n, h, w, co))
+    assert torch.equal(lazy.materialize(), dy_full)
+    for want_planes in (True, False):
+        Y0, V0, _ = ops.wino_dy_transform(dy_full, g, co, want_planes, True)
+        Y1, V1, _ = ops.wino_dy_transform(lazy, g, co, want_planes, True)
+        assert torch.equal(Y0, Y1), "wgrad planes"
+        if want_planes:
+            assert torch.equal(V0, V1), "dgrad planes"
+            del V0, V1
+        del Y0, Y1
+    kept = torch.randn(ops.wino_planes_shape(g), generator=g_).to(dev) if n < 32 else torch.randn(ops.wino_planes_shape(g), device=dev)
+    dw0, db0, p0 = ops.conv2d_wgrad_wino(None, dy_full, g, co, True, mo=4, planes=kept, dgrad_planes=True)
+    dw1, db1, p1 = ops.conv2d_wgrad_wino(None, lazy, g, co, True, mo=4, planes=kept, dgrad_planes=True)
+    assert torch.equal(dw0, dw1) and torch.equal(db0, db1) and torch.equal(p0, p1)
+    # the bias gradient is the plain sum of the scattered gradient
+    _close(db1, dy_full.double().sum((0, 1, 2)).float(), 1e-4, "dbias")
+    with pytest.raises(ValueError):
+        ops.wino_dy_transform(ops.PooledGrad(dpool, am, y, (n, h, w, co)), ops.make_geom(n, h + 4, w, ci, co, 3, 1, 1, 1), co)

@@ -1292,6 +1292,37 @@ def test_second_stream_schedule_is_bitwise_the_single_stream_step():
     assert torch.equal(l0, l1) and torch.equal(c0, c1)
 
 
+def test_pool_gradient_formed_inside_the_dy_pass_is_bitwise_the_scattered_one():
+    """Behind conv1_2 / conv2_2 / conv3_3 (fused conv -> ReLU -> 2x2 pool, Model.py:135-137) the engine never writes the pool's input
+    gradient: the layer's Winograd dy pass reads the pooled gradient, the argmax codes and the pooled output.  Same values, same
+    arithmetic: every output and gradient of a train step equals the engine with the scatter kernel, bit for bit; a layer whose
+    weights need no gradient falls back to the scatter and still gives the same data gradients."""
+    import grad_measure as M
+    from objectdetection_ssd_amd import Model
+    torch.manual_seed(12)
+    net = Model.SSD_300().to(DEV)
+    x, cl, bx = M.bench_batch(bs=2, seed=78)
+    res = {}
+    for lazy in (True, False):
+        net._engine.lazy_pool_grad = lazy
+        res[lazy] = M.train_step(net, x, cl, bx)
+    a, b = res[True], res[False]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and len(a[4]) == 71
+    for k in a[4]:
+        assert torch.equal(a[4][k], b[4][k]), k
+    frozen = ["model.features.2.weight", "model.features.2.bias"]                 # conv1_2 frozen: its dy must be materialised after all
+    P = dict(net.named_parameters())
+    for nme in frozen:
+        P[nme].requires_grad_(False)
+    net._engine.lazy_pool_grad = True
+    c = M.train_step(net, x, cl, bx)
+    for nme in frozen:
+        P[nme].requires_grad_(True)
+    for k in c[4]:
+        assert torch.equal(c[4][k], a[4][k]), k
+    assert not any(k in c[4] for k in frozen)
+
+
 def test_ssd512_at_its_per_gpu_batch_vs_oracle_and_direct_engine():
     """BASELINE configs[3] (build-defined SSD512, 16 images per GPU) at that batch: the forward + loss of the default engine against the
     oracle's restatement on the CPU (loc / conf / both losses 1e-4, per-prior classes bit-exact; parity UNPINNED by the reference,
