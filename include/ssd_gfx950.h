@@ -214,6 +214,10 @@ int ssd_conv3x3_wino_dgrad_planes(const float* dy_planes, const float* U_bwd, in
  * form; 0: never (batched GEMM + output transform kernels); 1: wherever the geometry allows. */
 int ssd_tune_set_wino_xform_blocks(int blocks);   /* grid cap of the Winograd transform kernels (default 8192; 64 .. 65535) */
 int ssd_tune_set_wino_fused(int mode);
+/* The plane GEMMs of the layers that do not take the one-kernel form: persistent 128 x 128 LDS-DMA kernel (gemm_nt.hip) instead of the
+ * generic 64 x 64 implicit-GEMM kernel.  1: wherever K % 32 == 0 and K >= 64; -1 (default) / 0: never -- measured no faster (both kernels
+ * sit at the device's sustained f32 MFMA rate); kept, tested bit-identical, as the evidence for that statement. */
+int ssd_tune_set_gemm_nt(int mode);
 /* The whole convolution (input transform too) in one kernel where the reduction length is 64 (128 when forced): -1 automatic, 0 never, 1 force.
  * ssd_conv3x3_wino_uses_full tells the caller whether a geometry's forward (0) / data gradient from dy (1) takes that kernel -- it then
  * needs no dgrad planes from ssd_wino4_dy_transform. */

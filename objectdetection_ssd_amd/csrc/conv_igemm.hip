@@ -1234,6 +1234,9 @@ __attribute__((visibility("hidden"))) void ssd_internal_prof_close(int slot, hip
     if (slot >= 0) (void)hipEventRecord(g_prof_ev[2 * slot + 1], st);
 }
 
+int ssd_internal_gemm_nt_wants(int M, int K, int N, int n_rows, int nbatch);
+int ssd_internal_gemm_nt(const float* a, const float* w, float* out, int M, int K, int N, int n_rows, int nbatch, size_t batch_a_elems,
+                         size_t batch_w_elems, hipStream_t st);
 // Internal (not part of the C ABI): `nbatch` independent GEMMs out[b][M][N] = a[b][M][K] * w[b][N][K]^T on the 64x64 f32 kernel
 // (the sixteen planes of a Winograd F(2x2,3x3) convolution).  K % 32 == 0; rows of w beyond n_rows read as zero.
 // ksplit > 1: every GEMM is cut into K slices that write raw partial tiles to out[b][slice][M][N] (the caller adds them up).
@@ -1258,15 +1261,18 @@ __attribute__((visibility("hidden"))) int ssd_internal_gemm_batched(const float*
         p.slab = out;
     }
     p.nbatch = nbatch; p.batch_a = batch_a_elems; p.batch_w = batch_w_elems; p.batch_out = (size_t)M * N;
+    const bool nt = ksplit == 1 && ssd_internal_gemm_nt_wants(M, K, N, n_rows, nbatch);      // the 128x128 LDS-DMA kernel (gemm_nt.hip)
     const int i = g_prof_on.load(std::memory_order_acquire) ? g_prof_n.fetch_add(1, std::memory_order_relaxed) : PROF_MAX;
     if (i < PROF_MAX) {                                  // measurement aid: this launch alone between two events of the library
         g_prof_flops[i] = 2.0 * M * K * N * nbatch;
-        g_prof_kind[i] = 0;
+        g_prof_kind[i] = nt ? 3 : 0;
         (void)hipEventRecord(g_prof_ev[2 * i], st);
-        const int e = launch_igemm<64, 64, 2, 2, 1, true>(p, st);
+        const int e = nt ? ssd_internal_gemm_nt(a, w, out, M, K, N, n_rows, nbatch, batch_a_elems, batch_w_elems, st)
+                         : launch_igemm<64, 64, 2, 2, 1, true>(p, st);
         (void)hipEventRecord(g_prof_ev[2 * i + 1], st);
         return e;
     }
+    if (nt) return ssd_internal_gemm_nt(a, w, out, M, K, N, n_rows, nbatch, batch_a_elems, batch_w_elems, st);
     return launch_igemm<64, 64, 2, 2, 1, true>(p, st);
 }
 

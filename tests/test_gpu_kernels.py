@@ -962,3 +962,46 @@ def test_winograd_dy_pass_from_the_pooled_gradient_equals_scatter_then_transform
     _close(db1, dy_full.double().sum((0, 1, 2)).float(), 1e-4, "dbias")
     with pytest.raises(ValueError):
         ops.wino_dy_transform(ops.PooledGrad(dpool, am, y, (n, h, w, co)), ops.make_geom(n, h + 4, w, ci, co, 3, 1, 1, 1), co)
+
+
+NT_CASES = [  # n, h, w, ci, co: full 128-wide tiles, ragged rows (tiles % 128 != 0), fewer than 128 rows, column tiles cut (co % 128 != 0), K = 32
+    (2, 38, 38, 256, 256), (1, 19, 19, 512, 128), (1, 10, 10, 256, 128), (2, 30, 26, 288, 100), (1, 75, 75, 128, 384), (3, 13, 21, 32, 160),
+]
+
+
+@pytest.mark.parametrize("case", NT_CASES)
+def test_winograd_plane_gemm_128_tile_dma_kernel_equals_generic_kernel(case):
+    """csrc/gemm_nt.hip (128 x 128 tile, LDS-DMA double buffer, XOR-swizzled unpadded rows, XCD-grouped block order) against the generic
+    64 x 64 implicit-GEMM kernel on the plane GEMMs of the Winograd forward and data gradient.  Both walk K in the same order with the
+    same MFMA, so the outputs must be EQUAL; both stay within 1e-4 of an f64 convolution.  Forced on (mode 1) it also takes shapes that
+    the automatic rule leaves to the generic kernel: cut column tiles, fewer rows than a tile, K = 32."""
+    from objectdetection_ssd_amd import _lib, ops
+    lib = _lib.load()
+    n, h, w, ci, co = case
+    dev = _dev()
+    full = (n, h, w, ci, co, 3, 1, 1, 1)
+    x, wt, b = _conv_data(full, seed=201)
+    x64 = x.double().requires_grad_(True)
+    y64 = F.conv2d(x64, wt.double(), b.double(), padding=1)
+    dy = torch.randn(y64.shape, generator=torch.Generator().manual_seed(202))
+    y64.backward(dy.double())
+    g = ops.make_geom(*full)
+    ld = ops.pad32(co)
+    uf, ub = ops.wino_weights(wt.to(dev), ld, mo=4)
+    xd = _nhwc(x).to(dev)
+    dy_p = torch.zeros(n, h, w, ld)
+    dy_p[..., :co] = _nhwc(dy)
+    dy_p = dy_p.to(dev)
+    out = {}
+    try:
+        _lib.check(lib.ssd_tune_set_wino_fused(0), "tune")                 # K <= 128 would otherwise take the one-kernel form
+        for mode in (0, 1):
+            _lib.check(lib.ssd_tune_set_gemm_nt(mode), "tune")
+            out[mode] = (ops.conv2d_fwd_wino(xd, uf, b.to(dev), g, True, ld=ld), ops.conv2d_dgrad_wino(dy_p, ub, g))
+    finally:
+        _lib.check(lib.ssd_tune_set_wino_fused(-1), "tune")
+        _lib.check(lib.ssd_tune_set_gemm_nt(-1), "tune")
+    assert torch.equal(out[0][0], out[1][0]), "forward differs between the two GEMM kernels"
+    assert torch.equal(out[0][1], out[1][1]), "data gradient differs between the two GEMM kernels"
+    _close(out[1][0][..., :co], _nhwc(F.relu(y64.detach())), what=f"fwd vs f64 {case}")
+    _close(out[1][1], _nhwc(x64.grad), what=f"dgrad vs f64 {case}")
