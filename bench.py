@@ -260,6 +260,7 @@ def main():
     ap.add_argument("--no-overlap-tail", action="store_true", help="tuning aid: everything on one stream")
     ap.add_argument("--overlap-wgrad", action="store_true", help="tuning aid: Winograd weight-gradient GEMMs on their own stream")
     ap.add_argument("--no-batch-weights", action="store_true", help="tuning aid: filter transforms / re-layouts layer by layer")
+    ap.add_argument("--no-wino-dilated", action="store_true", help="tuning aid: fc6 (dilation 4) on the direct kernels")
     ap.add_argument("--no-fuse-pool", action="store_true", help="tuning aid: conv -> ReLU -> 2x2 pool as separate kernels")
     ap.add_argument("--wino-wgrad-nt", action="store_true", help="tuning aid: Winograd weight gradient on transposed planes (NT GEMM)")
     ap.add_argument("--no-keep-planes", action="store_true", help="tuning aid: the Winograd weight gradient transforms x again")
@@ -357,6 +358,8 @@ def main():
     net._engine.overlap_wgrad = args.overlap_wgrad
     if args.no_batch_weights:
         net._engine.batch_weights = False
+    if args.no_wino_dilated:
+        net._engine.wino_dilated = False
     if args.no_fuse_pool:
         net._engine.fuse_pool = False
     if args.no_keep_planes:

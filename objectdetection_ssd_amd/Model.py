@@ -183,6 +183,7 @@ class _Engine:
         self.dual_dy = True       # backward: one pass over dy writes the planes of the weight gradient AND of the data gradient
         self.keep_planes = True   # training forward keeps the F(4x4) input planes of the layers whose weight gradient is Winograd
         self.fuse_pool = True     # Winograd F(4x4) layers in pool_after write the pooled map + argmax only
+        self.wino_dilated = True       # fc6 (3x3, dilation 4) in the Winograd domain too: 49 tiles x 36 products per image instead of 361 x 9
         self.lazy_pool_grad = True     # ... and in the backward their dy pass reads the pooled gradient: the pool's dx is never written
         self.relu_bits = True     # training forward: the input transform also leaves the ReLU mask of its input as bits for the dgrad epilogue
         self.prof = None          # bench.py: list collecting (label, kernel tag, flops, start event, end event)
@@ -235,7 +236,9 @@ class _Engine:
     WINO_MIN_CI = 64              # measured in the step with F(4x4): 256 -> 836, 128 -> 872, 64 -> 879 images/s (F(2x2): only >= 256 paid)
 
     def _wino_ok(self, g) -> bool:
-        return (self.wino and not self.bf16 and not self.x3 and g.R == 3 and g.S == 3 and g.stride == 1 and g.dil == 1 and g.pad == 1
+        # dilation d = padding (fc6, Model.py:149): d x d plain 3x3 convolutions on the sub-lattices of the map, F(4x4) tiles on each
+        dil_ok = g.dil == 1 or (self.wino_dilated and self.WINO_TILE == 4 and 2 <= g.dil <= 4)
+        return (self.wino and not self.bf16 and not self.x3 and g.R == 3 and g.S == 3 and g.stride == 1 and dil_ok and g.pad == g.dil
                 and g.Ci % 32 == 0 and g.Ci >= self.WINO_MIN_CI and g.H >= self.WINO_MIN_HW)
 
     def _wino_wgrad_ok(self, g, head: bool) -> bool:

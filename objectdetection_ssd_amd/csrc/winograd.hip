@@ -21,6 +21,21 @@ int ssd_internal_wino4_full(const float* x, const float* U, int tiles, int K, in
 
 namespace {
 
+// Dilated 3x3 convolutions (dilation D = padding, stride 1: fc6, Model.py:149) are D x D independent 3x3 / pad-1 convolutions, one per
+// sub-lattice x[D*i + a][D*j + b] of the map: y[D*i + a][D*j + b] = sum_rs w[r][s] x[D*(i + r - 1) + a][D*(j + s - 1) + b].  The F(4x4)
+// kernels therefore only need another map from (tile row, row inside the patch) to the image row: tile rows are numbered through the
+// sub-lattices of offsets 0 .. D-1 one after the other (offset a has ceil(ceil((H - a) / D) / 4) of them, first[a] = where they start).
+// D = 1 is the plain convolution: one lattice, image row = 4 * tile - 1 + patch row.  GEMMs, filters and plane layouts do not change.
+struct Lat { int D; int h0[4], w0[4]; };
+// tile row / column t of a map whose lattices start at first[]: offset of its sub-lattice, lattice coordinate of its first OUTPUT row
+__device__ __forceinline__ void lat_tile(const int (&first)[4], int D, int t, int& off, int& base) {
+    off = 0;
+#pragma unroll
+    for (int a = 1; a < 4; ++a)
+        if (a < D && t >= first[a]) off = a;
+    base = 4 * (t - first[off]);
+}
+
 // U[xi][n][k]: rows n = output channels of the GEMM, k = its reduction channels.
 // mode 0 (forward): n = co, k = ci, filter g[r][s] = w[co][ci][r][s]
 // mode 1 (dgrad)  : n = ci, k = co (padded to K), filter g[r][s] = w[co][ci][2-r][2-s]
@@ -365,7 +380,7 @@ __global__ void wino4_weight_kernel(const float* __restrict__ w, float* __restri
 // bits (optional): per (tile, channel quad) one 64-bit word, bit (a*4+b)*4+e = x[4th+a][4tw+b][4c4+e] > 0 -- the ReLU mask of this
 // layer's input on the tile grid its data gradient is written on: the dgrad epilogue then reads 1 bit instead of 32 per element.
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int H, int W, int C,
-                                                          int TH, int TW, unsigned long long* __restrict__ bits) {
+                                                          int TH, int TW, unsigned long long* __restrict__ bits, const Lat lat) {
     const int C4 = C >> 2;
     const size_t tiles = (size_t)N * TH * TW, total = tiles * C4;
     const size_t plane = tiles * C;
@@ -373,16 +388,19 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
         const int c4 = (int)(i % C4);
         const size_t tile = i / C4;
         const int tw = (int)(tile % TW), th = (int)((tile / TW) % TH), n = (int)(tile / ((size_t)TW * TH));
+        int offh, bh, offw, bw;
+        lat_tile(lat.h0, lat.D, th, offh, bh);
+        lat_tile(lat.w0, lat.D, tw, offw, bw);
         f32x4 t[6][6];                                       // B^T d, one input row at a time
         unsigned long long word = 0ull;
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
             f32x4 d[6];
-            const int iw = 4 * tw - 1 + b;
+            const int lw = bw - 1 + b, iw = lat.D * lw + offw;
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
-                const int ih = 4 * th - 1 + a;
-                const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                const int lh = bh - 1 + a, ih = lat.D * lh + offh;
+                const bool ok = lh >= 0 && lw >= 0 && ih < H && iw < W;
                 d[a] = ok ? *reinterpret_cast<const f32x4*>(x + (((size_t)n * H + ih) * W + iw) * C + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
                 if (a >= 1 && a <= 4 && b >= 1 && b <= 4) {
 #pragma unroll
@@ -416,7 +434,7 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
 __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ Mx, float* __restrict__ out, int N, int H, int W, int C,
                                                            int Cvalid, int ldo, int TH, int TW, const float* __restrict__ bias,
                                                            const float* __restrict__ mask, int relu, int accumulate,
-                                                           const unsigned long long* __restrict__ mask_bits) {
+                                                           const unsigned long long* __restrict__ mask_bits, const Lat lat) {
     const int C4 = C >> 2;
     const size_t tiles = (size_t)N * TH * TW, total = tiles * C4;
     const size_t plane = tiles * C;
@@ -424,6 +442,9 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
         const int c4 = (int)(i % C4);
         const size_t tile = i / C4;
         const int tw = (int)(tile % TW), th = (int)((tile / TW) % TH), n = (int)(tile / ((size_t)TW * TH));
+        int offh, bh, offw, bw;
+        lat_tile(lat.h0, lat.D, th, offh, bh);
+        lat_tile(lat.w0, lat.D, tw, offw, bw);
         const float* src = Mx + tile * C + c4 * 4;
         f32x4 t[4][6];                                       // A^T m, one plane column at a time
 #pragma unroll
@@ -448,11 +469,11 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
         }
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const int oh = 4 * th + a;
+            const int oh = lat.D * (bh + a) + offh;
             if (oh >= H) continue;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const int ow = 4 * tw + b;
+                const int ow = lat.D * (bw + b) + offw;
                 if (ow >= W) continue;
                 f32x4 v = bv;
 #pragma unroll
@@ -636,7 +657,7 @@ struct PoolSrc { const uint8_t* am; const float* gate; int Hp, Wp; };
 template <bool BIAS, bool POOLED = false>
 __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__ dy, float* __restrict__ Y, int N, int H, int W, int C,
                                                        int TH, int TW, float* __restrict__ part, int Cvalid, float* __restrict__ Vd,
-                                                       const PoolSrc ps = PoolSrc{nullptr, nullptr, 0, 0}) {
+                                                       const PoolSrc ps, const Lat lat) {
     const int C4 = C >> 2;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     const size_t tiles = (size_t)N * TH * TW, total = tiles * C4;
@@ -645,6 +666,9 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
         const int c4 = (int)(i % C4);
         const size_t tile = i / C4;
         const int tw = (int)(tile % TW), th = (int)((tile / TW) % TH), n = (int)(tile / ((size_t)TW * TH));
+        int offh, bh, offw, bw;                              // sub-lattice of the tile (POOLED sources are plain: D = 1)
+        lat_tile(lat.h0, lat.D, th, offh, bh);
+        lat_tile(lat.w0, lat.D, tw, offw, bw);
         f32x4 pg[4][4];                                      // POOLED: gated pooled gradient and codes of cells (2th-1+r, 2tw-1+q)
         uint32_t pc[4][4];
         if (POOLED) {
@@ -671,8 +695,9 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
         }
         // element (a, b) of the 6x6 patch whose corner is (4th-1, 4tw-1); a, b are compile-time after unrolling
         auto patch = [&](int a, int b) -> f32x4 {
-            const int ih = 4 * th - 1 + a, iw = 4 * tw - 1 + b;
-            const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+            const int lh = bh - 1 + a, lw = bw - 1 + b;
+            const int ih = lat.D * lh + offh, iw = lat.D * lw + offw;
+            const bool ok = lh >= 0 && lw >= 0 && ih < H && iw < W;
             if (!POOLED)
                 return ok ? *reinterpret_cast<const f32x4*>(dy + (((size_t)n * H + ih) * W + iw) * C + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
             const int r = (a + 1) >> 1, q = (b + 1) >> 1;
@@ -917,18 +942,38 @@ inline int grid_for(size_t total) {
     return (int)(b > cap ? cap : (b == 0 ? 1 : b));
 }
 
+// tile grid of an H x W map under dilation D (F(4x4) only): TH x TW tile rows / columns through all D x D sub-lattices
+struct LatPlan { Lat lat; int TH, TW; };
+LatPlan lat_plan(int H, int W, int D) {
+    LatPlan p{};
+    p.lat.D = D;
+    int th = 0, tw = 0;
+    for (int a = 0; a < 4; ++a) {
+        p.lat.h0[a] = th;
+        p.lat.w0[a] = tw;
+        if (a < D) {
+            const int sh = a < H ? (H - a + D - 1) / D : 0, sw = a < W ? (W - a + D - 1) / D : 0;       // rows / columns of sub-lattice a
+            th += (sh + 3) / 4;
+            tw += (sw + 3) / 4;
+        }
+    }
+    p.TH = th; p.TW = tw;
+    return p;
+}
+
 // one launch of the dy pass: bias_blocks > 0 = with the bias partial sums on a grid of exactly that many blocks; ps = pooled source or NULL
-void launch_dy_pass(const float* dy, float* Y, const ssd_conv_geom* g, int ldy, int TH, int TW, float* part, int bias_blocks, float* Vd,
+void launch_dy_pass(const float* dy, float* Y, const ssd_conv_geom* g, int ldy, const LatPlan& lp, float* part, int bias_blocks, float* Vd,
                     const PoolSrc* ps, hipStream_t st) {
+    const int TH = lp.TH, TW = lp.TW;
     const size_t tiles = (size_t)g->N * TH * TW;
     const PoolSrc none{nullptr, nullptr, 0, 0};
     if (bias_blocks > 0) {
-        if (ps) hipLaunchKernelGGL((wino4_dy_kernel<true, true>), dim3(bias_blocks), dim3(256), 0, st, dy, Y, g->N, g->H, g->W, ldy, TH, TW, part, g->Co, Vd, *ps);
-        else hipLaunchKernelGGL((wino4_dy_kernel<true, false>), dim3(bias_blocks), dim3(256), 0, st, dy, Y, g->N, g->H, g->W, ldy, TH, TW, part, g->Co, Vd, none);
+        if (ps) hipLaunchKernelGGL((wino4_dy_kernel<true, true>), dim3(bias_blocks), dim3(256), 0, st, dy, Y, g->N, g->H, g->W, ldy, TH, TW, part, g->Co, Vd, *ps, lp.lat);
+        else hipLaunchKernelGGL((wino4_dy_kernel<true, false>), dim3(bias_blocks), dim3(256), 0, st, dy, Y, g->N, g->H, g->W, ldy, TH, TW, part, g->Co, Vd, none, lp.lat);
     } else {
         const dim3 grid(grid_for(tiles * (ldy / 4)));
-        if (ps) hipLaunchKernelGGL((wino4_dy_kernel<false, true>), grid, dim3(256), 0, st, dy, Y, g->N, g->H, g->W, ldy, TH, TW, static_cast<float*>(nullptr), 0, Vd, *ps);
-        else hipLaunchKernelGGL((wino4_dy_kernel<false, false>), grid, dim3(256), 0, st, dy, Y, g->N, g->H, g->W, ldy, TH, TW, static_cast<float*>(nullptr), 0, Vd, none);
+        if (ps) hipLaunchKernelGGL((wino4_dy_kernel<false, true>), grid, dim3(256), 0, st, dy, Y, g->N, g->H, g->W, ldy, TH, TW, static_cast<float*>(nullptr), 0, Vd, *ps, lp.lat);
+        else hipLaunchKernelGGL((wino4_dy_kernel<false, false>), grid, dim3(256), 0, st, dy, Y, g->N, g->H, g->W, ldy, TH, TW, static_cast<float*>(nullptr), 0, Vd, none, lp.lat);
     }
 }
 
@@ -937,8 +982,10 @@ struct PooledOut { float* y; uint8_t* argmax; int Ho, Wo; };     // destination 
 int wino_conv(int mo, const float* in, int Cin, const float* U, int U_rows, float* out, int ldo, int Cout, const float* bias,
               const float* mask, int relu, int accumulate, int N, int H, int W, void* ws, size_t ws_bytes, hipStream_t st,
               const PooledOut* pooled = nullptr, float* V_keep = nullptr, const float* V_given = nullptr,
-              unsigned long long* bits_out = nullptr, const unsigned long long* mask_bits = nullptr) {
-    const int TH = (H + mo - 1) / mo, TW = (W + mo - 1) / mo, P = (mo + 2) * (mo + 2);
+              unsigned long long* bits_out = nullptr, const unsigned long long* mask_bits = nullptr, int D = 1) {
+    if (D < 1 || D > 4 || (D > 1 && (mo != 4 || pooled != nullptr))) return SSD_ERR_BAD_SHAPE;      // dilation: F(4x4), not into a pool
+    const LatPlan lp = lat_plan(H, W, D);
+    const int TH = mo == 4 ? lp.TH : (H + mo - 1) / mo, TW = mo == 4 ? lp.TW : (W + mo - 1) / mo, P = (mo + 2) * (mo + 2);
     const size_t tiles = (size_t)N * TH * TW;
     const int Cvalid = Cout;
     Cout = (Cout + 3) / 4 * 4;                 // the GEMM and the output transform work on whole 4-channel vectors: the filter rows
@@ -947,16 +994,16 @@ int wino_conv(int mo, const float* in, int Cin, const float* U, int U_rows, floa
     if (ws_bytes < vb + mb) return SSD_ERR_WORKSPACE;
     float* V = V_keep != nullptr ? V_keep : static_cast<float*>(ws);       // kept planes: the weight gradient multiplies them again
     float* Mx = reinterpret_cast<float*>(static_cast<char*>(ws) + vb);
-    if (V_given == nullptr && use_full(mo, Cin, Cout))                      // one kernel from the activation to the output
+    if (D == 1 && V_given == nullptr && use_full(mo, Cin, Cout))            // one kernel from the activation to the output
         return ssd_internal_wino4_full(in, U, (int)tiles, Cin, U_rows, Cout, out, ldo, Cvalid, bias, mask, mask_bits, relu, accumulate, H, W, TH,
                                        TW, pooled ? pooled->y : nullptr, pooled ? pooled->argmax : nullptr, pooled ? pooled->Ho : 0,
                                        pooled ? pooled->Wo : 0, V_keep, bits_out, st);
     if (V_given != nullptr) V = const_cast<float*>(V_given);                // input planes already formed (by the dy pass of the wgrad)
     else if (mo == 2) hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(tiles * (Cin / 4))), dim3(256), 0, st, in, V, N, H, W, Cin, TH, TW);
-    else hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(tiles * (Cin / 4))), dim3(256), 0, st, in, V, N, H, W, Cin, TH, TW, bits_out);
+    else hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(tiles * (Cin / 4))), dim3(256), 0, st, in, V, N, H, W, Cin, TH, TW, bits_out, lp.lat);
     SSD_CHECK_LAUNCH();
     if (mask_bits != nullptr && mo != 4) return SSD_ERR_BAD_SHAPE;
-    if (use_fused(mo, Cin, Cout))
+    if (D == 1 && use_fused(mo, Cin, Cout))
         return ssd_internal_wino4_gemm_out(V, U, (int)tiles, Cin, U_rows, Cout, out, ldo, Cvalid, bias, mask, mask_bits, relu, accumulate, H, W, TH, TW,
                                            pooled ? pooled->y : nullptr, pooled ? pooled->argmax : nullptr, pooled ? pooled->Ho : 0,
                                            pooled ? pooled->Wo : 0, st);
@@ -969,13 +1016,13 @@ int wino_conv(int mo, const float* in, int Cin, const float* U, int U_rows, floa
                            bias, mask, relu, accumulate);
     else
         hipLaunchKernelGGL(wino4_output_kernel, dim3(grid_for(tiles * (Cout / 4))), dim3(256), 0, st, Mx, out, N, H, W, Cout, Cvalid, ldo, TH,
-                           TW, bias, mask, relu, accumulate, mask_bits);
+                           TW, bias, mask, relu, accumulate, mask_bits, lp.lat);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
 }
 
 bool wino_geom_ok(const ssd_conv_geom* g) {
-    return g && g->R == 3 && g->S == 3 && g->stride == 1 && g->dil == 1 && g->pad == 1 && g->Ho == g->H && g->Wo == g->W && g->N > 0 &&
+    return g && g->R == 3 && g->S == 3 && g->stride == 1 && g->dil >= 1 && g->dil <= 4 && g->pad == g->dil && g->Ho == g->H && g->Wo == g->W && g->N > 0 &&
            g->H > 0 && g->W > 0 && g->Ci > 0 && g->Co > 0;
 }
 
@@ -1001,7 +1048,9 @@ extern "C" int ssd_wino_weights(const float* w_oihw, float* U_fwd, float* U_bwd,
 
 extern "C" size_t ssd_conv3x3_wino_workspace(const ssd_conv_geom* g, int direction, int mo) {
     if (!wino_geom_ok(g) || (mo != 2 && mo != 4)) return 0;
-    const size_t tiles = (size_t)g->N * ((g->H + mo - 1) / mo) * ((g->W + mo - 1) / mo), P = (size_t)(mo + 2) * (mo + 2);
+    if (mo == 2 && g->dil != 1) return 0;
+    const LatPlan lp = lat_plan(g->H, g->W, g->dil);
+    const size_t tiles = mo == 4 ? (size_t)g->N * lp.TH * lp.TW : (size_t)g->N * ((g->H + 1) / 2) * ((g->W + 1) / 2), P = (size_t)(mo + 2) * (mo + 2);
     const int co_pad = (g->Co + 31) / 32 * 32;
     const size_t cin = direction == 0 ? g->Ci : co_pad, cout = direction == 0 ? (size_t)(g->Co + 3) / 4 * 4 : (size_t)(g->Ci + 3) / 4 * 4;
     return align256(P * tiles * cin * 4) + align256(P * tiles * cout * 4);
@@ -1013,7 +1062,7 @@ extern "C" int ssd_conv3x3_wino_fwd(const float* x, const float* U_fwd, const fl
     if (!wino_geom_ok(g) || g->Ci % 32 != 0 || ldy < (g->Co + 3) / 4 * 4 || (mo != 2 && mo != 4)) return SSD_ERR_BAD_SHAPE;
     if (!ssd_aligned16(x) || !ssd_aligned16(y) || !ssd_aligned16(workspace) || !ssd_aligned16(U_fwd) || ldy % 4 != 0) return SSD_ERR_ALIGN;
     return wino_conv(mo, x, g->Ci, U_fwd, g->Co, y, ldy, g->Co, bias, nullptr, relu, 0, g->N, g->H, g->W, workspace, workspace_bytes,
-                     (hipStream_t)stream);
+                     (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, nullptr, g->dil);
 }
 
 extern "C" int ssd_conv3x3_wino_fwd_keep(const float* x, const float* U_fwd, const float* bias, float* y, int ldy, const ssd_conv_geom* g,
@@ -1030,7 +1079,7 @@ extern "C" int ssd_conv3x3_wino_fwd_keep_bits(const float* x, const float* U_fwd
     if (!ssd_aligned16(x) || !ssd_aligned16(y) || !ssd_aligned16(workspace) || !ssd_aligned16(U_fwd) || !ssd_aligned16(planes_keep) || ldy % 4 != 0)
         return SSD_ERR_ALIGN;
     return wino_conv(4, x, g->Ci, U_fwd, g->Co, y, ldy, g->Co, bias, nullptr, relu, 0, g->N, g->H, g->W, workspace, workspace_bytes,
-                     (hipStream_t)stream, nullptr, planes_keep, nullptr, reinterpret_cast<unsigned long long*>(relu_bits_out));
+                     (hipStream_t)stream, nullptr, planes_keep, nullptr, reinterpret_cast<unsigned long long*>(relu_bits_out), nullptr, g->dil);
 }
 
 extern "C" int ssd_conv3x3_wino_fwd_pool(const float* x, const float* U_fwd, const float* bias, float* y_pooled, uint8_t* argmax,
@@ -1044,7 +1093,7 @@ extern "C" int ssd_conv3x3_wino_fwd_pool_bits(const float* x, const float* U_fwd
                                               void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !U_fwd || !y_pooled || !workspace) return SSD_ERR_NULL;
     if (relu_bits_out && ((uintptr_t)relu_bits_out & 7)) return SSD_ERR_ALIGN;
-    if (!wino_geom_ok(g) || g->Ci % 32 != 0 || g->Co % 4 != 0) return SSD_ERR_BAD_SHAPE;
+    if (!wino_geom_ok(g) || g->dil != 1 || g->Ci % 32 != 0 || g->Co % 4 != 0) return SSD_ERR_BAD_SHAPE;
     if (!ssd_aligned16(x) || !ssd_aligned16(y_pooled) || !ssd_aligned16(workspace) || !ssd_aligned16(U_fwd) || (bias && !ssd_aligned16(bias)) ||
         (argmax && ((uintptr_t)argmax & 3)) || (planes_keep && !ssd_aligned16(planes_keep)))
         return SSD_ERR_ALIGN;
@@ -1064,18 +1113,19 @@ extern "C" int ssd_conv3x3_wino_dgrad(const float* dy, int ldy, const float* U_b
         (relu_mask && !ssd_aligned16(relu_mask)))
         return SSD_ERR_ALIGN;
     return wino_conv(mo, dy, Co_pad, U_bwd, g->Ci, dx, g->Ci, g->Ci, nullptr, relu_mask, 0, accumulate, g->N, g->H, g->W, workspace,
-                     workspace_bytes, (hipStream_t)stream);
+                     workspace_bytes, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, nullptr, g->dil);
 }
 
 namespace {
 constexpr int COLSUM_BLOCKS = 512;
 constexpr int DY_BIAS_BLOCKS = 2048;      // >= COLSUM_BLOCKS: rows of the bias-gradient partial buffer
 int g_wgrad_tn = 1;               // F(4x4) weight gradient on untransposed planes + the TN GEMM (0: transposed planes + the NT GEMM)
-struct WinoWgradPlan { int TH, TW, Tpad, ks, cdy, P; size_t tiles, yb, vb, zb, pb; };
+struct WinoWgradPlan { int TH, TW, Tpad, ks, cdy, P; size_t tiles, yb, vb, zb, pb; LatPlan lp; };
 WinoWgradPlan wino_wgrad_plan(const ssd_conv_geom* g, int ldy, int mo) {
     WinoWgradPlan w;
     w.P = (mo + 2) * (mo + 2);
-    w.TH = (g->H + mo - 1) / mo; w.TW = (g->W + mo - 1) / mo;
+    w.lp = lat_plan(g->H, g->W, mo == 4 ? g->dil : 1);
+    w.TH = mo == 4 ? w.lp.TH : (g->H + mo - 1) / mo; w.TW = mo == 4 ? w.lp.TW : (g->W + mo - 1) / mo;
     w.tiles = (size_t)g->N * w.TH * w.TW;
     w.Tpad = (int)((w.tiles + 31) / 32 * 32);
     w.cdy = ldy;
@@ -1115,7 +1165,7 @@ extern "C" int ssd_tune_set_wino_full(int mode) {
 
 // 1 if the forward (direction 0) / data gradient from dy (direction 1) of this geometry runs as ONE kernel from the activation (no planes read)
 extern "C" int ssd_conv3x3_wino_uses_full(const ssd_conv_geom* g, int direction) {
-    if (!wino_geom_ok(g)) return 0;
+    if (!wino_geom_ok(g) || g->dil != 1) return 0;
     const int co_pad = (g->Co + 31) / 32 * 32;
     return direction == 0 ? use_full(4, g->Ci, (g->Co + 3) / 4 * 4) : use_full(4, co_pad, g->Ci);
 }
@@ -1162,7 +1212,7 @@ extern "C" int ssd_conv3x3_wino_dgrad_bits(const float* dy, int ldy, const float
     if (!ssd_aligned16(dy) || !ssd_aligned16(dx) || !ssd_aligned16(workspace) || !ssd_aligned16(U_bwd) || ((uintptr_t)relu_bits & 7))
         return SSD_ERR_ALIGN;
     return wino_conv(4, dy, Co_pad, U_bwd, g->Ci, dx, g->Ci, g->Ci, nullptr, nullptr, 0, accumulate, g->N, g->H, g->W, workspace, workspace_bytes,
-                     (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<const unsigned long long*>(relu_bits));
+                     (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<const unsigned long long*>(relu_bits), g->dil);
 }
 extern "C" int ssd_conv3x3_wino_dgrad_planes_bits(const float* dy_planes, const float* U_bwd, int Co_pad, float* dx, const uint64_t* relu_bits,
                                                   int accumulate, const ssd_conv_geom* g, void* workspace, size_t workspace_bytes,
@@ -1173,7 +1223,7 @@ extern "C" int ssd_conv3x3_wino_dgrad_planes_bits(const float* dy_planes, const 
         return SSD_ERR_ALIGN;
     return wino_conv(4, nullptr, Co_pad, U_bwd, g->Ci, dx, g->Ci, g->Ci, nullptr, nullptr, 0, accumulate, g->N, g->H, g->W, workspace,
                      workspace_bytes, (hipStream_t)stream, nullptr, nullptr, dy_planes, nullptr,
-                     reinterpret_cast<const unsigned long long*>(relu_bits));
+                     reinterpret_cast<const unsigned long long*>(relu_bits), g->dil);
 }
 extern "C" int ssd_conv3x3_wino_dgrad_planes(const float* dy_planes, const float* U_bwd, int Co_pad, float* dx, const float* relu_mask,
                                              int accumulate, const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream) {
@@ -1183,7 +1233,7 @@ extern "C" int ssd_conv3x3_wino_dgrad_planes(const float* dy_planes, const float
         (relu_mask && !ssd_aligned16(relu_mask)))
         return SSD_ERR_ALIGN;
     return wino_conv(4, nullptr, Co_pad, U_bwd, g->Ci, dx, g->Ci, g->Ci, nullptr, relu_mask, 0, accumulate, g->N, g->H, g->W, workspace,
-                     workspace_bytes, (hipStream_t)stream, nullptr, nullptr, dy_planes);
+                     workspace_bytes, (hipStream_t)stream, nullptr, nullptr, dy_planes, nullptr, nullptr, g->dil);
 }
 namespace {
 int wino_wgrad(const float* x, const float* planes, const float* dy, int ldy, float* dw_oihw, float* dbias, const ssd_conv_geom* g, int mo,
@@ -1204,6 +1254,7 @@ int wino_wgrad(const float* x, const float* planes, const float* dy, int ldy, fl
     const dim3 gyd(gy > 16384 ? 16384 : gy), gxd(gx > 16384 ? 16384 : gx);
     int dy_bias_blocks = 0;
     if (dgrad_planes != nullptr && !(mo == 4 && (g_wgrad_tn || planes != nullptr))) return SSD_ERR_BAD_SHAPE;
+    if (g->dil != 1 && (pool != nullptr || !(mo == 4 && (g_wgrad_tn || planes != nullptr)))) return SSD_ERR_BAD_SHAPE;   // dilation: the lattice-aware kernels only
     if (mo == 4 && (g_wgrad_tn || planes != nullptr)) {
         // planes in the forward layout [plane][tile][channel]; the GEMM reduces over the tile rows of both.  The x planes are the
         // forward convolution's own B^T d B when the caller kept them.
@@ -1217,12 +1268,12 @@ int wino_wgrad(const float* x, const float* planes, const float* dy, int ldy, fl
             blocks = (blocks + unit - 1) / unit * unit;
             if (blocks > DY_BIAS_BLOCKS) blocks -= unit;
             dy_bias_blocks = blocks;
-            launch_dy_pass(dy, Yt, g, ldy, w.TH, w.TW, part, blocks, dgrad_planes, pool, st);
+            launch_dy_pass(dy, Yt, g, ldy, w.lp, part, blocks, dgrad_planes, pool, st);
         } else
-            launch_dy_pass(dy, Yt, g, ldy, w.TH, w.TW, nullptr, 0, dgrad_planes, pool, st);
+            launch_dy_pass(dy, Yt, g, ldy, w.lp, nullptr, 0, dgrad_planes, pool, st);
         if (planes == nullptr)
             hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(w.tiles * (g->Ci / 4))), dim3(256), 0, st, x, Vt, g->N, g->H, g->W, g->Ci, w.TH,
-                               w.TW, static_cast<unsigned long long*>(nullptr));
+                               w.TW, static_cast<unsigned long long*>(nullptr), w.lp.lat);
         SSD_CHECK_LAUNCH();
         TnParams q;
         q.a = Yt; q.b = planes != nullptr ? planes : Vt; q.out = Zs;
@@ -1312,13 +1363,14 @@ int dy_transform(const float* dy, int ldy, const ssd_conv_geom* g, float* wgrad_
     if (!ssd_aligned16(dy) || !ssd_aligned16(wgrad_planes) || (dgrad_planes_out && !ssd_aligned16(dgrad_planes_out)) ||
         (bias_partial && !ssd_aligned16(bias_partial)))
         return SSD_ERR_ALIGN;
-    const int TH = (g->H + 3) / 4, TW = (g->W + 3) / 4;
-    const size_t tiles = (size_t)g->N * TH * TW;
+    if (pool != nullptr && g->dil != 1) return SSD_ERR_BAD_SHAPE;
+    const LatPlan lp = lat_plan(g->H, g->W, g->dil);
+    const size_t tiles = (size_t)g->N * lp.TH * lp.TW;
     if (tiles >= (1ull << 31)) return SSD_ERR_BAD_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int blocks = bias_partial ? dy_bias_blocks_for(g, ldy, tiles) : 0;
     if (bias_partial && blocks == 0) return SSD_ERR_BAD_SHAPE;             // more than 1024 channels: use ssd_conv3x3_wino_wgrad_planes
-    launch_dy_pass(dy, wgrad_planes, g, ldy, TH, TW, bias_partial, blocks, dgrad_planes_out, pool, st);
+    launch_dy_pass(dy, wgrad_planes, g, ldy, lp, bias_partial, blocks, dgrad_planes_out, pool, st);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
 }
@@ -1333,7 +1385,7 @@ namespace {
 // the pooled gradient source of the two ..._pooled entry points, checked: the pool must be the 2x2 / stride-2 / no-pad one over this layer's output
 int pool_src(const ssd_conv_geom* g, int ldy, const float* dpool, const unsigned char* argmax, const float* y_pooled, int Hp, int Wp, PoolSrc* ps) {
     if (!dpool || !argmax || !y_pooled) return SSD_ERR_NULL;
-    if (!wino_geom_ok(g) || ldy != g->Co || Hp < g->H / 2 || Wp < g->W / 2 || Hp <= 0 || Wp <= 0 || 2 * Hp > g->H + 1 || 2 * Wp > g->W + 1)
+    if (!wino_geom_ok(g) || g->dil != 1 || ldy != g->Co || Hp < g->H / 2 || Wp < g->W / 2 || Hp <= 0 || Wp <= 0 || 2 * Hp > g->H + 1 || 2 * Wp > g->W + 1)
         return SSD_ERR_BAD_SHAPE;
     if (!ssd_aligned16(y_pooled) || ((uintptr_t)argmax & 3) != 0) return SSD_ERR_ALIGN;
     ps->am = argmax; ps->gate = y_pooled; ps->Hp = Hp; ps->Wp = Wp;

@@ -80,11 +80,19 @@ def conv_flops(g: ConvGeom) -> float:
     return 2.0 * g.N * g.Ho * g.Wo * g.Co * g.R * g.S * g.Ci
 
 
+def wino_tiles(g: ConvGeom) -> int:
+    """4x4 output tiles of the F(4x4,3x3) form of a 3x3 / stride-1 convolution with padding = dilation D: the D x D sub-lattices of the
+    map are tiled one by one (csrc/winograd.hip, struct Lat); D = 1 is the plain ceil(H/4) x ceil(W/4) grid."""
+    d = g.dil
+    th = sum((((g.H - a + d - 1) // d) + 3) // 4 for a in range(d) if a < g.H)
+    tw = sum((((g.W - a + d - 1) // d) + 3) // 4 for a in range(d) if a < g.W)
+    return g.N * th * tw
+
+
 def wino_flops(g: ConvGeom):
     """(direct-convolution FLOPs, FLOPs the 36 batched GEMMs of the F(4x4,3x3) form execute: 36 multiplies per 4x4 output tile
     instead of 144, on the tile grid padded to multiples of 4, output channels padded to 32)"""
-    tiles = g.N * ((g.H + 3) // 4) * ((g.W + 3) // 4)
-    return conv_flops(g), 2.0 * 36 * tiles * pad32(g.Co) * g.Ci
+    return conv_flops(g), 2.0 * 36 * wino_tiles(g) * pad32(g.Co) * g.Ci
 
 
 # ---- weights ---------------------------------------------------------------------------
@@ -624,13 +632,12 @@ def _wino_mo(u: torch.Tensor) -> int:
 
 
 def wino_planes_shape(g: ConvGeom):
-    return (36, g.N * ((g.H + 3) // 4) * ((g.W + 3) // 4), g.Ci)
+    return (36, wino_tiles(g), g.Ci)
 
 
 def wino_planes(g: ConvGeom, device) -> torch.Tensor:
     """Buffer for the F(4x4) transformed input of a convolution, [36][tiles][Ci] (include/ssd_gfx950.h ssd_conv3x3_wino_fwd_keep)."""
-    tiles = g.N * ((g.H + 3) // 4) * ((g.W + 3) // 4)
-    return torch.empty((36, tiles, g.Ci), device=device, dtype=torch.float32)
+    return torch.empty((36, wino_tiles(g), g.Ci), device=device, dtype=torch.float32)
 
 
 def wino_uses_full(g: ConvGeom, direction: int) -> bool:
@@ -641,8 +648,7 @@ def wino_uses_full(g: ConvGeom, direction: int) -> bool:
 def wino_relu_bits(g: ConvGeom, device) -> torch.Tensor:
     """Buffer for the ReLU mask of a convolution's INPUT as bits: one int64 word per (tile, channel quad) (include/ssd_gfx950.h
     ssd_conv3x3_wino_fwd_keep_bits)."""
-    tiles = g.N * ((g.H + 3) // 4) * ((g.W + 3) // 4)
-    return torch.empty((tiles, g.Ci // 4), device=device, dtype=torch.int64)
+    return torch.empty((wino_tiles(g), g.Ci // 4), device=device, dtype=torch.int64)
 
 
 def conv2d_fwd_wino(x: torch.Tensor, u_fwd: torch.Tensor, bias: Optional[torch.Tensor], g: ConvGeom, relu: bool,

@@ -1005,3 +1005,76 @@ def test_winograd_plane_gemm_128_tile_dma_kernel_equals_generic_kernel(case):
     assert torch.equal(out[0][1], out[1][1]), "data gradient differs between the two GEMM kernels"
     _close(out[1][0][..., :co], _nhwc(F.relu(y64.detach())), what=f"fwd vs f64 {case}")
     _close(out[1][1], _nhwc(x64.grad), what=f"dgrad vs f64 {case}")
+
+
+DILATED_CASES = [  # n, h, w, ci, co, dilation: fc6's shape class, odd maps, lattices of unequal size, a map smaller than the dilation
+    (2, 19, 19, 64, 96, 4), (1, 10, 13, 32, 64, 2), (2, 7, 5, 32, 32, 3), (1, 3, 3, 32, 32, 4), (1, 23, 17, 32, 40, 4), (32, 19, 19, 512, 1024, 4),
+]
+
+
+@pytest.mark.parametrize("case", DILATED_CASES)
+def test_winograd_on_the_sub_lattices_of_a_dilated_conv(case):
+    """fc6 is Conv2d(512, 1024, 3, padding=4, dilation=4) (Model.py:149): d x d independent 3x3 / pad-1 convolutions on the sub-lattices
+    x[d*i + a][d*j + b].  The F(4x4) transforms walk those lattices (csrc/winograd.hip, struct Lat); GEMMs and filters are the plain
+    ones.  Forward (+ bias, ReLU, kept planes), data gradient (from dy, from the planes of the shared dy pass, with mask / accumulate)
+    and weight + bias gradient against an f64 dilated convolution, 1e-4 of the scale; the split entry points equal the combined one."""
+    from objectdetection_ssd_amd import ops
+    n, h, w, ci, co, d = case
+    dev = _dev()
+    full = (n, h, w, ci, co, 3, 1, d, d)
+    big = n >= 32
+    if big:
+        gen = torch.Generator(device=dev).manual_seed(7)
+        x = torch.randn(n, ci, h, w, device=dev, generator=gen)
+        wt = torch.randn(co, ci, 3, 3, device=dev, generator=gen) * (2.0 / (ci * 9)) ** 0.5
+        b = torch.randn(co, device=dev, generator=gen) * 0.1
+        dy = torch.randn(n, co, h, w, device=dev, generator=gen)
+        # reference on the GPU through torch's own (MIOpen / rocBLAS) f64 convolution would not be ours either; use f32 CPU autograd in f64 on a slice
+        xs, dys = x[:2].cpu(), dy[:2].cpu()
+    else:
+        x, wt, b = _conv_data(full, seed=301)
+        dy = torch.randn(n, co, h, w, generator=torch.Generator().manual_seed(302))
+        xs, dys = x, dy
+    x64 = xs.double().requires_grad_(True)
+    w64 = wt.cpu().double().requires_grad_(True)
+    y64 = F.conv2d(x64, w64, b.cpu().double(), padding=d, dilation=d)
+    y64.backward(dys.double())
+    g = ops.make_geom(*full)
+    ld = ops.pad32(co)
+    assert ops.wino_tiles(g) == n * sum((((h - a + d - 1) // d) + 3) // 4 for a in range(min(d, h))) * sum((((w - a + d - 1) // d) + 3) // 4 for a in range(min(d, w)))
+    uf, ub = ops.wino_weights(wt.to(dev), ld, mo=4)
+    xd = _nhwc(x).to(dev)
+    dy_p = torch.zeros(n, h, w, ld, device=dev)
+    dy_p[..., :co] = _nhwc(dy).to(dev)
+    y, planes = ops.conv2d_fwd_wino(xd, uf, b.to(dev), g, True, ld=ld, keep_planes=True)
+    k = xs.shape[0]
+    _close(y[:k, ..., :co], _nhwc(F.relu(y64.detach())), what=f"dilated fwd {case}")
+    if ld != co:
+        assert float(y[..., co:].abs().max()) == 0.0
+    y2 = ops.conv2d_fwd_wino(xd, uf, b.to(dev), g, False, ld=ld)
+    _close(y2[:k, ..., :co], _nhwc(y64.detach()), what=f"dilated fwd no relu {case}")
+    dx = ops.conv2d_dgrad_wino(dy_p, ub, g)
+    _close(dx[:k], _nhwc(x64.grad), what=f"dilated dgrad {case}")
+    dw, db, dyp = ops.conv2d_wgrad_wino(None, dy_p, g, ld, True, mo=4, planes=planes, dgrad_planes=True)
+    dx2 = ops.conv2d_dgrad_wino(None, ub, g, planes=dyp)
+    _close(dx2, dx, tol=2e-5, what=f"dilated dgrad from the dy pass planes {case}")
+    prev = torch.randn(n, h, w, ci, device=dev)
+    dx3 = ops.conv2d_dgrad_wino(None, ub, g, dx=prev.clone(), relu_mask=xd, accumulate=True, planes=dyp)
+    assert torch.equal(dx3, torch.where(xd > 0, dx2 + prev, torch.zeros_like(dx2)))
+    if not big:
+        _close(dw, w64.grad, what=f"dilated wgrad {case}")
+        _close(db, dy.double().sum((0, 2, 3)), what=f"dilated bias grad {case}")
+    else:
+        # adjoint identity at the bench size: <dw, w> = <dy, conv(x, w)> (no bias), in f64 dots of the f32 results
+        y_nb = ops.conv2d_fwd_wino(xd, uf, None, g, False, ld=ld)
+        lhs = float((dw.double() * wt.double()).sum())
+        rhs = float((y_nb.double() * dy_p.double()).sum())
+        assert abs(lhs - rhs) <= 1e-4 * max(abs(rhs), float(wt.double().norm() * dw.double().abs().max())), (lhs, rhs)
+        _close(db, dy.double().sum((0, 2, 3)), what=f"dilated bias grad {case}")
+    # the two-call form of the weight gradient gives the same bits
+    Y, Vd, part = ops.wino_dy_transform(dy_p, g, ld, True, True)
+    dw2, db2 = ops.wino_wgrad_gemm(Y, planes, part, g, ld)
+    assert torch.equal(dw2, dw) and torch.equal(db2, db) and torch.equal(Vd, dyp)
+    # what the dilated form must refuse: the fused pool, F(2x2)
+    with pytest.raises((ValueError, RuntimeError)):
+        ops.conv2d_fwd_wino_pool(xd, uf, b.to(dev), g, False)
