@@ -233,6 +233,7 @@ int ssd_prof_gemm_collect_kinds(float* ms_out, double* flops_out, int* kinds_out
 int ssd_prof_gemm_collect(float* ms_out, double* flops_out, int max);
 int ssd_tune_set_igemm(int tile, int nbuf);
 int ssd_tune_set_igemm_stamps(uint64_t* device_buffer);   /* diagnostic: per-block shader-clock stamps (see conv_igemm.hip) */
+int ssd_tune_set_batched_units(int on);   /* 1 (default): the blocks of one (plane, part of the row tiles) of a batched plane GEMM share one XCD; 0: 3-D grid */
 int ssd_tune_set_igemm_lds_pad(int bytes);   /* extra dynamic LDS per block: caps resident blocks per CU (experiments) */
 int ssd_tune_set_wgrad(int bt, int nbuf, int blocks_per_cu);
 int ssd_tune_set_wgrad_patch(int shape);     /* f32 fused 3x3 kernel: -1 least padding, 0 = 4x8 pixel patches, 1 = 1x38, 2 = 2x19 */

@@ -44,6 +44,9 @@ struct IgemmParams {
     float rcp_howo, rcp_wo;     // 1 / (Ho*Wo), 1 / Wo for div_small_q (set by launch_igemm)
     int nbatch;                 // > 1: blockIdx.z-th problem of a batch of equal-shaped GEMMs (the 16 Winograd planes)
     size_t batch_a, batch_w, batch_out;      // element strides between the problems of a batch
+    // batched, no split-K: a unit = (problem, part of its row tiles) runs on ONE XCD (1-D grid, block ids of one residue mod 8), so a
+    // filter plane leaves HBM once per part instead of once per XCD; units = 0: the 3-D grid (x = tile, y = K slice, z = problem)
+    int units, msplit, mper, bpu;
     unsigned long long* stamps; // diagnostic (ssd_tune_set_igemm_stamps): shader-clock stamps of every 64th block, else NULL
 };
 
@@ -144,10 +147,20 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, const f32x1
 template <int BM, int BN, int WM, int WN, int NBUF, bool BATCHED = false>      // BATCHED: its own symbol, so profiles tell the Winograd GEMMs apart
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p_in) {
     IgemmParams p = p_in;
+    int unit_tile = -1;                                   // BATCHED with units: the logical tile of this block inside its problem
     if (BATCHED) {
-        p.a += (size_t)blockIdx.z * p.batch_a;
-        p.w += (size_t)blockIdx.z * p.batch_w;
-        p.out += (size_t)blockIdx.z * p.batch_out;
+        int batch = blockIdx.z;
+        if (p.units > 0) {
+            const int idx = (int)(blockIdx.x >> 3), unit = (idx / p.bpu) * 8 + (int)(blockIdx.x & 7), inner = idx % p.bpu;
+            if (unit >= p.units) return;                  // uniform: the grid is padded to whole rounds of 8 units
+            batch = unit / p.msplit;
+            const int part = unit - batch * p.msplit, tm = part * p.mper + inner / p.tiles_n;
+            if (tm >= min((part + 1) * p.mper, p.tiles_m)) return;     // uniform: the last part may be shorter
+            unit_tile = tm * p.tiles_n + inner % p.tiles_n;
+        }
+        p.a += (size_t)batch * p.batch_a;
+        p.w += (size_t)batch * p.batch_w;
+        p.out += (size_t)batch * p.batch_out;
     }
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;
@@ -161,7 +174,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p_in) {
     if (stamp) t_start = __builtin_readcyclecounter();
     const int wm = wave / WN, wn = wave % WN;
     const int nblk = p.tiles_m * p.tiles_n;
-    const int lid = xcd_swizzle(blockIdx.x, nblk);
+    const int lid = unit_tile >= 0 ? unit_tile : xcd_swizzle(blockIdx.x, nblk);
     const int tile_m = lid / p.tiles_n, tile_n = lid % p.tiles_n;   // n fastest: neighbours share A rows
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int chunk = tid & 7, row0 = tid >> 3;
@@ -327,6 +340,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p_in) {
 }
 
 int g_lds_pad = 0;            // tuning aid: extra dynamic LDS per block (caps the blocks resident per CU)
+int g_batched_units = 1;      // tuning aid (ssd_tune_set_batched_units): 0 = batched GEMMs on the 3-D grid
 unsigned long long* g_stamps = nullptr;   // diagnostic buffer (ssd_tune_set_igemm_stamps)
 int g_force_ksplit = -1;      // tuning aid: 1 = never split K, k > 1 = always k slices (when a workspace is given); -1 = automatic
 
@@ -371,6 +385,19 @@ int launch_igemm(IgemmParams& p, hipStream_t st) {
     p.rcp_howo = 1.0f / (float)(p.Ho * p.Wo);
     p.rcp_wo = 1.0f / (float)p.Wo;
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
+    p.units = 0;
+    if (BATCHED && ks == 1 && g_batched_units && p.tiles_m * p.tiles_n >= 8) {
+        p.msplit = 1;                                     // units a multiple of 8: every XCD gets the same number
+        for (int sp = 1; sp <= 8 && sp <= p.tiles_m; ++sp)
+            if ((p.nbatch * sp) % 8 == 0) { p.msplit = sp; break; }
+        p.mper = ssd_cdiv(p.tiles_m, p.msplit);
+        p.msplit = ssd_cdiv(p.tiles_m, p.mper);           // no empty part
+        p.units = p.nbatch * p.msplit;
+        p.bpu = p.mper * p.tiles_n;
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, NBUF, BATCHED>), dim3((unsigned)(ssd_cdiv(p.units, 8) * 8 * p.bpu)), dim3(256), g_lds_pad, st, p);
+        SSD_CHECK_LAUNCH();
+        return SSD_OK;
+    }
     hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, NBUF, BATCHED>), dim3(p.tiles_m * p.tiles_n, ks, BATCHED ? p.nbatch : 1), dim3(256),
                        g_lds_pad, st, p);
     SSD_CHECK_LAUNCH();
@@ -1208,6 +1235,10 @@ extern "C" int ssd_tune_set_igemm_stamps(uint64_t* device_buffer) {
 }
 
 // Tuning aid: extra dynamic LDS bytes per igemm block (occupancy cap experiments); 0 = none.
+extern "C" int ssd_tune_set_batched_units(int on) {
+    g_batched_units = on != 0;
+    return SSD_OK;
+}
 extern "C" int ssd_tune_set_igemm_lds_pad(int bytes) {
     if (bytes < 0 || bytes > 120 * 1024) return SSD_ERR_BAD_SHAPE;
     g_lds_pad = bytes;
