@@ -1,0 +1,51 @@
+"""Interleaved A/B of one library tuning switch on the full train step at batch 32 (same process, same device, alternating repetitions).
+
+    python tools/ab_step.py ssd_tune_set_wino_fused_waves 8 4
+"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from objectdetection_ssd_amd import Losses, Model, _lib  # noqa: E402
+from objectdetection_ssd_amd.ddp import FlatSGDDataParallel  # noqa: E402
+
+
+def main():
+    fn, vals = sys.argv[1], [int(v) for v in sys.argv[2:]]
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = Model.SSD_300().to(dev).train()
+    tr = FlatSGDDataParallel(net, lr=1e-4)
+    x, classes, boxes = bench.synth_batch(32, 1234, dev)
+
+    def steps(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            tr.zero_grad()
+            loc, conf = net(x)
+            l1, l2 = Losses.ssd((loc, conf), classes, boxes, norm_mode=1)
+            (l1 + l2).backward()
+            tr.reduce_and_step(Losses.last_match["n_pos"])
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    steps(5)
+    res = {v: [] for v in vals}
+    for rep in range(5):
+        for v in vals:
+            _lib.check(getattr(lib, fn)(v), "tune")
+            steps(2)
+            res[v].append(steps(15))
+    for v in vals:
+        r = sorted(res[v])
+        print(f"{fn}({v}): median {r[len(r) // 2]:.3f} ms/step  (min {r[0]:.3f}, max {r[-1]:.3f})")
+
+
+if __name__ == "__main__":
+    main()
