@@ -212,6 +212,7 @@ int ssd_conv3x3_wino_dgrad_planes(const float* dy_planes, const float* U_bwd, in
 /* Forward / dgrad of the F(4x4,3x3) entry points: 36 plane GEMMs + output transform in ONE kernel (accumulators of all planes in
  * registers, the M planes never reach memory) where the reduction length is a multiple of 64.  -1 (default): where it is the faster
  * form; 0: never (batched GEMM + output transform kernels); 1: wherever the geometry allows. */
+int ssd_tune_set_wino_bias_tail(int on);   /* 1 (default): the bias gradient's final column sums run as extra blocks of the weight gradient's finish kernel; 0: own launch */
 int ssd_tune_set_wino_xform_blocks(int blocks);   /* grid cap of the Winograd transform kernels (default 8192; 64 .. 65535) */
 int ssd_tune_set_wino_fused(int mode);
 /* The plane GEMMs of the layers that do not take the one-kernel form: persistent 128 x 128 LDS-DMA kernel (gemm_nt.hip) instead of the

@@ -105,6 +105,7 @@ SIGNATURES = {
     "ssd_tune_set_wino_wgrad_tn": (_I, [_I]),
     "ssd_tune_set_wino_fused": (_I, [_I]),
     "ssd_tune_set_gemm_nt": (_I, [_I]),
+    "ssd_tune_set_wino_bias_tail": (_I, [_I]),
     "ssd_tune_set_batched_units": (_I, [_I]),
     "ssd_tune_set_wino_full": (_I, [_I]),
     "ssd_conv3x3_wino_uses_full": (_I, [_G, _I]),

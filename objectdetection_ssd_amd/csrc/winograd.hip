@@ -323,10 +323,10 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 
 // final for the partial rows wino4_dy_kernel<true> leaves (row stride ldp = channels rounded up to 4): 16 channels per block as four
 // 16-byte quads, 64 lanes stride over the rows of each quad with two sums in flight, combined in lane order
-__global__ __launch_bounds__(256) void colsum_final4_kernel(const float* __restrict__ part, float* __restrict__ db, int nblk, int C, int ldp) {
+__device__ __forceinline__ void colsum_final4_body(const float* __restrict__ part, float* __restrict__ db, int nblk, int C, int ldp, int bx) {
     __shared__ f32x4 red[64][5];
     const int q = threadIdx.x & 3, l = threadIdx.x >> 2;
-    const int c0 = (blockIdx.x * 4 + q) * 4;
+    const int c0 = (bx * 4 + q) * 4;
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
     if (c0 < ldp)
         for (int k = l; k < nblk; k += 128) {
@@ -343,6 +343,12 @@ __global__ __launch_bounds__(256) void colsum_final4_kernel(const float* __restr
             if (c0 + e < C) db[c0 + e] = t[e];
     }
 }
+__global__ __launch_bounds__(256) void colsum_final4_kernel(const float* __restrict__ part, float* __restrict__ db, int nblk, int C, int ldp) {
+    colsum_final4_body(part, db, nblk, C, ldp, (int)blockIdx.x);
+}
+// the same work as extra blocks at the end of wino4_wgrad_finish_kernel's grid (one launch less per layer); part == NULL: none
+struct BiasTail { const float* part; float* db; int nblk, C, ldp; };
+int g_bias_tail = 1;              // tuning aid (ssd_tune_set_wino_bias_tail): 0 = the final sums as their own launch
 
 // ---- F(4x4, 3x3): 36 multiplies per 4x4 output tile (4x fewer than direct, 1.78x fewer than F(2x2)); 6x6 input patches, planes
 // 2.25x the tensor.  Interpolation points 0, +-1, +-2, inf (Lavin & Gray); coefficients up to 8 and 1/24, so the f32 result is
@@ -880,9 +886,13 @@ __global__ __launch_bounds__(256) void wino_splitk_sum_kernel(float* __restrict_
 // four neighbouring (co, ci) entries per thread: 16-byte loads of the 36 x ksplit partial planes (plane stride pstride floats), 144
 // contiguous output bytes
 __global__ __launch_bounds__(256) void wino4_wgrad_finish_kernel(const float* __restrict__ Zs, float* __restrict__ dw, int Co, int Ci, int ksplit,
-                                                                 size_t pstride) {
+                                                                 size_t pstride, int nfin, const BiasTail bt) {
+    if ((int)blockIdx.x >= nfin) {                                     // uniform: the bias gradient's final sums (blocks nfin ...)
+        colsum_final4_body(bt.part, bt.db, bt.nblk, bt.C, bt.ldp, (int)blockIdx.x - nfin);
+        return;
+    }
     const size_t total = (size_t)Co * Ci, quads = total >> 2;          // Ci % 4 == 0
-    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (size_t)gridDim.x * 256) {
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (size_t)nfin * 256) {
         const size_t i = q * 4;
         f32x4 z[6][6];                                       // all 36 planes in flight at once, then the remaining K slices in order
 #pragma unroll
@@ -1151,6 +1161,10 @@ WinoWgradPlan wino_wgrad_plan(const ssd_conv_geom* g, int ldy, int mo) {
 }
 }  // namespace
 
+extern "C" int ssd_tune_set_wino_bias_tail(int on) {
+    g_bias_tail = on != 0;
+    return SSD_OK;
+}
 extern "C" int ssd_tune_set_wino_xform_blocks(int blocks) {
     if (blocks < 64 || blocks > 65535) return SSD_ERR_BAD_SHAPE;
     g_xform_cap = blocks;
@@ -1310,15 +1324,19 @@ int wino_wgrad(const float* x, const float* planes, const float* dy, int ldy, fl
             SSD_CHECK_LAUNCH();
             ks_left = 1;
         }
-        hipLaunchKernelGGL(wino4_wgrad_finish_kernel, dim3(grid_for(total / 4)), dim3(256), 0, st, Zs, dw_oihw, g->Co, g->Ci, ks_left,
-                           (size_t)w.ks * total);
+        const int nfin = grid_for(total / 4), ldp = (g->Co + 3) / 4 * 4;
+        const bool tail = dbias && dy_bias_blocks > 0 && g_bias_tail;    // the bias gradient's final sums ride along as extra blocks
+        const BiasTail bt{tail ? part : nullptr, dbias, dy_bias_blocks, g->Co, ldp};
+        hipLaunchKernelGGL(wino4_wgrad_finish_kernel, dim3(nfin + (tail ? (ldp + 15) / 16 : 0)), dim3(256), 0, st, Zs, dw_oihw, g->Co, g->Ci,
+                           ks_left, (size_t)w.ks * total, nfin, bt);
     }
     SSD_CHECK_LAUNCH();
-    if (dbias && dy_bias_blocks > 0) {
+    if (dbias && dy_bias_blocks > 0 && !g_bias_tail) {
         const int ldp = (g->Co + 3) / 4 * 4;
         hipLaunchKernelGGL(colsum_final4_kernel, dim3((ldp + 15) / 16), dim3(256), 0, st, part, dbias, dy_bias_blocks, g->Co, ldp);
         SSD_CHECK_LAUNCH();
-    } else if (dbias) {
+    }
+    if (dbias && dy_bias_blocks == 0) {                                  // no partial sums from a dy pass (F(2x2), transposed planes, > 1024 channels)
         const size_t M = (size_t)g->N * g->H * g->W;
         int cq = 1;
         while (cq < (g->Co + 3) / 4 && cq < 256) cq <<= 1;
@@ -1447,15 +1465,13 @@ extern "C" int ssd_wino4_wgrad_gemm(const float* wgrad_planes, const float* x_pl
         SSD_CHECK_LAUNCH();
         ks_left = 1;
     }
-    hipLaunchKernelGGL(wino4_wgrad_finish_kernel, dim3(grid_for(total / 4)), dim3(256), 0, st, Zs, dw_oihw, g->Co, g->Ci, ks_left, (size_t)w.ks * total);
+    const int blocks = dbias ? dy_bias_blocks_for(g, ldy, w.tiles) : 0;
+    if (dbias && blocks == 0) return SSD_ERR_BAD_SHAPE;
+    const int nfin = grid_for(total / 4), ldp = (g->Co + 3) / 4 * 4;
+    const BiasTail bt{dbias ? bias_partial : nullptr, dbias, blocks, g->Co, ldp};
+    hipLaunchKernelGGL(wino4_wgrad_finish_kernel, dim3(nfin + (dbias ? (ldp + 15) / 16 : 0)), dim3(256), 0, st, Zs, dw_oihw, g->Co, g->Ci, ks_left,
+                       (size_t)w.ks * total, nfin, bt);
     SSD_CHECK_LAUNCH();
-    if (dbias) {
-        const int blocks = dy_bias_blocks_for(g, ldy, w.tiles);
-        if (blocks == 0) return SSD_ERR_BAD_SHAPE;
-        const int ldp = (g->Co + 3) / 4 * 4;
-        hipLaunchKernelGGL(colsum_final4_kernel, dim3((ldp + 15) / 16), dim3(256), 0, st, bias_partial, dbias, blocks, g->Co, ldp);
-        SSD_CHECK_LAUNCH();
-    }
     return SSD_OK;
 }
 
