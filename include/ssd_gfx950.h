@@ -243,6 +243,17 @@ int ssd_tune_set_wgrad_patch(int shape);     /* f32 fused 3x3 kernel: -1 least p
  * NCHW image batch (Dataset.py:39 layout) into [N*H*W][32] rows (k = (r*3+s)*3 + c, columns 27..31
  * zero); forward / wgrad are then the 1x1 cases of ssd_conv2d_fwd / ssd_conv2d_wgrad with Ci = 32. */
 int ssd_im2col_first(const float* x_nchw, float* out, int N, int H, int W, void* stream);
+/* conv1_1 + ReLU in one kernel (Model.py:135, features[0:2]): x (N,3,H,W) NCHW -> y (N,H,W,64) NHWC = relu(conv3x3 pad 1 + bias).
+ * w_rows: [64][32] filter rows in ssd_im2col_first's column order (k = (r*3+s)*3 + c, columns 27..31 zero).  col_out (may be NULL):
+ * the same pass also writes the (N,H,W,32) rows ssd_im2col_first would, for the weight gradient (ssd_conv2d_wgrad on them). */
+int ssd_conv1_first_fwd(const float* x_nchw, const float* w_rows, const float* bias, float* y_nhwc, float* col_out, int N, int H, int W,
+                        int relu, void* stream);
+/* Weight and bias gradient of conv1_1 from the NCHW input itself (autograd of Model.py:135 features[0]): dw_rows [64][32] in the column
+ * order above (columns 27..31 zero; ops.first_weight_grad turns them into OIHW), dbias [64] (may be NULL) = sum of dy over the pixels.
+ * dy (N,H,W,64) NHWC dense.  Workspace ssd_conv1_first_wgrad_workspace bytes (partial sums of the persistent workgroups, added in order). */
+size_t ssd_conv1_first_wgrad_workspace(int N, int H, int W);
+int ssd_conv1_first_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_rows, float* dbias, int N, int H, int W, void* workspace,
+                          size_t workspace_bytes, void* stream);
 
 /* ---- SSD_resnet34 (Model.py:12-126, BASELINE configs[4]) eval-mode forward pieces ----
  * Stem Conv2d(3,64,7,stride 2,pad 3) (Model.py:26 seq1[0]): general 3-channel NCHW im2col into [N*Ho*Wo][Kpad]

@@ -183,6 +183,7 @@ class _Engine:
         self.dual_dy = True       # backward: one pass over dy writes the planes of the weight gradient AND of the data gradient
         self.keep_planes = True   # training forward keeps the F(4x4) input planes of the layers whose weight gradient is Winograd
         self.fuse_pool = True     # Winograd F(4x4) layers in pool_after write the pooled map + argmax only
+        self.first_fused = True        # conv1_1 forward in one kernel (csrc/conv_first.hip) instead of im2col + 1x1 MFMA convolution
         self.wino_dilated = True       # fc6 (3x3, dilation 4) in the Winograd domain too: 49 tiles x 36 products per image instead of 361 x 9
         self.lazy_pool_grad = True     # ... and in the backward their dy pass reads the pooled gradient: the pool's dx is never written
         self.relu_bits = True     # training forward: the input transform also leaves the ReLU mask of its input as bits for the dgrad epilogue
@@ -358,8 +359,6 @@ class _Engine:
                 side_ctx = torch.cuda.stream(side)
                 side_ctx.__enter__()
             if kind == "conv_first":
-                # conv1_1 as im2col (K = 27 -> 32) + the 1x1 MFMA convolution
-                col = ops.im2col_first(x)
                 g = ops.make_geom(bs, x.shape[2], x.shape[3], 32, 64, 1, 1, 0, 1)
                 wkey = P[op["p"] + ".weight"]
                 sig = (wkey.data_ptr(), wkey._version)
@@ -368,8 +367,16 @@ class _Engine:
                     ent = [sig, None, ops.first_weight_rows(wkey), None]
                     self._wcache[op["p"]] = ent
                 bias = P[op["p"] + ".bias"].detach()
-                T[op["y"]] = self._timed("fwd " + op["p"], ops.igemm_tile(g, 0, self.bf16, self.x3) if self.prof is not None else "", 2.0 * bs * g.Ho * g.Wo * 64 * 27,
-                                         lambda: ops.conv2d_fwd(col, ent[2], bias, g, True, bf16=self.bf16))
+                flops1 = 2.0 * bs * g.Ho * g.Wo * 64 * 27
+                if self.first_fused and not self.bf16 and not self.x3:
+                    # one kernel from the NCHW batch: halo tile in LDS, K = 27 on the MFMA, bias + ReLU; the weight gradient's rows ride along
+                    T[op["y"]], col = self._timed("fwd " + op["p"], "conv_first_fwd_kernel", flops1,
+                                                  lambda: ops.conv1_first_fwd(x, ent[2], bias, True, want_col=False))
+                else:
+                    # conv1_1 as im2col (K = 27 -> 32) + the 1x1 MFMA convolution
+                    col = ops.im2col_first(x)
+                    T[op["y"]] = self._timed("fwd " + op["p"], ops.igemm_tile(g, 0, self.bf16, self.x3) if self.prof is not None else "", flops1,
+                                             lambda: ops.conv2d_fwd(col, ent[2], bias, g, True, bf16=self.bf16))
                 T["x_col"] = col
                 aux[op["y"]] = g
             elif kind == "conv":
@@ -636,8 +643,12 @@ class _Engine:
                 if need[op["p"] + ".weight"] or need[op["p"] + ".bias"]:
                     g = aux[op["y"]]
                     col = T["x_col"]
-                    dw, db = self._timed("wgrad " + op["p"], ops.wgrad_tile(g) if self.prof is not None else "", 2.0 * dy.numel() * 27,
-                                         lambda: ops.conv2d_wgrad(col, dy, g, g.Co, True))
+                    if col is None:                                    # the one-kernel forward left no [pixel][32] rows: gradient from x itself
+                        dw, db = self._timed("wgrad " + op["p"], "conv_first_wgrad_kernel", 2.0 * dy.numel() * 27,
+                                             lambda: ops.conv1_first_wgrad(T["x"], dy, True))
+                    else:
+                        dw, db = self._timed("wgrad " + op["p"], ops.wgrad_tile(g) if self.prof is not None else "", 2.0 * dy.numel() * 27,
+                                             lambda: ops.conv2d_wgrad(col, dy, g, g.Co, True))
                     grads[op["p"] + ".weight"], grads[op["p"] + ".bias"] = ops.first_weight_grad(dw), db
         if not joined:
             main.wait_event(join_event)

@@ -122,6 +122,9 @@ SIGNATURES = {
     "ssd_tune_set_wgrad": (_I, [_I, _I, _I]),
     "ssd_tune_set_wgrad_patch": (_I, [_I]),
     "ssd_im2col_first": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ssd_conv1_first_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ssd_conv1_first_wgrad_workspace": (_Z, [_I, _I, _I]),
+    "ssd_conv1_first_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _Z, _P]),
     "ssd_maxpool_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ssd_maxpool_bwd_gated": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ssd_maxpool_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

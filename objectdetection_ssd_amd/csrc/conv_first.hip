@@ -1,0 +1,264 @@
+// conv1_1 (Conv2d(3, 64, 3, padding=1) + ReLU on the caller's NCHW batch, Model.py:135 features[0:2]) in one kernel.
+//
+// The im2col form (elementwise.hip: im2col_first + a 1x1 MFMA convolution) writes 369 MB of [pixel][32] rows at batch 32 and reads
+// them back; the convolution itself is bound by its 737 MB of output.  Here a workgroup takes a 4 x 64 pixel tile: the 6 x 66 x 3 input
+// halo goes to LDS once (4.7 KB), every wave multiplies one tile row -- two blocks of 32 pixels x 64 channels x K = 27 (+1 zero) on
+// v_mfma_f32_32x32x2_f32, the A operand read straight from the halo image (k = (r*3+s)*3 + c selects a constant LDS offset, lanes
+// walk the pixels) -- and bias + ReLU + the NHWC store close it.  When the weight gradient wants them (training), the same workgroup
+// also writes its [pixel][32] rows from the halo image, so that the separate unfold pass and its read of x disappear as well.
+#include "common.h"
+
+namespace {
+
+constexpr int TH = 4, TW = 64, HH = TH + 2, HW_ = TW + 2, PLANE = HH * HW_;       // tile, halo, floats per channel plane of the halo
+
+// LDS offset (floats) of tap k = (r*3+s)*3 + c relative to the pixel's own position in plane 0; k = 27 (the zero column of the weights)
+// re-reads tap 26: a finite product with a zero weight unless x itself holds a NaN there, which the true sum would carry anyway
+__device__ __forceinline__ constexpr int tap_off(int k) {
+    const int kk = k < 27 ? k : 26;
+    return (kk % 3) * PLANE + (kk / 9) * HW_ + (kk / 3) % 3;
+}
+
+__global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wrows,
+                                                             const float* __restrict__ bias, float* __restrict__ y, float* __restrict__ col,
+                                                             int N, int H, int W, int tiles_h, int tiles_w, int relu) {
+    __shared__ float xs[3 * PLANE + 8];
+    __shared__ float ws[64 * 33];
+    __shared__ __attribute__((aligned(16))) float ys[4 * 32 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bx = blockIdx.x;
+    const int twi = bx % tiles_w, thi = (bx / tiles_w) % tiles_h, n = bx / (tiles_w * tiles_h);
+    const int h0 = thi * TH, w0 = twi * TW;
+    const size_t HWs = (size_t)H * W;
+    for (int e = tid; e < 3 * PLANE; e += 256) {
+        const int c = e / PLANE, rem = e - c * PLANE, r = rem / HW_, cc = rem - r * HW_;
+        const int ih = h0 - 1 + r, iw = w0 - 1 + cc;
+        xs[e] = ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) ? x[((size_t)n * 3 + c) * HWs + (size_t)ih * W + iw] : 0.f;
+    }
+    // the 64 x 32 filter rows: two coalesced 16-byte loads per thread into LDS (row stride 33: the fragment reads below walk the rows)
+    {
+        const f32x4 w0v = *reinterpret_cast<const f32x4*>(wrows + tid * 4), w1v = *reinterpret_cast<const f32x4*>(wrows + 1024 + tid * 4);
+        const int r0 = tid >> 3, c0 = (tid & 7) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ws[r0 * 33 + c0 + e] = w0v[e];
+            ws[(r0 + 32) * 33 + c0 + e] = w1v[e];
+        }
+    }
+    const int lr = lane & 31, lh = lane >> 5;
+    __syncthreads();
+    float bw[2][14];                                                   // B operand: w[co = 32 i + lr][k = 2 q + lh]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 14; ++q) bw[i][q] = ws[(32 * i + lr) * 33 + 2 * q + lh];
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+    const int base = wave * HW_ + lr;                                  // the wave's tile row, this lane's pixel of a 32-pixel block
+#pragma unroll
+    for (int q = 0; q < 14; ++q) {
+        const int off = lh ? tap_off(2 * q + 1) : tap_off(2 * q);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float a = xs[base + 32 * j + off];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[i][q], acc[j][i], 0, 0, 0);
+        }
+    }
+
+    // C/D map: channel = 32 i + (lane & 31), pixel of the block = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): a lane holds single channels of
+    // 16 pixels.  Stored like that (4 bytes per lane, 128-byte runs) the kernel writes at ~3 TB/s; so each 32-pixel block goes through
+    // a per-wave LDS image [pixel][64 ch] and leaves as 16 bytes per lane, 1 KB (four whole pixels) per instruction.
+    const int oh = h0 + wave;
+    float* ysw = ys + wave * (32 * 64);
+    float bv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) bv[i] = bias != nullptr ? bias[32 * i + lr] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[j][i][r] + bv[i];
+                if (relu) v = v < 0.f ? 0.f : v;                       // NaN stays NaN, like torch.relu
+                ysw[((r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + 32 * i + lr] = v;
+            }
+        // same wave writes and reads: the LDS queue is in order, no barrier
+        if (oh < H) {
+            float* po = y + (((size_t)n * H + oh) * W + w0 + 32 * j) * 64 + (lane & 15) * 4;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int px = 4 * t + (lane >> 4);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ysw + px * 64 + (lane & 15) * 4);
+                if (w0 + 32 * j + px < W) *reinterpret_cast<f32x4*>(po + (size_t)px * 64) = v;
+            }
+        }
+    }
+    if (col != nullptr) {                                              // uniform: the [pixel][32] rows of the weight gradient
+        // 8 threads per pixel (128 contiguous bytes), 32 pixels per pass; a thread keeps its 16-byte chunk, i.e. its four taps
+        const int chunk = tid & 7;
+        int toff[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = chunk * 4 + e;
+            toff[e] = k < 27 ? (k % 3) * PLANE + (k / 9) * HW_ + (k / 3) % 3 : -1;
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int pix = it * 32 + (tid >> 3), py = pix >> 6, px = pix & 63;
+            if (h0 + py < H && w0 + px < W) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = toff[e] >= 0 ? xs[py * HW_ + px + toff[e]] : 0.f;
+                *reinterpret_cast<f32x4*>(col + ((((size_t)n * H + h0 + py) * W + w0 + px) * 8 + chunk) * 4) = v;
+            }
+        }
+    }
+}
+
+
+// Weight + bias gradient of conv1_1 from the NCHW input itself (no [pixel][32] rows in memory):
+//   dw[co][k] = sum_p dy[p][co] * x[p + tap(k)][c(k)],  k = (r*3+s)*3 + c < 27;   column 27 multiplies ones: db[co] = sum_p dy[p][co].
+// Same 4 x 64 pixel tiles and halo image as the forward kernel; the reduction runs over the pixels: per 32-pixel block of its tile row a
+// wave stages dy [32 px][64 ch] in LDS (16-byte loads) and issues 16 x 2 v_mfma_f32_32x32x2_f32 (A = dy, lanes walk the channels;
+// B = the halo image at this lane's tap offset, or 1 for lane 27).  Workgroups are persistent (grid-stride over the tiles); their
+// [64][32] partial sums go to a slab that conv_first_wgrad_reduce_kernel adds up in block order (reproducible).
+__global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab,
+                                                               int N, int H, int W, int tiles_h, int tiles_w, int ntiles) {
+    __shared__ float xs[3 * PLANE + 8];
+    __shared__ __attribute__((aligned(16))) float ds[4 * 32 * 64];      // per wave: dy of one 32-pixel block; at the end: the waves' partial sums
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const size_t HWs = (size_t)H * W;
+    const int my_off = lr < 27 ? tap_off(lr) : 0;
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float* dsw = ds + wave * (32 * 64);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int twi = tile % tiles_w, thi = (tile / tiles_w) % tiles_h, n = tile / (tiles_w * tiles_h);
+        const int h0 = thi * TH, w0 = twi * TW;
+        // dy of this wave's tile row first (two blocks of 32 pixels: lane = (pixel 4 t + lane / 16, channel quad lane % 16); zero outside
+        // the image): 16 loads in flight while the halo image is fetched
+        const int oh = h0 + wave;
+        f32x4 dv[2][8];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float* src = dy + (((size_t)n * H + oh) * W + w0 + 32 * j) * 64 + (lane & 15) * 4;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int px = 4 * t + (lane >> 4);
+                dv[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (oh < H && w0 + 32 * j + px < W) dv[j][t] = *reinterpret_cast<const f32x4*>(src + (size_t)px * 64);
+            }
+        }
+        __syncthreads();                                               // the previous tile's halo image is no longer read
+        for (int e = tid; e < 3 * PLANE; e += 256) {
+            const int c = e / PLANE, rem = e - c * PLANE, r = rem / HW_, cc = rem - r * HW_;
+            const int ih = h0 - 1 + r, iw = w0 - 1 + cc;
+            xs[e] = ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) ? x[((size_t)n * 3 + c) * HWs + (size_t)ih * W + iw] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) *reinterpret_cast<f32x4*>(dsw + (4 * t + (lane >> 4)) * 64 + (lane & 15) * 4) = dv[j][t];
+            // the wave reads what it wrote itself: the LDS queue is in order
+            const int bbase = wave * HW_ + 32 * j + my_off;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int p = 2 * q + lh;                              // pixel of the block: the reduction index of this MFMA half
+                const float b = lr == 27 ? 1.f : xs[bbase + p];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(dsw[p * 64 + 32 * i + lr], b, acc[i], 0, 0, 0);
+            }
+        }
+    }
+    // D[m = channel][n = tap]: lane holds tap lr of channels 32 i + (reg & 3) + 8 (reg >> 2) + 4 lh; add the four waves in wave order
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ds[wave * 2048 + (32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + lr] = acc[i][r];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int idx = e * 256 + tid;
+        slab[(size_t)blockIdx.x * 2048 + idx] = ((ds[idx] + ds[2048 + idx]) + ds[4096 + idx]) + ds[6144 + idx];
+    }
+}
+
+// dw_rows[co][k] (k < 27; 27..31 zero) and db[co] = column 27, summed over the workgroups' partial slabs in a fixed order: a block owns 8
+// of the 2048 entries, its 256 threads = 8 entries x 32 slices of the slab list (four running sums each), then the slices in order
+__global__ __launch_bounds__(256) void conv_first_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw_rows, float* __restrict__ db,
+                                                                      int nblk) {
+    __shared__ float red[32][9];
+    const int e = threadIdx.x & 7, sl = threadIdx.x >> 3;
+    const int idx = blockIdx.x * 8 + e;                                // 0 .. 2047
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b = sl; b < nblk; b += 128) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (b + 32 * u < nblk) s[u] += slab[(size_t)(b + 32 * u) * 2048 + idx];
+    }
+    red[sl][e] = (s[0] + s[1]) + (s[2] + s[3]);
+    __syncthreads();
+    if (sl == 0) {
+        float v = red[0][e];
+        for (int k = 1; k < 32; ++k) v += red[k][e];
+        const int k = idx & 31, co = idx >> 5;
+        dw_rows[idx] = k < 27 ? v : 0.f;
+        if (k == 27 && db != nullptr) db[co] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int ssd_conv1_first_fwd(const float* x_nchw, const float* w_rows, const float* bias, float* y_nhwc, float* col_out, int N, int H,
+                                   int W, int relu, void* stream) {
+    if (!x_nchw || !w_rows || !y_nhwc) return SSD_ERR_NULL;
+    if (N <= 0 || H <= 0 || W <= 0) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(y_nhwc) || (col_out && !ssd_aligned16(col_out))) return SSD_ERR_ALIGN;
+    const int tiles_h = ssd_cdiv(H, TH), tiles_w = ssd_cdiv(W, TW);
+    const long long blocks = (long long)N * tiles_h * tiles_w;
+    if (blocks >= (1ll << 31)) return SSD_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(conv_first_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_nchw, w_rows, bias, y_nhwc, col_out,
+                       N, H, W, tiles_h, tiles_w, relu);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
+// Workgroups of the weight-gradient kernel: two rounds of the 768 the chip holds (3 per CU); each leaves 8 KB of partial sums.
+constexpr int WGRAD_BLOCKS = 1536;
+extern "C" size_t ssd_conv1_first_wgrad_workspace(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)WGRAD_BLOCKS * 2048 * sizeof(float);
+}
+
+extern "C" int ssd_conv1_first_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_rows, float* dbias, int N, int H, int W,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x_nchw || !dy_nhwc || !dw_rows || !workspace) return SSD_ERR_NULL;
+    if (N <= 0 || H <= 0 || W <= 0) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(dy_nhwc) || !ssd_aligned16(workspace)) return SSD_ERR_ALIGN;
+    const int tiles_h = ssd_cdiv(H, TH), tiles_w = ssd_cdiv(W, TW);
+    const long long ntiles = (long long)N * tiles_h * tiles_w;
+    if (ntiles >= (1ll << 31)) return SSD_ERR_BAD_SHAPE;
+    const int blocks = ntiles < WGRAD_BLOCKS ? (int)ntiles : WGRAD_BLOCKS;
+    if (workspace_bytes < (size_t)blocks * 2048 * sizeof(float)) return SSD_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* slab = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(conv_first_wgrad_kernel, dim3(blocks), dim3(256), 0, st, x_nchw, dy_nhwc, slab, N, H, W, tiles_h, tiles_w, (int)ntiles);
+    SSD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(conv_first_wgrad_reduce_kernel, dim3(256), dim3(256), 0, st, slab, dw_rows, dbias, blocks);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}

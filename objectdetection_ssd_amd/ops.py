@@ -295,6 +295,39 @@ def im2col_first(x_nchw: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def conv1_first_fwd(x_nchw: torch.Tensor, w_rows: torch.Tensor, bias: Optional[torch.Tensor], relu: bool = True, want_col: bool = False):
+    """conv1_1 (3 -> 64 channels, 3x3, pad 1) + bias + ReLU from the NCHW batch in one kernel -> (y (N,H,W,64) NHWC, col or None);
+    w_rows = `first_weight_rows(weight)`; want_col: also the (N,H,W,32) rows of `im2col_first` (the weight gradient's operand)."""
+    _req(x_nchw, "x"); _req(w_rows, "w_rows")
+    n, c, h, w = x_nchw.shape
+    if c != 3 or w_rows.numel() != 64 * 32:
+        raise ValueError("conv1_first_fwd expects 3 input channels and (64, 32) filter rows")
+    if bias is not None:
+        _req(bias, "bias")
+        if bias.numel() != 64:
+            raise ValueError("conv1_first_fwd: 64 biases")
+    y = torch.empty((n, h, w, 64), device=x_nchw.device, dtype=torch.float32)
+    col = torch.empty((n, h, w, 32), device=x_nchw.device, dtype=torch.float32) if want_col else None
+    check(_lib.load().ssd_conv1_first_fwd(x_nchw.data_ptr(), w_rows.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(col), n, h, w, int(relu), _stream()),
+          "conv1_first_fwd")
+    return y, col
+
+
+def conv1_first_wgrad(x_nchw: torch.Tensor, dy: torch.Tensor, want_bias: bool = True):
+    """Weight / bias gradient of conv1_1 from the NCHW input: -> (dw (64,32,1,1) rows for `first_weight_grad`, dbias (64,) or None)."""
+    _req(x_nchw, "x"); _req(dy, "dy")
+    n, c, h, w = x_nchw.shape
+    if c != 3 or tuple(dy.shape) != (n, h, w, 64):
+        raise ValueError("conv1_first_wgrad: x (N,3,H,W) and dy (N,H,W,64)")
+    lib = _lib.load()
+    ws = workspace(lib.ssd_conv1_first_wgrad_workspace(n, h, w), x_nchw.device, "first_wgrad")
+    dw = torch.empty((64, 32, 1, 1), device=x_nchw.device, dtype=torch.float32)
+    db = torch.empty((64,), device=x_nchw.device, dtype=torch.float32) if want_bias else None
+    check(lib.ssd_conv1_first_wgrad(x_nchw.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db), n, h, w, ws.data_ptr(), ws.numel(), _stream()),
+          "conv1_first_wgrad")
+    return dw, db
+
+
 def im2col_nchw3(x_nchw: torch.Tensor, k: int, stride: int, pad: int, kpad: Optional[int] = None) -> torch.Tensor:
     """(N,3,H,W) -> (N,Ho,Wo,Kpad) rows with k = (r*k+s)*3 + c, zero-padded to a multiple of 32 (ResNet-34 stem)."""
     _req(x_nchw, "x")

@@ -1078,3 +1078,69 @@ def test_winograd_on_the_sub_lattices_of_a_dilated_conv(case):
     # what the dilated form must refuse: the fused pool, F(2x2)
     with pytest.raises((ValueError, RuntimeError)):
         ops.conv2d_fwd_wino_pool(xd, uf, b.to(dev), g, False)
+
+
+@pytest.mark.parametrize("shape", [(2, 300, 300), (1, 37, 70), (3, 5, 5), (1, 64, 64), (2, 4, 129)])
+def test_conv1_1_forward_in_one_kernel(shape):
+    """csrc/conv_first.hip: Conv2d(3, 64, 3, padding=1) + ReLU (Model.py:135, features[0:2]) straight from the NCHW batch -- halo tile in
+    LDS, K = 27 on the MFMA -- against an f64 convolution (1e-4 of the scale), against the im2col + 1x1-convolution form it replaces
+    (2e-5: same sum, another order), and its optional [pixel][32] rows against `im2col_first` bit for bit; tiles cut by the map's edges,
+    maps smaller than a tile, a NaN in the input (must reach exactly the outputs whose window holds it)."""
+    from objectdetection_ssd_amd import ops
+    n, h, w = shape
+    dev = _dev()
+    g_ = torch.Generator().manual_seed(h * 7 + w)
+    x = torch.randn(n, 3, h, w, generator=g_)
+    wt = torch.randn(64, 3, 3, 3, generator=g_) * (2.0 / 27) ** 0.5
+    b = torch.randn(64, generator=g_) * 0.1
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    rows = ops.first_weight_rows(wt.to(dev))
+    xd = x.to(dev)
+    for relu in (True, False):
+        y, col = ops.conv1_first_fwd(xd, rows, b.to(dev), relu, want_col=True)
+        _close(y, _nhwc(F.relu(ref) if relu else ref), what=f"conv1_1 fused relu={relu} {shape}")
+        assert torch.equal(col, ops.im2col_first(xd))
+        y2, none = ops.conv1_first_fwd(xd, rows, b.to(dev), relu)
+        assert none is None and torch.equal(y2, y)
+    g = ops.make_geom(n, h, w, 32, 64, 1, 1, 0, 1)
+    old = ops.conv2d_fwd(ops.im2col_first(xd), rows, b.to(dev), g, True)
+    _close(y2 * 0 + ops.conv1_first_fwd(xd, rows, b.to(dev), True)[0], old, tol=2e-5, what=f"fused vs im2col form {shape}")
+    ynb, _ = ops.conv1_first_fwd(xd, rows, None, False)
+    _close(ynb, _nhwc(ref - b.double().view(1, -1, 1, 1)), what="no bias")
+    if h >= 5 and w >= 5:
+        xn = xd.clone()
+        xn[0, 1, 2, 3] = float("nan")
+        yn, _ = ops.conv1_first_fwd(xn, rows, b.to(dev), False)
+        bad = torch.isnan(yn[0]).any(dim=2)
+        want = torch.zeros(h, w, dtype=torch.bool, device=dev)
+        want[1:4, 2:5] = True
+        assert torch.equal(bad, want) and not torch.isnan(yn[1:]).any()
+
+
+@pytest.mark.parametrize("shape", [(2, 300, 300), (1, 37, 70), (3, 5, 5), (2, 4, 129), (32, 300, 300)])
+def test_conv1_1_weight_gradient_from_the_nchw_input(shape):
+    """csrc/conv_first.hip: dw / db of Conv2d(3, 64, 3, padding=1) (autograd of Model.py:135 features[0]) with the reduction over the
+    pixels on the MFMA, the [pixel][27] operand read from a halo image of x in LDS (never in memory), the bias gradient as a column of
+    ones.  Against f64 autograd (1e-4 of the scale; at batch 32 against the im2col + generic weight-gradient form, 2e-5) and bit-stable
+    from run to run (persistent workgroups, partial sums added in index order)."""
+    from objectdetection_ssd_amd import ops
+    n, h, w = shape
+    dev = _dev()
+    gen = torch.Generator(device=dev).manual_seed(h + w)
+    x = torch.randn(n, 3, h, w, device=dev, generator=gen)
+    dy = torch.randn(n, h, w, 64, device=dev, generator=gen)
+    dw, db = ops.conv1_first_wgrad(x, dy, True)
+    dw2, db2 = ops.conv1_first_wgrad(x, dy, True)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    assert float(dw.reshape(64, 32)[:, 27:].abs().max()) == 0.0
+    g = ops.make_geom(n, h, w, 32, 64, 1, 1, 0, 1)
+    dw_old, db_old = ops.conv2d_wgrad(ops.im2col_first(x), dy, g, 64, True)
+    _close(dw, dw_old, tol=2e-5, what=f"dw vs im2col form {shape}")
+    _close(db, db_old, tol=2e-5, what=f"db vs im2col form {shape}")
+    if n <= 3:
+        wt = torch.zeros(64, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(x.cpu().double(), wt, torch.zeros(64, dtype=torch.float64), padding=1)
+        y.backward(_nchw(dy.cpu().double()))
+        _close(ops.first_weight_grad(dw), wt.grad, what=f"dw vs f64 {shape}")
+        _close(db, dy.cpu().double().sum((0, 1, 2)), what=f"db vs f64 {shape}")
+    assert ops.conv1_first_wgrad(x, dy, False)[1] is None

@@ -1,6 +1,8 @@
-"""Interleaved A/B of one library tuning switch on the full train step at batch 32 (same process, same device, alternating repetitions).
+"""Interleaved A/B of one tuning switch on the full train step at batch 32 (same process, same device, alternating repetitions): a
+library switch (`ssd_tune_set_...`) or an attribute of the engine (`engine.<name>`).
 
-    python tools/ab_step.py ssd_tune_set_wino_fused_waves 8 4
+    python tools/ab_step.py ssd_tune_set_batched_units 0 1
+    python tools/ab_step.py engine.first_fused 0 1
 """
 import os
 import sys
@@ -39,7 +41,11 @@ def main():
     res = {v: [] for v in vals}
     for rep in range(5):
         for v in vals:
-            _lib.check(getattr(lib, fn)(v), "tune")
+            if fn.startswith("engine."):
+                setattr(net._engine, fn[7:], type(getattr(net._engine, fn[7:]))(v))
+                net.invalidate_weight_cache()
+            else:
+                _lib.check(getattr(lib, fn)(v), "tune")
             steps(2)
             res[v].append(steps(15))
     for v in vals:
