@@ -156,6 +156,7 @@ class _Engine:
         self.ops = early + late + side
         self._side_ids = {id(o) for o in side}
         self._late_first = id(late[0])
+        self.defer_tail_wgrad = True              # backward: the side group's weight gradients after its data-gradient chain, behind the join
         self.overlap_tail = True                  # False: everything on the caller's stream (bit-identical; interleaved A/B: 26.09 -> 25.85 ms)
         self._side_stream = None
         # Backward: the Winograd weight-gradient GEMMs (MFMA-bound, nothing waits for them) on their own stream beside the chain
@@ -506,14 +507,24 @@ class _Engine:
             dconf.record_stream(side)
             side_ctx = torch.cuda.stream(side)
             side_ctx.__enter__()
-        join_event = None
+        join_event = side_done = None
+        # The side group's weight gradients are not on the path to a8's gradient (the only thing the caller's stream needs from the group):
+        # they are enqueued AFTER the group's data-gradient chain, behind the join event.
+        deferred = []
+        defer = self.defer_tail_wgrad and self.prof is None
         for op in reversed(self.ops):
             kind = op["op"]
             if side_ctx is not None and id(op) not in self._side_ids:      # the side group is enqueued: back to the caller's stream
+                join_event = side.record_event()                           # every data gradient the caller's stream will read exists
+                for t in G.values():
+                    t.record_stream(main)
+                for wg in deferred:                                        # the side group's weight gradients: nothing waits for them
+                    wg()
+                deferred.clear()
                 side_ctx.__exit__(None, None, None)
                 side_ctx = None
-                join_event = side.record_event()
-                for t in list(G.values()) + list(grads.values()):
+                side_done = side.record_event()
+                for t in grads.values():
                     t.record_stream(main)
             if not joined and side_ctx is None and kind in ("conv", "pool", "conv_first"):      # first op that needs what the side group produced (a8's gradient)
                 main.wait_event(join_event)
@@ -547,8 +558,15 @@ class _Engine:
                         dw, db = res[0], res[1]
                         dyp = res[2] if dual else None
                     else:
-                        dw, db = self._timed("wgrad " + pre, ops.wgrad_tile(g) if self.prof is not None else "", ops.conv_flops(g),
-                                             lambda: ops.conv2d_wgrad(xin, dy, g, co_pad, True, bf16=self.bf16))
+                        def wg(pre=pre, a4=a4, xin=xin, dy=dy, g=g, co_pad=co_pad):
+                            dw_, db_ = self._timed("wgrad " + pre, ops.wgrad_tile(g) if self.prof is not None else "", ops.conv_flops(g),
+                                                   lambda: ops.conv2d_wgrad(xin, dy, g, co_pad, True, bf16=self.bf16))
+                            grads[pre + "_bb.weight"], grads[pre + "_cl.weight"] = dw_[:a4], dw_[a4:]
+                            grads[pre + "_bb.bias"], grads[pre + "_cl.bias"] = db_[:a4], db_[a4:]
+                        if side_ctx is not None and defer:
+                            deferred.append(wg)
+                        else:
+                            wg()
                     if dw is not None:
                         grads[pre + "_bb.weight"], grads[pre + "_cl.weight"] = dw[:a4], dw[a4:]
                         grads[pre + "_bb.bias"], grads[pre + "_cl.bias"] = db[:a4], db[a4:]
@@ -595,8 +613,15 @@ class _Engine:
                         dw, db = res[0], res[1]
                         dyp = res[2] if dual else None
                     else:
-                        dw, db = self._timed("wgrad " + op["p"], ops.wgrad_tile(g) if self.prof is not None else "", ops.conv_flops(g),
-                                             lambda: ops.conv2d_wgrad(xin, dy, g, g.Co, True, bf16=self.bf16))
+                        def wg(name=op["p"], xin=xin, dy=dy, g=g):
+                            grads[name + ".weight"], grads[name + ".bias"] = self._timed(
+                                "wgrad " + name, ops.wgrad_tile(g) if self.prof is not None else "", ops.conv_flops(g),
+                                lambda: ops.conv2d_wgrad(xin, dy, g, g.Co, True, bf16=self.bf16))
+                        if side_ctx is not None and defer:
+                            deferred.append(wg)
+                        else:
+                            wg()
+                        dw = None
                     if dw is not None:
                         grads[op["p"] + ".weight"], grads[op["p"] + ".bias"] = dw, db
                 if self._wino_ok(g):
@@ -652,6 +677,8 @@ class _Engine:
                     grads[op["p"] + ".weight"], grads[op["p"] + ".bias"] = ops.first_weight_grad(dw), db
         if not joined:
             main.wait_event(join_event)
+        if side_done is not None:
+            main.wait_event(side_done)
         if wgrad_used:
             main.wait_event(self._wgrad_stream.record_event())
         return grads
