@@ -234,6 +234,7 @@ int ssd_prof_gemm_collect_kinds(float* ms_out, double* flops_out, int* kinds_out
 int ssd_prof_gemm_collect(float* ms_out, double* flops_out, int max);
 int ssd_tune_set_igemm(int tile, int nbuf);
 int ssd_tune_set_igemm_stamps(uint64_t* device_buffer);   /* diagnostic: per-block shader-clock stamps (see conv_igemm.hip) */
+int ssd_tune_set_dgrad_parity(int on);   /* 1 (default): data gradients of stride-2 convolutions with their rows grouped by pixel parity (only the taps that reach a class are multiplied); 0: plain kernel */
 int ssd_tune_set_batched_units(int on);   /* 1 (default): the blocks of one (plane, part of the row tiles) of a batched plane GEMM share one XCD; 0: 3-D grid */
 int ssd_tune_set_igemm_lds_pad(int bytes);   /* extra dynamic LDS per block: caps resident blocks per CU (experiments) */
 int ssd_tune_set_wgrad(int bt, int nbuf, int blocks_per_cu);

@@ -107,6 +107,7 @@ SIGNATURES = {
     "ssd_tune_set_gemm_nt": (_I, [_I]),
     "ssd_tune_set_wino_bias_tail": (_I, [_I]),
     "ssd_tune_set_batched_units": (_I, [_I]),
+    "ssd_tune_set_dgrad_parity": (_I, [_I]),
     "ssd_tune_set_wino_full": (_I, [_I]),
     "ssd_conv3x3_wino_uses_full": (_I, [_G, _I]),
     "ssd_conv3x3_wino_dgrad_bits": (_I, [_P, _I, _P, _I, _P, _P, _I, _G, _P, _Z, _P]),

@@ -37,6 +37,7 @@ struct IgemmParams {
     int sm, sd;              // output coord multiplier; divisor (dgrad of strided conv)
     int off, dstep;          // tap 0 offset; per-tap step
     int M;                   // N*Ho*Wo
+    int M_img;               // PARITY: images in the batch
     int tiles_m, tiles_n;
     int relu, accumulate;
     int ksplit, kt_per_split;   // split-K (small grids, deep K): blockIdx.y = split; partial tiles go to `slab`
@@ -47,6 +48,11 @@ struct IgemmParams {
     // batched, no split-K: a unit = (problem, part of its row tiles) runs on ONE XCD (1-D grid, block ids of one residue mod 8), so a
     // filter plane leaves HBM once per part instead of once per XCD; units = 0: the 3-D grid (x = tile, y = K slice, z = problem)
     int units, msplit, mper, bpu;
+    // PARITY (data gradient of a stride-2 convolution, dilation 1): the M rows are the pixels of dx grouped by the parity (a, b) of
+    // their coordinates -- class c = 2a + b holds the rows par_base[c] .. of (n, i, j) -> pixel (2i + a, 2j + b), padded to whole
+    // 64-row tiles -- so that every block sees ONE class and multiplies only the taps of that parity (1, 2, 2 or 4 of the 9; the
+    // plain kernel multiplies zeros for the others).  par_hc[a] / par_wc[b]: rows / columns of dx with that parity.
+    int par_base[5], par_hc[2], par_wc[2];
     unsigned long long* stamps; // diagnostic (ssd_tune_set_igemm_stamps): shader-clock stamps of every 64th block, else NULL
 };
 
@@ -144,7 +150,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, const f32x1
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NBUF, bool BATCHED = false>      // BATCHED: its own symbol, so profiles tell the Winograd GEMMs apart
+template <int BM, int BN, int WM, int WN, int NBUF, bool BATCHED = false, bool PARITY = false>      // BATCHED: its own symbol, so profiles tell the Winograd GEMMs apart
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p_in) {
     IgemmParams p = p_in;
     int unit_tile = -1;                                   // BATCHED with units: the logical tile of this block inside its problem
@@ -186,13 +192,35 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p_in) {
     int a_h[A_ROWS], a_w[A_ROWS];
     unsigned a_base[A_ROWS], voff_a[A_ROWS];
     const int HoWo = p.Ho * p.Wo;
+    // PARITY: the class of this block's rows (uniform), its size and where it starts
+    int pc = 0;
+    if (PARITY) pc = (m0 >= p.par_base[1]) + (m0 >= p.par_base[2]) + (m0 >= p.par_base[3]);
+    const int pa = pc >> 1, pb = pc & 1, pHc = PARITY ? p.par_hc[pa] : 1, pWc = PARITY ? p.par_wc[pb] : 1;
+    const int pcnt = PARITY ? (p.par_base[pc + 1] - p.par_base[pc]) : 0;      // padded; rows beyond N * pHc * pWc are idle
+    const int pvalid = PARITY ? (p.M_img * pHc * pWc) : 0, pm0 = PARITY ? m0 - p.par_base[pc] : 0;
+    const float prcp_hw = PARITY ? 1.0f / (float)(pHc * pWc) : 0.f, prcp_w = PARITY ? 1.0f / (float)pWc : 0.f;
+    (void)pcnt;
 #pragma unroll
     for (int j = 0; j < A_ROWS; ++j) {
-        const int m = m0 + row0 + 32 * j;
-        const bool ok = m < p.M;
-        const int mm = ok ? m : 0;
-        const int n = div_small_q(mm, HoWo, p.rcp_howo), rem = mm - n * HoWo;
-        const int oh = div_small_q(rem, p.Wo, p.rcp_wo), ow = rem - oh * p.Wo;
+        int n, oh, ow;
+        bool ok;
+        if (PARITY) {
+            const int ml = pm0 + row0 + 32 * j;
+            ok = ml < pvalid;
+            const int mm = ok ? ml : 0;
+            n = div_small_q(mm, pHc * pWc, prcp_hw);
+            const int rem = mm - n * pHc * pWc, i = div_small_q(rem, pWc, prcp_w);
+            oh = 2 * i + pa;
+            ow = 2 * (rem - i * pWc) + pb;
+        } else {
+            const int m = m0 + row0 + 32 * j;
+            ok = m < p.M;
+            const int mm = ok ? m : 0;
+            n = div_small_q(mm, HoWo, p.rcp_howo);
+            const int rem = mm - n * HoWo;
+            oh = div_small_q(rem, p.Wo, p.rcp_wo);
+            ow = rem - oh * p.Wo;
+        }
         a_h[j] = ok ? oh * p.sm + p.off : -(1 << 24);       // never in range for a row past M
         a_w[j] = ow * p.sm + p.off;
         a_base[j] = (unsigned)n * (unsigned)(p.Ha * p.Wa * p.Ca) * 4u + chunk * 16u;
@@ -236,10 +264,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p_in) {
     const int kc = p.Ca / BK;          // K steps per tap
     // this block's K steps: all of them, or the blockIdx.y-th slice when the launch is split-K
     const int kt_begin = p.ksplit > 1 ? (int)blockIdx.y * p.kt_per_split : 0;
-    const int KT = p.ksplit > 1 ? min(T * kc - kt_begin, p.kt_per_split) : T * kc;
+    // PARITY: only the taps r = r_par, r_par + 2, ... / s = s_par, ... reach this class: (oh + off - r) must be even (dstep = -1)
+    const int r_par = PARITY ? ((pa + p.off) & 1) : 0, s_par = PARITY ? ((pb + p.off) & 1) : 0;
+    const int KT = PARITY ? ((p.R - r_par + 1) >> 1) * ((p.S - s_par + 1) >> 1) * kc
+                          : (p.ksplit > 1 ? min(T * kc - kt_begin, p.kt_per_split) : T * kc);
     f32x4 ra[A_ROWS], rb[B_ROWS];
-    int c_nxt = kt_begin % kc, r_nxt = (kt_begin / kc) / p.S, s_nxt = (kt_begin / kc) % p.S;
-    unsigned soff_a = (unsigned)c_nxt * BK * 4, soff_b = (unsigned)kt_begin * BK * 4;
+    int c_nxt = PARITY ? 0 : kt_begin % kc, r_nxt = PARITY ? r_par : (kt_begin / kc) / p.S, s_nxt = PARITY ? s_par : (kt_begin / kc) % p.S;
+    unsigned soff_a = (unsigned)c_nxt * BK * 4, soff_b = PARITY ? (unsigned)((r_par * p.S + s_par) * p.Ca) * 4u : (unsigned)kt_begin * BK * 4;
     tap_offsets(r_nxt, s_nxt);
 
     auto issue_into = [&](f32x4* qa, f32x4* qb) {
@@ -252,7 +283,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p_in) {
         if (++c_nxt == kc) {                                 // next tile starts a new tap
             c_nxt = 0;
             soff_a = 0;
-            if (++s_nxt == p.S) { s_nxt = 0; ++r_nxt; }
+            if (PARITY) {                                    // the next tap of this parity (rows of the filter are [tap][Ca])
+                s_nxt += 2;
+                if (s_nxt >= p.S) { s_nxt = s_par; r_nxt += 2; }
+                soff_b = (unsigned)((r_nxt * p.S + s_nxt) * p.Ca) * 4u;
+            } else if (++s_nxt == p.S) { s_nxt = 0; ++r_nxt; }
             tap_offsets(r_nxt, s_nxt);
         }
     };
@@ -332,6 +367,28 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p_in) {
             }
         return;
     }
+    if (PARITY) {                                         // rows -> pixels of dx: (n, i, j) of the class -> (2i + a, 2j + b); + previous dx, ReLU mask
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = pm0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (ml >= pvalid) continue;
+                const int n = div_small_q(ml, pHc * pWc, prcp_hw), rem = ml - n * pHc * pWc, ii = div_small_q(rem, pWc, prcp_w);
+                const size_t row = (((size_t)n * p.Ho + 2 * ii + pa) * p.Wo + 2 * (rem - ii * pWc) + pb) * p.ldo;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int nn = n0 + (wn * TN + j) * 32 + lr;
+                    if (nn < p.Nout) {
+                        float v = acc[i][j][r];
+                        if (p.accumulate) v += p.out[row + nn];
+                        if (p.mask != nullptr) v = p.mask[row + nn] > 0.f ? v : 0.f;
+                        p.out[row + nn] = v;
+                    }
+                }
+            }
+        return;
+    }
     igemm_epilogue<BM, TM, TN>(p, acc, m0, n0, wm, wn, lr, lh);
     if (stamp) {
         unsigned long long* o = p.stamps + (size_t)(blockIdx.x >> 6) * 4;
@@ -341,6 +398,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p_in) {
 
 int g_lds_pad = 0;            // tuning aid: extra dynamic LDS per block (caps the blocks resident per CU)
 int g_batched_units = 1;      // tuning aid (ssd_tune_set_batched_units): 0 = batched GEMMs on the 3-D grid
+int g_dgrad_parity = 1;       // tuning aid (ssd_tune_set_dgrad_parity): 0 = stride-2 data gradients on the plain kernel (3/4 of the taps multiply zeros)
 unsigned long long* g_stamps = nullptr;   // diagnostic buffer (ssd_tune_set_igemm_stamps)
 int g_force_ksplit = -1;      // tuning aid: 1 = never split K, k > 1 = always k slices (when a workspace is given); -1 = automatic
 
@@ -378,7 +436,7 @@ int pick_ksplit(int blocks, int kt, size_t tile_elems_total) {
     return k < 2 ? 1 : k;
 }
 
-template <int BM, int BN, int WM, int WN, int NBUF, bool BATCHED = false>
+template <int BM, int BN, int WM, int WN, int NBUF, bool BATCHED = false, bool PARITY = false>
 int launch_igemm(IgemmParams& p, hipStream_t st) {
     p.tiles_m = ssd_cdiv(p.M, BM);
     p.tiles_n = ssd_cdiv(p.Nout, BN);
@@ -394,11 +452,11 @@ int launch_igemm(IgemmParams& p, hipStream_t st) {
         p.msplit = ssd_cdiv(p.tiles_m, p.mper);           // no empty part
         p.units = p.nbatch * p.msplit;
         p.bpu = p.mper * p.tiles_n;
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, NBUF, BATCHED>), dim3((unsigned)(ssd_cdiv(p.units, 8) * 8 * p.bpu)), dim3(256), g_lds_pad, st, p);
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, NBUF, BATCHED, PARITY>), dim3((unsigned)(ssd_cdiv(p.units, 8) * 8 * p.bpu)), dim3(256), g_lds_pad, st, p);
         SSD_CHECK_LAUNCH();
         return SSD_OK;
     }
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, NBUF, BATCHED>), dim3(p.tiles_m * p.tiles_n, ks, BATCHED ? p.nbatch : 1), dim3(256),
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, NBUF, BATCHED, PARITY>), dim3(p.tiles_m * p.tiles_n, ks, BATCHED ? p.nbatch : 1), dim3(256),
                        g_lds_pad, st, p);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
@@ -1175,7 +1233,28 @@ static int conv2d_dgrad_impl(const float* dy, int ldy, const float* w_ihwo, int 
     p.Nout = g->Ci; p.Nrows = g->Ci; p.ldo = g->Ci; p.R = g->R; p.S = g->S;
     p.sm = 1; p.sd = g->stride; p.off = g->pad; p.dstep = -g->dil;
     p.M = g->N * g->H * g->W; p.relu = 0; p.accumulate = accumulate;
+    if (!bf16 && g_dgrad_parity && g->stride == 2 && g->dil == 1 && g_force_tile == TAUTO) {
+        // rows grouped by the parity of the dx pixel: every block multiplies only the taps that reach its class
+        int base = 0;
+        for (int c = 0; c < 4; ++c) {
+            const int hc = (g->H + 1 - (c >> 1)) / 2, wc = (g->W + 1 - (c & 1)) / 2;
+            p.par_base[c] = base;
+            p.par_hc[c >> 1] = hc; p.par_wc[c & 1] = wc;
+            base += (g->N * hc * wc + 63) / 64 * 64;
+        }
+        p.par_base[4] = base;
+        p.M_img = g->N;
+        p.M = base;
+        p.ksplit = 1;
+        p.stamps = nullptr;
+        return launch_igemm<64, 64, 2, 2, 1, false, true>(p, (hipStream_t)stream);
+    }
     return bf16 ? dispatch_igemm_bf16(p, (hipStream_t)stream) : dispatch_igemm(p, (hipStream_t)stream, ws, ws_bytes);
+}
+
+extern "C" int ssd_tune_set_dgrad_parity(int on) {
+    g_dgrad_parity = on != 0;
+    return SSD_OK;
 }
 
 extern "C" int ssd_conv2d_dgrad_ws(const float* dy, int ldy, const float* w_ihwo, int Co_pad, float* dx, const float* relu_mask,

@@ -1144,3 +1144,47 @@ def test_conv1_1_weight_gradient_from_the_nchw_input(shape):
         _close(ops.first_weight_grad(dw), wt.grad, what=f"dw vs f64 {shape}")
         _close(db, dy.cpu().double().sum((0, 1, 2)), what=f"db vs f64 {shape}")
     assert ops.conv1_first_wgrad(x, dy, False)[1] is None
+
+
+STRIDE2_CASES = [  # n, h, w, ci, co, k, pad: seq8.2 / seq9.2 shapes, even and odd maps, 1x1 / stride 2, pad 0, more images than a tile holds
+    (2, 19, 19, 64, 96, 3, 1), (3, 10, 10, 32, 64, 3, 1), (1, 8, 13, 32, 32, 3, 1), (2, 7, 6, 32, 40, 1, 0), (2, 9, 9, 32, 32, 3, 0),
+    (32, 19, 19, 256, 512, 3, 1),
+]
+
+
+@pytest.mark.parametrize("case", STRIDE2_CASES)
+def test_stride2_data_gradient_grouped_by_pixel_parity(case):
+    """dx of a stride-2 convolution (seq8.2 / seq9.2, Model.py:163-164): a dx pixel of parity (a, b) only receives the filter taps of one
+    parity -- 1, 2, 2 or 4 of the 9 -- while the plain implicit-GEMM kernel walks all nine and multiplies zeros for the rest.  The
+    PARITY instantiation groups the rows by class so that a block skips those taps.  Skipped products are exact zeros and the remaining
+    ones are added in the same order, so the result must EQUAL the plain kernel's (mask and accumulate included), and match autograd."""
+    from objectdetection_ssd_amd import _lib, ops
+    lib = _lib.load()
+    n, h, w, ci, co, k, pad = case
+    dev = _dev()
+    gen = torch.Generator(device=dev).manual_seed(h * 31 + w)
+    g = ops.make_geom(n, h, w, ci, co, k, 2, pad, 1)
+    ld = ops.pad32(co)
+    wt = torch.randn(co, ci, k, k, device=dev, generator=gen) * (2.0 / (ci * k * k)) ** 0.5
+    dy = torch.zeros(n, g.Ho, g.Wo, ld, device=dev)
+    dy[..., :co] = torch.randn(n, g.Ho, g.Wo, co, device=dev, generator=gen)
+    wb = ops.weight_ihwo(wt, ld)
+    prev = torch.randn(n, h, w, ci, device=dev, generator=gen)
+    mask = torch.randn(n, h, w, ci, device=dev, generator=gen).clamp_min(0)
+    out = {}
+    try:
+        _lib.check(lib.ssd_tune_set_igemm_splitk(1), "tune")               # the plain kernel without K slices: one sum order for both
+        for mode in (0, 1):
+            _lib.check(lib.ssd_tune_set_dgrad_parity(mode), "tune")
+            out[mode] = (ops.conv2d_dgrad(dy, wb, g), ops.conv2d_dgrad(dy, wb, g, dx=prev.clone(), relu_mask=mask, accumulate=True))
+    finally:
+        _lib.check(lib.ssd_tune_set_dgrad_parity(1), "tune")
+        _lib.check(lib.ssd_tune_set_igemm_splitk(-1), "tune")
+    assert torch.equal(out[0][0], out[1][0]), "plain vs parity-grouped data gradient"
+    assert torch.equal(out[0][1], out[1][1]), "with accumulate + mask"
+    assert torch.equal(out[1][1], torch.where(mask > 0, out[1][0] + prev, torch.zeros_like(prev)))
+    k_ = min(n, 2)
+    x64 = torch.zeros(k_, ci, h, w, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x64, wt.cpu().double(), None, stride=2, padding=pad)
+    y.backward(_nchw(dy[:k_, ..., :co].cpu().double()))
+    _close(out[1][0][:k_], _nhwc(x64.grad), what=f"stride-2 dgrad vs f64 {case}")
