@@ -183,15 +183,15 @@ class _Engine:
         self.grad_sink = None     # callable(name, gradient): called during backward the moment a parameter's gradient is ready
         self.dual_dy = True       # backward: one pass over dy writes the planes of the weight gradient AND of the data gradient
         self.keep_planes = True   # training forward keeps the F(4x4) input planes of the layers whose weight gradient is Winograd
-        self.fuse_pool = True     # Winograd F(4x4) layers in pool_after write the pooled map + argmax only
-        self.first_fused = True        # conv1_1 forward in one kernel (csrc/conv_first.hip) instead of im2col + 1x1 MFMA convolution
-        self.wino_dilated = True       # fc6 (3x3, dilation 4) in the Winograd domain too: 49 tiles x 36 products per image instead of 361 x 9
+        self.fuse_pool = True     # Winograd F(4x4) layers in pool_after write the pooled map + argmax only ...
         self.lazy_pool_grad = True     # ... and in the backward their dy pass reads the pooled gradient: the pool's dx is never written
+        self.first_fused = True        # conv1_1 forward and weight gradient straight from the NCHW batch (csrc/conv_first.hip), no im2col rows
+        self.wino_dilated = True       # fc6 (3x3, dilation 4) in the Winograd domain too: 49 tiles x 36 products per image instead of 361 x 9
         self.relu_bits = True     # training forward: the input transform also leaves the ReLU mask of its input as bits for the dgrad epilogue
         self.prof = None          # bench.py: list collecting (label, kernel tag, flops, start event, end event)
         self.bf16 = False         # True: forward / dgrad / fused-wgrad convolutions multiply bf16-rounded operands (f32 accumulate)
         self.x3 = False           # True: forward / dgrad convolutions form f32 products from three bf16 limbs per operand
-        self.wino = True          # f32 mode: Winograd F(2x2,3x3) for the 3x3 / stride-1 layers with >= WINO_MIN_CI input channels
+        self.wino = True          # f32 mode: Winograd F(4x4,3x3) (WINO_TILE) for the 3x3 / stride-1 layers with >= WINO_MIN_CI input channels
 
     def _timed(self, label, tag, flops, fn):
         """Run fn(); when profiling, bracket it with HIP events on the current stream."""
