@@ -399,3 +399,64 @@ def test_winograd_entry_points_validate_before_launching():
     assert d(OK_PTR, OK_PTR, 64, OK_PTR, ODD_PTR, 0, gb, OK_PTR, ws_d, None) == -5
     assert d(OK_PTR, OK_PTR, 64, OK_PTR, None, 0, gb, OK_PTR, 16, None) == -2
     assert lib.ssd_status_string(-5).startswith(b"pointer")
+
+
+def test_round2_entry_points_validate_and_size_without_a_gpu():
+    """Host-side rules of the entry points added in round 2, with made-up pointers that are never dereferenced: the tile count of a
+    dilated layer (d x d sub-lattices tiled one by one) as the workspace query sees it, what the dilated form refuses (fused pool,
+    F(2x2), pooled gradient source), the shape rules of the pooled-gradient source, conv1_1's one-kernel forms and the weight job table."""
+    import ctypes as C
+    from objectdetection_ssd_amd import _lib, ops
+    lib = _lib.load()
+    OK_PTR, ODD_PTR = 0x10000, 0x10004
+    # fc6: 19x19, dilation 4 -> lattices of 5,5,5,4 rows -> 2+2+2+1 = 7 tile rows per dimension
+    g6 = ops.make_geom(32, 19, 19, 512, 1024, 3, 1, 4, 4)
+    assert ops.wino_tiles(g6) == 32 * 49
+    for (h, w, d) in ((19, 19, 4), (10, 13, 2), (7, 5, 3), (3, 3, 4), (300, 300, 1), (75, 38, 1)):
+        g = ops.make_geom(2, h, w, 32, 32, 3, 1, d, d)
+        rows = sum(-(-len(range(a, h, d)) // 4) for a in range(d))
+        cols = sum(-(-len(range(b, w, d)) // 4) for b in range(d))
+        assert ops.wino_tiles(g) == 2 * rows * cols, (h, w, d)
+        assert lib.ssd_conv3x3_wino_workspace(C.byref(g), 0, 4) == 2 * (36 * 2 * rows * cols * 32 * 4)
+        if d > 1:
+            assert lib.ssd_conv3x3_wino_workspace(C.byref(g), 0, 2) == 0                         # no F(2x2) on sub-lattices
+    gb6 = C.byref(g6)
+    ws6 = lib.ssd_conv3x3_wino_workspace(gb6, 0, 4)
+    assert lib.ssd_conv3x3_wino_workspace(gb6, 0, 2) == 0                                       # no F(2x2) on sub-lattices
+    assert lib.ssd_conv3x3_wino_fwd_pool(OK_PTR, OK_PTR, None, OK_PTR, None, gb6, 0, None, OK_PTR, ws6, None) == -1     # nor the fused pool
+    assert lib.ssd_conv3x3_wino_uses_full(gb6, 0) == 0
+    g5 = ops.make_geom(2, 19, 19, 64, 64, 3, 1, 5, 5)
+    assert lib.ssd_conv3x3_wino_workspace(C.byref(g5), 0, 4) == 0                                # dilation 1 .. 4
+    gpd = ops.make_geom(2, 19, 19, 64, 64, 3, 1, 4, 2)
+    assert lib.ssd_conv3x3_wino_workspace(C.byref(gpd), 0, 4) == 0                               # padding must equal the dilation
+    # pooled-gradient source: the 2x2 / stride-2 pool over exactly this layer's output, ldy = Co, plain geometry only
+    g = ops.make_geom(2, 75, 75, 64, 64, 3, 1, 1, 1)
+    gb = C.byref(g)
+    f = lib.ssd_wino4_dy_transform_pooled
+    assert f(OK_PTR, OK_PTR, OK_PTR, 38, 38, 64, gb, OK_PTR, None, None, None) in (0, -4)        # accepted (a launch without a GPU may fail)
+    assert f(OK_PTR, OK_PTR, OK_PTR, 37, 37, 64, gb, None, None, None, None) == -3
+    assert f(OK_PTR, OK_PTR, OK_PTR, 36, 38, 64, gb, OK_PTR, None, None, None) == -1             # not this map's pool
+    assert f(OK_PTR, OK_PTR, OK_PTR, 39, 38, 64, gb, OK_PTR, None, None, None) == -1
+    assert f(OK_PTR, OK_PTR, OK_PTR, 38, 38, 96, gb, OK_PTR, None, None, None) == -1             # ldy must be Co
+    assert f(OK_PTR, 0x10002, OK_PTR, 38, 38, 64, gb, OK_PTR, None, None, None) == -5            # argmax words
+    assert f(OK_PTR, OK_PTR, OK_PTR, 10, 10, 1024, gb6, OK_PTR, None, None, None) == -1          # no pooled source on a dilated layer
+    # conv1_1 in one kernel
+    assert lib.ssd_conv1_first_fwd(None, OK_PTR, None, OK_PTR, None, 2, 300, 300, 1, None) == -3
+    assert lib.ssd_conv1_first_fwd(OK_PTR, OK_PTR, None, ODD_PTR, None, 2, 300, 300, 1, None) == -5
+    assert lib.ssd_conv1_first_fwd(OK_PTR, OK_PTR, None, OK_PTR, None, 0, 300, 300, 1, None) == -1
+    wsf = lib.ssd_conv1_first_wgrad_workspace(32, 300, 300)
+    assert wsf >= 768 * 2048 * 4                                                                  # one [64][32] partial per workgroup
+    assert lib.ssd_conv1_first_wgrad(OK_PTR, OK_PTR, OK_PTR, None, 32, 300, 300, OK_PTR, 16, None) == -2
+    assert lib.ssd_conv1_first_wgrad(OK_PTR, ODD_PTR, OK_PTR, None, 32, 300, 300, OK_PTR, wsf, None) == -5
+    # weight job table: block counts per job kind
+    job = _lib.WeightJob()
+    job.w0 = job.w1 = OK_PTR; job.out_fwd = OK_PTR; job.out_bwd = OK_PTR
+    job.co0 = job.co = 128; job.ci = 64; job.taps = 9; job.co_pad = 128; job.kind = 0
+    assert lib.ssd_weight_job_blocks(C.byref(job)) == (128 * 64 + 64 * 128 + 255) // 256
+    job.kind = 1
+    assert lib.ssd_weight_job_blocks(C.byref(job)) == (2 * 128 * 9 * 64 + 255) // 256
+    job.kind = 2; job.co = job.co0 = 64; job.ci = 3
+    assert lib.ssd_weight_job_blocks(C.byref(job)) == 64 * 32 // 256
+    job.kind = 9
+    assert lib.ssd_weight_job_blocks(C.byref(job)) == -1
+    assert lib.ssd_weights_prepare(None, OK_PTR, 1, 1, None) == -3
