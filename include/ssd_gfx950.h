@@ -224,7 +224,7 @@ int ssd_tune_set_gemm_nt(int mode);
  * needs no dgrad planes from ssd_wino4_dy_transform. */
 int ssd_tune_set_wino_full(int mode);
 int ssd_conv3x3_wino_uses_full(const ssd_conv_geom* g, int direction);
-int ssd_tune_set_wino_fused_stagger(int cycles);   /* first-round start delay step between CUs; -1 automatic, 0 none */
+int ssd_tune_set_wino_fused_stagger(int cycles);   /* first-round start delay step between CUs (shader cycles); -1 / 0 (default): none */
 int ssd_tune_set_wino_fused_stamps(uint64_t* device_buffer);   /* diagnostic: in-kernel phase stamps of the fused kernel; NULL = off */
 int ssd_tune_set_wino_wgrad_tn(int on);   /* 1 (default): F(4x4) weight gradient on untransposed planes + TN GEMM; 0: transposed planes */
 /* Measurement aid: arm / read back per-launch timings (library-owned HIP events) of the batched Winograd GEMM kernel.

@@ -301,7 +301,7 @@ int ssd_internal_prof_open(double flops, int kind, hipStream_t st);
 void ssd_internal_prof_close(int slot, hipStream_t st);
 namespace {
 unsigned long long* g_fused_stamps = nullptr;
-int g_fused_stagger = -1;         // -1: automatic; 0: none
+int g_fused_stagger = -1;         // -1 / 0: none; > 0: delay step in shader cycles
 }  // namespace
 
 // Diagnostic: device buffer of 8 x uint64 per 16 blocks (start, main loop start, main loop end, output transformed, stores issued,
@@ -332,7 +332,10 @@ __attribute__((visibility("hidden"))) int ssd_internal_wino4_gemm_out(const floa
     p.H = H; p.W = W; p.TH = TH; p.TW = TW;
     p.yp = yp; p.am = am; p.Ho = Ho; p.Wo = Wo;
     p.stamps = g_fused_stamps;
-    p.stagger = g_fused_stagger < 0 ? (K / FK) * 36 * 160 : g_fused_stagger;      // eight phases over about one workgroup's life
+    // The first-round start stagger (eight phases over about one workgroup's life: (K / 64) * 36 * 160 cycles per phase) made the kernel
+    // 1-3 % faster by itself, but in the train step its idle start costs more than it returns (23.69 vs 23.84 ms, interleaved A/B): off
+    // unless asked for.
+    p.stagger = g_fused_stagger < 0 ? 0 : g_fused_stagger;
     const long long nblk = (long long)p.groups * p.nblk_n;
     if (nblk >= (1ll << 31)) return SSD_ERR_BAD_SHAPE;
     const int slot = ssd_internal_prof_open(2.0 * 36 * tiles * (double)K * (double)(p.nblk_n * FN), 1, st);   // FLOPs the grid executes
