@@ -377,10 +377,10 @@ def main():
     def step():
         trainer.zero_grad()
         loc, conf = net(x)
-        l1, l2 = Losses.ssd((loc, conf), classes, boxes, norm_mode=1)     # un-normalised sums (ddp.py)
+        l1, l2, n_pos = Losses.ssd((loc, conf), classes, boxes, norm_mode=1, with_n_pos=True)     # un-normalised sums (ddp.py)
         (l1 + l2).backward()
-        trainer.reduce_and_step(Losses.last_match["n_pos"])
-        return l1, l2
+        trainer.reduce_and_step(n_pos)
+        return l1, l2, n_pos
 
     def fence():
         if world > 1:
@@ -394,7 +394,7 @@ def main():
     t0 = time.perf_counter()
     probe_a = _ops.clock_probe(dev)              # two tiny launches bracket the timed steps: average shader clock held
     for _ in range(args.steps):
-        l1, l2 = step()
+        l1, l2, n_pos_local = step()
     probe_b = _ops.clock_probe(dev)
     fence()
     elapsed = time.perf_counter() - t0
@@ -415,7 +415,15 @@ def main():
         host_ms += (time.perf_counter() - h0) / 3 * 1e3
     fence()
     n_pos = float(trainer.flat_grad[trainer.n].item())
-    loss = (float(l1.item()) + float(l2.item())) / max(float(Losses.last_match["n_pos"].item()), 1.0)
+    loss = (float(l1.item()) + float(l2.item())) / max(float(n_pos_local.item()), 1.0)
+    # self-check of the collective path: every rank adds 1 and its own rank id; rank 0 prints what arrived
+    ranks_seen, rank_id_sum = 1, 0
+    if world > 1:
+        t = torch.tensor([1.0, float(rank)], device=dev, dtype=torch.float64)
+        dist.all_reduce(t)
+        ranks_seen, rank_id_sum = int(t[0].item()), int(t[1].item())
+        if ranks_seen != world or rank_id_sum != world * (world - 1) // 2:
+            raise SystemExit(f"bench.py: the all-reduce saw {ranks_seen} ranks (id sum {rank_id_sum}), expected {world}")
 
     out = {"metric": "images/sec SSD300-VGG16 train step", "value": round(ips, 2), "unit": "images/sec",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
@@ -426,6 +434,8 @@ def main():
                                   f"SSD300-VGG16 train step (fwd + MultiBox loss + bwd + all-reduce + SGD), "
                                   f"batch {bs}/GPU, 300x300x3, 21 classes, 8732 priors (BASELINE configs[1])",
                       "global_batch": bs * world, "per_gpu_batch": bs, "parallelism": f"dp{world}" + (" (gradient all-reduce overlapped with backward)" if args.overlap_allreduce else ""),
+                      "ranks_seen": ranks_seen, "backend": (dist.get_backend() if world > 1 else "none (single process)"),
+                      "collective_env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC", "TORCH_NCCL_"))},
                       "train_gflop_per_image": TRAIN_GFLOP_PER_IMAGE,
                       "direct_conv_tflops_per_gpu": round(TRAIN_GFLOP_PER_IMAGE * ips / world / 1e3, 2),
                       "direct_conv_flops_over_f32_mfma_peak": round(TRAIN_GFLOP_PER_IMAGE * ips / world / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),

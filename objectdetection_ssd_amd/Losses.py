@@ -88,10 +88,12 @@ def _pack_targets(tr_classes: Sequence[torch.Tensor], tr_bboxs: Sequence[torch.T
     return gt, cls, _image_starts(start, dev)
 
 
-def ssd(outputs, tr_classes, tr_bboxs, norm_mode: int = 0):
+def ssd(outputs, tr_classes, tr_bboxs, norm_mode: int = 0, with_n_pos: bool = False):
     """outputs = (loc (bs,8732,4), conf (bs,8732,21)); tr_classes: list of (n_i,) float tensors with values
     0..19; tr_bboxs: list of (n_i,4) xyxy fractional boxes.  Returns (loc_loss, conf_loss) as 0-dim tensors
-    that support `+`, `.item()` and `.backward()` (train_function.py:82-94)."""
+    that support `+`, `.item()` and `.backward()` (train_function.py:82-94).
+    with_n_pos: also return this call's number of positive priors (0-dim device tensor) -- the data-parallel step
+    (ddp.py) takes it from here, not from the module global `last_match`, so two models / threads cannot mix theirs up."""
     loc, conf = outputs
     if loc.dim() != 3 or conf.dim() != 3 or loc.shape[0] != len(tr_bboxs) or loc.shape[1] not in (ancs_xywh.shape[0], 24564):
         raise ValueError(f"ssd(): outputs {tuple(loc.shape)}, {tuple(conf.shape)} do not match {len(tr_bboxs)} images "
@@ -99,7 +101,9 @@ def ssd(outputs, tr_classes, tr_bboxs, norm_mode: int = 0):
     gt, cls, img_start = _pack_targets(tr_classes, tr_bboxs, loc.device)
     if not loc.is_cuda:
         raise RuntimeError("ssd() runs on the gfx950 HIP kernels only (no CPU fallback): outputs must be device tensors")
-    l_loc, l_conf, _ = _MultiBoxLoss.apply(loc, conf, gt, cls, img_start, norm_mode)
+    l_loc, l_conf, n_pos = _MultiBoxLoss.apply(loc, conf, gt, cls, img_start, norm_mode)
+    if with_n_pos:
+        return l_loc, l_conf, n_pos.detach()
     return l_loc, l_conf
 
 

@@ -129,15 +129,32 @@ class _Elided:
 
 class _SinkDict(dict):
     """Gradient table of one backward pass that tells a listener about every entry as soon as it exists (ddp.py starts the
-    all-reduce of a bucket when its last gradient has been computed, while the rest of the backward is still running)."""
+    all-reduce of a bucket when its last gradient has been computed, while the rest of the backward is still running).
+
+    The listener is only ever called with the CALLER's stream current and with the producing kernel ordered before that stream's
+    position: gradients produced on the engine's side stream are held (`hold()`) until the caller's stream has waited for the side
+    stream's event (`release()`), so a collective the listener starts can never read a gradient that is still being written."""
 
     def __init__(self, sink):
         super().__init__()
         self._sink = sink
+        self._held = None
 
     def __setitem__(self, name, tensor):
         super().__setitem__(name, tensor)
-        self._sink(name, tensor)
+        if self._held is not None:
+            self._held.append((name, tensor))
+        else:
+            self._sink(name, tensor)
+
+    def hold(self):
+        if self._held is None:
+            self._held = []
+
+    def release(self):
+        held, self._held = self._held or [], None
+        for name, tensor in held:
+            self._sink(name, tensor)
 
 
 class _Engine:
@@ -181,6 +198,10 @@ class _Engine:
                     and op["relu"] and op["co"] % 4 == 0):
                 self.pool_after[op["y"]] = readers[0]
         self.grad_sink = None     # callable(name, gradient): called during backward the moment a parameter's gradient is ready
+        self.grad_out = None      # callable(names) -> flat f32 tensor or None: where the gradient of these consecutive parameters is to be written
+        self.sink_owns_grads = False   # True (ddp.py): gradients live in the listener's buffer, autograd is handed None for them
+        self.sink_early = False        # True: the listener acts on a gradient at once (overlapped all-reduce), so side-stream gradients are joined early
+        self._test_side_delay = None   # tests: callable run on the side stream in front of the deferred weight gradients
         self.dual_dy = True       # backward: one pass over dy writes the planes of the weight gradient AND of the data gradient
         self.keep_planes = True   # training forward keeps the F(4x4) input planes of the layers whose weight gradient is Winograd
         self.fuse_pool = True     # Winograd F(4x4) layers in pool_after write the pooled map + argmax only ...
@@ -349,16 +370,42 @@ class _Engine:
         overlap = self.overlap_tail and bool(self._side_ids)
         if overlap and self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=x.device)
-        side, side_ctx, fork = self._side_stream, None, None
+        side, fork = self._side_stream, None
+        side_ctx = [None]              # the stream context of the side group, left in `finally`: an exception must not leave the side stream current
+        try:
+            self._forward_ops(x, P, save, T, aux, heads, main, side, side_ctx, overlap, bs)
+        finally:
+            if side_ctx[0] is not None:
+                side_ctx[0].__exit__(None, None, None)
+        if side_ctx[0] is not None:
+            for op, packed, _ in heads:
+                if id(op) in self._side_ids:
+                    packed.record_stream(main)
+            main.wait_event(side.record_event())
+        heads.sort(key=lambda h: h[0]["scale"])                   # prior order: c_4, c_7, c_8, ... (Model.py:235)
+        P_total = sum(g.Ho * g.Wo * op["a"] for op, _, g in heads)
+        loc = torch.empty((bs, P_total, 4), device=x.device, dtype=torch.float32)
+        conf = torch.empty((bs, P_total, N_CLASSES), device=x.device, dtype=torch.float32)
+        off = 0
+        offs = {}
+        for op, packed, g in heads:
+            ops.heads_scatter(packed, ops.pad32(g.Co), loc, conf, bs, g.Ho * g.Wo, op["a"], off)
+            offs[op["p"]] = (off, g)
+            off += g.Ho * g.Wo * op["a"]
+        saved = dict(T=T, aux=aux, offs=offs, bs=bs) if save else None
+        return loc, conf, saved
+
+    def _forward_ops(self, x, P, save, T, aux, heads, main, side, side_ctx, overlap, bs):
+        fork = None
         for op in self.ops:
             kind = op["op"]
             if overlap and id(op) == self._late_first:
                 fork = main.record_event()                        # a8 (and everything before it) is enqueued
-            if overlap and side_ctx is None and id(op) in self._side_ids:
+            if overlap and side_ctx[0] is None and id(op) in self._side_ids:
                 side.wait_event(fork)
                 T[op["x"]].record_stream(side)
-                side_ctx = torch.cuda.stream(side)
-                side_ctx.__enter__()
+                side_ctx[0] = torch.cuda.stream(side)
+                side_ctx[0].__enter__()
             if kind == "conv_first":
                 g = ops.make_geom(bs, x.shape[2], x.shape[3], 32, 64, 1, 1, 0, 1)
                 wkey = P[op["p"] + ".weight"]
@@ -445,24 +492,6 @@ class _Engine:
                                      lambda: ops.conv2d_fwd_x3(xin, wf, bias, g, False, ld=ops.pad32(co)) if self.x3 else
                                      ops.conv2d_fwd(xin, wf, bias, g, False, ld=ops.pad32(co), bf16=self.bf16, w3=self._planes(pre, False)))
                 heads.append((op, packed, g))
-        if side_ctx is not None:
-            side_ctx.__exit__(None, None, None)
-            for op, packed, _ in heads:
-                if id(op) in self._side_ids:
-                    packed.record_stream(main)
-            main.wait_event(side.record_event())
-        heads.sort(key=lambda h: h[0]["scale"])                   # prior order: c_4, c_7, c_8, ... (Model.py:235)
-        P_total = sum(g.Ho * g.Wo * op["a"] for op, _, g in heads)
-        loc = torch.empty((bs, P_total, 4), device=x.device, dtype=torch.float32)
-        conf = torch.empty((bs, P_total, N_CLASSES), device=x.device, dtype=torch.float32)
-        off = 0
-        offs = {}
-        for op, packed, g in heads:
-            ops.heads_scatter(packed, ops.pad32(g.Co), loc, conf, bs, g.Ho * g.Wo, op["a"], off)
-            offs[op["p"]] = (off, g)
-            off += g.Ho * g.Wo * op["a"]
-        saved = dict(T=T, aux=aux, offs=offs, bs=bs) if save else None
-        return loc, conf, saved
 
     def _wgrad_gemm_async(self, main, Y, kept, part, g, ldy, assign):
         """Second half of a Winograd weight gradient on the weight-gradient stream: waits for what `main` has enqueued so far (the dy
@@ -479,12 +508,24 @@ class _Engine:
 
     # -- backward ---------------------------------------------------------------------------
     def backward(self, saved, dloc: torch.Tensor, dconf: torch.Tensor, P: Dict[str, torch.Tensor], need: Dict[str, bool]):
-        T, aux, offs, bs = saved["T"], saved["aux"], saved["offs"], saved["bs"]
         dloc = dloc.contiguous()
         dconf = dconf.contiguous()
         G: Dict[str, torch.Tensor] = {}
         arrived: Dict[str, int] = {}
         grads: Dict[str, torch.Tensor] = _SinkDict(self.grad_sink) if self.grad_sink is not None else {}
+        side_ctx = [None]              # left in `finally`: an exception must not leave the side stream current
+        try:
+            return self._backward_ops(saved, dloc, dconf, P, need, G, arrived, grads, side_ctx)
+        finally:
+            if side_ctx[0] is not None:
+                side_ctx[0].__exit__(None, None, None)
+
+    def _gout(self, *names):
+        """Where the gradient of these consecutive parameters is to be written (a flat view of the listener's buffer), or None."""
+        return None if self.grad_out is None else self.grad_out(names)
+
+    def _backward_ops(self, saved, dloc, dconf, P, need, G, arrived, grads, side_ctx):
+        T, aux, offs, bs = saved["T"], saved["aux"], saved["offs"], saved["bs"]
 
         def deliver(name, fn):
             """fn(dx, accumulate, mask) -> dx; mask only when this is the last contribution to a post-ReLU tensor."""
@@ -495,18 +536,22 @@ class _Engine:
             arrived[name] = k + 1
 
         main = torch.cuda.current_stream(dloc.device)
-        async_wgrad = self.overlap_wgrad and self.prof is None and self.dual_dy and self.WINO_TILE == 4
+        # (with a gradient listener every gradient is reported on the caller's stream: no third stream then)
+        async_wgrad = self.overlap_wgrad and self.prof is None and self.dual_dy and self.WINO_TILE == 4 and self.grad_sink is None
         if async_wgrad and self._wgrad_stream is None:
             self._wgrad_stream = torch.cuda.Stream(device=dloc.device)
         wgrad_used = False
         overlap = self.overlap_tail and bool(self._side_ids) and self._side_stream is not None
-        side, side_ctx, joined = self._side_stream, None, not overlap
+        side, joined = self._side_stream, not overlap
+        held = isinstance(grads, _SinkDict)
         if overlap:                                               # the reversed list starts with the side group
             side.wait_event(main.record_event())
             dloc.record_stream(side)
             dconf.record_stream(side)
-            side_ctx = torch.cuda.stream(side)
-            side_ctx.__enter__()
+            side_ctx[0] = torch.cuda.stream(side)
+            side_ctx[0].__enter__()
+            if held:
+                grads.hold()                                      # the listener hears of side-stream gradients once the caller's stream has waited for them
         join_event = side_done = None
         # The side group's weight gradients are not on the path to a8's gradient (the only thing the caller's stream needs from the group):
         # they are enqueued AFTER the group's data-gradient chain, behind the join event.
@@ -514,19 +559,27 @@ class _Engine:
         defer = self.defer_tail_wgrad and self.prof is None
         for op in reversed(self.ops):
             kind = op["op"]
-            if side_ctx is not None and id(op) not in self._side_ids:      # the side group is enqueued: back to the caller's stream
+            if side_ctx[0] is not None and id(op) not in self._side_ids:   # the side group is enqueued: back to the caller's stream
                 join_event = side.record_event()                           # every data gradient the caller's stream will read exists
                 for t in G.values():
                     t.record_stream(main)
+                if self._test_side_delay is not None:
+                    self._test_side_delay()
                 for wg in deferred:                                        # the side group's weight gradients: nothing waits for them
                     wg()
                 deferred.clear()
-                side_ctx.__exit__(None, None, None)
-                side_ctx = None
+                side_ctx[0].__exit__(None, None, None)
+                side_ctx[0] = None
                 side_done = side.record_event()
                 for t in grads.values():
                     t.record_stream(main)
-            if not joined and side_ctx is None and kind in ("conv", "pool", "conv_first"):      # first op that needs what the side group produced (a8's gradient)
+                if held and self.sink_early:
+                    # the listener starts a collective the moment a bucket is complete: order the side stream's gradients before the
+                    # caller's stream first (a listener that only collects hears of them at the end of the backward, below)
+                    main.wait_event(side_done)
+                    side_done = None
+                    grads.release()
+            if not joined and side_ctx[0] is None and kind in ("conv", "pool", "conv_first"):      # first op that needs what the side group produced (a8's gradient)
                 main.wait_event(join_event)
                 joined = True
             if kind == "head":
@@ -539,7 +592,7 @@ class _Engine:
                 dyp = None
                 dw = db = None
                 if any(need[pre + s] for s in ("_bb.weight", "_bb.bias", "_cl.weight", "_cl.bias")):
-                    if self._wino_wgrad_ok(g, True) and async_wgrad and side_ctx is None and aux.get("planes:" + pre) is not None \
+                    if self._wino_wgrad_ok(g, True) and async_wgrad and side_ctx[0] is None and aux.get("planes:" + pre) is not None \
                             and co_pad <= 1024:
                         kept = aux.pop("planes:" + pre)
                         Y, dyp, part = ops.wino_dy_transform(dy, g, co_pad, True, True)
@@ -554,16 +607,19 @@ class _Engine:
                         dual = kept is not None and self.dual_dy        # one pass over dy feeds the weight and the data gradient
                         res = self._timed("wgrad " + pre, "winograd_3x3", ops.wino_flops(g),
                                           lambda: ops.conv2d_wgrad_wino(xin, dy, g, co_pad, True, mo=self.WINO_TILE, planes=kept,
-                                                                        dgrad_planes=dual))
+                                                                        dgrad_planes=dual, dw_out=self._gout(pre + "_bb.weight", pre + "_cl.weight"),
+                                                                        db_out=self._gout(pre + "_bb.bias", pre + "_cl.bias")))
                         dw, db = res[0], res[1]
                         dyp = res[2] if dual else None
                     else:
                         def wg(pre=pre, a4=a4, xin=xin, dy=dy, g=g, co_pad=co_pad):
                             dw_, db_ = self._timed("wgrad " + pre, ops.wgrad_tile(g) if self.prof is not None else "", ops.conv_flops(g),
-                                                   lambda: ops.conv2d_wgrad(xin, dy, g, co_pad, True, bf16=self.bf16))
+                                                   lambda: ops.conv2d_wgrad(xin, dy, g, co_pad, True, bf16=self.bf16,
+                                                                            dw_out=self._gout(pre + "_bb.weight", pre + "_cl.weight"),
+                                                                            db_out=self._gout(pre + "_bb.bias", pre + "_cl.bias")))
                             grads[pre + "_bb.weight"], grads[pre + "_cl.weight"] = dw_[:a4], dw_[a4:]
                             grads[pre + "_bb.bias"], grads[pre + "_cl.bias"] = db_[:a4], db_[a4:]
-                        if side_ctx is not None and defer:
+                        if side_ctx[0] is not None and defer:
                             deferred.append(wg)
                         else:
                             wg()
@@ -593,7 +649,7 @@ class _Engine:
                             and not ops.wino_uses_full(g, 1) and self._wino_ok(g)):
                         dy = dy.materialize()
                 if need[op["p"] + ".weight"] or need[op["p"] + ".bias"]:
-                    if self._wino_wgrad_ok(g, False) and async_wgrad and side_ctx is None and aux.get("planes:" + op["p"]) is not None \
+                    if self._wino_wgrad_ok(g, False) and async_wgrad and side_ctx[0] is None and aux.get("planes:" + op["p"]) is not None \
                             and g.Co % 32 == 0 and g.Co <= 1024:
                         kept = aux.pop("planes:" + op["p"])
                         # the one-kernel data gradient reads dy itself: no B^T dy B planes to write
@@ -609,15 +665,17 @@ class _Engine:
                         dual = kept is not None and self.dual_dy and g.Co % 32 == 0 and not ops.wino_uses_full(g, 1)
                         res = self._timed("wgrad " + op["p"], "winograd_3x3", ops.wino_flops(g),
                                           lambda: ops.conv2d_wgrad_wino(xin, dy, g, g.Co, True, mo=self.WINO_TILE, planes=kept,
-                                                                        dgrad_planes=dual))
+                                                                        dgrad_planes=dual, dw_out=self._gout(op["p"] + ".weight"),
+                                                                        db_out=self._gout(op["p"] + ".bias")))
                         dw, db = res[0], res[1]
                         dyp = res[2] if dual else None
                     else:
                         def wg(name=op["p"], xin=xin, dy=dy, g=g):
                             grads[name + ".weight"], grads[name + ".bias"] = self._timed(
                                 "wgrad " + name, ops.wgrad_tile(g) if self.prof is not None else "", ops.conv_flops(g),
-                                lambda: ops.conv2d_wgrad(xin, dy, g, g.Co, True, bf16=self.bf16))
-                        if side_ctx is not None and defer:
+                                lambda: ops.conv2d_wgrad(xin, dy, g, g.Co, True, bf16=self.bf16, dw_out=self._gout(name + ".weight"),
+                                                         db_out=self._gout(name + ".bias")))
+                        if side_ctx[0] is not None and defer:
                             deferred.append(wg)
                         else:
                             wg()
@@ -659,7 +717,7 @@ class _Engine:
                 def run(dx, acc, mask, xin=xin, gamma=gamma, dy=dy, box=box):
                     if acc or mask is not None:
                         raise RuntimeError("L2-norm backward must deliver the first, non-final gradient of its input")
-                    dx, box["dg"] = ops.l2norm_bwd(xin, gamma, dy)
+                    dx, box["dg"] = ops.l2norm_bwd(xin, gamma, dy, dg_out=self._gout(op["p"]))
                     return dx
                 deliver(op["x"], run)
                 grads[op["p"]] = box["dg"].reshape(P[op["p"]].shape)
@@ -681,6 +739,8 @@ class _Engine:
             main.wait_event(side_done)
         if wgrad_used:
             main.wait_event(self._wgrad_stream.record_event())
+        if held:
+            grads.release()
         return grads
 
 
@@ -701,6 +761,10 @@ class _SSD300Function(torch.autograd.Function):
         need = {n: bool(f) for n, f in zip(eng.names, ctx.needs_input_grad[2:])}
         grads = eng.backward(ctx.saved, dloc, dconf, P, need)
         ctx.saved = None
+        if eng.sink_owns_grads and eng.grad_sink is not None:
+            # ddp.py: every gradient already sits in the flat buffer the all-reduce reads (the parameters' .grad are views of it);
+            # handing the views to autograd would make it clone 105 MB into fresh .grad tensors
+            return (None, None) + (None,) * len(eng.names)
         return (None, None) + tuple(grads.get(n) if need[n] else None for n in eng.names)
 
 

@@ -72,17 +72,29 @@ class FlatSGDDataParallel(torch.optim.Optimizer):
         self._has_momentum = False       # False: the next step starts the momentum buffer from the gradient, as torch.optim.SGD does
         self.steps = 0
         model._engine._wcache.clear()
+        # The backward writes every gradient straight into its slot of the flat buffer: the engine asks `_grad_out` where the
+        # gradient of a parameter (or of the two parameters a fused head convolution produces) goes and reports it through `_sink`;
+        # the parameters' .grad are the views.  A gradient that arrives as a tensor of its own (conv1_1's permuted rows; a caller
+        # that sets p.grad itself) is copied into its slot.
+        self._sizes, self._slots = sizes, slots
+        self._offs = [0]
+        for sl in slots:
+            self._offs.append(self._offs[-1] + sl)
+        self._index = {n: i for i, n in enumerate(self.names)}
+        self._view = dict(zip(self.names, self.grad_views))
+        self._arrived: set = set()
+        for p, v in zip(self.params, self.grad_views):
+            p.grad = v
+        eng = model._engine
+        eng.grad_sink, eng.grad_out, eng.sink_owns_grads, eng.sink_early = self._sink, self._grad_out, True, bool(overlap)
         # -- overlapped exchange: contiguous slices of the weight segment, filled from the back of the network first ------------
         self.overlap = bool(overlap)
         self._handles: list = []
         if self.overlap:
-            self._view = dict(zip(self.names, self.grad_views))
             self._bucket_of, self._bucket_rng, self._need = {}, [], []
             lo, cur = 0, []
             n_wn = len(self.w_names)
-            offs = [0]
-            for sl in slots:
-                offs.append(offs[-1] + sl)
+            offs = self._offs
             for i in range(n_wn):
                 cur.append(self.names[i])
                 last = i + 1 == n_wn
@@ -94,8 +106,6 @@ class FlatSGDDataParallel(torch.optim.Optimizer):
                     self._need.append(len(cur))
                     lo, cur = offs[i + 1], []
             self._left = list(self._need)
-            self._seen = 0
-            model._engine.grad_sink = self._sink
 
     @property
     def world(self) -> int:
@@ -117,9 +127,52 @@ class FlatSGDDataParallel(torch.optim.Optimizer):
         self.param_groups[1]["lr"] = float(value)
         self.param_groups[0]["lr"] = float(value) * ratio
 
+    def _from_reference_layout(self, state_dict):
+        """A checkpoint written by the single-GPU loop (train_function.py:116: `torch.optim.SGD` -- or this package's `optim.SGD` --
+        over train.py:44-55's groups) lists EVERY `requires_grad` parameter in `named_parameters()` order, biases in group 0 and the
+        rest in group 1: that includes the never-updated `model.classifier.*` of the VGG trunk, which have no slot here, and orders
+        the scale parameter first and the heads last.  Re-index such a state dict by parameter NAME into this optimizer's groups
+        (engine order, 35 + 36 entries).  Returns the state dict unchanged when it already has this optimizer's layout."""
+        groups = state_dict.get("param_groups", []) if isinstance(state_dict, dict) else []
+        mine = [len(g["params"]) for g in self.param_groups]
+        if len(groups) != 2 or [len(g["params"]) for g in groups] == mine:
+            return state_dict
+        named = [(n, p) for n, p in self.model.named_parameters() if p.requires_grad]
+        ref_b = [n for n, _ in named if n.endswith(".bias")]
+        ref_w = [n for n, _ in named if not n.endswith(".bias")]
+        if [len(g["params"]) for g in groups] != [len(ref_b), len(ref_w)]:
+            raise ValueError(f"optimizer state with groups of {[len(g['params']) for g in groups]} parameters fits neither this optimizer "
+                             f"({mine}) nor train.py's groups over this model ({[len(ref_b), len(ref_w)]})")
+        by_name = {}
+        for names, g in zip((ref_b, ref_w), groups):
+            for n, pid in zip(names, g["params"]):
+                by_name[n] = pid
+        n_wn = len(self.w_names)
+        order = self.names[n_wn:] + self.names[:n_wn]              # this optimizer's packed order: group 0 = biases, group 1 = weights
+        new_state, new_groups, k = {}, [], 0
+        for g, names in zip(groups, (self.names[n_wn:], self.names[:n_wn])):
+            ids = []
+            for n in names:
+                if n not in by_name:
+                    raise ValueError(f"checkpoint has no entry for parameter {n}")
+                if by_name[n] in state_dict["state"]:
+                    new_state[k] = state_dict["state"][by_name[n]]
+                ids.append(k)
+                k += 1
+            ng = {kk: vv for kk, vv in g.items() if kk not in ("params", "param_names")}
+            ng["params"] = ids
+            new_groups.append(ng)
+        assert k == len(order)
+        out = {kk: vv for kk, vv in state_dict.items() if kk not in ("state", "param_groups")}
+        out["state"], out["param_groups"] = new_state, new_groups
+        return out
+
     def load_state_dict(self, state_dict) -> None:
         """Restores lr / momentum / weight decay of both groups and every parameter's momentum buffer INTO the flat momentum
-        buffer; the step after a restore continues the momentum (a restore without buffers starts it afresh, like torch)."""
+        buffer; the step after a restore continues the momentum (a restore without buffers starts it afresh, like torch).
+        Accepts this optimizer's own state dicts and those of a train.py-style optimizer over the same model (re-indexed by
+        parameter name: `_from_reference_layout`)."""
+        state_dict = self._from_reference_layout(state_dict)
         super().load_state_dict(state_dict)
         have = [self.state.get(p, {}).get("momentum_buffer") for p in self.params]
         if any(h is not None for h in have) and not all(h is not None for h in have):
@@ -149,19 +202,38 @@ class FlatSGDDataParallel(torch.optim.Optimizer):
         return loss
 
     def zero_grad(self, set_to_none: bool = True) -> None:
-        for p in self.params:
-            p.grad = None
+        """Nothing is zeroed or freed: every slot of the flat buffer is overwritten by the next backward (and `reduce_gradients`
+        refuses a step whose backward did not deliver every gradient).  The parameters' .grad stay the views of the flat buffer."""
+        for p, v in zip(self.params, self.grad_views):
+            p.grad = v
+        self._arrived.clear()
         if self.overlap:                               # a step that died half-way must not leak its bookkeeping into the next
-            self._handles, self._left, self._seen = [], list(self._need), 0
+            self._handles, self._left = [], list(self._need)
+
+    def _grad_out(self, names):
+        """Engine callback: the flat slice the gradient of these CONSECUTIVE parameters is to be written to (one parameter, or the
+        loc + conf halves of a fused head convolution), or None when they are not adjacent, unpadded slots of the buffer."""
+        idx = [self._index.get(n) for n in names]
+        if any(i is None for i in idx):
+            return None
+        for a, b in zip(idx, idx[1:]):
+            if b != a + 1 or self._slots[a] != self._sizes[a]:
+                return None
+        lo = self._offs[idx[0]]
+        return self.flat_grad[lo:self._offs[idx[-1]] + self._sizes[idx[-1]]]
 
     def _sink(self, name: str, grad: torch.Tensor) -> None:
-        """Engine callback during backward: park the gradient in its slot; when a weight slice is complete, start its all-reduce."""
+        """Engine callback during backward, on the caller's stream, the gradient's kernel ordered before it: note the arrival (copy the
+        gradient into its slot if it was not written there); overlapped mode: when a weight slice is complete, start its all-reduce."""
         view = self._view.get(name)
         if view is None:
             return
-        view.copy_(grad.reshape(view.shape))
-        self._seen += 1
-        b = self._bucket_of.get(name)
+        if grad.data_ptr() != view.data_ptr():
+            view.copy_(grad.reshape(view.shape))
+        if name in self._arrived:
+            raise RuntimeError(f"gradient of {name} delivered twice in one step (zero_grad() starts a step)")
+        self._arrived.add(name)
+        b = self._bucket_of.get(name) if self.overlap else None
         if b is None:                                  # biases travel with n_pos in the closing collective
             return
         self._left[b] -= 1
@@ -170,9 +242,9 @@ class FlatSGDDataParallel(torch.optim.Optimizer):
             self._handles.append(dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _finish_overlapped(self, n_pos: torch.Tensor) -> None:
-        if self._seen != len(self.names) or any(self._left):
+        if len(self._arrived) != len(self.names) or any(self._left):
             raise RuntimeError("overlapped gradient exchange: the backward did not deliver every parameter's gradient "
-                               f"({self._seen} of {len(self.names)})")
+                               f"({len(self._arrived)} of {len(self.names)})")
         self.flat_grad[self.n:self.n + 1].copy_(n_pos.reshape(1))
         if self.world > 1:
             tail = dist.all_reduce(self.flat_grad[self.n_w:self.n + 1], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -180,20 +252,23 @@ class FlatSGDDataParallel(torch.optim.Optimizer):
                 h.wait()                                # the compute stream waits for the collectives, the host does not
         self._handles = []
         self._left = list(self._need)
-        self._seen = 0
+        self._arrived.clear()
         torch.reciprocal(self.flat_grad[self.n:self.n + 1], out=self.inv_npos)
 
     def reduce_gradients(self, n_pos: torch.Tensor) -> None:
-        """Pack this rank's gradients (of the UN-normalised loss sums) and its positive-prior count
-        (`Losses.last_match['n_pos']`) into the flat buffer and all-reduce it once; afterwards
-        `flat_grad[:n] * inv_npos` is the gradient of the reference loss at the global batch."""
+        """All-reduce the flat buffer once: this rank's gradients of the UN-normalised loss sums (written there by the backward) and
+        its positive-prior count (`Losses.ssd(..., with_n_pos=True)`); afterwards `flat_grad[:n] * inv_npos` is the gradient of the
+        reference loss at the global batch."""
         if self.overlap:
             return self._finish_overlapped(n_pos)
-        grads = [p.grad for p in self.params]
-        if any(g is None for g in grads):
-            missing = [n for n, g in zip(self.names, grads) if g is None]
-            raise RuntimeError(f"parameters without gradient: {missing[:4]}...")
-        torch._foreach_copy_(self.grad_views, grads)
+        late = [i for i, n in enumerate(self.names) if n not in self._arrived]
+        if late:                                         # gradients the caller put into .grad itself (no engine callback)
+            gs = [self.params[i].grad for i in late]
+            bad = [self.names[i] for i, g in zip(late, gs) if g is None or g.data_ptr() == self.grad_views[i].data_ptr()]
+            if bad:
+                raise RuntimeError(f"parameters without gradient: {bad[:4]}...")
+            torch._foreach_copy_([self.grad_views[i] for i in late], [g.reshape(self.grad_views[i].shape) for i, g in zip(late, gs)])
+        self._arrived.clear()
         self.flat_grad[self.n:self.n + 1].copy_(n_pos.reshape(1))
         if self.world > 1:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)    # the one collective per step

@@ -41,6 +41,20 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+def _grad_dst(dst: Optional[torch.Tensor], shape, device, name: str) -> torch.Tensor:
+    """Destination of a parameter gradient: a fresh tensor, or the caller's buffer (ddp.py hands out views of its flat gradient
+    buffer, so the kernel writes the gradient where the all-reduce reads it)."""
+    if dst is None:
+        return torch.empty(shape, device=device, dtype=torch.float32)
+    _req(dst, name)
+    n = 1
+    for d in shape:
+        n *= d
+    if dst.numel() != n or dst.device != device:
+        raise ValueError(f"{name}: destination has {dst.numel()} elements on {dst.device}, the gradient has {n} on {device}")
+    return dst.view(shape)
+
+
 def conv_out_hw(h: int, w: int, k: int, stride: int, pad: int, dil: int) -> Tuple[int, int]:
     return ((h + 2 * pad - dil * (k - 1) - 1) // stride + 1, (w + 2 * pad - dil * (k - 1) - 1) // stride + 1)
 
@@ -266,8 +280,9 @@ def workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:
     return buf
 
 
-def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, g: ConvGeom, ldy: int, want_bias: bool = True, bf16: bool = False):
-    """-> (dw (Co,Ci,R,S) OIHW, dbias (Co,) or None)."""
+def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, g: ConvGeom, ldy: int, want_bias: bool = True, bf16: bool = False,
+                 dw_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None):
+    """-> (dw (Co,Ci,R,S) OIHW, dbias (Co,) or None); dw_out / db_out: write the gradients there (same element counts)."""
     _req(x, "x"); _req(dy, "dy")
     if tuple(x.shape) != (g.N, g.H, g.W, g.Ci):
         raise ValueError("x shape does not match geometry")
@@ -276,8 +291,8 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, g: ConvGeom, ldy: int, want_
     lib = _lib.load()
     nbytes = lib.ssd_conv2d_wgrad_workspace(C.byref(g))
     ws = workspace(nbytes, x.device)
-    dw = torch.empty((g.Co, g.Ci, g.R, g.S), device=x.device, dtype=torch.float32)
-    db = torch.empty((g.Co,), device=x.device, dtype=torch.float32) if want_bias else None
+    dw = _grad_dst(dw_out, (g.Co, g.Ci, g.R, g.S), x.device, "dw_out")
+    db = _grad_dst(db_out, (g.Co,), x.device, "db_out") if want_bias else None
     fn = lib.ssd_conv2d_wgrad_bf16 if bf16 else lib.ssd_conv2d_wgrad
     check(fn(x.data_ptr(), dy.data_ptr(), ldy, dw.data_ptr(), _ptr(db), C.byref(g), ws.data_ptr(), ws.numel(), _stream()),
           "conv2d_wgrad")
@@ -446,7 +461,8 @@ def l2norm_fwd(x: torch.Tensor, gamma: torch.Tensor) -> torch.Tensor:
     return y
 
 
-def l2norm_bwd(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, dx: Optional[torch.Tensor] = None):
+def l2norm_bwd(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, dx: Optional[torch.Tensor] = None,
+               dg_out: Optional[torch.Tensor] = None):
     _req(x, "x"); _req(gamma, "gamma"); _req(dy, "dy")
     c = x.shape[-1]
     m = x.numel() // c
@@ -455,7 +471,7 @@ def l2norm_bwd(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, dx: Optio
     lib = _lib.load()
     ws = workspace(lib.ssd_l2norm_bwd_workspace(m, c), x.device)
     dx = torch.empty_like(x) if dx is None else _req(dx, "dx")
-    dg = torch.empty((c,), device=x.device, dtype=torch.float32)
+    dg = _grad_dst(dg_out, (c,), x.device, "dg_out")
     check(lib.ssd_l2norm_bwd(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), dx.data_ptr(), dg.data_ptr(), m, c,
                              ws.data_ptr(), ws.numel(), _stream()), "l2norm_bwd")
     return dx, dg
@@ -793,7 +809,8 @@ def conv2d_dgrad_wino(dy: Optional[torch.Tensor], u_bwd: torch.Tensor, g: ConvGe
 
 
 def conv2d_wgrad_wino(x: Optional[torch.Tensor], dy: torch.Tensor, g: ConvGeom, ldy: int, want_bias: bool = True, mo: int = 2,
-                      planes: Optional[torch.Tensor] = None, dgrad_planes: bool = False):
+                      planes: Optional[torch.Tensor] = None, dgrad_planes: bool = False,
+                      dw_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None):
     """Winograd F(mo x mo, 3x3) weight gradient, mo = 2 or 4 -> (dw (Co,Ci,3,3) OIHW, dbias (Co,) or None).
     planes: the transformed input the forward kept (`conv2d_fwd_wino(..., keep_planes=True)`); x is then not read.
     dgrad_planes (needs planes): the pass over dy also forms this layer's dgrad input planes -> (dw, dbias, planes_dy (36, tiles, ldy))
@@ -819,8 +836,8 @@ def conv2d_wgrad_wino(x: Optional[torch.Tensor], dy: torch.Tensor, g: ConvGeom, 
         raise ValueError("conv2d_wgrad_wino: not a 3x3 / stride 1 / pad 1 geometry")
     dev = planes.device if pooled else dy.device
     ws = workspace(nbytes, dev, "wino")
-    dw = torch.empty((g.Co, g.Ci, 3, 3), device=dev, dtype=torch.float32)
-    db = torch.empty((g.Co,), device=dev, dtype=torch.float32) if want_bias else None
+    dw = _grad_dst(dw_out, (g.Co, g.Ci, 3, 3), dev, "dw_out")
+    db = _grad_dst(db_out, (g.Co,), dev, "db_out") if want_bias else None
     if dgrad_planes and planes is None:
         raise ValueError("conv2d_wgrad_wino: dgrad_planes needs the kept forward planes")
     if planes is not None:
@@ -877,7 +894,8 @@ def _pooled_args(dy: "PooledGrad", g: ConvGeom, ldy: int):
     return dy.dpool.data_ptr(), dy.argmax.data_ptr(), dy.y_pooled.data_ptr(), dy.dpool.shape[1], dy.dpool.shape[2]
 
 
-def wino_wgrad_gemm(wgrad_planes: torch.Tensor, x_planes: torch.Tensor, bias_partial: Optional[torch.Tensor], g: ConvGeom, ldy: int):
+def wino_wgrad_gemm(wgrad_planes: torch.Tensor, x_planes: torch.Tensor, bias_partial: Optional[torch.Tensor], g: ConvGeom, ldy: int,
+                    dw_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None):
     """Second half: the TN GEMMs over the tiles, the inverse transform and the bias gradient -> (dw (Co,Ci,3,3), dbias or None).
     Runs on the CURRENT stream, which may differ from the one `wino_dy_transform` ran on (the caller orders them with an event)."""
     _req(wgrad_planes, "wgrad_planes"); _req(x_planes, "x_planes")
@@ -887,8 +905,8 @@ def wino_wgrad_gemm(wgrad_planes: torch.Tensor, x_planes: torch.Tensor, bias_par
     lib = _lib.load()
     dev = x_planes.device
     ws = workspace(lib.ssd_wino4_wgrad_gemm_workspace(C.byref(g), ldy), dev, "wino_wgrad")
-    dw = torch.empty((g.Co, g.Ci, 3, 3), device=dev, dtype=torch.float32)
-    db = torch.empty((g.Co,), device=dev, dtype=torch.float32) if bias_partial is not None else None
+    dw = _grad_dst(dw_out, (g.Co, g.Ci, 3, 3), dev, "dw_out")
+    db = _grad_dst(db_out, (g.Co,), dev, "db_out") if bias_partial is not None else None
     check(lib.ssd_wino4_wgrad_gemm(wgrad_planes.data_ptr(), x_planes.data_ptr(), ldy, _ptr(bias_partial), dw.data_ptr(), _ptr(db), C.byref(g),
                                    ws.data_ptr(), ws.numel(), _stream()), "wino_wgrad_gemm")
     return dw, db

@@ -213,3 +213,160 @@ def test_flat_allreduce_and_global_normalisation_world2():
         np.testing.assert_allclose(mine["dloc"] * mine["n_pos"] * inv0, ref["dloc"][sl], rtol=1e-5, atol=1e-9)
         # hard-negative mining is per image (Losses.py:189-194), so the selection does not depend on the shard
         np.testing.assert_allclose(mine["dconf"] * mine["n_pos"] * inv0, ref["dconf"][sl], rtol=1e-5, atol=1e-9)
+
+
+# ---- world sizes 4 and 8: bucket boundaries and arrival order of the overlapped exchange ------------------------------------
+class _Wide(nn.Module):
+    """Nine weight tensors of uneven sizes (slots pad to multiples of 4) so that 1 KB buckets cut the weight segment in several
+    places, some exactly on a parameter boundary, some mid-way through a run of small tensors."""
+
+    def __init__(self):
+        super().__init__()
+        sizes = [(7, 5, 3, 3), (64, 3, 1, 1), (3, 3, 3, 3), (33, 8, 1, 1), (5, 5, 1, 1), (128, 2, 1, 1), (1, 6, 1, 1), (16, 16, 1, 1), (9, 1, 1, 1)]
+        names = []
+        for i, sh in enumerate(sizes):
+            c = nn.Conv2d(sh[1], sh[0], (sh[2], sh[3]))
+            setattr(self, f"l{i}", c)
+            names += [f"l{i}.weight", f"l{i}.bias"]
+        self._engine = types.SimpleNamespace(names=names, _wcache={})
+
+
+def _order_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from objectdetection_ssd_amd.ddp import FlatSGDDataParallel
+        torch.manual_seed(0)
+        a, b, c = _Wide(), _Wide(), _Wide()
+        plain = FlatSGDDataParallel(a, lr=0.1)
+        over = FlatSGDDataParallel(b, lr=0.1, overlap=True, bucket_bytes=1024)
+        tiny = FlatSGDDataParallel(c, lr=0.1, overlap=True, bucket_bytes=4)            # every weight its own bucket
+        assert len(over._bucket_rng) >= 3 and len(tiny._bucket_rng) == len(tiny.w_names)
+        for tr in (over, tiny):                                                        # buckets tile the weight segment exactly
+            assert tr._bucket_rng[0][0] == 0 and tr._bucket_rng[-1][1] == tr.n_w
+            assert all(x[1] == y[0] for x, y in zip(tr._bucket_rng, tr._bucket_rng[1:]))
+        # the engine hooks are installed in both modes; destinations are views of the flat buffer
+        for net, tr in ((a, plain), (b, over)):
+            assert net._engine.grad_sink is not None and net._engine.sink_owns_grads and net._engine.sink_early == tr.overlap
+            dst = net._engine.grad_out(("l1.weight",))
+            assert dst.data_ptr() == tr._view["l1.weight"].data_ptr() and dst.numel() == 192
+            assert net._engine.grad_out(("l0.weight", "l1.weight")) is None           # 315 elements pad to 316: not contiguous
+            assert net._engine.grad_out(("l1.weight", "l2.weight")).numel() == 192 + 81
+            assert net._engine.grad_out(("nope",)) is None
+        g = torch.Generator().manual_seed(500 + rank)
+        local = {n: torch.randn(p.shape, generator=g) for n, p in zip(plain.names, plain.params)}
+        n_pos = torch.tensor(2.0 + rank)
+        # plain: half of the gradients are written in place (the engine path), half arrive as foreign tensors
+        plain.zero_grad()
+        for i, n in enumerate(plain.names):
+            if i % 2 == 0:
+                a._engine.grad_out((n,)).copy_(local[n].reshape(-1))
+                a._engine.grad_sink(n, plain._view[n])
+            else:
+                a._engine.grad_sink(n, local[n])
+        plain.reduce_gradients(n_pos)
+        # overlapped: three different arrival orders (a backward's reverse order, forward order, a per-rank-independent shuffle --
+        # every rank must issue the collectives of the buckets in the same order, so the shuffle is seeded identically)
+        results, slices = [], []
+        for tr, net in ((over, b), (tiny, c)):
+            for order in (list(reversed(tr.names)), list(tr.names), [tr.names[i] for i in torch.randperm(len(tr.names), generator=torch.Generator().manual_seed(9)).tolist()]):
+                tr.zero_grad()
+                for n in order:
+                    net._engine.grad_sink(n, local[n])
+                tr.reduce_gradients(n_pos)
+                # (a ring all-reduce adds the ranks' contributions in an order that depends on where an element sits in the reduced
+                # buffer, so slices and the whole buffer agree to rounding, not bit for bit, once more than two ranks add up)
+                results.append(torch.allclose(tr.flat_grad[:tr.n + 1], plain.flat_grad[:plain.n + 1], rtol=1e-5, atol=1e-6)
+                               and float(tr.inv_npos) == float(plain.inv_npos))
+                slices.append(tr.flat_grad[:tr.n].clone().numpy())
+        # a second delivery of one gradient within a step is refused
+        over.zero_grad()
+        b._engine.grad_sink("l0.bias", local["l0.bias"])
+        try:
+            b._engine.grad_sink("l0.bias", local["l0.bias"])
+            twice = False
+        except RuntimeError:
+            twice = True
+        expect_npos = sum(2.0 + r for r in range(world))
+        q.put((rank, results, twice, float(plain.flat_grad[plain.n]) == expect_npos, plain.flat_grad[:plain.n].clone().numpy(),
+               torch.cat([local[n].reshape(-1) for n in plain.names]).numpy(), slices))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_overlapped_exchange_bucket_boundaries_and_order_world_4_and_8(world):
+    """The N = 4 and N = 8 ranks of the driver's scaling runs, rehearsed under gloo: whatever the bucket size and the order the
+    gradients arrive in, the overlapped exchange leaves the same flat buffer as the single all-reduce, on every rank, and that
+    buffer holds the sum over ranks; gradients written in place and gradients handed over as tensors mix freely."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_order_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    total = sum(o[5] for o in out)
+    for rank, results, twice, npos_ok, flat, _, slices in out:
+        assert all(results), (rank, results)
+        assert twice and npos_ok
+        assert np.array_equal(flat, out[0][4])                          # every rank holds the same reduced buffer, bit for bit
+        for mine, first in zip(slices, out[0][6]):
+            assert np.array_equal(mine, first)                          # ... in the overlapped exchange too, whatever the arrival order
+    # the flat buffer pads every slot to 4 floats: compare parameter by parameter
+    from objectdetection_ssd_amd.ddp import FlatSGDDataParallel
+    ref = FlatSGDDataParallel(_Wide(), lr=0.1)
+    pos = 0
+    for i, sz in enumerate(ref._sizes):
+        np.testing.assert_allclose(out[0][4][ref._offs[i]:ref._offs[i] + sz], total[pos:pos + sz], rtol=1e-5, atol=1e-6)
+        pos += sz
+
+
+def test_bench_rendezvous_at_eight_ranks():
+    """`python bench.py --gpus 8 --rendezvous-only`: the launch path of the driver's N = 8 run (self-started ranks, process group,
+    one all-reduce) without touching a GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--backend", "gloo", "--rendezvous-only"],
+                       capture_output=True, text=True, timeout=900, env=dict(env, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout
+    assert json.loads(line[0]) == {"rendezvous": True, "n_gpus": 8, "backend": "gloo", "ranks_counted": 8}
+
+
+def test_data_parallel_optimizer_loads_a_single_gpu_checkpoint():
+    """train_function.py:27,116: the checkpoint's `optimizer_state_dict` comes from `torch.optim.SGD` over train.py:44-55's groups --
+    every requires_grad parameter in named_parameters() order, the dead `model.classifier.*` included.  FlatSGDDataParallel re-indexes
+    it by name: each parameter's momentum lands in ITS slot of the flat momentum buffer."""
+    from objectdetection_ssd_amd import Model
+    from objectdetection_ssd_amd.ddp import FlatSGDDataParallel
+    torch.manual_seed(0)
+    net = Model.SSD_300()
+    biases = [p for n, p in net.named_parameters() if p.requires_grad and n.endswith(".bias")]
+    rest = [p for n, p in net.named_parameters() if p.requires_grad and not n.endswith(".bias")]
+    ref = torch.optim.SGD([{"params": biases, "lr": 2e-4}, {"params": rest}], lr=1e-4, momentum=0.9, weight_decay=5e-4)
+    names = {id(p): n for n, p in net.named_parameters()}
+    for gi, grp in enumerate(ref.param_groups):                   # a momentum buffer that encodes (group, position): value = name hash
+        for p in grp["params"]:
+            if names[id(p)].startswith("model.classifier"):
+                continue                                           # never receives a gradient: no state, as in a real run
+            ref.state[p]["momentum_buffer"] = torch.full_like(p, float(sum(map(ord, names[id(p)])) % 997))
+    sd = ref.state_dict()
+    assert [len(g["params"]) for g in sd["param_groups"]] == [38, 39]
+    dp = FlatSGDDataParallel(Model.SSD_300(), lr=1.0)
+    assert [len(g["params"]) for g in dp.param_groups] == [35, 36]
+    dp.load_state_dict(sd)
+    assert dp._has_momentum and dp.param_groups[0]["lr"] == 2e-4 and dp.param_groups[1]["lr"] == 1e-4
+    for n, mv in zip(dp.names, dp.mom_views):
+        assert float(mv.flatten()[0]) == float(sum(map(ord, n)) % 997) and bool((mv == mv.flatten()[0]).all()), n
+    # its own layout still round-trips
+    dp2 = FlatSGDDataParallel(Model.SSD_300(), lr=1.0)
+    dp2.load_state_dict(dp.state_dict())
+    assert torch.equal(dp2.flat_mom, dp.flat_mom)

@@ -419,9 +419,9 @@ def test_flat_sgd_data_parallel_step_equals_torch_sgd():
         (l1 + l2).backward()
         opt.step()
         dp.zero_grad()
-        m1, m2 = Losses.ssd(b(x), cl, bx, norm_mode=1)
+        m1, m2, n_pos = Losses.ssd(b(x), cl, bx, norm_mode=1, with_n_pos=True)
         (m1 + m2).backward()
-        dp.reduce_and_step(Losses.last_match["n_pos"])
+        dp.reduce_and_step(n_pos)
     na, nb = dict(a.named_parameters()), dict(b.named_parameters())
     for k in a._engine.names:
         ref = na[k].detach()
@@ -548,9 +548,9 @@ def test_overlapped_gradient_exchange_equals_the_single_allreduce_path():
     for _ in range(3):
         for net, tr in ((a, da), (b, db)):
             tr.zero_grad()
-            l1, l2 = Losses.ssd(net(x), cl, bx, norm_mode=1)
+            l1, l2, n_pos = Losses.ssd(net(x), cl, bx, norm_mode=1, with_n_pos=True)
             (l1 + l2).backward()
-            tr.reduce_and_step(Losses.last_match["n_pos"])
+            tr.reduce_and_step(n_pos)
     assert torch.equal(da.flat_param, db.flat_param)
     assert torch.equal(da.flat_grad[:da.n + 1], db.flat_grad[:db.n + 1])
 
@@ -1155,9 +1155,9 @@ def test_data_parallel_optimizer_checkpoint_roundtrip_with_the_real_kernel(tmp_p
 
     def step(n, o):
         o.zero_grad()
-        l1, l2 = Losses.ssd(n(x), cl, bx, norm_mode=1)
+        l1, l2, n_pos = Losses.ssd(n(x), cl, bx, norm_mode=1, with_n_pos=True)
         (l1 + l2).backward()
-        o.reduce_gradients(Losses.last_match["n_pos"])
+        o.reduce_gradients(n_pos)
         o.step()
 
     a, oa = make()
@@ -1200,14 +1200,18 @@ def _dp_rank(rank, world, port, q):
         net = net.to(DEV).train()
         dp = FlatSGDDataParallel(net, lr=1e-3, momentum=0.9, weight_decay=5e-4, overlap=(rank >= 0 and os.environ.get("DP_OVERLAP") == "1"))
         dp.broadcast_parameters(0)
+        if os.environ.get("DP_SIDE_DELAY") == "1":
+            # ~20 ms of nothing on the engine's side stream in front of the tail group's deferred weight gradients: a collective
+            # that did not wait for them would read the flat buffer long before they are written
+            net._engine._test_side_delay = lambda: torch.cuda._sleep(40_000_000)
         x = np.random.default_rng(81).standard_normal((4, 3, 300, 300), dtype=np.float32)
         boxes, classes = synth_gt(np.random.default_rng(82), 4)
         sl = slice(2 * rank, 2 * rank + 2)
         for _ in range(2):
             dp.zero_grad()
-            l1, l2 = Losses.ssd(net(_t(x[sl])), [_t(c) for c in classes[sl]], [_t(b) for b in boxes[sl]], norm_mode=1)
+            l1, l2, n_pos = Losses.ssd(net(_t(x[sl])), [_t(c) for c in classes[sl]], [_t(b) for b in boxes[sl]], norm_mode=1, with_n_pos=True)
             (l1 + l2).backward()
-            dp.reduce_and_step(Losses.last_match["n_pos"])
+            dp.reduce_and_step(n_pos)
         torch.cuda.synchronize()
         q.put((rank, dp.flat_param.cpu().numpy(), float(dp.flat_grad[dp.n].item())))
     finally:
@@ -1254,6 +1258,34 @@ def test_two_rank_data_parallel_step_of_the_real_engine_equals_the_global_batch_
     got, want = torch.from_numpy(out[0][1]), probe.flat_param.cpu()
     err = float((got - want).abs().max())
     assert err <= 2e-5 * max(1.0, float(want.abs().max())), err
+
+
+def test_overlapped_exchange_waits_for_gradients_written_on_the_side_stream():
+    """ADVICE (round 2): with the tail group on a second stream, a 16 MB bucket mixes gradients of the caller's stream (conv_fc7)
+    with gradients the side stream writes later (c_8, seq8).  The listener must hear of the latter only once the caller's stream has
+    waited for them.  Two ranks, overlapped exchange, the side stream held up by 20 ms in front of its deferred weight gradients:
+    parameters after two steps are bit-identical to the single all-reduce run (two-rank sums commute)."""
+    import socket
+    import torch.multiprocessing as mp
+    res = {}
+    for mode, env in (("plain", {"DP_OVERLAP": "0", "DP_SIDE_DELAY": "0"}), ("overlap_delayed", {"DP_OVERLAP": "1", "DP_SIDE_DELAY": "1"})):
+        s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+        os.environ.update(env)
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_dp_rank, args=(r, 2, port, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        try:
+            out = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+        finally:
+            for p in procs:
+                p.join(timeout=120)
+        assert all(p.exitcode == 0 for p in procs)
+        assert np.array_equal(out[0][1], out[1][1])
+        res[mode] = out[0][1]
+    os.environ["DP_SIDE_DELAY"] = "0"
+    assert np.array_equal(res["plain"], res["overlap_delayed"])
 
 
 def test_second_stream_schedule_is_bitwise_the_single_stream_step():

@@ -20,9 +20,9 @@ for rep in range(6):
         x, classes, boxes = batches[it % 4]
         tr.zero_grad()
         loc, conf = net(x)
-        l1, l2 = Losses.ssd((loc, conf), classes, boxes, norm_mode=1)
+        l1, l2, n_pos = Losses.ssd((loc, conf), classes, boxes, norm_mode=1, with_n_pos=True)
         (l1 + l2).backward()
-        tr.reduce_and_step(Losses.last_match["n_pos"])
+        tr.reduce_and_step(n_pos)
     torch.cuda.synchronize()
     npos = float(Losses.last_match["n_pos"])
     print(f"rep {rep}: {(time.perf_counter() - t0) / 50 * 1e3:.3f} ms/step  loss {(float(l1) + float(l2)) / max(npos, 1):.4f}  "
