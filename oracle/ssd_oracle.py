@@ -416,8 +416,29 @@ def _conv_bf16_operands():
 _VGG_ACT = ("a1_1", "a1_2", "a2_1", "a2_2", "a3_1", "a3_2", "a3_3", "a4_1", "a4_2", "a4_3", "a5_1", "a5_2", "a5_3")
 
 
-def ssd300_forward(x, params, return_features: bool = False, variant: int = 300, operand_round: str = None, acts: dict = None):
+def pinned_max_pool(z, code, k: int, stride: int, pad: int):
+    """Max pool with the arg-max GIVEN: y[n,c,oh,ow] = z[n,c, oh*stride - pad + code // k, ow*stride - pad + code % k], `code` (N,C,Ho,Wo)
+    the window index r*k + s the HIP pools store (csrc/elementwise.hip maxpool_fwd_kernel).  Differentiable in z (a gather)."""
+    import torch
+    N, C, H, W = z.shape
+    Ho, Wo = code.shape[2], code.shape[3]
+    code = code.long()
+    ih = torch.arange(Ho).view(1, 1, Ho, 1) * stride - pad + code // k
+    iw = torch.arange(Wo).view(1, 1, 1, Wo) * stride - pad + code % k
+    if bool((ih < 0).any() or (ih >= H).any() or (iw < 0).any() or (iw >= W).any()):
+        raise ValueError("pinned_max_pool: an arg-max code points outside the map")
+    return z.flatten(2).gather(2, (ih * W + iw).flatten(2)).view(N, C, Ho, Wo)
+
+
+def ssd300_forward(x, params, return_features: bool = False, variant: int = 300, operand_round: str = None, acts: dict = None,
+                   decisions: dict = None):
     """x (bs,3,300,300) f32 NCHW torch tensor -> loc (bs,8732,4), conf (bs,8732,21).
+    decisions (tests only): the discrete choices of ANOTHER evaluation of the same network, which this one then follows instead of
+    making its own -- {"relu": {activation name: bool mask NCHW}, "pool": {pool name p1..p5: (arg-max codes (N,C,Ho,Wo), gate or
+    None)}}.  ReLU becomes `z * mask`; a max pool becomes a gather at the given arg-max (times `gate` = "pooled output > 0" where the
+    other evaluation fused conv -> ReLU -> pool and left no full-resolution mask).  With the decisions pinned the network is one
+    fixed linear-in-pieces function: two evaluations differ by arithmetic only, not by a ReLU / arg-max that flipped on a last-bit
+    difference (which is a discrete jump of one gradient path).
     operand_round="bf16": every convolution multiplies bf16-rounded operands with f32 accumulation (`_conv_bf16_operands`:
     BASELINE.json configs[2]); pools, L2-norm, biases, ReLU and the tensors between layers stay f32.
     acts: optional dict, filled with every post-ReLU activation (NCHW, detached) under the build's tensor names
@@ -438,33 +459,51 @@ def ssd300_forward(x, params, return_features: bool = False, variant: int = 300,
     first = {} if operand_round is None else {"wgrad_f32": True}
     feats = {}
     h = x
+    pin_relu = None if decisions is None else decisions["relu"]
+    pin_pool = None if decisions is None else decisions["pool"]
+
+    def relu(z, name):
+        if pin_relu is None:
+            return F.relu(z)
+        m = pin_relu.get(name)
+        return z if m is None else z * m.to(z.dtype)       # no mask: the pool behind this layer carries the gate
+
+    def pool(z, name, k, stride, pad=0, ceil=False):
+        if pin_pool is None:
+            return F.max_pool2d(z, k, stride, padding=pad, ceil_mode=ceil)
+        code, gate = pin_pool[name]
+        y = pinned_max_pool(z, code, k, stride, pad)
+        return y if gate is None else y * gate.to(z.dtype)
+
     pools_after = {2: False, 4: False, 7: True, 10: False}   # conv ordinal -> ceil_mode
+    n_pool = 0
     for li, idx in enumerate(VGG_CONV_IDX):
-        h = F.relu(conv2d(h, params[f"model.features.{idx}.weight"],
-                          params[f"model.features.{idx}.bias"], padding=1, **(first if li == 0 else {})))
+        h = relu(conv2d(h, params[f"model.features.{idx}.weight"],
+                        params[f"model.features.{idx}.bias"], padding=1, **(first if li == 0 else {})), _VGG_ACT[li])
         n = li + 1
         if acts is not None:
             acts[_VGG_ACT[li]] = h.detach()
         if n == 10:
             feats["conv4_3"] = h
         if n in pools_after:
-            h = F.max_pool2d(h, 2, 2, ceil_mode=pools_after[n])
-    h = F.max_pool2d(h, 3, 1, padding=1)
+            n_pool += 1
+            h = pool(h, f"p{n_pool}", 2, 2, ceil=pools_after[n])
+    h = pool(h, "p5", 3, 1, pad=1)
     c43 = feats["conv4_3"]
     norm = c43.pow(2).sum(dim=1, keepdim=True).sqrt()
     c43n = c43 / norm * params["rescaling_conv_4_3"]
-    h = F.relu(conv2d(h, params["conv_fc6.weight"], params["conv_fc6.bias"], padding=4, dilation=4))
+    h = relu(conv2d(h, params["conv_fc6.weight"], params["conv_fc6.bias"], padding=4, dilation=4), "a6")
     if acts is not None:
         acts["n4_3"], acts["a6"] = c43n.detach(), h.detach()
-    h = F.relu(conv2d(h, params["conv_fc7.weight"], params["conv_fc7.bias"]))
+    h = relu(conv2d(h, params["conv_fc7.weight"], params["conv_fc7.bias"]), "a7")
     if acts is not None:
         acts["a7"] = h.detach()
     srcs = [c43n, h]
     for name, _, _, _, stride, pad in (AUX if variant == 300 else AUX_512):
-        h = F.relu(conv2d(h, params[f"{name}.0.weight"], params[f"{name}.0.bias"]))
+        h = relu(conv2d(h, params[f"{name}.0.weight"], params[f"{name}.0.bias"]), "a" + name[3:] + "a")
         if acts is not None:
             acts["a" + name[3:] + "a"] = h.detach()
-        h = F.relu(conv2d(h, params[f"{name}.2.weight"], params[f"{name}.2.bias"], stride=stride, padding=pad))
+        h = relu(conv2d(h, params[f"{name}.2.weight"], params[f"{name}.2.bias"], stride=stride, padding=pad), "a" + name[3:])
         if acts is not None:
             acts["a" + name[3:]] = h.detach()
         srcs.append(h)
@@ -481,9 +520,12 @@ def ssd300_forward(x, params, return_features: bool = False, variant: int = 300,
     return loc, conf
 
 
-def multibox_loss_torch(loc, conf, boxes, classes, pri_cxcywh=None):
+def multibox_loss_torch(loc, conf, boxes, classes, pri_cxcywh=None, neg_select=None):
     """Differentiable torch-CPU form of multibox_loss (same selection logic,
-    matching done by match_priors) used as the CPU train-step baseline."""
+    matching done by match_priors) used as the CPU train-step baseline.
+    neg_select (tests only): bool (bs, P), the hard negatives ANOTHER evaluation picked; used instead of this one's own top-k
+    (the decision-pinned comparison: a negative that enters or leaves the top-k on a last-bit difference of its cross-entropy is a
+    discrete jump of the conf gradient)."""
     import torch
     import torch.nn.functional as F
     if pri_cxcywh is None:
@@ -501,6 +543,12 @@ def multibox_loss_torch(loc, conf, boxes, classes, pri_cxcywh=None):
     cce = F.cross_entropy(conf.reshape(-1, C), cls_t.reshape(-1), reduction="none").view(bs, P)
     neg = cce.clone()
     neg[pos] = 0.
+    if neg_select is not None:
+        sel = torch.as_tensor(neg_select, dtype=torch.bool)
+        if tuple(sel.shape) != (bs, P) or bool((sel & pos).any()) or not bool((sel.sum(1) == torch.clamp(3 * pos.sum(1), max=P - pos.sum(1))).all()):
+            raise ValueError("neg_select must pick min(3 * n_pos, n_neg) negatives per image")
+        conf_loss = (cce[sel].sum() + cce[pos].sum()) / pos.sum().to(cce.dtype)
+        return loc_loss, conf_loss
     neg_sorted, _ = neg.sort(dim=1, descending=True)
     k = 3 * pos.sum(dim=1, keepdim=True)
     hn = torch.arange(P)[None, :] < k

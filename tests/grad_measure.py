@@ -120,3 +120,47 @@ def layerwise_forward_distance(net, params, conv_dtype):
             continue
         out[name] = rel_l2(got.permute(0, 3, 1, 2), ref)
     return out, float((loc.cpu() - lo).abs().max() / lo.abs().max().clamp_min(1)), float((conf.cpu() - co).abs().max() / co.abs().max().clamp_min(1))
+
+
+# ---- decision-pinned comparison (independent of the code under test: no measured table) ------------------------------------
+# relative L2 per gradient tensor; fixed numbers, NOT written by tools/grad_bars.py.  Measured on an MI355X (round 3): worst tensor
+# 1.6e-6 on the direct engine (c_11_cl.weight), 7.7e-6 on the Winograd engine (conv1_1.weight); medians 2.9e-7 / 1.6e-6.
+PINNED_BAR = {"direct": 1e-5, "wino": 5e-5}
+
+
+def gpu_decisions(net, x, classes, boxes):
+    """The discrete choices of the HIP forward + loss on this batch: ReLU masks and max-pool arg-max codes as the engine saved
+    them for its backward, and the hard negatives its loss kernel selected -> (decisions for O.ssd300_forward, neg_select)."""
+    from objectdetection_ssd_amd import Losses, ops
+    from objectdetection_ssd_amd.Model import _Elided
+    net.train()
+    eng = net._engine
+    with torch.no_grad():
+        loc, conf, saved = eng.forward(x, net._forward_params(), save=True)
+    T, aux = saved["T"], saved["aux"]
+    relu, pool = {}, {}
+    for op in eng.ops:
+        if op["op"] in ("conv", "conv_first") and op["y"] in eng.relu_out:
+            t = T[op["y"]]
+            relu[op["y"]] = None if isinstance(t, _Elided) else (t > 0).permute(0, 3, 1, 2).cpu()
+        elif op["op"] == "pool":
+            gate = (T[op["y"]] > 0).permute(0, 3, 1, 2).cpu() if isinstance(T[op["x"]], _Elided) else None
+            pool[op["y"]] = (aux[op["y"]].permute(0, 3, 1, 2).cpu(), gate)
+    gt, cls_t, img_start = Losses._pack_targets(classes, boxes, loc.device)
+    pri, pri_xyxy = Losses._priors_on(loc.device, loc.shape[1])
+    out = ops.multibox_loss(loc.contiguous(), conf.contiguous(), gt, cls_t, img_start, pri, pri_xyxy, Losses.IOU_THRESHOLD,
+                            Losses.NEG_POS_RATIO, 0, want_grads=True)
+    torch.cuda.synchronize()
+    neg = (out["cls"] == O.BG_CLASS) & (out["dconf"].abs().amax(-1) > 0)
+    return {"relu": relu, "pool": pool}, neg.cpu()
+
+
+def f64_pinned_grads(params, decisions, neg_select):
+    """f64 CPU evaluation of the oracle network on the f64 case FOLLOWING the given decisions -> (a1, a2, {name: grad f64})."""
+    x, boxes, classes = f64_case()
+    P = {k: v.detach().clone().double().requires_grad_(True) for k, v in params.items()}
+    loc, conf = O.ssd300_forward(torch.from_numpy(x).double(), P, decisions=decisions)
+    a1, a2 = O.multibox_loss_torch(loc, conf, [torch.from_numpy(b) for b in boxes], [torch.from_numpy(c) for c in classes],
+                                   neg_select=neg_select)
+    (a1 + a2).backward()
+    return float(a1), float(a2), {k: v.grad for k, v in P.items()}

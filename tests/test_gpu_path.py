@@ -272,6 +272,35 @@ def test_train_step_gradients_vs_f64_oracle(golden_net, engine):
         assert v <= (1e-2 if early else 1e-3), (k, v)
 
 
+@pytest.mark.parametrize("engine", ["direct", "wino"])
+def test_train_step_gradients_vs_decision_pinned_f64_oracle(golden_net, engine):
+    """The gradient check that does not depend on a table measured with the code under test.  The f64 oracle is run FOLLOWING the
+    discrete decisions of the HIP forward (its ReLU masks, its max-pool arg-max codes, its hard negatives -- exported from what the
+    engine saves for its own backward): both sides then evaluate the same fixed piecewise-linear function, no ReLU or pool flips on
+    a last-bit difference, and what remains is arithmetic error alone.  Every one of the 71 gradient tensors must be within ONE
+    fixed bar of the f64 result: 1e-5 relative L2 on the exact-f32 direct engine, 5e-5 on the Winograd engine (F(4x4,3x3)
+    re-associates the sums with coefficients up to 8 and 1/24) -- measured 1.6e-6 / 7.7e-6 at worst, i.e. the 1e-3 .. 4e-3 that
+    conv1 / conv2 show against an UNPINNED f64 run (tests/golden/grad_bars.json) is flip noise, not arithmetic."""
+    import grad_measure as M
+    net, params, _ = golden_net
+    x, boxes, classes = M.f64_case()
+    xd, cl, bx = M._t(x), [M._t(c) for c in classes], [M._t(b) for b in boxes]
+    M.set_engine(net, engine)
+    try:
+        decisions, neg = M.gpu_decisions(net, xd, cl, bx)
+        _, _, l1, l2, grads = M.train_step(net, xd, cl, bx)
+    finally:
+        M.set_engine(net, "wino")
+    assert any(m is None for m in decisions["relu"].values()) == (engine == "wino")       # Winograd fuses three conv -> ReLU -> pool layers
+    a1, a2, g64 = M.f64_pinned_grads(params, decisions, neg)
+    assert abs(l1 - a1) <= 1e-4 * max(1, a1) and abs(l2 - a2) <= 1e-4 * max(1, a2)
+    assert len(g64) == 71
+    rows = sorted(((M.rel_l2(grads[k], g64[k]), k) for k in g64), reverse=True)
+    print(f"decision-pinned f64 distance [{engine}]: worst " + ", ".join(f"{k} {v:.2e}" for v, k in rows[:6]) + f"; median {rows[35][0]:.2e}")
+    bad = [(k, v) for v, k in rows if v > M.PINNED_BAR[engine]]
+    assert not bad, bad
+
+
 def test_train_step_at_bench_batch_winograd_vs_direct_engine():
     """bench.py's own step at bench.py's size: batch 32 of its synthetic input through the default engine (Winograd F(4x4) with
     kept planes, fused pools, the shared dy pass) against the direct exact-f32 MFMA engine: loc / conf / losses within 1e-4 of

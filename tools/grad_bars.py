@@ -3,6 +3,11 @@ engine, and write the table the tests use as bars (tests/golden/grad_bars.json; 
 
     python tools/grad_bars.py [out.json]        (GPU box; default gpurun_out/grad_bars.json -- copy it to tests/golden/)
 
+This table is a REGRESSION RECORD of unpinned runs (two independent evaluations whose ReLU / max-pool / hard-negative decisions
+differ in a few places out of ~1e8, each a discrete jump of one gradient path).  The bar that does not depend on the code under
+test is `tests/test_gpu_path.py::test_train_step_gradients_vs_decision_pinned_f64_oracle`: the f64 oracle follows the HIP
+forward's own decisions and every tensor must be within a FIXED 1e-5 (direct) / 5e-5 (Winograd) of it (`grad_measure.PINNED_BAR`).
+
 Metrics (71 tensors each):
   f64_wino / f64_direct     relative L2 to an f64 CPU evaluation of the oracle network (bs 2, all six scales positive)
   cpu32_f64                 the f32 CPU oracle's own distance to f64 on that input (context: what "the reference" achieves)
