@@ -101,6 +101,44 @@ int ssd_conv3x3_halo_dgrad_bf16(const float* dy, int ldy, const void* w3_ihwo, i
                                 const float* relu_mask, int accumulate, const ssd_conv_geom* g, void* stream);
 int ssd_tune_set_halo(int mode);         /* 3x3/s1 halo-tile kernel: 0 = off, 1 = 8x8 patches, 2 = 8x16 patches, -1 = automatic */
 
+/* ---- bf16 TENSORS (round 3; BASELINE.json configs[2] "bf16 convs" with activations and gradients stored in bf16) ------------
+ * 3x3 / stride 1 / pad 1 convolution, forward (flip = 0) and data gradient (flip = 1: the same convolution with the taps
+ * mirrored), replacing nn.Conv2d(+ReLU) of Model.py:135-143,176-184 and its autograd data gradient.
+ *   x        [N][H][W][ldx] bf16 (forward: the input activation; data gradient: dy), K = reduction channels per tap (multiple of 64, <= ldx)
+ *   w        [w_rows][9][K] bf16 (forward: OHWI copy of the f32 master; data gradient: IHWO); rows >= w_rows count as zero
+ *   out      [N][H][W][ldo] bf16, or f32 when out_f32 (the heads): columns 0 .. n_out-1 are written (n_out % 4 == 0; bias, if given, has n_out entries)
+ *   out = [accumulate: out +] conv (+ bias) -> [relu] -> [relu_mask (bf16, out's layout): kept where mask > 0]
+ * f32 accumulation on v_mfma_f32_32x32x16_bf16, one rounding to bf16 at the store. */
+int ssd_conv3x3_bf16(const void* x, int ldx, const void* w, int w_rows, int K, const float* bias, void* out, int ldo, int n_out,
+                     int out_f32, const void* relu_mask, int accumulate, int relu, int flip, int N, int H, int W, void* stream);
+int ssd_tune_set_conv_bf16(int mode, int bn);    /* position space 0 / 1 / 2 (patches 8x32, 16x16, flat), N tile 64 / 128; -1 = automatic */
+/* Weight gradient of a 3x3 / stride 1 / pad 1 / dilation 1 layer from bf16 x (N,H,W,Ci) and bf16 dy (N,H,W,ldy): dw (Co,Ci,3,3) and dbias
+ * in f32 (the fused nine-tap bf16 MFMA kernel; workspace ssd_conv2d_wgrad_workspace(g)); SSD_ERR_BAD_SHAPE for other geometries. */
+int ssd_conv3x3_wgrad_bf16t(const void* x_bf16, const void* dy_bf16, int ldy, float* dw_oihw, float* dbias, const ssd_conv_geom* g,
+                            void* workspace, size_t workspace_bytes, void* stream);
+/* conv1_1 (Model.py:135) in the bf16-tensor mode: x (f32 NCHW image) and the filter rows rounded to bf16, f32 accumulate, y stored as
+ * bf16 NHWC; its weight gradient from the f32 image and the bf16 dy (f32 arithmetic). */
+int ssd_conv1_first_fwd_bf16(const float* x_nchw, const float* w_rows, const float* bias, void* y_nhwc_bf16, int N, int H, int W, int relu,
+                             void* stream);
+int ssd_conv1_first_wgrad_bf16(const float* x_nchw, const void* dy_nhwc_bf16, float* dw_rows, float* dbias, int N, int H, int W,
+                               void* workspace, size_t workspace_bytes, void* stream);
+/* Max pooling (Model.py:135-142), conv4_3 L2 normalisation (Model.py:206-209) and the heads' gradient gather on bf16 NHWC tensors
+ * (C % 8 == 0; argmax codes as in ssd_maxpool_fwd; f32 arithmetic, one rounding at the store).  ssd_maxpool_bwd_bf16: relu_mask (the bf16
+ * activation, dx kept where > 0) and accumulate, or y_gate (the bf16 pooled output: the gated form, no accumulate). */
+int ssd_maxpool_fwd_bf16(const void* x, void* y, uint8_t* argmax, int N, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo,
+                         void* stream);
+int ssd_maxpool_bwd_bf16(const void* dy, const uint8_t* argmax, void* dx, const void* relu_mask, const void* y_gate, int accumulate, int N,
+                         int H, int W, int C, int k, int stride, int pad, int Ho, int Wo, void* stream);
+int ssd_l2norm_fwd_bf16(const void* x, const float* gamma, void* y, int M, int C, void* stream);
+size_t ssd_l2norm_bwd_bf16_workspace(int M, int C);
+int ssd_l2norm_bwd_bf16(const void* x, const float* gamma, const void* dy, void* dx, float* dgamma, int M, int C, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int ssd_heads_gather_bf16(const float* dloc, const float* dconf, void* packed_bf16, int ld, int N, int HW, int A, int prior_off, int P,
+                          int ncls, void* stream);
+int ssd_cast_f32_bf16(const float* x, void* y_bf16, size_t n, void* stream);      /* n % 8 == 0 */
+int ssd_cast_bf16_f32(const void* x_bf16, float* y, size_t n, void* stream);
+/* ssd_weights_prepare job kind 3: out_fwd = bf16 OHWI [co_pad][taps][ci], out_bwd = bf16 IHWO [ci][taps][pad1] (pad1 >= co, zero filled). */
+
 /* dw_oihw[n][c][r][s] = sum_m dy[m][n] * x[pix(m,tap)][c];  dbias[n] = sum_m dy[m][n]
  * (dbias may be NULL).  Deterministic: split-K partial slabs in `workspace`, then a
  * fixed-order reduction. */

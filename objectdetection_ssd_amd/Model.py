@@ -119,6 +119,15 @@ def param_names(op_list: List[dict]) -> List[str]:
     return names
 
 
+def _cat_flat(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """cat((a, b)) of two 1-D parameters -- without a copy when b starts where a ends in one storage (ddp.py lays the loc and conf
+    biases of a head side by side in its flat parameter buffer)."""
+    if (a.dim() == 1 and b.dim() == 1 and a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and a.storage_offset() + a.numel() == b.storage_offset()):
+        return torch.as_strided(a, (a.numel() + b.numel(),), (1,), a.storage_offset())
+    return torch.cat((a, b))
+
+
 class _Elided:
     """Stands in the activation table for a tensor that a fused kernel consumed without writing it: shape only.  In the backward it
     takes the ReLU-mask slot of its pool, which then gates by the pooled output (`maxpool_bwd(..., y_gate=)`)."""
@@ -211,6 +220,11 @@ class _Engine:
         self.relu_bits = True     # training forward: the input transform also leaves the ReLU mask of its input as bits for the dgrad epilogue
         self.prof = None          # bench.py: list collecting (label, kernel tag, flops, start event, end event)
         self.bf16 = False         # True: forward / dgrad / fused-wgrad convolutions multiply bf16-rounded operands (f32 accumulate)
+        # bf16 mode: the VGG trunk (conv1_1 ... pool5, the L2-norm and the c_4 head's input) keeps its activations and gradients in bf16 in
+        # HBM -- written once by the producing kernel -- and runs csrc/conv_bf16.hip (LDS-DMA halo kernel), the bf16-input nine-tap weight
+        # gradient and the bf16 pools / L2-norm; fc6 onwards (19x19 maps and smaller) stays on the f32-tensor bf16-operand kernels.
+        # False: the round-2 form (every tensor f32 in HBM, operands rounded on their way into LDS).
+        self.bf16_tensors = True
         self.x3 = False           # True: forward / dgrad convolutions form f32 products from three bf16 limbs per operand
         self.wino = True          # f32 mode: Winograd F(4x4,3x3) (WINO_TILE) for the 3x3 / stride-1 layers with >= WINO_MIN_CI input channels
 
@@ -240,7 +254,7 @@ class _Engine:
             self._wcache[key] = ent
         if need_bwd and ent[3] is None:
             ent[3] = ops.weight_ihwo(ent[1], co_pad)
-        if self.x3 or self.bf16:                      # pre-split limb planes of the layouts in use
+        if self.x3 or (self.bf16 and not self.bf16_tensors):      # pre-split limb planes of the layouts in use
             if len(ent) == 4:
                 ent += [None, None]
             if ent[4] is None:
@@ -287,17 +301,40 @@ class _Engine:
         ent = self._wcache.get(key)
         return None if ent is None or len(ent) < 6 else ent[5 if bwd else 4]
 
+    def _t16(self, g, xin) -> bool:
+        """bf16-tensor mode: this convolution runs csrc/conv_bf16.hip (3x3 / stride 1 / pad 1 on a bf16 input, Ci a multiple of 64)."""
+        return (self.bf16 and self.bf16_tensors and g.R == 3 and g.S == 3 and g.stride == 1 and g.dil == 1 and g.pad == 1 and g.Ci % 64 == 0
+                and (xin is None or xin.dtype == torch.bfloat16))
+
+    def _bf16_weights(self, key: str, tensors):
+        """bf16 OHWI (co, 9, ci) and IHWO (ci, 9, pad64(co)) copies of a 3x3 filter (+ the bias padded to a multiple of 4), cached."""
+        sig = tuple((t.data_ptr(), t._version) for t in tensors)
+        ent = self._wcache.get("b16:" + key)
+        if ent is None or ent[0] != sig:
+            w = (tensors[0] if len(tensors) == 1 else torch.cat(list(tensors), 0)).detach()
+            co, ci = int(w.shape[0]), int(w.shape[1])
+            wf = w.permute(0, 2, 3, 1).reshape(co, 9, ci).contiguous().to(torch.bfloat16)
+            wb = torch.zeros((ci, 9, ops.pad64(co)), device=w.device, dtype=torch.bfloat16)
+            wb[:, :, :co] = w.permute(1, 2, 3, 0).reshape(ci, 9, co)
+            ent = (sig, wf, wb)
+            self._wcache["b16:" + key] = ent
+        return ent[1], ent[2]
+
     def _prepare_weights_batched(self, x: torch.Tensor, P: Dict[str, torch.Tensor]) -> None:
         """Fill the weight cache for a training step with one launch.  The output buffers persist across steps (rewritten in place, on the
         caller's stream, after the previous step's last use); the job table is rebuilt only when a parameter's storage or the input
         size changes."""
-        sig = (x.shape[2], x.shape[3], self.wino, self.WINO_TILE, self.WINO_MIN_CI, self.WINO_MIN_HW) + tuple(P[n].data_ptr() for n in self.names)
+        sig = (x.shape[2], x.shape[3], self.wino, self.WINO_TILE, self.WINO_MIN_CI, self.WINO_MIN_HW, self.bf16, self.bf16_tensors) + tuple(P[n].data_ptr() for n in self.names)
         if self._wtable is None or self._wtable[0] != sig:
             jobs, entries = [], []
             bs, hw, dev = x.shape[0], {"x": (x.shape[2], x.shape[3])}, x.device
+            b16 = {"x": False}                     # which tensors the forward will hold in bf16 (mirrors the dtype flow of `forward`)
             for op in self.ops:
                 kind = op["op"]
+                if kind in ("pool", "l2norm"):
+                    b16[op["y"]] = b16[op["x"]]
                 if kind == "conv_first":
+                    b16[op["y"]] = self.bf16 and self.bf16_tensors
                     hw[op["y"]] = hw[op["x"]]
                     w = P[op["p"] + ".weight"]
                     rows = torch.empty((64, 1, 32), device=dev, dtype=torch.float32)
@@ -318,10 +355,19 @@ class _Engine:
                         co = op["a"] * (4 + N_CLASSES)
                         g = ops.make_geom(bs, h, w_, op["ci"], co, 3, 1, 1, 1)
                         tensors, co_pad = (P[op["p"] + "_bb.weight"], P[op["p"] + "_cl.weight"]), ops.pad32(co)
+                    t16 = self._t16(g, None) and b16[op["x"]]
+                    if kind == "conv":
+                        b16[op["y"]] = t16
                     co_all = sum(t.shape[0] for t in tensors)
                     job = dict(w0=tensors[0].detach(), w1=tensors[1].detach() if len(tensors) > 1 else None, co0=tensors[0].shape[0], co=co_all,
                                ci=g.Ci, taps=g.R * g.S, co_pad=co_pad)
-                    if self._wino_ok(g) and self.WINO_TILE == 4:
+                    # bf16-tensor mode: which layers see a bf16 input is decided by the trunk's structure (everything up to pool5, the c_4 head)
+                    if t16:
+                        wf = torch.empty((co_all, 9, g.Ci), device=dev, dtype=torch.bfloat16)
+                        wb = torch.empty((g.Ci, 9, ops.pad64(co_all)), device=dev, dtype=torch.bfloat16)
+                        jobs.append(dict(job, kind=3, co_pad=co_all, pad1=ops.pad64(co_all), out_fwd=wf, out_bwd=wb))
+                        entries.append((op["p"], "b16", tensors, (wf, wb)))
+                    elif self._wino_ok(g) and self.WINO_TILE == 4:
                         uf = torch.empty((36, co_all, g.Ci), device=dev, dtype=torch.float32)
                         ub = torch.empty((36, g.Ci, co_pad), device=dev, dtype=torch.float32)
                         jobs.append(dict(job, kind=0, out_fwd=uf, out_bwd=ub))
@@ -338,7 +384,9 @@ class _Engine:
         table.run()
         for key, what, tensors, bufs in entries:
             lsig = tuple((t.data_ptr(), t._version) for t in tensors)
-            if what == "wino":
+            if what == "b16":
+                self._wcache["b16:" + key] = (lsig, bufs[0], bufs[1])
+            elif what == "wino":
                 self._wcache["wino:" + key] = (lsig, bufs[0], bufs[1])
             elif what == "layout":
                 self._wcache[key] = [lsig, None, bufs[0], bufs[1]]
@@ -361,7 +409,7 @@ class _Engine:
             # (data_ptr, _version) cannot see writes through `.data` (p.data.mul_(), dist.broadcast(p.data), EMA swaps).
             # The backward of this step reads what this forward stored.
             self._wcache.clear()
-            if self.batch_weights and not self.bf16 and not self.x3:
+            if self.batch_weights and not self.x3 and (not self.bf16 or self.bf16_tensors):
                 self._prepare_weights_batched(x, P)
         T = {"x": x}
         aux = {}
@@ -416,7 +464,12 @@ class _Engine:
                     self._wcache[op["p"]] = ent
                 bias = P[op["p"] + ".bias"].detach()
                 flops1 = 2.0 * bs * g.Ho * g.Wo * 64 * 27
-                if self.first_fused and not self.bf16 and not self.x3:
+                if self.bf16 and self.bf16_tensors:
+                    # bf16-tensor mode: operands rounded to bf16 inside the kernel, bf16 NHWC out; the weight gradient reads x itself
+                    T[op["y"]] = self._timed("fwd " + op["p"], "conv_first_fwd_kernel", flops1,
+                                             lambda: ops.conv1_first_fwd_bf16(x, ent[2], bias, True))
+                    col = None
+                elif self.first_fused and not self.bf16 and not self.x3:
                     # one kernel from the NCHW batch: halo tile in LDS, K = 27 on the MFMA, bias + ReLU; the weight gradient's rows ride along
                     T[op["y"]], col = self._timed("fwd " + op["p"], "conv_first_fwd_kernel", flops1,
                                                   lambda: ops.conv1_first_fwd(x, ent[2], bias, True, want_col=False))
@@ -431,6 +484,14 @@ class _Engine:
                 xin = T[op["x"]]
                 g = ops.make_geom(bs, xin.shape[1], xin.shape[2], op["ci"], op["co"], op["k"], op["s"], op["pad"], op["dil"])
                 bias = P[op["p"] + ".bias"].detach()
+                if self._t16(g, xin):
+                    wf16, _ = self._bf16_weights(op["p"], (P[op["p"] + ".weight"],))
+                    T[op["y"]] = self._timed("fwd " + op["p"], "conv3x3_bf16_kernel", ops.conv_flops(g),
+                                             lambda: ops.conv3x3_bf16(xin, wf16, bias, op["co"], op["relu"]))
+                    aux[op["y"]] = g
+                    continue
+                if xin.dtype == torch.bfloat16:                   # boundary of the bf16 trunk (pool5 -> fc6): the kernels below take f32 tensors
+                    xin = T[op["x"] + ":f32"] = ops.cast_f32(xin)
                 if self._wino_ok(g):
                     uf, _ = self._wino_weights(op["p"], (P[op["p"] + ".weight"],), op["co"])
                     pl = self.pool_after.get(op["y"]) if (self.fuse_pool and self.WINO_TILE == 4) else None
@@ -477,7 +538,17 @@ class _Engine:
                 co = a * (4 + N_CLASSES)
                 g = ops.make_geom(bs, xin.shape[1], xin.shape[2], op["ci"], co, 3, 1, 1, 1)
                 pre = op["p"]
-                bias = torch.cat((P[pre + "_bb.bias"].detach(), P[pre + "_cl.bias"].detach()))
+                bias = _cat_flat(P[pre + "_bb.bias"].detach(), P[pre + "_cl.bias"].detach())
+                if self._t16(g, xin) and co % 4 == 0:
+                    wf16, _ = self._bf16_weights(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]))
+                    ld = ops.pad32(co)
+                    out = torch.empty((bs, g.H, g.W, ld), device=xin.device, dtype=torch.float32)      # pad columns are never read
+                    packed = self._timed("fwd " + pre, "conv3x3_bf16_kernel", ops.conv_flops(g),
+                                         lambda: ops.conv3x3_bf16(xin, wf16, bias, co, False, out=out, out_f32=True, ldo=ld))
+                    heads.append((op, packed, g))
+                    continue
+                if xin.dtype == torch.bfloat16:
+                    xin = T[op["x"] + ":f32"] = T.get(op["x"] + ":f32") if T.get(op["x"] + ":f32") is not None else ops.cast_f32(xin)
                 if self._wino_ok(g):
                     uf, _ = self._wino_weights(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]), ops.pad32(co))
                     keep = save and self.keep_planes and self.WINO_TILE == 4 and self._wino_wgrad_ok(g, True)
@@ -586,9 +657,26 @@ class _Engine:
                 pre = op["p"]
                 off, g = offs[pre]
                 co_pad = ops.pad32(g.Co)
-                dy = ops.heads_gather(dloc, dconf, co_pad, bs, g.Ho * g.Wo, op["a"], off)
                 xin = T[op["x"]]
                 a4 = 4 * op["a"]
+                if self._t16(g, xin) and g.Co % 4 == 0:
+                    # bf16 trunk: packed bf16 dy (K of the data gradient padded to 64), nine-tap bf16 weight gradient, LDS-DMA data gradient
+                    ld = ops.pad64(g.Co)
+                    dy = ops.heads_gather_bf16(dloc, dconf, ld, bs, g.Ho * g.Wo, op["a"], off).view(bs, g.Ho, g.Wo, ld)
+                    if any(need[pre + s] for s in ("_bb.weight", "_bb.bias", "_cl.weight", "_cl.bias")):
+                        dw, db = self._timed("wgrad " + pre, "wgrad3x3_bf16_kernel", ops.conv_flops(g),
+                                             lambda: ops.conv3x3_wgrad_bf16t(xin, dy, g, ld, True, dw_out=self._gout(pre + "_bb.weight", pre + "_cl.weight"),
+                                                                             db_out=self._gout(pre + "_bb.bias", pre + "_cl.bias")))
+                        grads[pre + "_bb.weight"], grads[pre + "_cl.weight"] = dw[:a4], dw[a4:]
+                        grads[pre + "_bb.bias"], grads[pre + "_cl.bias"] = db[:a4], db[a4:]
+                    _, wb16 = self._bf16_weights(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]))
+                    deliver(op["x"], lambda dx, acc, mask: self._timed(
+                        "dgrad " + pre, "conv3x3_bf16_kernel", ops.conv_flops(g),
+                        lambda: ops.conv3x3_bf16(dy, wb16, None, g.Ci, False, flip=True, out=dx, relu_mask=mask, accumulate=acc)))
+                    continue
+                if xin.dtype == torch.bfloat16:
+                    xin = T[op["x"] + ":f32"]
+                dy = ops.heads_gather(dloc, dconf, co_pad, bs, g.Ho * g.Wo, op["a"], off)
                 dyp = None
                 dw = db = None
                 if any(need[pre + s] for s in ("_bb.weight", "_bb.bias", "_cl.weight", "_cl.bias")):
@@ -641,6 +729,20 @@ class _Engine:
                 g = aux[op["y"]]
                 xin = T[op["x"]]
                 dyp = None
+                if self._t16(g, xin) and dy.dtype == torch.bfloat16:
+                    name = op["p"]
+                    if need[name + ".weight"] or need[name + ".bias"]:
+                        grads[name + ".weight"], grads[name + ".bias"] = self._timed(
+                            "wgrad " + name, "wgrad3x3_bf16_kernel", ops.conv_flops(g),
+                            lambda: ops.conv3x3_wgrad_bf16t(xin, dy, g, g.Co, True, dw_out=self._gout(name + ".weight"), db_out=self._gout(name + ".bias")))
+                    _, wb16 = self._bf16_weights(name, (P[name + ".weight"],))
+                    deliver(op["x"], lambda dx, acc, mask: self._timed(
+                        "dgrad " + name, "conv3x3_bf16_kernel", ops.conv_flops(g),
+                        lambda: ops.conv3x3_bf16(dy, wb16, None, g.Ci, False, flip=True, out=dx, relu_mask=mask, accumulate=acc)))
+                    continue
+                to_bf16 = xin.dtype == torch.bfloat16         # boundary of the bf16 trunk: this layer ran on the f32 copy, its dx goes back as bf16
+                if to_bf16:
+                    xin = T[op["x"] + ":f32"]
                 if isinstance(dy, ops.PooledGrad):
                     # dy exists only behind its pool; the Winograd dy pass of this layer can form it on the fly when that pass feeds
                     # both the weight gradient and the data gradient -- otherwise it is scattered to memory after all
@@ -691,6 +793,15 @@ class _Engine:
                                                       bits=bits if mask is not None else None)))
                     continue
                 _, wb = self._layouts(op["p"], (P[op["p"] + ".weight"],), op["co"], True)
+                if to_bf16:
+                    def boundary(dx, acc, mask, dy=dy, wb=wb, g=g, name=op["p"]):
+                        if acc or mask is not None or dx is not None:
+                            raise RuntimeError("the bf16 trunk's boundary tensor must have one consumer and no ReLU of its own")
+                        d32 = self._timed("dgrad " + name, ops.igemm_tile(g, 1, self.bf16, self.x3) if self.prof is not None else "", ops.conv_flops(g),
+                                          lambda: ops.conv2d_dgrad(dy, wb, g, None, None, False, bf16=self.bf16, w3=self._planes(name, True)))
+                        return ops.cast_bf16(d32)
+                    deliver(op["x"], boundary)
+                    continue
                 deliver(op["x"], lambda dx, acc, mask: self._timed(
                     "dgrad " + op["p"], ops.igemm_tile(g, 1, self.bf16, self.x3) if self.prof is not None else "", ops.conv_flops(g),
                     lambda: ops.conv2d_dgrad_x3(dy, wb, g, dx, mask, acc) if self.x3 else
@@ -728,7 +839,7 @@ class _Engine:
                     col = T["x_col"]
                     if col is None:                                    # the one-kernel forward left no [pixel][32] rows: gradient from x itself
                         dw, db = self._timed("wgrad " + op["p"], "conv_first_wgrad_kernel", 2.0 * dy.numel() * 27,
-                                             lambda: ops.conv1_first_wgrad(T["x"], dy, True))
+                                             lambda: (ops.conv1_first_wgrad_bf16 if dy.dtype == torch.bfloat16 else ops.conv1_first_wgrad)(T["x"], dy, True))
                     else:
                         dw, db = self._timed("wgrad " + op["p"], ops.wgrad_tile(g) if self.prof is not None else "", 2.0 * dy.numel() * 27,
                                              lambda: ops.conv2d_wgrad(col, dy, g, g.Co, True))

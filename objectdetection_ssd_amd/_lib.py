@@ -71,6 +71,19 @@ SIGNATURES = {
     "ssd_conv2d_fwd_accum": (_I, [_P, _P, _P, _P, _I, _G, _I, _P]),
     "ssd_conv2d_fwd_accum_bf16": (_I, [_P, _P, _P, _P, _I, _G, _I, _P]),
     "ssd_channel_affine": (_I, [_P, _P, _P, _P, C.c_size_t, _I, _I, _P]),
+    "ssd_conv3x3_bf16": (_I, [_P, _I, _P, _I, _I, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ssd_tune_set_conv_bf16": (_I, [_I, _I]),
+    "ssd_conv3x3_wgrad_bf16t": (_I, [_P, _P, _I, _P, _P, _G, _P, _Z, _P]),
+    "ssd_conv1_first_fwd_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ssd_conv1_first_wgrad_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _Z, _P]),
+    "ssd_maxpool_fwd_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ssd_maxpool_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ssd_l2norm_fwd_bf16": (_I, [_P, _P, _P, _I, _I, _P]),
+    "ssd_l2norm_bwd_bf16_workspace": (_Z, [_I, _I]),
+    "ssd_l2norm_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _Z, _P]),
+    "ssd_heads_gather_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ssd_cast_f32_bf16": (_I, [_P, _P, _Z, _P]),
+    "ssd_cast_bf16_f32": (_I, [_P, _P, _Z, _P]),
     "ssd_conv3x3_halo_fwd_bf16": (_I, [_P, _P, _I, _P, _P, _I, _G, _I, _P]),
     "ssd_conv3x3_halo_dgrad_bf16": (_I, [_P, _I, _P, _I, _P, _P, _I, _G, _P]),
     "ssd_conv2d_wgrad_workspace": (_Z, [_G]),

@@ -19,9 +19,17 @@ __device__ __forceinline__ constexpr int tap_off(int k) {
     return (kk % 3) * PLANE + (kk / 9) * HW_ + (kk / 3) % 3;
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// BF16 (the bf16-tensor mode, BASELINE.json configs[2]): x and the filter are rounded to bf16 on their way into LDS -- the products
+// of two bf16 values are exact in the f32 MFMA, so this is the bf16-operand convolution with f32 accumulation -- and y is stored
+// as bf16 NHWC (`y` then points to bf16).
+template <bool BF16>
 __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wrows,
                                                              const float* __restrict__ bias, float* __restrict__ y, float* __restrict__ col,
                                                              int N, int H, int W, int tiles_h, int tiles_w, int relu) {
+    auto rnd = [](float v) { return BF16 ? (float)(__bf16)v : v; };
     __shared__ float xs[3 * PLANE + 8];
     __shared__ float ws[64 * 33];
     __shared__ __attribute__((aligned(16))) float ys[4 * 32 * 64];
@@ -33,7 +41,7 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
     for (int e = tid; e < 3 * PLANE; e += 256) {
         const int c = e / PLANE, rem = e - c * PLANE, r = rem / HW_, cc = rem - r * HW_;
         const int ih = h0 - 1 + r, iw = w0 - 1 + cc;
-        xs[e] = ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) ? x[((size_t)n * 3 + c) * HWs + (size_t)ih * W + iw] : 0.f;
+        xs[e] = ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) ? rnd(x[((size_t)n * 3 + c) * HWs + (size_t)ih * W + iw]) : 0.f;
     }
     // the 64 x 32 filter rows: two coalesced 16-byte loads per thread into LDS (row stride 33: the fragment reads below walk the rows)
     {
@@ -41,8 +49,8 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
         const int r0 = tid >> 3, c0 = (tid & 7) * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            ws[r0 * 33 + c0 + e] = w0v[e];
-            ws[(r0 + 32) * 33 + c0 + e] = w1v[e];
+            ws[r0 * 33 + c0 + e] = rnd(w0v[e]);
+            ws[(r0 + 32) * 33 + c0 + e] = rnd(w1v[e]);
         }
     }
     const int lr = lane & 31, lh = lane >> 5;
@@ -92,12 +100,25 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
             }
         // same wave writes and reads: the LDS queue is in order, no barrier
         if (oh < H) {
-            float* po = y + (((size_t)n * H + oh) * W + w0 + 32 * j) * 64 + (lane & 15) * 4;
+            if constexpr (BF16) {                                      // 8 lanes per pixel (128 bytes of bf16), 8 pixels per instruction
+                __bf16* po = reinterpret_cast<__bf16*>(y) + (((size_t)n * H + oh) * W + w0 + 32 * j) * 64 + (lane & 7) * 8;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int px = 4 * t + (lane >> 4);
-                const f32x4 v = *reinterpret_cast<const f32x4*>(ysw + px * 64 + (lane & 15) * 4);
-                if (w0 + 32 * j + px < W) *reinterpret_cast<f32x4*>(po + (size_t)px * 64) = v;
+                for (int t = 0; t < 4; ++t) {
+                    const int px = 8 * t + (lane >> 3);
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(ysw + px * 64 + (lane & 7) * 8);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(ysw + px * 64 + (lane & 7) * 8 + 4);
+                    if (w0 + 32 * j + px < W)
+                        *reinterpret_cast<bf16x8*>(po + (size_t)px * 64) = bf16x8{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3],
+                                                                                  (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+                }
+            } else {
+                float* po = y + (((size_t)n * H + oh) * W + w0 + 32 * j) * 64 + (lane & 15) * 4;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int px = 4 * t + (lane >> 4);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(ysw + px * 64 + (lane & 15) * 4);
+                    if (w0 + 32 * j + px < W) *reinterpret_cast<f32x4*>(po + (size_t)px * 64) = v;
+                }
             }
         }
     }
@@ -130,6 +151,8 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
 // wave stages dy [32 px][64 ch] in LDS (16-byte loads) and issues 16 x 2 v_mfma_f32_32x32x2_f32 (A = dy, lanes walk the channels;
 // B = the halo image at this lane's tap offset, or 1 for lane 27).  Workgroups are persistent (grid-stride over the tiles); their
 // [64][32] partial sums go to a slab that conv_first_wgrad_reduce_kernel adds up in block order (reproducible).
+// DY_BF16: dy is the bf16 NHWC gradient of the bf16-tensor mode (x stays the caller's f32 image; f32 products and sums)
+template <bool DY_BF16>
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab,
                                                                int N, int H, int W, int tiles_h, int tiles_w, int ntiles) {
     __shared__ float xs[3 * PLANE + 8];
@@ -153,12 +176,19 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
         f32x4 dv[2][8];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const float* src = dy + (((size_t)n * H + oh) * W + w0 + 32 * j) * 64 + (lane & 15) * 4;
+            const size_t so = (((size_t)n * H + oh) * W + w0 + 32 * j) * 64 + (lane & 15) * 4;
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const int px = 4 * t + (lane >> 4);
                 dv[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (oh < H && w0 + 32 * j + px < W) dv[j][t] = *reinterpret_cast<const f32x4*>(src + (size_t)px * 64);
+                if (oh < H && w0 + 32 * j + px < W) {
+                    if constexpr (DY_BF16) {
+                        const bf16x4 b = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(dy) + so + (size_t)px * 64);
+                        dv[j][t] = f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+                    } else {
+                        dv[j][t] = *reinterpret_cast<const f32x4*>(dy + so + (size_t)px * 64);
+                    }
+                }
             }
         }
         __syncthreads();                                               // the previous tile's halo image is no longer read
@@ -223,18 +253,31 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_reduce_kernel(const floa
 
 }  // namespace
 
-extern "C" int ssd_conv1_first_fwd(const float* x_nchw, const float* w_rows, const float* bias, float* y_nhwc, float* col_out, int N, int H,
-                                   int W, int relu, void* stream) {
+static int conv1_first_fwd_impl(const float* x_nchw, const float* w_rows, const float* bias, void* y_nhwc, float* col_out, int N, int H,
+                                int W, int relu, void* stream, bool bf16) {
     if (!x_nchw || !w_rows || !y_nhwc) return SSD_ERR_NULL;
     if (N <= 0 || H <= 0 || W <= 0) return SSD_ERR_BAD_SHAPE;
     if (!ssd_aligned16(y_nhwc) || (col_out && !ssd_aligned16(col_out))) return SSD_ERR_ALIGN;
     const int tiles_h = ssd_cdiv(H, TH), tiles_w = ssd_cdiv(W, TW);
     const long long blocks = (long long)N * tiles_h * tiles_w;
     if (blocks >= (1ll << 31)) return SSD_ERR_BAD_SHAPE;
-    hipLaunchKernelGGL(conv_first_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_nchw, w_rows, bias, y_nhwc, col_out,
-                       N, H, W, tiles_h, tiles_w, relu);
+    if (bf16)
+        hipLaunchKernelGGL(conv_first_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_nchw, w_rows, bias,
+                           static_cast<float*>(y_nhwc), col_out, N, H, W, tiles_h, tiles_w, relu);
+    else
+        hipLaunchKernelGGL(conv_first_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_nchw, w_rows, bias,
+                           static_cast<float*>(y_nhwc), col_out, N, H, W, tiles_h, tiles_w, relu);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
+}
+extern "C" int ssd_conv1_first_fwd(const float* x_nchw, const float* w_rows, const float* bias, float* y_nhwc, float* col_out, int N, int H,
+                                   int W, int relu, void* stream) {
+    return conv1_first_fwd_impl(x_nchw, w_rows, bias, y_nhwc, col_out, N, H, W, relu, stream, false);
+}
+// bf16-tensor mode: x and the filter rounded to bf16 (f32 accumulate), y stored as bf16 NHWC
+extern "C" int ssd_conv1_first_fwd_bf16(const float* x_nchw, const float* w_rows, const float* bias, void* y_nhwc_bf16, int N, int H, int W,
+                                        int relu, void* stream) {
+    return conv1_first_fwd_impl(x_nchw, w_rows, bias, y_nhwc_bf16, nullptr, N, H, W, relu, stream, true);
 }
 
 // Workgroups of the weight-gradient kernel: two rounds of the 768 the chip holds (3 per CU); each leaves 8 KB of partial sums.
@@ -244,8 +287,18 @@ extern "C" size_t ssd_conv1_first_wgrad_workspace(int N, int H, int W) {
     return (size_t)WGRAD_BLOCKS * 2048 * sizeof(float);
 }
 
+static int conv1_first_wgrad_impl(const float* x_nchw, const void* dy_nhwc, float* dw_rows, float* dbias, int N, int H, int W,
+                                  void* workspace, size_t workspace_bytes, void* stream, bool dy_bf16);
 extern "C" int ssd_conv1_first_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_rows, float* dbias, int N, int H, int W,
                                      void* workspace, size_t workspace_bytes, void* stream) {
+    return conv1_first_wgrad_impl(x_nchw, dy_nhwc, dw_rows, dbias, N, H, W, workspace, workspace_bytes, stream, false);
+}
+extern "C" int ssd_conv1_first_wgrad_bf16(const float* x_nchw, const void* dy_nhwc_bf16, float* dw_rows, float* dbias, int N, int H, int W,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+    return conv1_first_wgrad_impl(x_nchw, dy_nhwc_bf16, dw_rows, dbias, N, H, W, workspace, workspace_bytes, stream, true);
+}
+static int conv1_first_wgrad_impl(const float* x_nchw, const void* dy_nhwc, float* dw_rows, float* dbias, int N, int H, int W,
+                                  void* workspace, size_t workspace_bytes, void* stream, bool dy_bf16) {
     if (!x_nchw || !dy_nhwc || !dw_rows || !workspace) return SSD_ERR_NULL;
     if (N <= 0 || H <= 0 || W <= 0) return SSD_ERR_BAD_SHAPE;
     if (!ssd_aligned16(dy_nhwc) || !ssd_aligned16(workspace)) return SSD_ERR_ALIGN;
@@ -256,7 +309,12 @@ extern "C" int ssd_conv1_first_wgrad(const float* x_nchw, const float* dy_nhwc, 
     if (workspace_bytes < (size_t)blocks * 2048 * sizeof(float)) return SSD_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float* slab = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(conv_first_wgrad_kernel, dim3(blocks), dim3(256), 0, st, x_nchw, dy_nhwc, slab, N, H, W, tiles_h, tiles_w, (int)ntiles);
+    if (dy_bf16)
+        hipLaunchKernelGGL(conv_first_wgrad_kernel<true>, dim3(blocks), dim3(256), 0, st, x_nchw, static_cast<const float*>(dy_nhwc), slab, N, H, W,
+                           tiles_h, tiles_w, (int)ntiles);
+    else
+        hipLaunchKernelGGL(conv_first_wgrad_kernel<false>, dim3(blocks), dim3(256), 0, st, x_nchw, static_cast<const float*>(dy_nhwc), slab, N, H, W,
+                           tiles_h, tiles_w, (int)ntiles);
     SSD_CHECK_LAUNCH();
     hipLaunchKernelGGL(conv_first_wgrad_reduce_kernel, dim3(256), dim3(256), 0, st, slab, dw_rows, dbias, blocks);
     SSD_CHECK_LAUNCH();

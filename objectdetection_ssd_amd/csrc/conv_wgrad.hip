@@ -9,6 +9,7 @@
 // LDS tiles are [pixel][channel] exactly as they arrive from NHWC memory; the MFMA
 // operands (A = dy^T, B = x) are read one float per lane with consecutive lanes on
 // consecutive channels (ds_read_b32, conflict-free).
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -404,7 +405,10 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int row0, int col0
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// IN_BF16: x and dy are bf16 tensors (the bf16-tensor mode): 8-byte loads of the same four channels per thread, straight into LDS
+template <bool IN_BF16>
 __global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const WgradParams p) {
+    constexpr unsigned ES = IN_BF16 ? 2u : 4u;                  // bytes per element of x / dy
     constexpr int BT = 64, CHUNKS = 16, RPP = 16;
     __shared__ __attribute__((aligned(16))) __bf16 Ys[PH * PW * LDT];
     __shared__ __attribute__((aligned(16))) __bf16 Xs[HPIX * LDT];
@@ -430,8 +434,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const WgradParams
     const bool y_col_ok = co0 + chunk * 4 < p.ldy;
     const bool x_col_ok = ci0 + chunk * 4 < p.Ci;
     const bool do_bias = p.bias_slab != nullptr && tile_ci == 0;
-    const unsigned y_col = (unsigned)(co0 + chunk * 4) * 4u, x_col = (unsigned)(ci0 + chunk * 4) * 4u;
-    const unsigned ldy4 = (unsigned)p.ldy * 4u, ci4 = (unsigned)p.Ci * 4u;
+    const unsigned y_col = (unsigned)(co0 + chunk * 4) * ES, x_col = (unsigned)(ci0 + chunk * 4) * ES;
+    const unsigned ldy4 = (unsigned)p.ldy * ES, ci4 = (unsigned)p.Ci * ES;
 
     const __amdgpu_buffer_rsrc_t srd_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t srd_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
@@ -448,7 +452,13 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const WgradParams
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-    f32x4 ry[2], rx[4];
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    typedef typename std::conditional<IN_BF16, u32x2, f32x4>::type raw_t;      // four channels as they come from memory
+    raw_t ry[2], rx[4];
+    auto load4 = [](__amdgpu_buffer_rsrc_t srd, unsigned voff) -> raw_t {
+        if constexpr (IN_BF16) return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(srd, (int)voff, 0, 0));
+        else return buf_load16(srd, voff, 0);
+    };
 
     auto issue_loads = [&](int patch) {
         const int n = patch / per_img, rem = patch - n * per_img;
@@ -458,22 +468,29 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const WgradParams
             const int oh = oh0 + ypy[j], ow = ow0 + ypx[j];
             const bool ok = y_col_ok && oh < p.Ho && ow < p.Wo;
             const unsigned v = ok ? (unsigned)((n * p.Ho + oh) * p.Wo + ow) * ldy4 + y_col : OOB;
-            ry[j] = buf_load16(srd_y, v, 0);
+            ry[j] = load4(srd_y, v);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int ih = oh0 + xhy[j] - 1, iw = ow0 + xhx[j] - 1;
             const bool ok = x_col_ok && (prow + RPP * j) < HPIX && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
             const unsigned v = ok ? (unsigned)((n * p.H + ih) * p.W + iw) * ci4 + x_col : OOB;
-            rx[j] = buf_load16(srd_x, v, 0);
+            rx[j] = load4(srd_x, v);
         }
     };
-    auto to_bf16 = [](const f32x4 v) { return bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]}; };
+    auto to_bf16 = [](const raw_t v) -> bf16x4 {
+        if constexpr (IN_BF16) return __builtin_bit_cast(bf16x4, v);
+        else return bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    };
     auto store_tile = [&]() {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            *reinterpret_cast<bf16x4*>(&Ys[(prow + RPP * j) * LDT + chunk * 4]) = to_bf16(ry[j]);
-            if (do_bias) bsum += ry[j];                       // bias gradient from the unrounded values
+            const bf16x4 b = to_bf16(ry[j]);
+            *reinterpret_cast<bf16x4*>(&Ys[(prow + RPP * j) * LDT + chunk * 4]) = b;
+            if (do_bias) {                                    // bias gradient: f32 sums of dy as it is stored
+                if constexpr (IN_BF16) bsum += f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+                else bsum += ry[j];
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -666,7 +683,7 @@ extern "C" size_t ssd_conv2d_wgrad_workspace(const ssd_conv_geom* g) {
 }
 
 static int conv2d_wgrad_impl(const float* x, const float* dy, int ldy, float* dw_oihw, float* dbias,
-                             const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream, bool bf16) {
+                             const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream, bool bf16, bool in_bf16 = false) {
     if (!g || !x || !dy || !dw_oihw || !workspace) return SSD_ERR_NULL;
     if (g->Ci % 4 != 0 || ldy % 4 != 0 || ldy < g->Co) return SSD_ERR_BAD_SHAPE;
     if (!ssd_aligned16(x) || !ssd_aligned16(dy) || !ssd_aligned16(workspace)) return SSD_ERR_ALIGN;
@@ -676,7 +693,8 @@ static int conv2d_wgrad_impl(const float* x, const float* dy, int ldy, float* dw
     WgradParams p{};
     p.x = x; p.dy = dy;
     {
-        const size_t xb = (size_t)g->N * g->H * g->W * g->Ci * 4, yb = (size_t)g->N * g->Ho * g->Wo * ldy * 4;
+        const size_t es = in_bf16 ? 2 : 4;
+        const size_t xb = (size_t)g->N * g->H * g->W * g->Ci * es, yb = (size_t)g->N * g->Ho * g->Wo * ldy * es;
         if (xb >= 0xF0000000ull || yb >= 0xF0000000ull) return SSD_ERR_BAD_SHAPE;   // 32-bit buffer offsets
         p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)yb;
     }
@@ -688,8 +706,11 @@ static int conv2d_wgrad_impl(const float* x, const float* dy, int ldy, float* dw
     p.tiles_co = pl.tiles_co; p.tiles_ci = pl.tiles_ci;
     const int T = g->R * g->S;
     const int nblk = T * pl.tiles_co * pl.tiles_ci * pl.nsplit;
-    if (pl.fused && bf16) {
-        hipLaunchKernelGGL(wgrad3x3_bf16_kernel, dim3(pl.tiles_co * pl.tiles_ci * pl.nsplit), dim3(256), 0, st, p);
+    if (in_bf16 && !(pl.fused && bf16)) return SSD_ERR_BAD_SHAPE;       // bf16 tensors: the fused nine-tap kernel only
+    if (pl.fused && bf16 && in_bf16) {
+        hipLaunchKernelGGL(wgrad3x3_bf16_kernel<true>, dim3(pl.tiles_co * pl.tiles_ci * pl.nsplit), dim3(256), 0, st, p);
+    } else if (pl.fused && bf16) {
+        hipLaunchKernelGGL(wgrad3x3_bf16_kernel<false>, dim3(pl.tiles_co * pl.tiles_ci * pl.nsplit), dim3(256), 0, st, p);
     } else if (pl.fused) {
         const dim3 grid(pl.tiles_co * pl.tiles_ci * pl.nsplit);
         if (pl.shape == 1) hipLaunchKernelGGL((wgrad3x3_kernel<1, 38>), grid, dim3(256), 0, st, p);
@@ -743,4 +764,11 @@ extern "C" int ssd_conv2d_wgrad(const float* x, const float* dy, int ldy, float*
 extern "C" int ssd_conv2d_wgrad_bf16(const float* x, const float* dy, int ldy, float* dw_oihw, float* dbias,
                                      const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream) {
     return conv2d_wgrad_impl(x, dy, ldy, dw_oihw, dbias, g, workspace, workspace_bytes, stream, true);
+}
+// bf16-tensor mode: x (N,H,W,Ci) and dy (N,Ho,Wo,ldy) are bf16; 3x3 / stride 1 / pad 1 / dilation 1 layers (the fused nine-tap kernel);
+// SSD_ERR_BAD_SHAPE for any other geometry.  dw / dbias f32.
+extern "C" int ssd_conv3x3_wgrad_bf16t(const void* x_bf16, const void* dy_bf16, int ldy, float* dw_oihw, float* dbias,
+                                       const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream) {
+    return conv2d_wgrad_impl(static_cast<const float*>(x_bf16), static_cast<const float*>(dy_bf16), ldy, dw_oihw, dbias, g, workspace,
+                             workspace_bytes, stream, true, true);
 }

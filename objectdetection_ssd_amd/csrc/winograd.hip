@@ -1531,6 +1531,20 @@ __global__ __launch_bounds__(256) void weight_jobs_kernel(const ssd_weight_job* 
             const int t = (int)(rest % T), ci = (int)(rest / T);
             j.out_bwd[e] = co < Co ? src(co, ci, t) : 0.f;
         }
+    } else if (j.kind == 3) {                        // bf16-tensor mode: OHWI [co_pad][T][Ci] and IHWO [Ci][T][pad1] as bf16 (pad1 = K of the data gradient)
+        const size_t total_f = (size_t)j.co_pad * T * Ci, total_b = (size_t)Ci * T * j.pad1;
+        if (i < total_f) {
+            const int ci = (int)(i % Ci);
+            const size_t rest = i / Ci;
+            const int t = (int)(rest % T), co = (int)(rest / T);
+            if (j.out_fwd != nullptr) reinterpret_cast<__bf16*>(j.out_fwd)[i] = (__bf16)(co < Co ? src(co, ci, t) : 0.f);
+        } else if (i < total_f + total_b && j.out_bwd != nullptr) {
+            const size_t e = i - total_f;
+            const int co = (int)(e % j.pad1);
+            const size_t rest = e / j.pad1;
+            const int t = (int)(rest % T), ci = (int)(rest / T);
+            reinterpret_cast<__bf16*>(j.out_bwd)[e] = (__bf16)(co < Co ? src(co, ci, t) : 0.f);
+        }
     } else {                                         // conv1_1 rows for the im2col GEMM: [Co][32], k = (r*3+s)*3 + c, zero padded
         const size_t total = (size_t)Co * 32;
         if (i < total) {
@@ -1547,6 +1561,7 @@ extern "C" int ssd_weight_job_blocks(const ssd_weight_job* job) {
     if (job->kind == 0) elems = (size_t)job->co * job->ci + (job->out_bwd ? (size_t)job->ci * job->co_pad : 0);
     else if (job->kind == 1) elems = (size_t)job->co_pad * job->taps * job->ci * (job->out_bwd ? 2 : 1);
     else if (job->kind == 2) elems = (size_t)job->co * 32;
+    else if (job->kind == 3) elems = (size_t)job->co_pad * job->taps * job->ci + (job->out_bwd ? (size_t)job->ci * job->taps * job->pad1 : 0);
     else return -1;
     const size_t b = (elems + 255) / 256;
     return b >= (1u << 30) ? -1 : (int)b;

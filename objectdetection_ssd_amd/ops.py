@@ -267,6 +267,117 @@ def conv2d_dgrad(dy: torch.Tensor, w_ihwo: torch.Tensor, g: ConvGeom, dx: Option
     return dx
 
 
+def conv3x3_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], n_out: int, relu: bool, flip: bool = False,
+                 out: Optional[torch.Tensor] = None, out_f32: bool = False, ldo: Optional[int] = None,
+                 relu_mask: Optional[torch.Tensor] = None, accumulate: bool = False, K: Optional[int] = None) -> torch.Tensor:
+    """3x3 / stride 1 / pad 1 convolution on bf16 tensors (csrc/conv_bf16.hip).  x (N,H,W,ldx) bf16; w (rows, 9, K) bf16 -- the
+    OHWI copy of the weights for the forward, the IHWO copy with flip=True for the data gradient (x is then dy);
+    -> out (N,H,W,ldo) bf16 (f32 with out_f32), columns 0..n_out-1 written: [accumulate: out +] conv (+ bias) -> [relu] -> [mask > 0]."""
+    _req(x, "x", torch.bfloat16); _req(w, "w", torch.bfloat16)
+    if x.dim() != 4 or w.dim() != 3 or w.shape[1] != 9:
+        raise ValueError("conv3x3_bf16: x (N,H,W,ldx), w (rows,9,K)")
+    n, h, wd, ldx = x.shape
+    K = int(w.shape[2]) if K is None else K
+    if K != w.shape[2] or K % 64 != 0 or K > ldx or n_out % 4 != 0:
+        raise ValueError("conv3x3_bf16: K must be the weights' row length, a multiple of 64 and <= ldx; n_out % 4 == 0")
+    ldo = n_out if ldo is None else ldo
+    odt = torch.float32 if out_f32 else torch.bfloat16
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate needs an existing out")
+        out = torch.empty((n, h, wd, ldo), device=x.device, dtype=odt) if ldo == n_out else torch.zeros((n, h, wd, ldo), device=x.device, dtype=odt)
+    else:
+        _req(out, "out", odt)
+        if out.numel() != n * h * wd * ldo:
+            raise ValueError("conv3x3_bf16: out size")
+    if bias is not None:
+        _req(bias, "bias")
+        if bias.numel() < n_out:
+            raise ValueError("conv3x3_bf16: bias needs n_out entries")
+    if relu_mask is not None:
+        _req(relu_mask, "relu_mask", torch.bfloat16)
+        if relu_mask.numel() != out.numel() or out_f32:
+            raise ValueError("conv3x3_bf16: relu_mask must have the layout of a bf16 out")
+    check(_lib.load().ssd_conv3x3_bf16(x.data_ptr(), ldx, w.data_ptr(), int(w.shape[0]), K, _ptr(bias), out.data_ptr(), ldo, n_out,
+                                       int(out_f32), _ptr(relu_mask), int(accumulate), int(relu), int(flip), n, h, wd, _stream()),
+          "conv3x3_bf16")
+    return out
+
+
+def pad64(c: int) -> int:
+    return (c + 63) // 64 * 64
+
+
+def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+    """f32 -> bf16 (round to nearest even), same shape; numel % 8 == 0"""
+    _req(x, "x")
+    y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    check(_lib.load().ssd_cast_f32_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "cast_f32_bf16")
+    return y
+
+
+def cast_f32(x: torch.Tensor) -> torch.Tensor:
+    _req(x, "x", torch.bfloat16)
+    y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    check(_lib.load().ssd_cast_bf16_f32(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "cast_bf16_f32")
+    return y
+
+
+def conv1_first_fwd_bf16(x_nchw: torch.Tensor, w_rows: torch.Tensor, bias: Optional[torch.Tensor], relu: bool = True) -> torch.Tensor:
+    """conv1_1 in the bf16-tensor mode: f32 NCHW image -> bf16 NHWC (N,H,W,64); operands rounded to bf16, f32 accumulate."""
+    _req(x_nchw, "x"); _req(w_rows, "w_rows")
+    n, c, h, w = x_nchw.shape
+    if c != 3 or w_rows.numel() != 64 * 32:
+        raise ValueError("conv1_first_fwd_bf16 expects 3 input channels and (64, 32) filter rows")
+    if bias is not None:
+        _req(bias, "bias")
+    y = torch.empty((n, h, w, 64), device=x_nchw.device, dtype=torch.bfloat16)
+    check(_lib.load().ssd_conv1_first_fwd_bf16(x_nchw.data_ptr(), w_rows.data_ptr(), _ptr(bias), y.data_ptr(), n, h, w, int(relu), _stream()),
+          "conv1_first_fwd_bf16")
+    return y
+
+
+def conv1_first_wgrad_bf16(x_nchw: torch.Tensor, dy: torch.Tensor, want_bias: bool = True):
+    """conv1_1 weight / bias gradient from the f32 NCHW image and the bf16 NHWC dy -> (dw rows (64,32,1,1), dbias or None), f32."""
+    _req(x_nchw, "x"); _req(dy, "dy", torch.bfloat16)
+    n, c, h, w = x_nchw.shape
+    if c != 3 or tuple(dy.shape) != (n, h, w, 64):
+        raise ValueError("conv1_first_wgrad_bf16: x (N,3,H,W) and dy (N,H,W,64)")
+    lib = _lib.load()
+    ws = workspace(lib.ssd_conv1_first_wgrad_workspace(n, h, w), x_nchw.device, "first_wgrad")
+    dw = torch.empty((64, 32, 1, 1), device=x_nchw.device, dtype=torch.float32)
+    db = torch.empty((64,), device=x_nchw.device, dtype=torch.float32) if want_bias else None
+    check(lib.ssd_conv1_first_wgrad_bf16(x_nchw.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db), n, h, w, ws.data_ptr(), ws.numel(), _stream()),
+          "conv1_first_wgrad_bf16")
+    return dw, db
+
+
+def conv3x3_wgrad_bf16t(x: torch.Tensor, dy: torch.Tensor, g: ConvGeom, ldy: int, want_bias: bool = True,
+                        dw_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None):
+    """Weight gradient of a 3x3 / s1 / p1 layer from bf16 x (N,H,W,Ci) and bf16 dy (N,H,W,ldy) -> (dw (Co,Ci,3,3), dbias) f32."""
+    _req(x, "x", torch.bfloat16); _req(dy, "dy", torch.bfloat16)
+    if tuple(x.shape) != (g.N, g.H, g.W, g.Ci) or dy.numel() != g.N * g.Ho * g.Wo * ldy or ldy < g.Co:
+        raise ValueError("conv3x3_wgrad_bf16t: shapes do not match the geometry")
+    lib = _lib.load()
+    ws = workspace(lib.ssd_conv2d_wgrad_workspace(C.byref(g)), x.device)
+    dw = _grad_dst(dw_out, (g.Co, g.Ci, 3, 3), x.device, "dw_out")
+    db = _grad_dst(db_out, (g.Co,), x.device, "db_out") if want_bias else None
+    check(lib.ssd_conv3x3_wgrad_bf16t(x.data_ptr(), dy.data_ptr(), ldy, dw.data_ptr(), _ptr(db), C.byref(g), ws.data_ptr(), ws.numel(), _stream()),
+          "conv3x3_wgrad_bf16t")
+    return dw, db
+
+
+def heads_gather_bf16(dloc: torch.Tensor, dconf: torch.Tensor, ld: int, n: int, hw: int, a: int, prior_off: int) -> torch.Tensor:
+    _req(dloc, "dloc"); _req(dconf, "dconf")
+    p, ncls = dconf.shape[1], dconf.shape[2]
+    if tuple(dloc.shape) != (n, p, 4) or dconf.shape[0] != n:
+        raise ValueError("heads_gather shapes")
+    packed = torch.empty((n * hw, ld), device=dloc.device, dtype=torch.bfloat16)
+    check(_lib.load().ssd_heads_gather_bf16(dloc.data_ptr(), dconf.data_ptr(), packed.data_ptr(), ld, n, hw, a, prior_off, p, ncls, _stream()),
+          "heads_gather_bf16")
+    return packed
+
+
 _ws_cache = {}
 
 
@@ -402,9 +513,17 @@ def pool_out(h: int, k: int, stride: int, pad: int, ceil_mode: bool) -> int:
 
 
 def maxpool_fwd(x: torch.Tensor, k: int, stride: int, pad: int, ceil_mode: bool, want_argmax: bool = True):
-    _req(x, "x")
+    """NHWC max pool -> (y, argmax codes or None); a bf16 x takes the bf16-tensor kernels (csrc/elementwise_bf16.hip)."""
     n, h, w, c = x.shape
     ho, wo = pool_out(h, k, stride, pad, ceil_mode), pool_out(w, k, stride, pad, ceil_mode)
+    if x.dtype == torch.bfloat16:
+        _req(x, "x", torch.bfloat16)
+        y = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.bfloat16)
+        am = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.uint8) if want_argmax else None
+        check(_lib.load().ssd_maxpool_fwd_bf16(x.data_ptr(), y.data_ptr(), _ptr(am), n, h, w, c, k, stride, pad, ho, wo, _stream()),
+              "maxpool_fwd_bf16")
+        return y, am
+    _req(x, "x")
     y = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.float32)
     am = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.uint8) if want_argmax else None
     check(_lib.load().ssd_maxpool_fwd(x.data_ptr(), y.data_ptr(), _ptr(am), n, h, w, c, k, stride, pad, ho, wo, _stream()),
@@ -417,9 +536,30 @@ def maxpool_bwd(dy: torch.Tensor, argmax: torch.Tensor, in_shape, k: int, stride
                 y_gate: Optional[torch.Tensor] = None):
     """y_gate: the pooled OUTPUT; with it (and no accumulate / relu_mask) the ReLU mask of the pool's input is applied as
     y > 0 per window, which reads a quarter of the bytes of relu_mask = x."""
-    _req(dy, "dy"); _req(argmax, "argmax", torch.uint8)
     n, h, w, c = in_shape
     _, ho, wo, c2 = dy.shape
+    if dy.dtype == torch.bfloat16:
+        _req(dy, "dy", torch.bfloat16); _req(argmax, "argmax", torch.uint8)
+        if c2 != c or tuple(argmax.shape) != tuple(dy.shape):
+            raise ValueError("maxpool_bwd shapes")
+        if y_gate is not None and (accumulate or relu_mask is not None):
+            raise ValueError("y_gate replaces relu_mask and cannot accumulate")
+        for t, nm in ((y_gate, "y_gate"), (relu_mask, "relu_mask")):
+            if t is not None:
+                _req(t, nm, torch.bfloat16)
+        if y_gate is not None and tuple(y_gate.shape) != tuple(dy.shape):
+            raise ValueError("y_gate must be the pooled output")
+        if dx is None:
+            if accumulate:
+                raise ValueError("accumulate needs an existing dx")
+            dx = torch.empty((n, h, w, c), device=dy.device, dtype=torch.bfloat16)
+        _req(dx, "dx", torch.bfloat16)
+        if dx.numel() != n * h * w * c or (relu_mask is not None and relu_mask.numel() != dx.numel()):
+            raise ValueError("dx / relu_mask size")
+        check(_lib.load().ssd_maxpool_bwd_bf16(dy.data_ptr(), argmax.data_ptr(), dx.data_ptr(), _ptr(relu_mask), _ptr(y_gate), int(accumulate),
+                                               n, h, w, c, k, stride, pad, ho, wo, _stream()), "maxpool_bwd_bf16")
+        return dx
+    _req(dy, "dy"); _req(argmax, "argmax", torch.uint8)
     if c2 != c or tuple(argmax.shape) != tuple(dy.shape):
         raise ValueError("maxpool_bwd shapes")
     if y_gate is not None:
@@ -452,10 +592,14 @@ def maxpool_bwd(dy: torch.Tensor, argmax: torch.Tensor, in_shape, k: int, stride
 
 
 def l2norm_fwd(x: torch.Tensor, gamma: torch.Tensor) -> torch.Tensor:
-    _req(x, "x"); _req(gamma, "gamma")
+    _req(x, "x", x.dtype if x.dtype == torch.bfloat16 else torch.float32); _req(gamma, "gamma")
     c = x.shape[-1]
     if gamma.numel() != c:
         raise ValueError("gamma length")
+    if x.dtype == torch.bfloat16:
+        y = torch.empty_like(x)
+        check(_lib.load().ssd_l2norm_fwd_bf16(x.data_ptr(), gamma.data_ptr(), y.data_ptr(), x.numel() // c, c, _stream()), "l2norm_fwd_bf16")
+        return y
     y = torch.empty_like(x)
     check(_lib.load().ssd_l2norm_fwd(x.data_ptr(), gamma.data_ptr(), y.data_ptr(), x.numel() // c, c, _stream()), "l2norm_fwd")
     return y
@@ -463,9 +607,20 @@ def l2norm_fwd(x: torch.Tensor, gamma: torch.Tensor) -> torch.Tensor:
 
 def l2norm_bwd(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, dx: Optional[torch.Tensor] = None,
                dg_out: Optional[torch.Tensor] = None):
-    _req(x, "x"); _req(gamma, "gamma"); _req(dy, "dy")
     c = x.shape[-1]
     m = x.numel() // c
+    if x.dtype == torch.bfloat16:
+        _req(x, "x", torch.bfloat16); _req(gamma, "gamma"); _req(dy, "dy", torch.bfloat16)
+        if dy.numel() != x.numel():
+            raise ValueError("dy size")
+        lib = _lib.load()
+        ws = workspace(lib.ssd_l2norm_bwd_bf16_workspace(m, c), x.device)
+        dx = torch.empty_like(x) if dx is None else _req(dx, "dx", torch.bfloat16)
+        dg = _grad_dst(dg_out, (c,), x.device, "dg_out")
+        check(lib.ssd_l2norm_bwd_bf16(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), dx.data_ptr(), dg.data_ptr(), m, c, ws.data_ptr(),
+                                      ws.numel(), _stream()), "l2norm_bwd_bf16")
+        return dx, dg
+    _req(x, "x"); _req(gamma, "gamma"); _req(dy, "dy")
     if dy.numel() != x.numel():
         raise ValueError("dy size")
     lib = _lib.load()
@@ -926,13 +1081,14 @@ class WeightTable:
         for a, j in zip(arr, jobs):
             for t in (j["w0"], j.get("w1"), j.get("out_fwd"), j.get("out_bwd")):
                 if t is not None:
-                    _req(t, "weight job tensor")
+                    _req(t, "weight job tensor", t.dtype if (j["kind"] == 3 and t.dtype == torch.bfloat16) else torch.float32)
                     self.keep.append(t)
             a.w0 = j["w0"].data_ptr()
             a.w1 = j["w1"].data_ptr() if j.get("w1") is not None else j["w0"].data_ptr()
             a.out_fwd = _ptr(j.get("out_fwd"))
             a.out_bwd = _ptr(j.get("out_bwd"))
             a.co0, a.co, a.ci, a.taps, a.co_pad, a.kind = j["co0"], j["co"], j["ci"], j["taps"], j["co_pad"], j["kind"]
+            a.pad1 = j.get("pad1", 0)
             nb = lib.ssd_weight_job_blocks(C.byref(a))
             if nb <= 0:
                 raise ValueError("bad weight job")

@@ -1188,3 +1188,149 @@ def test_stride2_data_gradient_grouped_by_pixel_parity(case):
     y = F.conv2d(x64, wt.cpu().double(), None, stride=2, padding=pad)
     y.backward(_nchw(dy[:k_, ..., :co].cpu().double()))
     _close(out[1][0][:k_], _nhwc(x64.grad), what=f"stride-2 dgrad vs f64 {case}")
+
+
+# ---- bf16 TENSORS (round 3): csrc/conv_bf16.hip ------------------------------------------------------------------------------
+def _bf16_ulps(got, ref_f32):
+    """distance of a bf16 result from the f32 reference in units of the reference's bf16 spacing (2^-8 relative)"""
+    g, r = got.detach().cpu().float(), ref_f32.detach().cpu().float()
+    return (g - r).abs() / (r.abs().clamp_min(1e-3) * 2.0 ** -8)
+
+
+HALO_BF16_CASES = [
+    # mode, bn, N, H, W, K (in channels), n_out, w_rows
+    (0, 128, 2, 11, 45, 128, 128, 128),      # 8x32 patches, ragged in both directions
+    (0, 128, 1, 17, 33, 64, 160, 150),       # second N tile half empty, zero weight rows (a head: 150 -> pad 160)
+    (0, 64, 2, 19, 40, 64, 64, 64),          # 16x32 patches, one chunk, single halo buffer
+    (0, 64, 1, 33, 35, 128, 64, 64),         # ... two chunks: the halo is re-loaded between them
+    (1, 128, 2, 19, 23, 192, 256, 256),      # 16x16 patches, three chunks
+    (1, 64, 1, 16, 16, 64, 64, 64),
+    (2, 128, 3, 13, 11, 128, 128, 128),      # flat: tiles span images
+    (2, 128, 2, 38, 38, 64, 128, 100),       # flat at a real map size, head-like rows
+    (2, 64, 2, 19, 19, 128, 64, 64),
+    (-1, -1, 1, 75, 75, 64, 128, 128),       # automatic choice: 16x16 patches
+    (-1, -1, 1, 10, 10, 64, 128, 128),       # automatic: flat
+]
+
+
+@pytest.mark.parametrize("case", HALO_BF16_CASES)
+def test_conv3x3_on_bf16_tensors_forward_and_data_gradient(case):
+    """3x3 / s1 / p1 convolution with activations, gradients and weights in bf16 (f32 accumulate), every position space and both
+    N tiles: forward (bias + ReLU, bf16 out; f32 out as the heads take it) and data gradient (mirrored taps, += an existing dx,
+    ReLU mask from the bf16 activation) against torch-CPU f32 convolutions of the SAME bf16 operands.  f32 outputs within 2e-5
+    of the scale; bf16 outputs are the f32 result rounded once: within one bf16 spacing of the reference everywhere (a sum that
+    lands near a rounding boundary may go either way) and exactly the rounded reference in >= 99 % of the elements."""
+    from objectdetection_ssd_amd import _lib, ops
+    mode, bn, n, h, w, k, n_out, rows = case
+    dev = _dev()
+    g = torch.Generator().manual_seed(hash(case) % 10000)
+    x = torch.randn(n, h, w, k, generator=g).bfloat16()
+    wt = (torch.randn(rows, 9, k, generator=g) * (2.0 / (9 * k)) ** 0.5).bfloat16()
+    bias = torch.zeros(n_out)
+    bias[:rows] = torch.randn(rows, generator=g)
+    _lib.check(_lib.load().ssd_tune_set_conv_bf16(mode, bn), "tune")
+    try:
+        w_nchw = torch.zeros(n_out, k, 3, 3)
+        w_nchw[:rows] = wt.float().reshape(rows, 3, 3, k).permute(0, 3, 1, 2)
+        ref = F.conv2d(x.float().permute(0, 3, 1, 2), w_nchw, bias, padding=1)
+        y32 = ops.conv3x3_bf16(x.to(dev), wt.to(dev), bias.to(dev), n_out, relu=False, out_f32=True)
+        _close(_nchw(y32), ref, 2e-5, "forward, f32 out")
+        y = ops.conv3x3_bf16(x.to(dev), wt.to(dev), bias.to(dev), n_out, relu=True)
+        assert y.dtype == torch.bfloat16
+        u = _bf16_ulps(_nchw(y), ref.relu())
+        assert float(u.max()) <= 1.5, float(u.max())          # (the spacing doubles at a power of two: 1 spacing of the larger side)
+        assert float((_nchw(y).cpu() == ref.relu().bfloat16()).float().mean()) >= 0.99
+        # wider output rows: columns beyond n_out stay untouched
+        ld = n_out + 32
+        canvas = torch.full((n, h, w, ld), 7.0, dtype=torch.bfloat16, device=dev)
+        ops.conv3x3_bf16(x.to(dev), wt.to(dev), bias.to(dev), n_out, relu=True, out=canvas, ldo=ld)
+        assert torch.equal(canvas[..., :n_out], y) and bool((canvas[..., n_out:] == 7.0).all())
+        # data gradient of a convolution with `rows` input channels... here: dy has k channels, dx has n_out; weights [n_out rows][9][k]
+        dy = x
+        prev = torch.randn(n, h, w, n_out, generator=g).bfloat16()
+        act = torch.randn(n, h, w, n_out, generator=g).relu().bfloat16()
+        w_t = torch.zeros(k, n_out, 3, 3)
+        w_t[:, :rows] = wt.float().reshape(rows, 3, 3, k).permute(3, 0, 1, 2)            # conv_transpose2d weight: (in = k, out = n_out, r, s)
+        dref = F.conv_transpose2d(dy.float().permute(0, 3, 1, 2), w_t, padding=1)
+        dref = (dref + prev.float().permute(0, 3, 1, 2)) * (act.float().permute(0, 3, 1, 2) > 0)
+        dx = prev.clone().to(dev)
+        ops.conv3x3_bf16(dy.to(dev), wt.to(dev), None, n_out, relu=False, flip=True, out=dx, relu_mask=act.to(dev), accumulate=True)
+        u = _bf16_ulps(_nchw(dx), dref)
+        assert float(u.max()) <= 1.5, float(u.max())          # (the spacing doubles at a power of two: 1 spacing of the larger side)
+        assert float((_nchw(dx).cpu() == dref.bfloat16()).float().mean()) >= 0.99
+        assert bool((dx[act.to(dev) <= 0] == 0).all())
+    finally:
+        _lib.check(_lib.load().ssd_tune_set_conv_bf16(-1, -1), "tune")
+
+
+@pytest.mark.parametrize("k,s,p,ceil,hw", POOLS)
+def test_maxpool_on_bf16_tensors(k, s, p, ceil, hw):
+    """bf16 pools: values and arg-max codes equal the f32 kernel's on the same (bf16-representable) input, the three backward forms
+    (plain + ReLU mask + accumulate, gated by the pooled output, the 2x2 scatter) equal the f32 kernel's result rounded once."""
+    from objectdetection_ssd_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(k * 100 + hw)
+    x = torch.randn(2, hw, hw + 3, 16, generator=g).relu().bfloat16()
+    y32, am32 = ops.maxpool_fwd(x.float().to(dev), k, s, p, ceil)
+    y16, am16 = ops.maxpool_fwd(x.to(dev), k, s, p, ceil)
+    assert y16.dtype == torch.bfloat16 and torch.equal(y16.float(), y32) and torch.equal(am16, am32)
+    dy = torch.randn(y32.shape, generator=g).bfloat16()
+    prev = torch.randn(x.shape, generator=g).bfloat16()
+    ref = ops.maxpool_bwd(dy.float().to(dev), am32, tuple(x.shape), k, s, p, prev.float().to(dev).clone(), x.float().to(dev), True)
+    got = ops.maxpool_bwd(dy.to(dev), am16, tuple(x.shape), k, s, p, prev.to(dev).clone(), x.to(dev), True)
+    assert got.dtype == torch.bfloat16 and torch.equal(got, ref.bfloat16())
+    ref = ops.maxpool_bwd(dy.float().to(dev), am32, tuple(x.shape), k, s, p, y_gate=y32)
+    got = ops.maxpool_bwd(dy.to(dev), am16, tuple(x.shape), k, s, p, y_gate=y16)
+    assert torch.equal(got, ref.bfloat16())
+
+
+def test_l2norm_gather_casts_on_bf16_tensors():
+    from objectdetection_ssd_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 7, 5, 512, generator=g).bfloat16()
+    gamma = (20 + torch.randn(512, generator=g)).to(dev)
+    y = ops.l2norm_fwd(x.to(dev), gamma)
+    ref = ops.l2norm_fwd(x.float().to(dev), gamma)
+    assert y.dtype == torch.bfloat16 and float((y.float() - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max())
+    dy = torch.randn(x.shape, generator=g).bfloat16()
+    dx, dg = ops.l2norm_bwd(x.to(dev), gamma, dy.to(dev))
+    rdx, rdg = ops.l2norm_bwd(x.float().to(dev), gamma, dy.float().to(dev))
+    assert dx.dtype == torch.bfloat16 and float((dx.float() - rdx).abs().max()) <= 2.0 ** -8 * float(rdx.abs().max())
+    _close(dg, rdg, 1e-5, "dgamma")
+    # gather: bf16 packed rows = the f32 kernel's, rounded; pad columns zero
+    n, hw, a, P = 2, 9, 4, 60
+    dloc, dconf = torch.randn(n, P, 4, generator=g).to(dev), torch.randn(n, P, 21, generator=g).to(dev)
+    p16 = ops.heads_gather_bf16(dloc, dconf, 128, n, hw, a, 12)
+    p32 = ops.heads_gather(dloc, dconf, 128, n, hw, a, 12)
+    assert torch.equal(p16, p32.bfloat16()) and bool((p16[:, 100:] == 0).all())
+    t = torch.randn(64, 24, generator=g).to(dev)
+    assert torch.equal(ops.cast_bf16(t), t.bfloat16()) and torch.equal(ops.cast_f32(t.bfloat16()), t.bfloat16().float())
+
+
+def test_conv1_1_and_nine_tap_weight_gradient_on_bf16_tensors():
+    """conv1_1 with bf16-rounded operands and bf16 NHWC output + its weight gradient from a bf16 dy; the fused nine-tap weight gradient
+    fed bf16 x / dy equals the same kernel fed the f32 copies of those values (identical products, identical order)."""
+    from objectdetection_ssd_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 3, 21, 70, generator=g)
+    w = torch.randn(64, 3, 3, 3, generator=g) * 0.2
+    b = torch.randn(64, generator=g)
+    rows = ops.first_weight_rows(w.to(dev))
+    y = ops.conv1_first_fwd_bf16(x.to(dev), rows, b.to(dev), True)
+    ref = F.conv2d(x.bfloat16().float(), w.bfloat16().float(), b, padding=1).relu()
+    u = _bf16_ulps(_nchw(y), ref)
+    assert y.dtype == torch.bfloat16 and float(u.max()) <= 1.5 and float((_nchw(y).cpu() == ref.bfloat16()).float().mean()) >= 0.99
+    dy = torch.randn(2, 21, 70, 64, generator=g).bfloat16()
+    dw16, db16 = ops.conv1_first_wgrad_bf16(x.to(dev), dy.to(dev), True)
+    dw32, db32 = ops.conv1_first_wgrad(x.to(dev), dy.float().to(dev), True)
+    assert torch.equal(dw16, dw32) and torch.equal(db16, db32)
+    for (n, h, w_, ci, co, ldy) in ((2, 19, 23, 64, 128, 128), (1, 38, 38, 128, 100, 128), (3, 9, 12, 256, 64, 64)):
+        geom = ops.make_geom(n, h, w_, ci, co, 3, 1, 1, 1)
+        xa = torch.randn(n, h, w_, ci, generator=g).bfloat16()
+        da = torch.randn(n, h, w_, ldy, generator=g).bfloat16()
+        da[..., co:] = 0
+        dwa, dba = ops.conv3x3_wgrad_bf16t(xa.to(dev), da.to(dev), geom, ldy, True)
+        dwb, dbb = ops.conv2d_wgrad(xa.float().to(dev), da.float().to(dev), geom, ldy, True, bf16=True)
+        assert torch.equal(dwa, dwb) and torch.equal(dba, dbb)
