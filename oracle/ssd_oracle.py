@@ -376,7 +376,24 @@ def bf16_round(t):
     return t.to(torch.bfloat16).to(t.dtype)
 
 
-def _conv_bf16_operands():
+def _round_store():
+    """Identity that rounds to bf16 in BOTH directions: the value on the way forward (an activation stored in bf16) and its gradient on
+    the way back (the gradient tensor stored in bf16).  The bf16-tensor mode of the build (csrc/conv_bf16.hip & co.) has exactly these
+    rounding points on the VGG trunk."""
+    import torch
+
+    class RoundStore(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return bf16_round(x)
+
+        @staticmethod
+        def backward(ctx, g):
+            return bf16_round(g)
+    return RoundStore.apply
+
+
+def _conv_bf16_operands(bias_from_rounded: bool = False):
     """conv2d of BASELINE.json configs[2] ("bf16 convs"): operands rounded to bf16, products accumulated in f32, tensors and
     bias in f32.  Forward y = conv(r(x), r(w)) + b; data gradient dx = conv^T(r(dy), r(w)); weight gradient corr(r(x), r(dy))
     for the 3x3 / stride 1 / pad 1 / dilation 1 layers (the fused bf16 weight-gradient kernel) and corr(x, dy) in plain f32 for
@@ -385,6 +402,9 @@ def _conv_bf16_operands():
     through the im2col buffer on the f32 kernel)."""
     import torch
     import torch.nn.functional as F
+
+    def fused_geom(w, stride, padding, dilation):
+        return tuple(w.shape[2:]) == (3, 3) and stride == 1 and padding == 1 and dilation == 1
 
     class ConvBf16Operands(torch.autograd.Function):
         @staticmethod
@@ -405,7 +425,8 @@ def _conv_bf16_operands():
                 xa, da = (bf16_round(x), bf16_round(dy)) if fused else (x, dy)
                 dw = torch.nn.grad.conv2d_weight(xa, w.shape, da, stride=stride, padding=padding, dilation=dilation)
             if ctx.needs_input_grad[2]:
-                db = dy.sum(dim=(0, 2, 3))
+                # bf16-tensor mode: dy exists in bf16 only (the heads' packed gradient is rounded by the gather), the sum is f32
+                db = (bf16_round(dy) if (bias_from_rounded and fused_geom(w, stride, padding, dilation)) else dy).sum(dim=(0, 2, 3))
             return dx, dw, db, None, None, None, None
 
     def conv(x, w, b=None, stride=1, padding=0, dilation=1, wgrad_f32=False):
@@ -431,8 +452,10 @@ def pinned_max_pool(z, code, k: int, stride: int, pad: int):
 
 
 def ssd300_forward(x, params, return_features: bool = False, variant: int = 300, operand_round: str = None, acts: dict = None,
-                   decisions: dict = None):
+                   decisions: dict = None, store_round: bool = False):
     """x (bs,3,300,300) f32 NCHW torch tensor -> loc (bs,8732,4), conf (bs,8732,21).
+    store_round (with operand_round="bf16"): the bf16-TENSOR mode -- the VGG trunk's tensors (conv1_1 .. conv5_3 outputs, the pools'
+    outputs, the L2-norm's output) are stored in bf16, and so are their gradients (`_round_store`); fc6 onwards keeps f32 tensors.
     decisions (tests only): the discrete choices of ANOTHER evaluation of the same network, which this one then follows instead of
     making its own -- {"relu": {activation name: bool mask NCHW}, "pool": {pool name p1..p5: (arg-max codes (N,C,Ho,Wo), gate or
     None)}}.  ReLU becomes `z * mask`; a max pool becomes a gather at the given arg-max (times `gate` = "pooled output > 0" where the
@@ -455,8 +478,11 @@ def ssd300_forward(x, params, return_features: bool = False, variant: int = 300,
     import torch.nn.functional as F
     if operand_round not in (None, "bf16"):
         raise ValueError("operand_round must be None or 'bf16'")
-    conv2d = F.conv2d if operand_round is None else _conv_bf16_operands()
+    if store_round and operand_round != "bf16":
+        raise ValueError("store_round needs operand_round='bf16'")
+    conv2d = F.conv2d if operand_round is None else _conv_bf16_operands(bias_from_rounded=store_round)
     first = {} if operand_round is None else {"wgrad_f32": True}
+    rs = _round_store() if store_round else (lambda t: t)
     feats = {}
     h = x
     pin_relu = None if decisions is None else decisions["relu"]
@@ -478,8 +504,8 @@ def ssd300_forward(x, params, return_features: bool = False, variant: int = 300,
     pools_after = {2: False, 4: False, 7: True, 10: False}   # conv ordinal -> ceil_mode
     n_pool = 0
     for li, idx in enumerate(VGG_CONV_IDX):
-        h = relu(conv2d(h, params[f"model.features.{idx}.weight"],
-                        params[f"model.features.{idx}.bias"], padding=1, **(first if li == 0 else {})), _VGG_ACT[li])
+        h = rs(relu(conv2d(h, params[f"model.features.{idx}.weight"],
+                           params[f"model.features.{idx}.bias"], padding=1, **(first if li == 0 else {})), _VGG_ACT[li]))
         n = li + 1
         if acts is not None:
             acts[_VGG_ACT[li]] = h.detach()
@@ -487,11 +513,11 @@ def ssd300_forward(x, params, return_features: bool = False, variant: int = 300,
             feats["conv4_3"] = h
         if n in pools_after:
             n_pool += 1
-            h = pool(h, f"p{n_pool}", 2, 2, ceil=pools_after[n])
-    h = pool(h, "p5", 3, 1, pad=1)
+            h = rs(pool(h, f"p{n_pool}", 2, 2, ceil=pools_after[n]))
+    h = rs(pool(h, "p5", 3, 1, pad=1))
     c43 = feats["conv4_3"]
     norm = c43.pow(2).sum(dim=1, keepdim=True).sqrt()
-    c43n = c43 / norm * params["rescaling_conv_4_3"]
+    c43n = rs(c43 / norm * params["rescaling_conv_4_3"])
     h = relu(conv2d(h, params["conv_fc6.weight"], params["conv_fc6.bias"], padding=4, dilation=4), "a6")
     if acts is not None:
         acts["n4_3"], acts["a6"] = c43n.detach(), h.detach()

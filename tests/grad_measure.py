@@ -58,10 +58,10 @@ def f64_case():
     return x, boxes, classes
 
 
-def f64_oracle_grads(params, operand_round=None, dtype=torch.float64):
+def f64_oracle_grads(params, operand_round=None, dtype=torch.float64, store_round=False):
     x, boxes, classes = f64_case()
     P = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in params.items()}
-    loc, conf = O.ssd300_forward(torch.from_numpy(x).to(dtype), P, operand_round=operand_round)
+    loc, conf = O.ssd300_forward(torch.from_numpy(x).to(dtype), P, operand_round=operand_round, store_round=store_round)
     a1, a2 = O.multibox_loss_torch(loc, conf, [torch.from_numpy(b) for b in boxes], [torch.from_numpy(c) for c in classes])
     (a1 + a2).backward()
     return loc.detach(), conf.detach(), float(a1), float(a2), {k: v.grad.double() for k, v in P.items()}
@@ -106,7 +106,8 @@ def layerwise_forward_distance(net, params, conv_dtype):
     x, _, _ = f64_case()
     acts = {}
     with torch.no_grad():
-        lo, co = O.ssd300_forward(torch.from_numpy(x), params, operand_round=None if conv_dtype == "f32" else conv_dtype, acts=acts)
+        lo, co = O.ssd300_forward(torch.from_numpy(x), params, operand_round=None if conv_dtype == "f32" else conv_dtype, acts=acts,
+                                  store_round=conv_dtype == "bf16" and net._engine.bf16_tensors)
     set_engine(net, "wino", conv_dtype)
     try:
         with torch.no_grad():
@@ -118,7 +119,7 @@ def layerwise_forward_distance(net, params, conv_dtype):
         got = saved["T"].get(name)
         if got is None or not torch.is_tensor(got):           # consumed by a fused kernel without being written (f32 Winograd + pool)
             continue
-        out[name] = rel_l2(got.permute(0, 3, 1, 2), ref)
+        out[name] = rel_l2(got.float().permute(0, 3, 1, 2), ref)
     return out, float((loc.cpu() - lo).abs().max() / lo.abs().max().clamp_min(1)), float((conf.cpu() - co).abs().max() / co.abs().max().clamp_min(1))
 
 

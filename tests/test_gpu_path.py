@@ -686,20 +686,26 @@ def test_bf16_conv_mode_config3(golden_net):
     `bf16_act`): conv1_1 3e-8, conv1_2 1e-6, conv2_1 3e-5, conv2_2 9e-5, conv3 2e-4 .. 1e-3, saturating at the mode's own
     rounding noise (~1e-2 = distance of the bf16 oracle to the f32 oracle) from conv4 on.  So: the first layers, where no flip
     has happened yet, must agree to f32 accuracy; every activation, loc / conf and every gradient must stay within 2 x its
-    measured distance and within the mode's own noise; losses within 1e-3; per-prior classes bit-exact."""
+    measured distance and within the mode's own noise; losses within 1e-3; per-prior classes bit-exact.
+    Round 3: the mode stores the VGG trunk's activations and gradients in bf16 (`_Engine.bf16_tensors`); the oracle has the same rounding
+    points (`ssd300_forward(operand_round="bf16", store_round=True)`: every trunk tensor and its gradient rounded once, at the store)."""
     import grad_measure as M
     from objectdetection_ssd_amd import Losses
     net, params, z = golden_net
+    assert net._engine.bf16_tensors
     table = M.load_bars()
     acts, e_loc, e_conf = M.layerwise_forward_distance(net, params, "bf16")
     assert set(acts) == set(table["bf16_act"]) and len(acts) == 24
-    assert acts["a1_1"] <= 1e-6 and acts["a1_2"] <= 1e-5 and acts["a2_1"] <= 1e-4        # before any rounding flip: f32-accurate
+    # before the flips compound.  bf16-tensor mode (round 3): the compared tensors are themselves rounded to bf16 at the store, so a sum
+    # that lands next to a rounding boundary differs by one bf16 spacing (2^-8 relative) in that element -- conv1_1 (K = 27) is bit-equal
+    # to the oracle, conv1_2 has a few such elements in 1e5 (1.9e-5 relative L2 measured), conv2_1 7.8e-5
+    assert acts["a1_1"] <= 1e-6 and acts["a1_2"] <= 1e-4 and acts["a2_1"] <= 3e-4
     bad = [(k, v, M.bar(table, "bf16_act", k)) for k, v in acts.items() if v > M.bar(table, "bf16_act", k, 1e-6)]
     assert not bad, bad
     noise = table["bf16_mode_noise"]
     assert e_loc <= min(2 * table["bf16_oracle_out"]["loc"], 1.5 * noise["loc"])
     assert e_conf <= min(2 * table["bf16_oracle_out"]["conf"], 1.5 * noise["conf"])
-    lo, co, a1, a2, gref = M.f64_oracle_grads(params, operand_round="bf16", dtype=torch.float32)
+    lo, co, a1, a2, gref = M.f64_oracle_grads(params, operand_round="bf16", dtype=torch.float32, store_round=net._engine.bf16_tensors)
     lo32, co32, *_ = M.f64_oracle_grads(params, dtype=torch.float32)
     x, boxes, classes = M.f64_case()
     ref_match = O.multibox_loss(lo.numpy(), co.numpy(), boxes, classes, want_grads=False)
@@ -732,17 +738,24 @@ def test_bf16_conv_mode_at_bench_batch():
     net = Model.SSD_300().to(DEV)
     x, cl, bx = M.bench_batch()
     out = {}
-    for mode in ("f32", "bf16"):
-        M.set_engine(net, "wino", mode)
-        loc, conf, l1, l2, g = M.train_step(net, x, cl, bx)
+    for mode in ("f32", "bf16", "bf16_f32_tensors"):
+        M.set_engine(net, "wino", mode[:4].rstrip("_"))
+        net._engine.bf16_tensors = mode != "bf16_f32_tensors"        # the round-2 form (f32 tensors, operands rounded into LDS) stays selectable
+        try:
+            loc, conf, l1, l2, g = M.train_step(net, x, cl, bx)
+        finally:
+            net._engine.bf16_tensors = True
         assert torch.isfinite(loc).all() and torch.isfinite(conf).all()
         out[mode] = (l1, l2, Losses.last_match["cls"].clone(), torch.cat([g[n].flatten() for n in sorted(g)]))
-    a, b = out["f32"], out["bf16"]
-    assert abs(a[0] - b[0]) <= 2e-2 * a[0] and abs(a[1] - b[1]) <= 2e-2 * a[1]
-    assert torch.equal(a[2], b[2])
-    assert torch.isfinite(b[3]).all()
-    cos = float(torch.dot(a[3], b[3]) / (a[3].norm() * b[3].norm()))
-    assert cos > 0.99, cos
+    M.set_engine(net, "wino", "f32")
+    a = out["f32"]
+    for mode in ("bf16", "bf16_f32_tensors"):
+        b = out[mode]
+        assert abs(a[0] - b[0]) <= 2e-2 * a[0] and abs(a[1] - b[1]) <= 2e-2 * a[1]
+        assert torch.equal(a[2], b[2])
+        assert torch.isfinite(b[3]).all()
+        cos = float(torch.dot(a[3], b[3]) / (a[3].norm() * b[3].norm()))
+        assert cos > 0.99, (mode, cos)
 
 
 def test_f32x3_mode_is_f32_accurate(golden_net):

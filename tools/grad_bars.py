@@ -64,7 +64,7 @@ def main():
     table["wd32_out"] = {"loc": float((res["wino"][0] - res["direct"][0]).abs().max() / res["direct"][0].abs().max().clamp_min(1)),
                          "conf": float((res["wino"][1] - res["direct"][1]).abs().max() / res["direct"][1].abs().max().clamp_min(1))}
     del res
-    lo, co, a1, a2, gbo = M.f64_oracle_grads(params, operand_round="bf16", dtype=torch.float32)
+    lo, co, a1, a2, gbo = M.f64_oracle_grads(params, operand_round="bf16", dtype=torch.float32, store_round=net._engine.bf16_tensors)
     M.set_engine(net, "wino", "bf16")
     loc, conf, l1, l2, g = M.gpu_f64_case(net)
     M.set_engine(net, "wino", "f32")
