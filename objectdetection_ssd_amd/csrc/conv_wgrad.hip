@@ -405,13 +405,17 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int row0, int col0
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// IN_BF16: x and dy are bf16 tensors (the bf16-tensor mode): 8-byte loads of the same four channels per thread, straight into LDS
-template <bool IN_BF16>
+// IN_BF16: x and dy are bf16 tensors (the bf16-tensor mode): 8-byte loads of the same four channels per thread, straight into LDS.
+// TAPS = 9: 3x3 filter with padding = dilation = DIL (DIL = 1: the VGG layers and heads; DIL = 4: fc6, Model.py:149 -- the halo of a
+// 4 x 8 patch is then 12 x 16 pixels); TAPS = 1: 1x1 filter (fc7, the aux blocks' first convolutions: no halo, one accumulator).
+template <bool IN_BF16, int TAPS, int DIL>
 __global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const WgradParams p) {
     constexpr unsigned ES = IN_BF16 ? 2u : 4u;                  // bytes per element of x / dy
     constexpr int BT = 64, CHUNKS = 16, RPP = 16;
+    constexpr int PADX = TAPS == 9 ? DIL : 0;
+    constexpr int HHd = PH + 2 * PADX, HWd = PW + 2 * PADX, HPIXd = HHd * HWd, XP = (HPIXd + RPP - 1) / RPP;
     __shared__ __attribute__((aligned(16))) __bf16 Ys[PH * PW * LDT];
-    __shared__ __attribute__((aligned(16))) __bf16 Xs[HPIX * LDT];
+    __shared__ __attribute__((aligned(16))) __bf16 Xs[HPIXd * LDT];
     __shared__ float bias_red[256 * 4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -440,21 +444,21 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const WgradParams
     const __amdgpu_buffer_rsrc_t srd_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t srd_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
 
-    int ypy[2], ypx[2], xhy[4], xhx[4];
+    int ypy[2], ypx[2], xhy[XP], xhx[XP];
 #pragma unroll
     for (int j = 0; j < 2; ++j) { const int q = prow + RPP * j; ypy[j] = q / PW; ypx[j] = q % PW; }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const int q = prow + RPP * j; xhy[j] = q / HW; xhx[j] = q % HW; }
+    for (int j = 0; j < XP; ++j) { const int q = prow + RPP * j; xhy[j] = q / HWd; xhx[j] = q % HWd; }
 
-    f32x16 acc[9];
+    f32x16 acc[TAPS];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     typedef typename std::conditional<IN_BF16, u32x2, f32x4>::type raw_t;      // four channels as they come from memory
-    raw_t ry[2], rx[4];
+    raw_t ry[2], rx[XP];
     auto load4 = [](__amdgpu_buffer_rsrc_t srd, unsigned voff) -> raw_t {
         if constexpr (IN_BF16) return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(srd, (int)voff, 0, 0));
         else return buf_load16(srd, voff, 0);
@@ -471,9 +475,9 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const WgradParams
             ry[j] = load4(srd_y, v);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ih = oh0 + xhy[j] - 1, iw = ow0 + xhx[j] - 1;
-            const bool ok = x_col_ok && (prow + RPP * j) < HPIX && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        for (int j = 0; j < XP; ++j) {
+            const int ih = oh0 + xhy[j] - PADX, iw = ow0 + xhx[j] - PADX;
+            const bool ok = x_col_ok && (prow + RPP * j) < HPIXd && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
             const unsigned v = ok ? (unsigned)((n * p.H + ih) * p.W + iw) * ci4 + x_col : OOB;
             rx[j] = load4(srd_x, v);
         }
@@ -493,8 +497,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const WgradParams
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (prow + RPP * j < HPIX) *reinterpret_cast<bf16x4*>(&Xs[(prow + RPP * j) * LDT + chunk * 4]) = to_bf16(rx[j]);
+        for (int j = 0; j < XP; ++j)
+            if (prow + RPP * j < HPIXd) *reinterpret_cast<bf16x4*>(&Xs[(prow + RPP * j) * LDT + chunk * 4]) = to_bf16(rx[j]);
     };
 
     if (pb < pe) {
@@ -508,13 +512,18 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const WgradParams
             for (int ks = 0; ks < 2; ++ks) {
                 // k = 8*lh + j  <->  patch pixel (py = 2ks + lh, px = j)
                 const bf16x8 a = tr_frag(Ys, (2 * ks + lh) * PW, wm * 32, lane);
+                if constexpr (TAPS == 9) {
 #pragma unroll
-                for (int r = 0; r < 3; ++r)
+                    for (int r = 0; r < 3; ++r)
 #pragma unroll
-                    for (int s2 = 0; s2 < 3; ++s2) {
-                        const bf16x8 b = tr_frag(Xs, (2 * ks + lh + r) * HW + s2, wn * 32, lane);
-                        acc[r * 3 + s2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[r * 3 + s2], 0, 0, 0);
-                    }
+                        for (int s2 = 0; s2 < 3; ++s2) {
+                            const bf16x8 b = tr_frag(Xs, (2 * ks + lh + r * DIL) * HWd + s2 * DIL, wn * 32, lane);
+                            acc[r * 3 + s2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[r * 3 + s2], 0, 0, 0);
+                        }
+                } else {
+                    const bf16x8 b = tr_frag(Xs, (2 * ks + lh) * HWd, wn * 32, lane);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[0], 0, 0, 0);
+                }
             }
             __syncthreads();
             if (more) {
@@ -524,14 +533,14 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const WgradParams
         }
     }
 
-    float* slab = p.slab + (size_t)split * p.Co * 9 * p.Ci;
+    float* slab = p.slab + (size_t)split * p.Co * TAPS * p.Ci;
     const int ci = ci0 + wn * 32 + lr;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int co = co0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
-            if (co < p.Co && ci < p.Ci) slab[((size_t)co * 9 + t) * p.Ci + ci] = acc[t][q];
+            if (co < p.Co && ci < p.Ci) slab[((size_t)co * TAPS + t) * p.Ci + ci] = acc[t][q];
         }
     if (do_bias) {
 #pragma unroll
@@ -625,6 +634,10 @@ WgradPlan plan_wgrad(const ssd_conv_geom* g, bool bf16 = false) {
     }
     pl.fused = g->R == 3 && g->S == 3 && g->stride == 1 && g->dil == 1 && g->pad == 1 && g_force_fused != 0 &&
                (g_force_fused == 1 || bf16 || waste[pl.shape] <= 1.12);   // bf16: the fused kernel is 6x the f32 rate, patch waste is irrelevant
+    // bf16 operands: the patch kernel also takes fc6 (3x3, padding = dilation = 4) and the 1x1 / stride-1 layers (fc7, seq8.0 ... seq11.0)
+    if (bf16 && g_force_fused != 0 && g->stride == 1 && g->R == g->S &&
+        ((g->R == 3 && g->dil == 4 && g->pad == 4) || (g->R == 1 && g->pad == 0)))
+        pl.fused = true;
     if (pl.fused) {
         pl.bt = 64; pl.nbuf = 1;
         pl.tiles_co = ssd_cdiv(g->Co, 64);
@@ -706,11 +719,19 @@ static int conv2d_wgrad_impl(const float* x, const float* dy, int ldy, float* dw
     p.tiles_co = pl.tiles_co; p.tiles_ci = pl.tiles_ci;
     const int T = g->R * g->S;
     const int nblk = T * pl.tiles_co * pl.tiles_ci * pl.nsplit;
-    if (in_bf16 && !(pl.fused && bf16)) return SSD_ERR_BAD_SHAPE;       // bf16 tensors: the fused nine-tap kernel only
-    if (pl.fused && bf16 && in_bf16) {
-        hipLaunchKernelGGL(wgrad3x3_bf16_kernel<true>, dim3(pl.tiles_co * pl.tiles_ci * pl.nsplit), dim3(256), 0, st, p);
-    } else if (pl.fused && bf16) {
-        hipLaunchKernelGGL(wgrad3x3_bf16_kernel<false>, dim3(pl.tiles_co * pl.tiles_ci * pl.nsplit), dim3(256), 0, st, p);
+    if (in_bf16 && !(pl.fused && bf16)) return SSD_ERR_BAD_SHAPE;       // bf16 tensors: the patch kernel only
+    if (pl.fused && bf16) {
+        const dim3 grid(pl.tiles_co * pl.tiles_ci * pl.nsplit);
+        const int form = g->R == 1 ? 2 : (g->dil == 4 ? 1 : 0);
+        if (in_bf16) {
+            if (form == 0) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<true, 9, 1>), grid, dim3(256), 0, st, p);
+            else if (form == 1) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<true, 9, 4>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((wgrad3x3_bf16_kernel<true, 1, 1>), grid, dim3(256), 0, st, p);
+        } else {
+            if (form == 0) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<false, 9, 1>), grid, dim3(256), 0, st, p);
+            else if (form == 1) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<false, 9, 4>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((wgrad3x3_bf16_kernel<false, 1, 1>), grid, dim3(256), 0, st, p);
+        }
     } else if (pl.fused) {
         const dim3 grid(pl.tiles_co * pl.tiles_ci * pl.nsplit);
         if (pl.shape == 1) hipLaunchKernelGGL((wgrad3x3_kernel<1, 38>), grid, dim3(256), 0, st, p);

@@ -393,44 +393,45 @@ def _round_store():
     return RoundStore.apply
 
 
-def _conv_bf16_operands(bias_from_rounded: bool = False):
-    """conv2d of BASELINE.json configs[2] ("bf16 convs"): operands rounded to bf16, products accumulated in f32, tensors and
-    bias in f32.  Forward y = conv(r(x), r(w)) + b; data gradient dx = conv^T(r(dy), r(w)); weight gradient corr(r(x), r(dy))
-    for the 3x3 / stride 1 / pad 1 / dilation 1 layers (the fused bf16 weight-gradient kernel) and corr(x, dy) in plain f32 for
-    every other geometry (1x1, dilated, strided, unpadded: those weight gradients stay on the f32 kernels); the bias gradient
-    is the f32 sum of the unrounded dy.  `wgrad_f32=True` forces the f32 weight gradient (conv1_1: its weight gradient runs
-    through the im2col buffer on the f32 kernel)."""
+def _conv_bf16_operands():
+    """conv2d of BASELINE.json configs[2] ("bf16 convs"): operands rounded to bf16, products accumulated in f32, bias in f32.
+    Forward y = conv(r(x), r(w)) + b; data gradient dx = conv^T(r(dy), r(w)); weight gradient corr(r(x), r(dy)) for the geometries the
+    bf16 patch kernel takes (stride 1 and: 3x3 with padding = dilation in {1, 4}, or 1x1 without padding -- the VGG layers, the heads on
+    the large maps, fc6, fc7 and the aux blocks' first convolutions) and corr(x, dy) in plain f32 for the others (strided / unpadded 3x3:
+    those weight gradients stay on the f32 kernels).  The bias gradient is the f32 sum of dy as it is STORED: unrounded where dy is an
+    f32 tensor, rounded (`dy_bf16=True`) where the build holds dy in bf16 only (the c_4 head's packed gradient in the bf16-tensor mode).
+    `wgrad_f32=True` forces the f32 weight gradient (conv1_1: K = 27 from the f32 image)."""
     import torch
     import torch.nn.functional as F
 
-    def fused_geom(w, stride, padding, dilation):
-        return tuple(w.shape[2:]) == (3, 3) and stride == 1 and padding == 1 and dilation == 1
+    def patch_geom(w, stride, padding, dilation):
+        k = tuple(w.shape[2:])
+        return stride == 1 and ((k == (3, 3) and padding == dilation and dilation in (1, 4)) or (k == (1, 1) and padding == 0))
 
     class ConvBf16Operands(torch.autograd.Function):
         @staticmethod
-        def forward(ctx, x, w, b, stride, padding, dilation, wgrad_f32):
+        def forward(ctx, x, w, b, stride, padding, dilation, wgrad_f32, dy_bf16):
             ctx.save_for_backward(x, w)
-            ctx.cfg = (stride, padding, dilation, wgrad_f32)
+            ctx.cfg = (stride, padding, dilation, wgrad_f32, dy_bf16)
             return F.conv2d(bf16_round(x), bf16_round(w), b, stride=stride, padding=padding, dilation=dilation)
 
         @staticmethod
         def backward(ctx, dy):
             x, w = ctx.saved_tensors
-            stride, padding, dilation, wgrad_f32 = ctx.cfg
+            stride, padding, dilation, wgrad_f32, dy_bf16 = ctx.cfg
             dx = dw = db = None
             if ctx.needs_input_grad[0]:
                 dx = torch.nn.grad.conv2d_input(x.shape, bf16_round(w), bf16_round(dy), stride=stride, padding=padding, dilation=dilation)
             if ctx.needs_input_grad[1]:
-                fused = (tuple(w.shape[2:]) == (3, 3) and stride == 1 and padding == 1 and dilation == 1 and not wgrad_f32)
+                fused = patch_geom(w, stride, padding, dilation) and not wgrad_f32
                 xa, da = (bf16_round(x), bf16_round(dy)) if fused else (x, dy)
                 dw = torch.nn.grad.conv2d_weight(xa, w.shape, da, stride=stride, padding=padding, dilation=dilation)
             if ctx.needs_input_grad[2]:
-                # bf16-tensor mode: dy exists in bf16 only (the heads' packed gradient is rounded by the gather), the sum is f32
-                db = (bf16_round(dy) if (bias_from_rounded and fused_geom(w, stride, padding, dilation)) else dy).sum(dim=(0, 2, 3))
-            return dx, dw, db, None, None, None, None
+                db = (bf16_round(dy) if dy_bf16 else dy).sum(dim=(0, 2, 3))
+            return dx, dw, db, None, None, None, None, None
 
-    def conv(x, w, b=None, stride=1, padding=0, dilation=1, wgrad_f32=False):
-        return ConvBf16Operands.apply(x, w, b, stride, padding, dilation, wgrad_f32)
+    def conv(x, w, b=None, stride=1, padding=0, dilation=1, wgrad_f32=False, dy_bf16=False):
+        return ConvBf16Operands.apply(x, w, b, stride, padding, dilation, wgrad_f32, dy_bf16)
     return conv
 
 
@@ -480,7 +481,7 @@ def ssd300_forward(x, params, return_features: bool = False, variant: int = 300,
         raise ValueError("operand_round must be None or 'bf16'")
     if store_round and operand_round != "bf16":
         raise ValueError("store_round needs operand_round='bf16'")
-    conv2d = F.conv2d if operand_round is None else _conv_bf16_operands(bias_from_rounded=store_round)
+    conv2d = F.conv2d if operand_round is None else _conv_bf16_operands()
     first = {} if operand_round is None else {"wgrad_f32": True}
     rs = _round_store() if store_round else (lambda t: t)
     feats = {}
@@ -536,8 +537,9 @@ def ssd300_forward(x, params, return_features: bool = False, variant: int = 300,
     bs = x.shape[0]
     locs, confs = [], []
     for (name, _, _), s in zip(HEADS if variant == 300 else HEADS_512, srcs):
-        bb = conv2d(s, params[f"{name}_bb.weight"], params[f"{name}_bb.bias"], padding=1)
-        cl = conv2d(s, params[f"{name}_cl.weight"], params[f"{name}_cl.bias"], padding=1)
+        hk = {"dy_bf16": True} if (store_round and name == "c_4") else {}      # the bf16 trunk's head: its packed gradient exists in bf16 only
+        bb = conv2d(s, params[f"{name}_bb.weight"], params[f"{name}_bb.bias"], padding=1, **hk)
+        cl = conv2d(s, params[f"{name}_cl.weight"], params[f"{name}_cl.bias"], padding=1, **hk)
         locs.append(bb.permute(0, 2, 3, 1).reshape(bs, -1, 4))
         confs.append(cl.permute(0, 2, 3, 1).reshape(bs, -1, 21))
     loc, conf = torch.cat(locs, 1), torch.cat(confs, 1)

@@ -287,7 +287,7 @@ def test_every_kernel_variant(case):
         lib.ssd_tune_set_wgrad_patch(-1)
 
 
-@pytest.mark.parametrize("case", [CONV_CASES[i] for i in (0, 1, 2, 4, 5, 6, 10, 11)])
+@pytest.mark.parametrize("case", [CONV_CASES[i] for i in (0, 1, 2, 4, 5, 6, 8, 10, 11)])
 def test_conv_bf16_operand_variant(case):
     """bf16-operand kernels (configs[2]): against an f32 torch conv of the SAME bf16-rounded operands the result must
     agree to f32 accuracy (bf16 x bf16 products are exact in f32); against the unrounded conv it is bf16-accurate."""
@@ -327,9 +327,9 @@ def test_conv_bf16_operand_variant(case):
     finally:
         lib.ssd_tune_set_igemm_bf16(-1)
         lib.ssd_tune_set_halo(-1)
-    # weight gradient: bf16 fused nine-tap kernel where it applies (every 3x3 s1 p1 layer), f32 kernels elsewhere
+    # weight gradient: the bf16 patch kernel where it applies (stride 1 and: 3x3 with padding = dilation 1 or 4, or 1x1), f32 kernels elsewhere
     dw, db = ops.conv2d_wgrad(_nhwc(x).to(dev), dy_p.to(dev), g, ld, True, bf16=True)
-    fused = k == 3 and s == 1 and p == 1 and d == 1          # in bf16 mode every such layer takes the fused kernel
+    fused = s == 1 and ((k == 3 and p == d and d in (1, 4)) or (k == 1 and p == 0))
     ref_dw = wr.grad if fused else None
     if ref_dw is None:                                    # f32 path: unrounded x
         x2 = x.clone().requires_grad_(False)
@@ -663,8 +663,8 @@ def test_bf16_operand_kernels_at_bench_batch(layer):
     dx = ops.conv2d_dgrad(dyd, wb, g, bf16=True, w3=wb3)
     _close(dx, _nhwc(xr.grad), tol=2e-5, what=f"bf16 dgrad @32 {layer}")
     dw, db = ops.conv2d_wgrad(xd, dyd, g, co, True, bf16=True)
-    if (k, s, p, d) == (3, 1, 1, 1):
-        ref_dw = wr.grad                                                   # fused bf16 kernel: both operands rounded
+    if s == 1 and ((k == 3 and p == d and d in (1, 4)) or (k == 1 and p == 0)):
+        ref_dw = wr.grad                                                   # bf16 patch kernel (incl. fc6 / the 1x1 layers): both operands rounded
     else:
         w2 = wt.clone().requires_grad_(True)                               # f32 kernel: unrounded x and dy
         F.conv2d(x, w2, None, stride=s, padding=p, dilation=d).backward(dy)
