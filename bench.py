@@ -60,7 +60,7 @@ def host_cores():
     return n
 
 
-def cpu_baseline(max_threads: int = 16):
+def cpu_baseline(max_threads: int = 16, variant: int = 300, bs_big: int = PER_GPU_BATCH):
     """the oracle (CPU restatement of the reference path: the same ATen CPU kernels the reference
     dispatches to) timed on this box's host cores for the same synthetic step at bs=2 and bs=32, fwd / loss / bwd / SGD
     separately.  Bounded sample (~20-30 s): bs=2 2 warm-up + 5 timed, bs=32 1 warm-up + 2 timed, median.  Also returns the
@@ -71,24 +71,28 @@ def cpu_baseline(max_threads: int = 16):
     cores = max(1, min(have, max_threads))       # one GPU's CPU share on the box is 16 cores; more threads than that thrash
     torch.set_num_threads(cores)
     res, first_losses = {}, None
-    for bs, warm, iters in ((2, 2, 5), (PER_GPU_BATCH, 1, 2)):
-        params = {k: v.requires_grad_(True) for k, v in O.ssd300_random_params(0).items()}
+    pri = None if variant == 300 else O.create_priors_ssd512()
+    plan = ((2, 2, 5), (bs_big, 1, 2)) if variant == 300 else ((2, 1, 2), (bs_big, 0, 1))      # SSD512: ~3x the work per image, fewer runs
+    for bs, warm, iters in plan:
+        params = {k: v.requires_grad_(True) for k, v in O.ssd300_random_params(0, variant=variant).items()}
         opt = torch.optim.SGD(list(params.values()), lr=1e-4, momentum=0.9, weight_decay=5e-4)
         x, classes, boxes = synth_batch(bs, 1234, "cpu")
+        if variant == 512:
+            x = torch.randn(bs, 3, 512, 512, generator=torch.Generator().manual_seed(1234))
         rows = []
         for it in range(warm + iters):
             t0 = time.perf_counter()
             opt.zero_grad()
-            loc, conf = O.ssd300_forward(x, params)
+            loc, conf = O.ssd300_forward(x, params, variant=variant)
             t1 = time.perf_counter()
-            l1, l2 = O.multibox_loss_torch(loc, conf, boxes, classes)
+            l1, l2 = O.multibox_loss_torch(loc, conf, boxes, classes, pri_cxcywh=pri)
             t2 = time.perf_counter()
             (l1 + l2).backward()
             t3 = time.perf_counter()
             opt.step()
             t4 = time.perf_counter()
             rows.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3))
-            if it == 0 and bs == PER_GPU_BATCH:
+            if it == 0 and bs == bs_big:
                 first_losses = (float(l1), float(l2))
         med = np.median(np.asarray(rows[warm:]), axis=0)
         res[bs] = {"images_per_sec": round(bs / float(med.sum()), 3), "fwd_s": round(float(med[0]), 4), "loss_s": round(float(med[1]), 4),
@@ -98,11 +102,12 @@ def cpu_baseline(max_threads: int = 16):
         cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
     except Exception:
         pass
-    out = {"value": res[PER_GPU_BATCH]["images_per_sec"], "unit": "images/sec", "cores": cores, "host_cores": have, "cpu": cpu_model,
+    out = {"value": res[bs_big]["images_per_sec"], "unit": "images/sec", "cores": cores, "host_cores": have, "cpu": cpu_model,
            "kind": "port",
-           "sample": f"oracle torch-CPU train step (fwd+loss+bwd+SGD) on the bench's own synthetic batch, bs={PER_GPU_BATCH}: 1 warm-up + 2 timed "
-                     f"(value); bs=2: 2 warm-up + 5 timed; medians; {cores} threads of {have} host cores",
-           "bs2": res[2], f"bs{PER_GPU_BATCH}": res[PER_GPU_BATCH]}
+           "sample": f"oracle torch-CPU train step (fwd+loss+bwd+SGD) of SSD{variant} on the bench's own synthetic batch, bs={bs_big}: "
+                     f"{plan[1][1]} warm-up + {plan[1][2]} timed (value); bs=2: {plan[0][1]} warm-up + {plan[0][2]} timed; medians; "
+                     f"{cores} threads of {have} host cores",
+           "bs2": res[2], f"bs{bs_big}": res[bs_big]}
     return out, first_losses
 
 
@@ -125,11 +130,54 @@ def gpu_losses_at_oracle_weights(dev, bs: int, conv_dtype: str = "f32"):
     return float(l1.item()), float(l2.item())
 
 
+class conv_flop_counter:
+    """Counts the direct-convolution FLOPs of every convolution the ops layer launches inside the `with` block (2*M*Co*K each):
+    the algorithmic work of one pass, read off the geometry of the calls themselves."""
+
+    NAMES = ("conv2d_fwd", "conv2d_fwd_x3", "conv2d_fwd_wino", "conv2d_fwd_wino_pool", "conv2d_dgrad", "conv2d_dgrad_x3", "conv2d_dgrad_wino",
+             "conv2d_wgrad", "conv2d_wgrad_wino")
+
+    def __enter__(self):
+        from objectdetection_ssd_amd import ops
+        self.ops, self.saved, self.flops = ops, {}, 0.0
+        for n in self.NAMES:
+            f = getattr(ops, n)
+            self.saved[n] = f
+
+            def wrapped(*a, _f=f, **k):
+                g = next((v for v in list(a) + list(k.values()) if isinstance(v, ops.ConvGeom)), None)
+                if g is not None:
+                    self.flops += ops.conv_flops(g)
+                return _f(*a, **k)
+            setattr(ops, n, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        for n, f in self.saved.items():
+            setattr(self.ops, n, f)
+        return False
+
+
+def timed_cpu(fn, min_seconds: float = 3.0, max_iters: int = 5):
+    """median wall time of fn() on the host: one warm-up, then up to max_iters runs or min_seconds, whichever comes first"""
+    fn()
+    ts = []
+    t_all = time.perf_counter()
+    while len(ts) < max_iters and (not ts or time.perf_counter() - t_all < min_seconds):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), len(ts)
+
+
 def aux_workload(args, world, rank, dev):
     """configs[4]: no exchange step in either half, so N ranks are N independent replicas."""
     from objectdetection_ssd_amd import Losses, Model
     bs = args.batch
     g = torch.Generator().manual_seed(1234 + rank)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    threads = max(1, min(host_cores(), 16))
+    roof_kind, per_pass_flops, per_pass_bytes, cpu_fn, cpu_units, cpu_sample, prof_net = None, None, None, None, 0, "", None
     if args.workload == "resnet34":
         torch.manual_seed(0)
         net = Model.SSD_resnet34(20).to(dev).eval()
@@ -140,6 +188,17 @@ def aux_workload(args, world, rank, dev):
         step = lambda: net(x)                                              # noqa: E731
         metric = "images/sec SSD_resnet34 eval forward (224x224, 63 priors)"
         dtype = args.conv_dtype
+        with conv_flop_counter() as fc:
+            with torch.no_grad():
+                net(x)
+        roof_kind, per_pass_flops = "mfma", fc.flops
+
+        def cpu_fn():
+            import ssd_oracle as O
+            st = O.ssd_resnet34_random_state(0)
+            with torch.no_grad():
+                O.ssd_resnet34_forward(torch.randn(4, 3, 224, 224), st)
+        cpu_units, cpu_sample = 4, "oracle ssd_resnet34_forward (torch-CPU, eval mode) on 4 images of 224x224, state built inside the timed call"
     elif args.workload in ("infer", "infer-graph"):
         # SSD300 inference forward (no decode) at --batch images: eager launches vs one HIP-graph replay
         torch.manual_seed(0)
@@ -156,6 +215,15 @@ def aux_workload(args, world, rank, dev):
         metric = f"images/sec SSD300-VGG16 inference forward ({'HIP graph replay' if args.workload == 'infer-graph' else 'eager launches'})"
         dtype = args.conv_dtype
         extra = {}
+        roof_kind, per_pass_flops, prof_net = "mfma", 62.747e9 * bs, net        # forward conv FLOPs per image
+
+        def cpu_fn():
+            import ssd_oracle as O
+            with torch.no_grad():
+                O.ssd300_forward(torch.randn(2, 3, 300, 300), cpu_fn.params)
+        import ssd_oracle as _O
+        cpu_fn.params = _O.ssd300_random_params(0)
+        cpu_units, cpu_sample = 2, "oracle ssd300_forward (torch-CPU) on 2 images of 300x300"
     elif args.workload == "preprocess":
         # (f)-3: VOC-sized 8-bit images (375x500 / 500x375 / 333x500) already in HBM -> normalised (bs,3,300,300)
         from objectdetection_ssd_amd import Dataset, _lib, ops
@@ -175,6 +243,13 @@ def aux_workload(args, world, rank, dev):
         metric = "images/sec device input pipeline (PIL-exact resize to 300x300 + normalize, VOC-sized sources)"
         dtype = "u8 -> f32"
         extra = {"algorithmic_bytes_per_image": int(off / bs + 3 * 300 * 300 * 4)}
+        roof_kind, per_pass_bytes = "hbm", float(off + bs * 3 * 300 * 300 * 4)
+
+        def cpu_fn():
+            import ssd_oracle as O
+            for a in imgs[:8]:
+                O.preprocess_image(a)
+        cpu_units, cpu_sample = 8, "oracle preprocess_image (numpy restatement of Pillow's resize + normalise) on 8 of the VOC-sized images"
     elif args.workload == "map":
         # (f)-4: 4952 images (VOC07 test size) x 200 detections, ~2.4 GT per image, resident in HBM
         from objectdetection_ssd_amd import ops
@@ -200,6 +275,16 @@ def aux_workload(args, world, rank, dev):
         dtype = "f32 IoU / f64 precision-recall"
         bs = n_img
         extra = {"detections": D, "ground_truth": G}
+        roof_kind, per_pass_bytes = "hbm", float(D * 24 + G * 20 + (n_img + 1) * 8)      # boxes + class + score per detection, box + class per GT, offsets
+        n_cpu = 300
+
+        def cpu_fn():
+            import ssd_oracle as O
+            dstart = np.arange(n_cpu + 1) * per
+            O.get_map([db[dstart[i]:dstart[i + 1]] for i in range(n_cpu)], [dc[dstart[i]:dstart[i + 1]] for i in range(n_cpu)],
+                      [np.linspace(1, 0, per, dtype=np.float32)] * n_cpu, [gb[gstart[i]:gstart[i + 1]] for i in range(n_cpu)],
+                      [gc[gstart[i]:gstart[i + 1]] for i in range(n_cpu)])
+        cpu_units, cpu_sample = n_cpu, f"oracle get_map (numpy restatement of Util.get_map) on the first {n_cpu} images x {per} detections"
     else:
         l = (torch.randn(bs, 8732, 4, generator=g)).to(dev)
         c = (3 * torch.randn(bs, 8732, 21, generator=g)).to(dev)
@@ -207,6 +292,14 @@ def aux_workload(args, world, rank, dev):
         step = lambda: Losses.inference_batch(l, c, wh)                    # noqa: E731
         metric = "images/sec batched decode + per-class NMS + top-200 (8732 priors, conf ~ 3*randn)"
         dtype = "f32"
+        roof_kind, per_pass_bytes = "hbm", float(bs * 8732 * 25 * 4)                   # 0.87 MB read per image
+
+        def cpu_fn():
+            import ssd_oracle as O
+            ln, cn = l[:2].cpu().numpy(), c[:2].cpu().numpy()
+            for i in range(2):
+                O.decode_nms(ln[i], cn[i], 500.0, 375.0)
+        cpu_units, cpu_sample = 2, "oracle decode_nms (numpy restatement of Losses.inference) on 2 of the images"
     if args.workload in ("resnet34", "decode"):
         extra = {}
 
@@ -227,13 +320,117 @@ def aux_workload(args, world, rank, dev):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
-        print(json.dumps({"metric": metric, "value": round(bs * world * args.steps / elapsed, 2), "unit": "images/sec", "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-                          "config": dict({"workload": f"{args.workload} (see --help), {bs} images per pass per GPU", "global_batch": bs * world,
-                                          "parallelism": f"replicas x{world}"}, **extra)}))
+        ms = elapsed / args.steps * 1e3
+        line = {"metric": metric, "value": round(bs * world * args.steps / elapsed, 2), "unit": "images/sec", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+                "config": dict({"workload": f"{args.workload} (see --help), {bs} images per pass per GPU", "global_batch": bs * world,
+                                "parallelism": f"replicas x{world}"}, **extra)}
+        if roof_kind == "hbm":
+            ach = per_pass_bytes / (ms * 1e-3) / 1e9
+            line["roofline"] = {"bound": "hbm", "kernel": "whole pass (every kernel of the workload between the two fences)",
+                                "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": None,
+                                "algorithmic_bytes_per_pass": int(per_pass_bytes),
+                                "note": "launch- / latency-bound at this size: the pass is a handful of short dependent kernels, not a stream"}
+        elif roof_kind == "mfma":
+            peak = 2500.0 if args.conv_dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+            ach = per_pass_flops / (ms * 1e-3) / 1e12
+            line["roofline"] = {"bound": "mfma", "kernel": "whole pass (direct-convolution FLOPs of every convolution / ms_per_step)",
+                                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                                "algorithmic_gflop_per_pass": round(per_pass_flops / 1e9, 2),
+                                "note": "a speed-up-over-direct figure where Winograd layers execute fewer FLOPs than counted"}
+            if prof_net is not None and args.workload == "infer" and not args.no_roofline:
+                line["roofline"]["dominant_kernel"] = roofline_of(prof_net, step, args.conv_dtype, ms)
+        if cpu_fn is not None and world == 1 and not args.no_cpu_baseline:
+            torch.set_num_threads(threads)
+            sec, iters = timed_cpu(cpu_fn)
+            line["cpu_baseline"] = {"value": round(cpu_units / sec, 3), "unit": "images/sec", "cores": threads, "host_cores": host_cores(), "kind": "port",
+                                    "sample": cpu_sample + f"; median of {iters} timed runs after one warm-up, {threads} torch threads"}
+        print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def roofline_of(net, step, conv_dtype: str, ms: float, layers: bool = False) -> dict:
+    """The `roofline` object of one configuration: three more steps in the engine's profiling mode (every conv kernel between two HIP
+    events on the stream it is launched on; the batched Winograd GEMMs additionally by the library's own per-launch events), the kernel
+    with the largest summed time against the dense MFMA peak of the dtype it multiplies in."""
+    eng = net._engine
+    agg = {}
+    rows = []
+    from objectdetection_ssd_amd import _lib as _l
+    import ctypes as _C
+    gemm_tag = "igemm_kernel<64, 64, 2, 2, 1, true"
+    fused_tag = "wino4_gemm_out_kernel"
+    exec_flops = 0.0
+    for _ in range(3):
+        eng.prof = []
+        _l.check(_l.load().ssd_prof_gemm_begin(), "prof")        # the batched Winograd GEMM launches, each by itself
+        step()
+        torch.cuda.synchronize()
+        ms_buf, fl_buf, kind_buf = (_C.c_float * 1024)(), (_C.c_double * 1024)(), (_C.c_int * 1024)()
+        ng = _l.load().ssd_prof_gemm_collect_kinds(ms_buf, fl_buf, kind_buf, 1024)
+        for i in range(max(ng, 0)):
+            a = agg.setdefault(fused_tag if kind_buf[i] == 1 else gemm_tag, [0.0, 0.0, 0])
+            a[0] += ms_buf[i] * 1e-3; a[1] += fl_buf[i]; a[2] += 1
+        for label, tag, flops, e0, e1, executed in eng.prof:
+            exec_flops += executed
+            dt = e0.elapsed_time(e1) * 1e-3
+            a = agg.setdefault(tag, [0.0, 0.0, 0])
+            a[0] += dt; a[1] += flops; a[2] += 1
+            rows.append((label, tag, flops, dt))
+        eng.prof = None
+    # dominant KERNEL: the Winograd ops are composites (two transform kernels around sixteen batched GEMMs), listed in by_kernel
+    # but not eligible -- a roofline row has to be one kernel that the rocprof summary can be held against
+    tag, (tsum, fsum, n) = max(((k, v) for k, v in agg.items() if not k.startswith("winograd")), key=lambda kv: kv[1][0])
+    ach = fsum / tsum / 1e12
+    traffic = None            # HBM bytes per launch from the committed PMC passes of this round (a pointer: counters cannot be collected in the timed run)
+    traffic_file = "r03_bf16_traffic.json" if conv_dtype == "bf16" else "r03_traffic.json"
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", traffic_file)))
+        if tj["kernel"] == tag:
+            traffic = tj["bytes_per_launch"]
+    except Exception:
+        pass
+    # dense peak of the dtype the kernel multiplies in; an f32x3 product costs six bf16 MFMAs, so its ceiling in
+    # algorithmic f32 FLOPs is a sixth of the bf16 peak
+    on_bf16_mfma = "bf16" in tag or (conv_dtype == "bf16" and tag.startswith("conv3x3_halo"))
+    if conv_dtype == "f32" or (conv_dtype == "bf16" and not on_bf16_mfma):
+        peak, peak_note = PEAK_F32_MFMA_TFLOPS, "f32 MFMA dense"
+    elif conv_dtype == "bf16":
+        peak, peak_note = 2500.0, "bf16 MFMA dense (v_mfma_f32_32x32x16_bf16); `achieved` counts the direct convolution's FLOPs of the launches, not the tile padding"
+    else:
+        peak, peak_note = round(2500.0 / 6, 1), "bf16 MFMA dense / 6 limb products per f32 product"
+    if tag == fused_tag:
+        peak_note += ("; the fused Winograd kernel (36 plane GEMMs + output transform, all planes' accumulators in registers): `achieved` is "
+                      "its EXECUTED rate over the whole kernel, epilogue included")
+    if tag == gemm_tag:
+        peak_note += ("; this is the batched GEMM inside the Winograd ops, timed by itself: `achieved` is its EXECUTED rate (4/9 resp. 1/4 of "
+                      "the direct convolution's FLOPs plus tile padding); the ops it serves are the `winograd_3x3` row of by_kernel, in "
+                      "direct-convolution FLOPs")
+    if tag.startswith("winograd"):
+        peak_note += ("; the ops of this tag are Winograd F(2x2,3x3) convolutions (input transform + 16 batched igemm_kernel<64,64> "
+                      "GEMMs + output transform): `achieved` counts the direct convolution's FLOPs, the GEMMs execute 2.25x fewer")
+    roof = {"bound": "mfma", "kernel": tag + ", ...>", "achieved": round(ach, 2),
+                       "peak": peak, "peak_note": peak_note, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                       "traffic": traffic, "traffic_unit": f"bytes per launch (profiles/{traffic_file})", "launches_timed": n, "avg_launch_ms": round(tsum / n * 1e3, 4),
+                       "avg_launch_gflop": round(fsum / n / 1e9, 3),
+                       "step_executed_gflop": round(exec_flops / 3 / 1e9, 1),
+                       "step_executed_frac": round(exec_flops / 3 / (ms * 1e-3) / 1e12 / (2500.0 if conv_dtype == "bf16" else PEAK_F32_MFMA_TFLOPS), 4),
+                       "step_executed_note": "MFMA FLOPs the step's convolution kernels execute (Winograd layers: 36 multiplies per 4x4 tile) / "
+                                             "ms_per_step / " + ("bf16" if conv_dtype == "bf16" else "f32") + " MFMA peak -- the whole-step roofline fraction",
+                       "all_conv_kernels_tflops": round(sum(a[1] for a in agg.values()) / sum(a[0] for a in agg.values()) / 1e12, 2),
+                       "by_kernel": {k: {"ms_per_step": round(a[0] / 3 * 1e3, 3), "tflops": round(a[1] / a[0] / 1e12, 2),
+                                         "launches_per_step": a[2] // 3} for k, a in sorted(agg.items())}}
+    if layers:                       # per-layer table: mean over the three profiled steps
+        per = {}
+        for label, tag, flops, dt in rows:
+            e = per.setdefault(label, [tag, flops, 0.0, 0])
+            e[2] += dt; e[3] += 1
+        for label, (tag, flops, tsum_l, cnt) in per.items():
+            dt = tsum_l / cnt
+            print(f"{label:32s} {tag:28s} {flops / 1e9:9.2f} GF {dt * 1e3:8.3f} ms {flops / dt / 1e12:7.2f} TF/s", file=sys.stderr)
+    return roof
 
 
 def main():
@@ -367,6 +564,16 @@ def main():
         net._engine.keep_planes = False
     if args.no_dual_dy:
         net._engine.dual_dy = False
+    train_gflop = TRAIN_GFLOP_PER_IMAGE
+    if args.variant == 512:
+        # direct-convolution FLOPs of one SSD512 train step per image, from the geometry of the step's own convolution calls
+        with conv_flop_counter() as fc:
+            xp = torch.randn(1, 3, 512, 512, device=dev)
+            lo_, co_ = net(xp)
+            (lo_.sum() + co_.sum()).backward()
+        net.zero_grad(set_to_none=True)
+        conv1_1 = 2.0 * 512 * 512 * 64 * 27
+        train_gflop = (fc.flops + 2 * conv1_1) / 1e9              # conv1_1 runs its own kernels (forward + weight gradient, no data gradient)
     trainer = FlatSGDDataParallel(net, lr=1e-4, momentum=0.9, weight_decay=5e-4, overlap=args.overlap_allreduce)
     trainer.broadcast_parameters(0)
     bs = args.batch
@@ -425,20 +632,22 @@ def main():
         if ranks_seen != world or rank_id_sum != world * (world - 1) // 2:
             raise SystemExit(f"bench.py: the all-reduce saw {ranks_seen} ranks (id sum {rank_id_sum}), expected {world}")
 
-    out = {"metric": "images/sec SSD300-VGG16 train step", "value": round(ips, 2), "unit": "images/sec",
+    out = {"metric": "images/sec SSD300-VGG16 train step" if args.variant == 300 else "images/sec SSD512-VGG16 (build-defined) train step",
+           "value": round(ips, 2), "unit": "images/sec",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": {"f32": "f32", "f32x3": "f32 (fwd/dgrad products from three bf16 limbs per operand, f32 accumulate)",
                      "bf16": "bf16 operands (convs), f32 accumulate / loss"}[args.conv_dtype], "data": "synthetic",
-           "config": {"workload": ("" if args.variant == 300 else "[build-defined SSD512, FLOP figures below are the SSD300 ones] ") +
-                                  f"SSD300-VGG16 train step (fwd + MultiBox loss + bwd + all-reduce + SGD), "
-                                  f"batch {bs}/GPU, 300x300x3, 21 classes, 8732 priors (BASELINE configs[1])",
+           "config": {"workload": (f"SSD300-VGG16 train step (fwd + MultiBox loss + bwd + all-reduce + SGD), "
+                                   f"batch {bs}/GPU, 300x300x3, 21 classes, 8732 priors (BASELINE configs[1])") if args.variant == 300 else
+                                  (f"build-defined SSD512-VGG16 train step (NOT in the reference; BASELINE configs[3] per-GPU leg): fwd + MultiBox loss + "
+                                   f"bwd + all-reduce + SGD, batch {bs}/GPU, 512x512x3, 21 classes, 24564 priors"),
                       "global_batch": bs * world, "per_gpu_batch": bs, "parallelism": f"dp{world}" + (" (gradient all-reduce overlapped with backward)" if args.overlap_allreduce else ""),
                       "ranks_seen": ranks_seen, "backend": (dist.get_backend() if world > 1 else "none (single process)"),
                       "collective_env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC", "TORCH_NCCL_"))},
-                      "train_gflop_per_image": TRAIN_GFLOP_PER_IMAGE,
-                      "direct_conv_tflops_per_gpu": round(TRAIN_GFLOP_PER_IMAGE * ips / world / 1e3, 2),
-                      "direct_conv_flops_over_f32_mfma_peak": round(TRAIN_GFLOP_PER_IMAGE * ips / world / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+                      "train_gflop_per_image": round(train_gflop, 3),
+                      "direct_conv_tflops_per_gpu": round(train_gflop * ips / world / 1e3, 2),
+                      "direct_conv_flops_over_f32_mfma_peak": round(train_gflop * ips / world / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
                       "direct_conv_note": "algorithmic (direct-convolution) FLOPs of the step / time: a speed-up-over-direct figure, NOT a roofline "
                                           "fraction (Winograd executes 1/4 .. 4/9 of them); the executed fraction is roofline.step_executed_frac",
                       "last_loss_per_rank": round(loss, 5), "n_pos_global_last": n_pos,
@@ -456,80 +665,7 @@ def main():
         for _ in range(3):                 # keep the collectives of rank 0's profiling steps matched
             step()
     if not args.no_roofline and rank == 0:
-        eng = net._engine
-        agg = {}
-        rows = []
-        from objectdetection_ssd_amd import _lib as _l
-        import ctypes as _C
-        gemm_tag = "igemm_kernel<64, 64, 2, 2, 1, true"
-        fused_tag = "wino4_gemm_out_kernel"
-        exec_flops = 0.0
-        for _ in range(3):
-            eng.prof = []
-            _l.check(_l.load().ssd_prof_gemm_begin(), "prof")        # the batched Winograd GEMM launches, each by itself
-            step()
-            torch.cuda.synchronize()
-            ms_buf, fl_buf, kind_buf = (_C.c_float * 1024)(), (_C.c_double * 1024)(), (_C.c_int * 1024)()
-            ng = _l.load().ssd_prof_gemm_collect_kinds(ms_buf, fl_buf, kind_buf, 1024)
-            for i in range(max(ng, 0)):
-                a = agg.setdefault(fused_tag if kind_buf[i] == 1 else gemm_tag, [0.0, 0.0, 0])
-                a[0] += ms_buf[i] * 1e-3; a[1] += fl_buf[i]; a[2] += 1
-            for label, tag, flops, e0, e1, executed in eng.prof:
-                exec_flops += executed
-                dt = e0.elapsed_time(e1) * 1e-3
-                a = agg.setdefault(tag, [0.0, 0.0, 0])
-                a[0] += dt; a[1] += flops; a[2] += 1
-                rows.append((label, tag, flops, dt))
-            eng.prof = None
-        # dominant KERNEL: the Winograd ops are composites (two transform kernels around sixteen batched GEMMs), listed in by_kernel
-        # but not eligible -- a roofline row has to be one kernel that the rocprof summary can be held against
-        tag, (tsum, fsum, n) = max(((k, v) for k, v in agg.items() if not k.startswith("winograd")), key=lambda kv: kv[1][0])
-        ach = fsum / tsum / 1e12
-        traffic = None            # HBM bytes per launch from the committed PMC passes (cannot be collected live)
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-            if tj["kernel"] == tag:
-                traffic = tj["bytes_per_launch"]
-        except Exception:
-            pass
-        # dense peak of the dtype the kernel multiplies in; an f32x3 product costs six bf16 MFMAs, so its ceiling in
-        # algorithmic f32 FLOPs is a sixth of the bf16 peak
-        mfma_f32 = tag.startswith("igemm_kernel") or tag.startswith("wgrad")
-        if args.conv_dtype == "f32" or (mfma_f32 and "bf16" not in tag and not (args.conv_dtype == "bf16" and tag.startswith("wgrad3x3"))):
-            peak, peak_note = PEAK_F32_MFMA_TFLOPS, "f32 MFMA dense"
-        elif args.conv_dtype == "bf16":
-            peak, peak_note = 2500.0, "bf16 MFMA dense"
-        else:
-            peak, peak_note = round(2500.0 / 6, 1), "bf16 MFMA dense / 6 limb products per f32 product"
-        if tag == fused_tag:
-            peak_note += ("; the fused Winograd kernel (36 plane GEMMs + output transform, all planes' accumulators in registers): `achieved` is "
-                          "its EXECUTED rate over the whole kernel, epilogue included")
-        if tag == gemm_tag:
-            peak_note += ("; this is the batched GEMM inside the Winograd ops, timed by itself: `achieved` is its EXECUTED rate (4/9 resp. 1/4 of "
-                          "the direct convolution's FLOPs plus tile padding); the ops it serves are the `winograd_3x3` row of by_kernel, in "
-                          "direct-convolution FLOPs")
-        if tag.startswith("winograd"):
-            peak_note += ("; the ops of this tag are Winograd F(2x2,3x3) convolutions (input transform + 16 batched igemm_kernel<64,64> "
-                          "GEMMs + output transform): `achieved` counts the direct convolution's FLOPs, the GEMMs execute 2.25x fewer")
-        out["roofline"] = {"bound": "mfma", "kernel": tag + ", ...>", "achieved": round(ach, 2),
-                           "peak": peak, "peak_note": peak_note, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                           "traffic": traffic, "traffic_unit": "bytes per launch (profiles/r02_traffic.json)", "launches_timed": n, "avg_launch_ms": round(tsum / n * 1e3, 4),
-                           "avg_launch_gflop": round(fsum / n / 1e9, 3),
-                           "step_executed_gflop": round(exec_flops / 3 / 1e9, 1),
-                           "step_executed_frac": round(exec_flops / 3 / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                           "step_executed_note": "MFMA FLOPs the step's convolution kernels execute (Winograd layers: 36 multiplies per 4x4 tile) / "
-                                                 "ms_per_step / f32 MFMA peak -- the whole-step roofline fraction",
-                           "all_conv_kernels_tflops": round(sum(a[1] for a in agg.values()) / sum(a[0] for a in agg.values()) / 1e12, 2),
-                           "by_kernel": {k: {"ms_per_step": round(a[0] / 3 * 1e3, 3), "tflops": round(a[1] / a[0] / 1e12, 2),
-                                             "launches_per_step": a[2] // 3} for k, a in sorted(agg.items())}}
-        if args.layers:                       # per-layer table: mean over the three profiled steps
-            per = {}
-            for label, tag, flops, dt in rows:
-                e = per.setdefault(label, [tag, flops, 0.0, 0])
-                e[2] += dt; e[3] += 1
-            for label, (tag, flops, tsum_l, cnt) in per.items():
-                dt = tsum_l / cnt
-                print(f"{label:32s} {tag:28s} {flops / 1e9:9.2f} GF {dt * 1e3:8.3f} ms {flops / dt / 1e12:7.2f} TF/s", file=sys.stderr)
+        out["roofline"] = roofline_of(net, step, args.conv_dtype, ms, args.layers)
     if world == 1 and args.conv_dtype == "f32" and args.variant == 300 and not args.no_bf16_leg:
         # BASELINE configs[2] ("bf16 convs", 32 images per GPU): the same step with bf16-operand forward / dgrad / 3x3-wgrad convolutions
         # (f32 accumulate, f32 loss and optimizer), a few steps beside the headline so that the driver's record holds a number for it.
@@ -544,17 +680,21 @@ def main():
         fence()
         bms = (time.perf_counter() - b0) / args.steps * 1e3
         out["config"]["bf16_operand_mode"] = {"images_per_sec": round(bs / bms * 1e3, 1), "ms_per_step": round(bms, 3), "steps": args.steps,
-                                              "note": "BASELINE configs[2] per-GPU leg: bf16 conv operands, f32 accumulate / loss / SGD; same batch, same process"}
+                                              "note": "BASELINE configs[2] per-GPU leg: bf16 convolutions (VGG trunk: activations and gradients stored in "
+                                                      "bf16), f32 accumulate / loss / SGD; same batch, same process",
+                                              "direct_conv_tflops": round(TRAIN_GFLOP_PER_IMAGE * bs / bms, 2)}
+        if not args.no_roofline:
+            out["config"]["bf16_operand_mode"]["roofline"] = roofline_of(net, step, "bf16", bms)
         net.conv_dtype = "f32"
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"], cpu_losses = cpu_baseline()
+        out["cpu_baseline"], cpu_losses = cpu_baseline(variant=args.variant, bs_big=bs)
         if args.variant == 300 and cpu_losses is not None:
             # BASELINE.json metric: "loss delta vs CPU" -- same seeded batch, same seed-0 weights, HIP path vs the oracle
-            g1, g2 = gpu_losses_at_oracle_weights(dev, PER_GPU_BATCH, args.conv_dtype)
+            g1, g2 = gpu_losses_at_oracle_weights(dev, bs, args.conv_dtype)
             out["loss_delta_vs_cpu"] = {"loc": abs(g1 - cpu_losses[0]), "conf": abs(g2 - cpu_losses[1]),
-                                        "gpu": [g1, g2], "cpu": list(cpu_losses), "batch": PER_GPU_BATCH,
+                                        "gpu": [g1, g2], "cpu": list(cpu_losses), "batch": bs,
                                         "tolerance": 1e-4, "conv_dtype": args.conv_dtype,
                                         "within_tolerance": bool(abs(g1 - cpu_losses[0]) <= 1e-4 * max(1.0, abs(cpu_losses[0])) and
                                                                  abs(g2 - cpu_losses[1]) <= 1e-4 * max(1.0, abs(cpu_losses[1])))}

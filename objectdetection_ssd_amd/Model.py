@@ -701,7 +701,7 @@ class _Engine:
                         dyp = res[2] if dual else None
                     else:
                         def wg(pre=pre, a4=a4, xin=xin, dy=dy, g=g, co_pad=co_pad):
-                            dw_, db_ = self._timed("wgrad " + pre, ops.wgrad_tile(g) if self.prof is not None else "", ops.conv_flops(g),
+                            dw_, db_ = self._timed("wgrad " + pre, ops.wgrad_tile(g, self.bf16) if self.prof is not None else "", ops.conv_flops(g),
                                                    lambda: ops.conv2d_wgrad(xin, dy, g, co_pad, True, bf16=self.bf16,
                                                                             dw_out=self._gout(pre + "_bb.weight", pre + "_cl.weight"),
                                                                             db_out=self._gout(pre + "_bb.bias", pre + "_cl.bias")))
@@ -774,7 +774,7 @@ class _Engine:
                     else:
                         def wg(name=op["p"], xin=xin, dy=dy, g=g):
                             grads[name + ".weight"], grads[name + ".bias"] = self._timed(
-                                "wgrad " + name, ops.wgrad_tile(g) if self.prof is not None else "", ops.conv_flops(g),
+                                "wgrad " + name, ops.wgrad_tile(g, self.bf16) if self.prof is not None else "", ops.conv_flops(g),
                                 lambda: ops.conv2d_wgrad(xin, dy, g, g.Co, True, bf16=self.bf16, dw_out=self._gout(name + ".weight"),
                                                          db_out=self._gout(name + ".bias")))
                         if side_ctx[0] is not None and defer:
@@ -841,7 +841,7 @@ class _Engine:
                         dw, db = self._timed("wgrad " + op["p"], "conv_first_wgrad_kernel", 2.0 * dy.numel() * 27,
                                              lambda: (ops.conv1_first_wgrad_bf16 if dy.dtype == torch.bfloat16 else ops.conv1_first_wgrad)(T["x"], dy, True))
                     else:
-                        dw, db = self._timed("wgrad " + op["p"], ops.wgrad_tile(g) if self.prof is not None else "", 2.0 * dy.numel() * 27,
+                        dw, db = self._timed("wgrad " + op["p"], ops.wgrad_tile(g, self.bf16) if self.prof is not None else "", 2.0 * dy.numel() * 27,
                                              lambda: ops.conv2d_wgrad(col, dy, g, g.Co, True))
                     grads[op["p"] + ".weight"], grads[op["p"] + ".bias"] = ops.first_weight_grad(dw), db
         if not joined:

@@ -202,11 +202,22 @@ __global__ __launch_bounds__(256) void l2norm_bwd_bf16_kernel(const __bf16* __re
     for (int c = threadIdx.x; c < 512; c += 256) dg_slab[(size_t)blockIdx.x * 512 + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
 
+// out[c] = sum_k slab[k][c], c < 512: 16 columns per block, 16 threads per column stride over the slabs (16 loads in flight per column
+// instead of one dependent chain), then a fixed-order LDS sum -- reproducible
 __global__ __launch_bounds__(256) void slab_sum512_kernel(const float* __restrict__ slab, float* __restrict__ out, int nslab) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float part[16][17];
+    const int c = threadIdx.x & 15, l = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + c;
     float s = 0.f;
-    for (int k = 0; k < nslab; ++k) s += slab[(size_t)k * 512 + c];
-    out[c] = s;
+    for (int k = l; k < nslab; k += 16) s += slab[(size_t)k * 512 + i];
+    part[l][c] = s;
+    __syncthreads();
+    if (l == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += part[k][c];
+        out[i] = t;
+    }
 }
 
 // packed[m][c] (bf16, ld columns, pad columns zero) from dloc (N,P,4) / dconf (N,P,ncls) f32
@@ -301,7 +312,7 @@ extern "C" int ssd_l2norm_bwd_bf16(const void* x, const float* gamma, const void
     hipLaunchKernelGGL(l2norm_bwd_bf16_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const __bf16*>(x), gamma,
                        static_cast<const __bf16*>(dy), static_cast<__bf16*>(dx), slab, M);
     SSD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(slab_sum512_kernel, dim3(2), dim3(256), 0, st, slab, dgamma, blocks);
+    hipLaunchKernelGGL(slab_sum512_kernel, dim3(32), dim3(256), 0, st, slab, dgamma, blocks);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
 }

@@ -83,7 +83,9 @@ def igemm_tile(g: ConvGeom, direction: int, bf16: bool = False, x3: bool = False
     return f"igemm_kernel<{bm.value}, {bn.value}"
 
 
-def wgrad_tile(g: ConvGeom) -> str:
+def wgrad_tile(g: ConvGeom, bf16: bool = False) -> str:
+    if bf16 and g.stride == 1 and g.R == g.S and ((g.R == 3 and g.pad == g.dil and g.dil in (1, 4)) or (g.R == 1 and g.pad == 0)):
+        return "wgrad3x3_bf16_kernel"                   # the bf16 patch kernel (csrc/conv_wgrad.hip plan_wgrad)
     bt, ns = C.c_int(0), C.c_int(0)
     check(_lib.load().ssd_conv2d_wgrad_tile(C.byref(g), C.byref(bt), C.byref(ns)), "wgrad_tile")
     return "wgrad3x3_kernel" if bt.value == 3 else f"wgrad_kernel<{bt.value}"
