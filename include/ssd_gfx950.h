@@ -106,7 +106,7 @@ int ssd_tune_set_halo(int mode);         /* 3x3/s1 halo-tile kernel: 0 = off, 1 
  * mirrored), replacing nn.Conv2d(+ReLU) of Model.py:135-143,176-184 and its autograd data gradient.
  *   x        [N][H][W][ldx] bf16 (forward: the input activation; data gradient: dy), K = reduction channels per tap (multiple of 64, <= ldx)
  *   w        [w_rows][9][K] bf16 (forward: OHWI copy of the f32 master; data gradient: IHWO); rows >= w_rows count as zero
- *   out      [N][H][W][ldo] bf16, or f32 when out_f32 (the heads): columns 0 .. n_out-1 are written (n_out % 4 == 0; bias, if given, has n_out entries)
+ *   out      [N][H][W][ldo] bf16, or f32 when out_f32 (the heads): columns 0 .. n_out-1 are written (n_out % 4 == 0; bias, if given, has w_rows entries)
  *   out = [accumulate: out +] conv (+ bias) -> [relu] -> [relu_mask (bf16, out's layout): kept where mask > 0]
  * f32 accumulation on v_mfma_f32_32x32x16_bf16, one rounding to bf16 at the store. */
 int ssd_conv3x3_bf16(const void* x, int ldx, const void* w, int w_rows, int K, const float* bias, void* out, int ldo, int n_out,
@@ -257,6 +257,7 @@ int ssd_tune_set_wino_fused(int mode);
  * generic 64 x 64 implicit-GEMM kernel.  1: wherever K % 32 == 0 and K >= 64; -1 (default) / 0: never -- measured no faster (both kernels
  * sit at the device's sustained f32 MFMA rate); kept, tested bit-identical, as the evidence for that statement. */
 int ssd_tune_set_gemm_nt(int mode);
+int ssd_has_experimental(void);           /* 1 if built with SSD_EXPERIMENTAL: gemm_nt.hip and wino4_full_kernel (both off by default, forced by ssd_tune_set_gemm_nt(1) / ssd_tune_set_wino_full(1)) are present */
 /* The whole convolution (input transform too) in one kernel where the reduction length is 64 (128 when forced): -1 automatic, 0 never, 1 force.
  * ssd_conv3x3_wino_uses_full tells the caller whether a geometry's forward (0) / data gradient from dy (1) takes that kernel -- it then
  * needs no dgrad planes from ssd_wino4_dy_transform. */

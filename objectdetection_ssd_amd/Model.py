@@ -306,6 +306,15 @@ class _Engine:
         return (self.bf16 and self.bf16_tensors and g.R == 3 and g.S == 3 and g.stride == 1 and g.dil == 1 and g.pad == 1 and g.Ci % 64 == 0
                 and (xin is None or xin.dtype == torch.bfloat16))
 
+    def _head16(self, op, g) -> bool:
+        """bf16-tensor mode: this head, although its input is an f32 tensor, runs csrc/conv_bf16.hip on a bf16 copy of it -- where the map is
+        large enough to pay (19x19) and the head is the FIRST to deliver its input's gradient (so that gradient needs neither += nor a
+        ReLU mask from the kernel, which writes it as f32)."""
+        if not (self._t16(g, None) and g.H >= 16):
+            return False
+        readers = [o for o in self.ops if o["x"] == op["x"]]
+        return readers[-1] is op
+
     def _bf16_weights(self, key: str, tensors):
         """bf16 OHWI (co, 9, ci) and IHWO (ci, 9, pad64(co)) copies of a 3x3 filter (+ the bias padded to a multiple of 4), cached."""
         sig = tuple((t.data_ptr(), t._version) for t in tensors)
@@ -355,7 +364,7 @@ class _Engine:
                         co = op["a"] * (4 + N_CLASSES)
                         g = ops.make_geom(bs, h, w_, op["ci"], co, 3, 1, 1, 1)
                         tensors, co_pad = (P[op["p"] + "_bb.weight"], P[op["p"] + "_cl.weight"]), ops.pad32(co)
-                    t16 = self._t16(g, None) and b16[op["x"]]
+                    t16 = self._t16(g, None) and (b16[op["x"]] or (kind == "head" and self._head16(op, g)))
                     if kind == "conv":
                         b16[op["y"]] = t16
                     co_all = sum(t.shape[0] for t in tensors)
@@ -539,12 +548,15 @@ class _Engine:
                 g = ops.make_geom(bs, xin.shape[1], xin.shape[2], op["ci"], co, 3, 1, 1, 1)
                 pre = op["p"]
                 bias = _cat_flat(P[pre + "_bb.bias"].detach(), P[pre + "_cl.bias"].detach())
-                if self._t16(g, xin) and co % 4 == 0:
+                if self._head16(op, g) and xin.dtype == torch.float32:
+                    # a head on an f32 tensor outside the bf16 trunk (c_7 on fc7's output): one cast, then the LDS-DMA kernel
+                    xin = T[op["x"] + ":b16"] = ops.cast_bf16(xin)
+                if self._t16(g, xin):
                     wf16, _ = self._bf16_weights(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]))
-                    ld = ops.pad32(co)
+                    ld, co4 = ops.pad32(co), (co + 3) // 4 * 4
                     out = torch.empty((bs, g.H, g.W, ld), device=xin.device, dtype=torch.float32)      # pad columns are never read
                     packed = self._timed("fwd " + pre, "conv3x3_bf16_kernel", ops.conv_flops(g),
-                                         lambda: ops.conv3x3_bf16(xin, wf16, bias, co, False, out=out, out_f32=True, ldo=ld))
+                                         lambda: ops.conv3x3_bf16(xin, wf16, bias, co4, False, out=out, out_f32=True, ldo=ld))
                     heads.append((op, packed, g))
                     continue
                 if xin.dtype == torch.bfloat16:
@@ -659,8 +671,12 @@ class _Engine:
                 co_pad = ops.pad32(g.Co)
                 xin = T[op["x"]]
                 a4 = 4 * op["a"]
-                if self._t16(g, xin) and g.Co % 4 == 0:
+                x16 = T.get(op["x"] + ":b16")
+                if x16 is not None or self._t16(g, xin):
                     # bf16 trunk: packed bf16 dy (K of the data gradient padded to 64), nine-tap bf16 weight gradient, LDS-DMA data gradient
+                    f32_dx = x16 is not None                  # the head ran on a bf16 copy of an f32 tensor: its dx goes back as f32
+                    if f32_dx:
+                        xin = x16
                     ld = ops.pad64(g.Co)
                     dy = ops.heads_gather_bf16(dloc, dconf, ld, bs, g.Ho * g.Wo, op["a"], off).view(bs, g.Ho, g.Wo, ld)
                     if any(need[pre + s] for s in ("_bb.weight", "_bb.bias", "_cl.weight", "_cl.bias")):
@@ -670,9 +686,13 @@ class _Engine:
                         grads[pre + "_bb.weight"], grads[pre + "_cl.weight"] = dw[:a4], dw[a4:]
                         grads[pre + "_bb.bias"], grads[pre + "_cl.bias"] = db[:a4], db[a4:]
                     _, wb16 = self._bf16_weights(pre, (P[pre + "_bb.weight"], P[pre + "_cl.weight"]))
-                    deliver(op["x"], lambda dx, acc, mask: self._timed(
-                        "dgrad " + pre, "conv3x3_bf16_kernel", ops.conv_flops(g),
-                        lambda: ops.conv3x3_bf16(dy, wb16, None, g.Ci, False, flip=True, out=dx, relu_mask=mask, accumulate=acc)))
+                    def dgrad16(dx, acc, mask, dy=dy, wb16=wb16, g=g, pre=pre, f32_dx=f32_dx):
+                        if f32_dx and (acc or mask is not None or dx is not None):
+                            raise RuntimeError("a head on a bf16 copy must be the first to deliver its input's gradient")
+                        return self._timed("dgrad " + pre, "conv3x3_bf16_kernel", ops.conv_flops(g),
+                                           lambda: ops.conv3x3_bf16(dy, wb16, None, g.Ci, False, flip=True, out=dx, out_f32=f32_dx, relu_mask=mask,
+                                                                    accumulate=acc))
+                    deliver(op["x"], dgrad16)
                     continue
                 if xin.dtype == torch.bfloat16:
                     xin = T[op["x"] + ":f32"]

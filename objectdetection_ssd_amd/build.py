@@ -47,6 +47,8 @@ def _compile(src: str, force: bool, verbose: bool) -> str:
             os.path.join(os.path.dirname(PKG), "include", "ssd_gfx950.h"), os.path.abspath(__file__)]
     if force or _stale(obj, deps):
         extra = os.environ.get("SSD_HIPCC_FLAGS", "").split()          # experiments only (e.g. -DSSD_IGEMM_SETPRIO=1)
+        if os.environ.get("SSD_EXPERIMENTAL", "") not in ("", "0"):
+            extra.append("-DSSD_EXPERIMENTAL")                        # + the default-off kernels (gemm_nt.hip, wino4_full_kernel)
         cmd = [_hipcc(), *COMMON, *PER_FILE.get(src, []), *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

@@ -307,7 +307,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(const HaloParams p
                 const int n = n0 + (wn * TN + j) * 32 + 8 * g + 4 * lh;
                 if (ok && n < p.Nout) {
                     f32x4 v = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
-                    if (p.bias != nullptr) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                    if (p.bias != nullptr) {                       // the bias has Nrows entries (a head: 150 of the 152 stored columns)
+                        if (n + 3 < p.Nrows) {
+                            v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (n + e < p.Nrows) v[e] += p.bias[n + e];
+                        }
+                    }
                     const size_t o = pix * p.ldo + n;
                     if (p.accumulate) {
                         if (p.out_f32) {

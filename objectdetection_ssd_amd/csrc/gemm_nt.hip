@@ -18,6 +18,7 @@
 // Rows beyond M / beyond the filter rows are clamped to the last valid row on load and never stored.
 #include "common.h"
 
+#ifdef SSD_EXPERIMENTAL
 namespace {
 
 struct NtParams {
@@ -208,12 +209,19 @@ __global__ __launch_bounds__(256) void wino_gemm_nt_kernel(const NtParams p) {
     }
 }
 
+}  // namespace
+#endif  // SSD_EXPERIMENTAL
+
+namespace {
 int g_nt_mode = -1;                // -1 / 0: the generic 64x64 kernel; 1: this kernel whenever the shape allows
 
 }  // namespace
 
 extern "C" int ssd_tune_set_gemm_nt(int mode) {
     if (mode < -1 || mode > 1) return SSD_ERR_BAD_SHAPE;
+#ifndef SSD_EXPERIMENTAL
+    if (mode == 1) return SSD_ERR_BAD_SHAPE;       // the kernel is not in this build (python -m objectdetection_ssd_amd.build with SSD_EXPERIMENTAL=1)
+#endif
     g_nt_mode = mode;
     return SSD_OK;
 }
@@ -232,6 +240,9 @@ __attribute__((visibility("hidden"))) int ssd_internal_gemm_nt(const float* a, c
                                                                int nbatch, size_t batch_a_elems, size_t batch_w_elems, hipStream_t st) {
     if (!a || !w || !out) return SSD_ERR_NULL;
     if (K % 32 != 0 || K < 64 || M < 1 || N < 1 || n_rows < 1 || nbatch < 1) return SSD_ERR_BAD_SHAPE;
+#ifndef SSD_EXPERIMENTAL
+    return SSD_ERR_BAD_SHAPE;
+#else
     NtParams p;
     p.a = a; p.w = w; p.out = out;
     p.M = M; p.N = N; p.K = K; p.n_rows = n_rows;
@@ -246,4 +257,15 @@ __attribute__((visibility("hidden"))) int ssd_internal_gemm_nt(const float* a, c
     hipLaunchKernelGGL((wino_gemm_nt_kernel<128, 128>), dim3((unsigned)(8 * bpx)), dim3(256), 0, st, p);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
+#endif
+}
+
+// 1 when the library was built with SSD_EXPERIMENTAL (the kernels that measured no better than the shipped ones and are off by default:
+// the persistent 128 x 128 NT plane GEMM of this file, the one-kernel Winograd convolution `wino4_full_kernel`)
+extern "C" int ssd_has_experimental(void) {
+#ifdef SSD_EXPERIMENTAL
+    return 1;
+#else
+    return 0;
+#endif
 }

@@ -383,6 +383,7 @@ struct FullParams {
     unsigned long long* stamps;
 };
 
+#ifdef SSD_EXPERIMENTAL
 constexpr int GT = 32;                          // tiles per workgroup
 constexpr int KH = 32;                          // channels of K per pass (V of one pass: 36 x 32 tiles x 32 k floats = 144 KB of LDS)
 constexpr int VS_F = 36 * GT * KH;
@@ -650,6 +651,8 @@ __global__ __launch_bounds__(512, 2) void wino4_full_kernel(const FullParams p) 
     }
 }
 
+#endif  // SSD_EXPERIMENTAL
+
 }  // namespace
 
 // Internal: the whole convolution from the NHWC activation (K = 64 or 128 channels).  V_keep / bits_out may be NULL.
@@ -658,6 +661,9 @@ __attribute__((visibility("hidden"))) int ssd_internal_wino4_full(const float* x
                                                                    const unsigned long long* mask_bits, int relu, int accumulate, int H, int W,
                                                                    int TH, int TW, float* yp, uint8_t* am, int Ho, int Wo, float* V_keep,
                                                                    unsigned long long* bits_out, hipStream_t st) {
+#ifndef SSD_EXPERIMENTAL
+    return SSD_ERR_BAD_SHAPE;                       // not in this build (SSD_EXPERIMENTAL=1 python -m objectdetection_ssd_amd.build)
+#else
     if ((K != 64 && K != 128) || tiles <= 0 || Nout <= 0 || Nout % 4 != 0 || Nrows <= 0) return SSD_ERR_BAD_SHAPE;
     if ((size_t)Nrows * K >= (1ull << 32)) return SSD_ERR_BAD_SHAPE;
     FullParams p;
@@ -679,4 +685,5 @@ __attribute__((visibility("hidden"))) int ssd_internal_wino4_full(const float* x
     ssd_internal_prof_close(slot, st);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
+#endif
 }

@@ -1173,6 +1173,9 @@ extern "C" int ssd_tune_set_wino_xform_blocks(int blocks) {
 
 extern "C" int ssd_tune_set_wino_full(int mode) {
     if (mode < -1 || mode > 1) return SSD_ERR_BAD_SHAPE;
+#ifndef SSD_EXPERIMENTAL
+    if (mode == 1) return SSD_ERR_BAD_SHAPE;       // wino4_full_kernel is not in this build
+#endif
     g_full = mode;
     return SSD_OK;
 }

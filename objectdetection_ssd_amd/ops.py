@@ -294,8 +294,8 @@ def conv3x3_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
             raise ValueError("conv3x3_bf16: out size")
     if bias is not None:
         _req(bias, "bias")
-        if bias.numel() < n_out:
-            raise ValueError("conv3x3_bf16: bias needs n_out entries")
+        if bias.numel() < min(n_out, int(w.shape[0])):
+            raise ValueError("conv3x3_bf16: bias needs one entry per weight row")
     if relu_mask is not None:
         _req(relu_mask, "relu_mask", torch.bfloat16)
         if relu_mask.numel() != out.numel() or out_f32:

@@ -537,7 +537,9 @@ def ssd300_forward(x, params, return_features: bool = False, variant: int = 300,
     bs = x.shape[0]
     locs, confs = [], []
     for (name, _, _), s in zip(HEADS if variant == 300 else HEADS_512, srcs):
-        hk = {"dy_bf16": True} if (store_round and name == "c_4") else {}      # the bf16 trunk's head: its packed gradient exists in bf16 only
+        # the heads that run the bf16-tensor kernels (c_4 on the bf16 trunk, c_7 on a bf16 copy of fc7's output): their packed gradient
+        # exists in bf16 only, so the bias gradient sums the rounded values
+        hk = {"dy_bf16": True} if (store_round and name in ("c_4", "c_7")) else {}
         bb = conv2d(s, params[f"{name}_bb.weight"], params[f"{name}_bb.bias"], padding=1, **hk)
         cl = conv2d(s, params[f"{name}_cl.weight"], params[f"{name}_cl.bias"], padding=1, **hk)
         locs.append(bb.permute(0, 2, 3, 1).reshape(bs, -1, 4))

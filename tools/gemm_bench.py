@@ -1,4 +1,5 @@
-"""Times the plane GEMMs of the Winograd layers with K >= 256 by themselves (the library's own event pair around each launch), the generic
+"""(the kernels this tool forces -- gemm_nt.hip / wino4_full_kernel -- need a library built with SSD_EXPERIMENTAL=1)
+Times the plane GEMMs of the Winograd layers with K >= 256 by themselves (the library's own event pair around each launch), the generic
 64 x 64 kernel (ssd_tune_set_gemm_nt 0) against the 128 x 128 LDS-DMA kernel (1), interleaved in one process at batch 32.
 
     python tools/gemm_bench.py [rounds]

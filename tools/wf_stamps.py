@@ -1,4 +1,5 @@
-"""In-kernel phase stamps of the fused Winograd kernel (diagnostic): shares of prologue / main loop / epilogue per workgroup."""
+"""(the kernels this tool forces -- gemm_nt.hip / wino4_full_kernel -- need a library built with SSD_EXPERIMENTAL=1)
+In-kernel phase stamps of the fused Winograd kernel (diagnostic): shares of prologue / main loop / epilogue per workgroup."""
 import os, sys
 import numpy as np
 import torch

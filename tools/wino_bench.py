@@ -1,4 +1,5 @@
-"""Times the F(4x4,3x3) forward / dgrad entry points per bench layer at batch 32 with the fused GEMM + output-transform kernel
+"""(the kernels this tool forces -- gemm_nt.hip / wino4_full_kernel -- need a library built with SSD_EXPERIMENTAL=1)
+Times the F(4x4,3x3) forward / dgrad entry points per bench layer at batch 32 with the fused GEMM + output-transform kernel
 (ssd_tune_set_wino_fused 1) and without it (0), interleaved in one process; checks that the two forms agree.
 
     python tools/wino_bench.py [rounds]
