@@ -53,11 +53,128 @@ struct HaloParams {
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// Fragment reads as inline asm + hand-counted lgkmcnt waits: for its own ds_reads the compiler (ROCm 7.2) waits lgkmcnt(0) -- everything,
+// the reads it has just issued for later steps included -- every few steps; an asm read is invisible to that pass, so the count is ours:
+// LDS operations retire in issue order, `lgkmcnt(N)` with N = reads issued AFTER the ones a step needs leaves exactly those in flight.
+__device__ __forceinline__ bf16x8 lds_read16(unsigned addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_lgkm_n(int n) {   // n: a constant after unrolling, a multiple of 3 up to 9
+    if (n >= 9) wait_lgkm<9>();
+    else if (n == 6) wait_lgkm<6>();
+    else if (n == 3) wait_lgkm<3>();
+    else wait_lgkm<0>();
+}
 __device__ __forceinline__ void wait_vm(int n) {       // n: a constant after unrolling (0..3); folds to one s_waitcnt
     if (n >= 3) wait_vmcnt<3>();
     else if (n == 2) wait_vmcnt<2>();
     else if (n == 1) wait_vmcnt<1>();
     else wait_vmcnt<0>();
+}
+
+// One 32 x 32 accumulator of D^T: this lane holds pixel `pix` (valid if ok) and, per quad g, the four consecutive channels n_lane + 8 g .. + 3:
+// out = [accumulate: out +] acc (+ bias) -> [relu] -> [mask > 0], 8-byte (bf16) or 16-byte (f32) stores straight to NHWC memory.
+__device__ __forceinline__ void store_acc(const HaloParams& p, const f32x16& acc, bool ok, size_t pix, int n_lane) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int n = n_lane + 8 * g;
+        if (ok && n < p.Nout) {
+            f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+            if (p.bias != nullptr) {                       // the bias has Nrows entries (a head: 150 of the 152 stored columns)
+                if (n + 3 < p.Nrows) {
+                    v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.Nrows) v[e] += p.bias[n + e];
+                }
+            }
+            const size_t o = pix * p.ldo + n;
+            if (p.accumulate) {
+                if (p.out_f32) {
+                    v += *reinterpret_cast<const f32x4*>(static_cast<const float*>(p.out) + o);
+                } else {
+                    const bf16x4 pv = *reinterpret_cast<const bf16x4*>(static_cast<const __bf16*>(p.out) + o);
+                    v += f32x4{(float)pv[0], (float)pv[1], (float)pv[2], (float)pv[3]};
+                }
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];          // NaN stays NaN, like torch.relu
+            }
+            if (p.mask != nullptr) {
+                const bf16x4 mk = *reinterpret_cast<const bf16x4*>(p.mask + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (float)mk[e] > 0.f ? v[e] : 0.f;
+            }
+            if (p.out_f32) {
+                *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + o) = v;
+            } else {
+                *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.out) + o) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            }
+        }
+    }
+}
+
+// Coalesced form of the epilogue for bf16 outputs without accumulation: the wave parks its (TM*32 pixels) x (TN*32 channels) result --
+// bias and ReLU applied, rounded to bf16 -- in a private LDS slot as [pixel][channel] rows (row stride +16 bytes: the 8-byte writes of
+// 16 pixels then fall on 16 different bank pairs), reads it back 16 bytes per lane and stores whole channel runs: TN*64 contiguous bytes
+// per pixel and instruction instead of the 8-byte pieces of store_acc (measured on conv1_2: the scattered stores cost more than the
+// MFMAs).  The ReLU mask of a data gradient is applied on the way out (a select commutes with the rounding), read with the same 16-byte
+// pattern.  The same wave writes and reads its slot (LDS operations retire in order): no barrier inside.  pix_of(row, ok) -> pixel index.
+template <int TM, int TN, typename PixOf>
+__device__ __forceinline__ void store_tile_staged(const HaloParams& p, const f32x16 (&acc)[TN][TM], unsigned char* slot, int n_wave, int lane,
+                                                  PixOf pix_of) {
+    constexpr int RB = TN * 64, RS = RB + 16, LPR = RB / 16, RPI = 64 / LPR;      // row bytes, row stride, lanes per row, rows per instruction
+    const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = j * 32 + 8 * g + 4 * lh, n = n_wave + c;
+                f32x4 v = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
+                if (p.bias != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.Nrows) v[e] += p.bias[n + e];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
+                }
+                *reinterpret_cast<bf16x4*>(slot + (i * 32 + lr) * RS + c * 2) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            }
+    __bf16* const out = static_cast<__bf16*>(p.out);
+#pragma unroll
+    for (int pass = 0; pass < TM * 32 / RPI; ++pass) {
+        const int row = pass * RPI + lane / LPR, ch = (lane % LPR) * 8, n = n_wave + ch;
+        bool ok;
+        const size_t pix = pix_of(row, ok);
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(slot + row * RS + ch * 2);
+        if (ok && n < p.Nout) {
+            const size_t o = pix * p.ldo + n;
+            if (n + 8 <= p.Nout) {
+                if (p.mask != nullptr) {
+                    const bf16x8 mk = *reinterpret_cast<const bf16x8*>(p.mask + o);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (float)mk[e] > 0.f ? v[e] : (__bf16)0.f;
+                }
+                *reinterpret_cast<bf16x8*>(out + o) = v;
+            } else {                                          // the last, partial group of channels (Nout % 8 == 4)
+                if (p.mask != nullptr) {
+                    const bf16x4 mk = *reinterpret_cast<const bf16x4*>(p.mask + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (float)mk[e] > 0.f ? v[e] : (__bf16)0.f;
+                }
+                *reinterpret_cast<bf16x4*>(out + o) = bf16x4{v[0], v[1], v[2], v[3]};
+            }
+        }
+    }
 }
 
 // TM x TN 32x32 accumulators per wave, WVM x WVN waves; MODE as above; PH = patch rows (modes 0, 1); APW = halo pieces
@@ -282,71 +399,191 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(const HaloParams p
     }
 
     // ---- epilogue: acc[j][i][reg] = out[pixel m(i, lr)][channel n0 + (wn*TN+j)*32 + 8*(reg>>2) + 4*lh + (reg&3)] ------------------
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = (wm * TM + i) * 32 + lr;
-        bool ok;
-        size_t pix;
+    auto pix_of_m = [&](int m, bool& ok) -> size_t {
         if constexpr (MODE == 2) {
             const int fq = q0 + m;
             const int fqq = fq < p.total_q ? fq : 0;
             const int n = fqq / p.img_pitch, rem = fqq - n * p.img_pitch;
             const int y = rem / p.Wp, x = rem - y * p.Wp;
             ok = fq < p.total_q && y < p.H && x < p.W;
-            pix = (size_t)(n * p.H + y) * p.W + x;
+            return (size_t)(n * p.H + y) * p.W + x;
         } else {
             const int py = m / PW, px = m - py * PW;
             const int y = oy0 + py, x = ox0 + px;
             ok = y < p.H && x < p.W;
-            pix = (size_t)(img * p.H + y) * p.W + x;
+            return (size_t)(img * p.H + y) * p.W + x;
         }
+    };
+    constexpr int SLOT = TM * 32 * (TN * 64 + 16);            // bytes of a wave's staging slot
+    if (!p.out_f32 && !p.accumulate && (p.ldo & 7) == 0 && 8 * SLOT <= (int)sizeof(lds)) {
+        // (the last stage ended with a barrier: every wave is done with the halo and weight buffers, the slots reuse them)
+        store_tile_staged<TM, TN>(p, acc, lds + wave * SLOT, n0 + wn * TN * 32, lane,
+                                  [&](int row, bool& ok) { return pix_of_m(wm * TM * 32 + row, ok); });
+        return;
+    }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+    for (int i = 0; i < TM; ++i) {
+        bool ok;
+        const size_t pix = pix_of_m((wm * TM + i) * 32 + lr, ok);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + (wn * TN + j) * 32 + 8 * g + 4 * lh;
-                if (ok && n < p.Nout) {
-                    f32x4 v = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
-                    if (p.bias != nullptr) {                       // the bias has Nrows entries (a head: 150 of the 152 stored columns)
-                        if (n + 3 < p.Nrows) {
-                            v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                        } else {
+        for (int j = 0; j < TN; ++j) store_acc(p, acc[j][i], ok, pix, n0 + (wn * TN + j) * 32 + 4 * lh);
+    }
+}
+
+// ---- K = 64, at most 64 output channels (conv1_2 forward and data gradient, Model.py:135 features[2]) -----------------------------
+// The general kernel spends a third of such a block outside its nine stages (halo + first weight tiles in, 64 KB of results out, one
+// workgroup per CU so nothing covers it).  Here a PERSISTENT workgroup keeps all nine taps of the 64 x 64 filter in LDS (72 KB, loaded
+// once) and walks its share of the 8 x 32 patches with two halo buffers: the next patch's halo arrives by LDS-DMA while this one is
+// multiplied, nothing inside a patch needs a barrier (halo and filter are complete), one barrier per patch swaps the buffers, and the
+// stores of a patch drain under the next patch's MFMAs.  The layer is then bound by its HBM bytes (in + out = 0.74 GB at batch 32).
+__global__ __launch_bounds__(512, 2) void conv3x3_bf16_k64_kernel(const HaloParams p) {
+    constexpr int TM = 2, WVN = 2, PH = 8, PW = 32, HW = PW + 2, HH = PH + 2;
+    constexpr int NPIECE = (HH * HW + 7) / 8, A_BYTES = NPIECE * 1024, W_BYTES = 9 * 64 * 128, APW = (NPIECE + 7) / 8;
+    static_assert(2 * A_BYTES + W_BYTES <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(128))) unsigned char lds[2 * A_BYTES + W_BYTES];
+    unsigned char* const Ws = lds + 2 * A_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WVN, wn = wave % WVN;
+    const int lr = lane & 31, lh = lane >> 5;
+    const __bf16* const zero = reinterpret_cast<const __bf16*>(g_zero_page);
+    const int per_img = p.npw * p.nph, ntiles = p.tiles_m;
+
+    // halo piece i of this wave (q = wave + 8 i < NPIECE) of the patch at (img, oy0, ox0) -> buffer buf.  Everything that does not depend
+    // on the patch is computed once: the lane's halo pixel (hy, hx) and its offset from the patch origin; per patch only the bounds
+    // test and one add remain (the address arithmetic of six pieces per patch was a quarter of the patch's issue slots otherwise).
+    int a_hy[APW], a_hx[APW], a_rel[APW];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (n + e < p.Nrows) v[e] += p.bias[n + e];
-                        }
-                    }
-                    const size_t o = pix * p.ldo + n;
-                    if (p.accumulate) {
-                        if (p.out_f32) {
-                            v += *reinterpret_cast<const f32x4*>(static_cast<const float*>(p.out) + o);
-                        } else {
-                            const bf16x4 pv = *reinterpret_cast<const bf16x4*>(static_cast<const __bf16*>(p.out) + o);
-                            v += f32x4{(float)pv[0], (float)pv[1], (float)pv[2], (float)pv[3]};
-                        }
-                    }
-                    if (p.relu) {
+    for (int i = 0; i < APW; ++i) {
+        const int h = (wave + 8 * i) * 8 + (lane >> 3), pc = lane & 7;
+        const int hy = h / HW, hx = h - hy * HW;
+        a_hy[i] = h < HH * HW ? hy - 1 : -(1 << 20);           // rows past the halo: never inside the map
+        a_hx[i] = hx - 1;
+        a_rel[i] = ((hy - 1) * p.W + (hx - 1)) * p.ldx + (pc ^ ((hx >> 1) & 7)) * 8;
+    }
+    auto issue_halo = [&](int i, int img, int oy0, int ox0, int buf) {
+        const int q = wave + 8 * i;
+        if (q >= NPIECE) return;                               // wave-uniform
+        const int y = oy0 + a_hy[i], x = ox0 + a_hx[i];
+        const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        const __bf16* src = ok ? p.x + ((size_t)(img * p.H + oy0) * p.W + ox0) * p.ldx + a_rel[i] : zero;
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), (lds_void*)(lds + buf * A_BYTES + q * 1024), 16, 0, 0);
+    };
+    auto origin = [&](int tile, int& img, int& oy0, int& ox0) {
+        img = tile / per_img;
+        const int prem = tile - img * per_img, ty = prem / p.npw;
+        oy0 = ty * PH;
+        ox0 = (prem - ty * p.npw) * PW;
+    };
+    // the filter: 72 pieces (tap t, rows 8 r .. 8 r + 7), nine per wave
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];          // NaN stays NaN, like torch.relu
-                    }
-                    if (p.mask != nullptr) {
-                        const bf16x4 mk = *reinterpret_cast<const bf16x4*>(p.mask + o);
+    for (int i = 0; i < 9; ++i) {
+        const int q = wave + 8 * i, t = q >> 3, row = (q & 7) * 8 + (lane >> 3), pc = lane & 7;
+        const int c = pc ^ ((row >> 1) & 7);
+        const __bf16* src = row < p.Nrows ? p.w + ((size_t)row * 9 + t) * p.K + c * 8 : zero;
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), (lds_void*)(Ws + q * 1024), 16, 0, 0);
+    }
+    int tile = blockIdx.x;
+    int img = 0, oy0 = 0, ox0 = 0;                             // origin of the current patch
+    if (tile < ntiles) {
+        origin(tile, img, oy0, ox0);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = (float)mk[e] > 0.f ? v[e] : 0.f;
-                    }
-                    if (p.out_f32) {
-                        *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + o) = v;
-                    } else {
-                        *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.out) + o) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                    }
+        for (int i = 0; i < APW; ++i) issue_halo(i, img, oy0, ox0, 0);
+    }
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    int hbase[TM], kbase[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = (wm * TM + i) * 32 + lr, py = m / PW, px = m - py * PW;
+        hbase[i] = py * HW + px;
+        kbase[i] = px;
+    }
+    const int wrow = wn * 32 + lr;
+    int w_off[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) w_off[ks] = wrow * 128 + (((2 * ks + lh) ^ ((wrow >> 1) & 7)) << 4);
+
+    const unsigned lds_addr = (unsigned)(size_t)(lds_void*)lds;        // LDS byte address of the buffers (for the asm fragment reads)
+    for (int it = 0; tile < ntiles; ++it, tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        int nimg = 0, noy0 = 0, nox0 = 0;
+        if (next < ntiles) origin(next, nimg, noy0, nox0);
+        f32x16 acc[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        // 36 k-steps (9 taps x 4), fully unrolled; the fragments of step s + 3 are requested before the MFMAs of step s (four register
+        // sets, counted waits): with one step of lookahead every step waited ~200 cycles (eight waves' LDS traffic) for 64 cycles of MFMAs
+        constexpr int LOOK = 3;
+        bf16x8 xf[LOOK + 1][TM], wf[LOOK + 1];
+        const unsigned a_lds = lds_addr + (it & 1) * A_BYTES, w_lds = lds_addr + 2 * A_BYTES;
+        auto load_step = [&](int set, int st) {
+            const int t = st >> 2, ks = st & 3;
+            const int r = t / 3, s2 = t - 3 * r;
+            const int dr = p.flip ? 2 - r : r, ds = p.flip ? 2 - s2 : s2;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                xf[set][i] = lds_read16(a_lds + (hbase[i] + dr * HW + ds) * 128 + (((2 * ks + lh) ^ (((kbase[i] + ds) >> 1) & 7)) << 4));
+            wf[set] = lds_read16(w_lds + t * 8192 + w_off[ks]);
+        };
+#pragma unroll
+        for (int st = 0; st < LOOK; ++st) load_step(st, st);
+#pragma unroll
+        for (int st = 0; st < 36; ++st) {
+            if (st + LOOK < 36) load_step((st + LOOK) % (LOOK + 1), st + LOOK);
+            // the next patch's halo: one DMA per k-step at the start of the patch (an LDS-DMA holds the issue port ~100 cycles)
+#ifndef K64_NO_DMA
+            if (st < APW && next < ntiles) issue_halo(st, nimg, noy0, nox0, (it & 1) ^ 1);
+#endif
+            if (st == 26) wait_vmcnt<0>();                    // ~5 taps after the last DMA and a whole patch after the last stores: nothing left to wait for
+            wait_lgkm_n(3 * (36 - 1 - st < LOOK ? 36 - 1 - st : LOOK));          // the reads of the steps after this one may stay in flight
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[st % (LOOK + 1)], xf[st % (LOOK + 1)][i], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            auto pix_of_m = [&](int m, bool& ok) -> size_t {
+                const int py = m / PW, px = m - py * PW;
+                const int y = oy0 + py, x = ox0 + px;
+                ok = y < p.H && x < p.W;
+                return (size_t)(img * p.H + y) * p.W + x;
+            };
+            constexpr int SLOT = TM * 32 * (64 + 16);
+            static_assert(8 * SLOT <= A_BYTES, "the eight staging slots reuse the halo buffer of the patch just multiplied");
+#ifdef K64_NO_STORE
+            if (acc[0][0] == 123.456f)                         // probe build: keep the accumulators alive, store nothing
+#endif
+            if (!p.out_f32 && !p.accumulate && (p.ldo & 7) == 0) {
+                __builtin_amdgcn_s_barrier();                  // every wave has read its last fragment of this patch's halo
+                asm volatile("" ::: "memory");
+                f32x16 acc1[1][TM];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc1[0][i] = acc[i];
+                store_tile_staged<TM, 1>(p, acc1, lds + (it & 1) * A_BYTES + wave * SLOT, wn * 32, lane,
+                                         [&](int row, bool& ok) { return pix_of_m(wm * TM * 32 + row, ok); });
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    bool ok;
+                    const size_t pix = pix_of_m((wm * TM + i) * 32 + lr, ok);
+                    store_acc(p, acc[i], ok, pix, wn * 32 + 4 * lh);
                 }
             }
         }
+        __builtin_amdgcn_s_barrier();                          // every wave is done with this halo buffer and has seen the next one land
+        asm volatile("" ::: "memory");
+        img = nimg; oy0 = noy0; ox0 = nox0;
     }
 }
 
 int g_force_mode = -1;      // tuning aid: position space (0 / 1 / 2), -1 = by map size
 int g_force_bn = -1;        // tuning aid: 64 / 128, -1 = by channel count
+int g_k64 = 1;              // tuning aid: 0 = never the persistent K = 64 kernel
 
 template <int TM, int TN, int WVM, int WVN, int MODE, int PH, int APW, bool ADBL>
 int launch(HaloParams& p, hipStream_t st) {
@@ -376,6 +613,16 @@ int dispatch(HaloParams& p, hipStream_t st) {
     if (mode == 2 && p.W + 2 > 63) mode = 1;
     int bn = g_force_bn;
     if (bn < 0) bn = p.Nout <= 64 ? 64 : 128;
+    if (bn == 64 && mode == 0 && p.K == 64 && p.Nout <= 64 && g_k64 != 0) {
+        p.npw = ssd_cdiv(p.W, 32);
+        p.nph = ssd_cdiv(p.H, 8);
+        p.tiles_m = p.N * p.npw * p.nph;
+        p.tiles_n = 1;
+        const int blocks = p.tiles_m < 256 ? p.tiles_m : 256;                 // one persistent workgroup per CU
+        hipLaunchKernelGGL(conv3x3_bf16_k64_kernel, dim3(blocks), dim3(512), 0, st, p);
+        SSD_CHECK_LAUNCH();
+        return SSD_OK;
+    }
     if (bn == 64) {
         // 64 output channels: wave tile 64 x 64 over 512 positions (16 x 32 patches; one halo buffer, K has one or two chunks here)
         if (mode == 0) return launch<2, 2, 8, 1, 0, 16, 10, false>(p, st);
@@ -396,6 +643,11 @@ extern "C" int ssd_tune_set_conv_bf16(int mode, int bn) {
     g_force_bn = bn;
     return SSD_OK;
 }
+// Tuning aid: 0 = conv1_2-shaped launches (K = 64, <= 64 output channels, 8 x 32 patches) on the general kernel instead of the persistent one.
+extern "C" int ssd_tune_set_conv_bf16_k64(int on) {
+    g_k64 = on ? 1 : 0;
+    return SSD_OK;
+}
 
 // see include/ssd_gfx950.h
 extern "C" int ssd_conv3x3_bf16(const void* x, int ldx, const void* w, int w_rows, int K, const float* bias, void* out, int ldo, int n_out,
@@ -405,7 +657,7 @@ extern "C" int ssd_conv3x3_bf16(const void* x, int ldx, const void* w, int w_row
         ldo % 4 != 0 || w_rows <= 0)
         return SSD_ERR_BAD_SHAPE;
     if ((long)N * (H + 1) * (W + 2) >= (1L << 30)) return SSD_ERR_BAD_SHAPE;
-    if (!ssd_aligned16(x) || !ssd_aligned16(w) || !ssd_aligned16(out) || (bias && !ssd_aligned16(bias)) || (relu_mask && ((uintptr_t)relu_mask & 7)))
+    if (!ssd_aligned16(x) || !ssd_aligned16(w) || !ssd_aligned16(out) || (bias && !ssd_aligned16(bias)) || (relu_mask && !ssd_aligned16(relu_mask)))
         return SSD_ERR_ALIGN;
     HaloParams p = {};
     p.x = static_cast<const __bf16*>(x); p.w = static_cast<const __bf16*>(w); p.bias = bias; p.out = out;

@@ -1207,7 +1207,9 @@ HALO_BF16_CASES = [
     # mode, bn, N, H, W, K (in channels), n_out, w_rows
     (0, 128, 2, 11, 45, 128, 128, 128),      # 8x32 patches, ragged in both directions
     (0, 128, 1, 17, 33, 64, 160, 150),       # second N tile half empty, zero weight rows (a head: 150 -> pad 160)
-    (0, 64, 2, 19, 40, 64, 64, 64),          # 16x32 patches, one chunk, single halo buffer
+    (0, 64, 2, 19, 40, 64, 64, 64),          # K = 64, 64 channels: the persistent kernel (filter resident in LDS, two halo buffers)
+    (0, 64, 4, 70, 260, 64, 64, 64),         # ... 324 patches for 256 workgroups: the patch loop runs twice for some
+    (0, 64, 1, 20, 70, 64, 48, 48),          # ... fewer filter rows than the tile
     (0, 64, 1, 33, 35, 128, 64, 64),         # ... two chunks: the halo is re-loaded between them
     (1, 128, 2, 19, 23, 192, 256, 256),      # 16x16 patches, three chunks
     (1, 64, 1, 16, 16, 64, 64, 64),
