@@ -111,6 +111,7 @@ int ssd_tune_set_halo(int mode);         /* 3x3/s1 halo-tile kernel: 0 = off, 1 
  * f32 accumulation on v_mfma_f32_32x32x16_bf16, one rounding to bf16 at the store. */
 int ssd_conv3x3_bf16(const void* x, int ldx, const void* w, int w_rows, int K, const float* bias, void* out, int ldo, int n_out,
                      int out_f32, const void* relu_mask, int accumulate, int relu, int flip, int N, int H, int W, void* stream);
+int ssd_tune_set_conv_bf16_mfma(int rows);        /* MFMA shape of the bf16-tensor convolution kernels: 32 (32x32x16, default) or 16 (16x16x32) */
 int ssd_tune_set_conv_bf16_k64(int on);          /* 0 = K = 64 / <= 64-channel launches on the general kernel instead of the persistent one */
 int ssd_tune_set_conv_bf16(int mode, int bn);    /* position space 0 / 1 / 2 (patches 8x32, 16x16, flat), N tile 64 / 128; -1 = automatic */
 /* Weight gradient of a 3x3 / stride 1 / pad 1 / dilation 1 layer from bf16 x (N,H,W,Ci) and bf16 dy (N,H,W,ldy): dw (Co,Ci,3,3) and dbias

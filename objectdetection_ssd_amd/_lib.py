@@ -74,6 +74,7 @@ SIGNATURES = {
     "ssd_conv3x3_bf16": (_I, [_P, _I, _P, _I, _I, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ssd_tune_set_conv_bf16": (_I, [_I, _I]),
     "ssd_tune_set_conv_bf16_k64": (_I, [_I]),
+    "ssd_tune_set_conv_bf16_mfma": (_I, [_I]),
     "ssd_has_experimental": (_I, []),
     "ssd_conv3x3_wgrad_bf16t": (_I, [_P, _P, _I, _P, _P, _G, _P, _Z, _P]),
     "ssd_conv1_first_fwd_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -25,6 +25,7 @@
 //   1  2-D patches of 16 x 16                                                    (75^2)
 //   2  flat: q runs over [image][H+1][W+2] (one zero row between images, two zero columns per row), a tile is BM
 //      consecutive q; positions on a zero row / column compute garbage that is never stored   (38^2, 19^2, 10^2 ...)
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -62,11 +63,13 @@ __device__ __forceinline__ bf16x8 lds_read16(unsigned addr) {
     return v;
 }
 template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void wait_lgkm_n(int n) {   // n: a constant after unrolling, a multiple of 3 up to 9
-    if (n >= 9) wait_lgkm<9>();
-    else if (n == 6) wait_lgkm<6>();
-    else if (n == 3) wait_lgkm<3>();
-    else wait_lgkm<0>();
+__device__ __forceinline__ void wait_lgkm_n(int n) {   // n: a constant after unrolling (0..15); folds to one s_waitcnt
+    switch (n) {
+        case 0: wait_lgkm<0>(); break;   case 1: wait_lgkm<1>(); break;   case 2: wait_lgkm<2>(); break;   case 3: wait_lgkm<3>(); break;
+        case 4: wait_lgkm<4>(); break;   case 5: wait_lgkm<5>(); break;   case 6: wait_lgkm<6>(); break;   case 7: wait_lgkm<7>(); break;
+        case 8: wait_lgkm<8>(); break;   case 9: wait_lgkm<9>(); break;   case 10: wait_lgkm<10>(); break; case 11: wait_lgkm<11>(); break;
+        case 12: wait_lgkm<12>(); break; case 13: wait_lgkm<13>(); break; case 14: wait_lgkm<14>(); break; default: wait_lgkm<15>(); break;
+    }
 }
 __device__ __forceinline__ void wait_vm(int n) {       // n: a constant after unrolling (0..3); folds to one s_waitcnt
     if (n >= 3) wait_vmcnt<3>();
@@ -75,49 +78,65 @@ __device__ __forceinline__ void wait_vm(int n) {       // n: a constant after un
     else wait_vmcnt<0>();
 }
 
-// One 32 x 32 accumulator of D^T: this lane holds pixel `pix` (valid if ok) and, per quad g, the four consecutive channels n_lane + 8 g .. + 3:
-// out = [accumulate: out +] acc (+ bias) -> [relu] -> [mask > 0], 8-byte (bf16) or 16-byte (f32) stores straight to NHWC memory.
-__device__ __forceinline__ void store_acc(const HaloParams& p, const f32x16& acc, bool ok, size_t pix, int n_lane) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int n = n_lane + 8 * g;
-        if (ok && n < p.Nout) {
-            f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-            if (p.bias != nullptr) {                       // the bias has Nrows entries (a head: 150 of the 152 stored columns)
-                if (n + 3 < p.Nrows) {
-                    v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e < p.Nrows) v[e] += p.bias[n + e];
-                }
-            }
-            const size_t o = pix * p.ldo + n;
-            if (p.accumulate) {
-                if (p.out_f32) {
-                    v += *reinterpret_cast<const f32x4*>(static_cast<const float*>(p.out) + o);
-                } else {
-                    const bf16x4 pv = *reinterpret_cast<const bf16x4*>(static_cast<const __bf16*>(p.out) + o);
-                    v += f32x4{(float)pv[0], (float)pv[1], (float)pv[2], (float)pv[3]};
-                }
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];          // NaN stays NaN, like torch.relu
-            }
-            if (p.mask != nullptr) {
-                const bf16x4 mk = *reinterpret_cast<const bf16x4*>(p.mask + o);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (float)mk[e] > 0.f ? v[e] : 0.f;
-            }
-            if (p.out_f32) {
-                *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + o) = v;
+// Four consecutive output channels n .. n+3 of one pixel (a quad of an accumulator of D^T):
+// out = [accumulate: out +] v (+ bias) -> [relu] -> [mask > 0], one 8-byte (bf16) or 16-byte (f32) store straight to NHWC memory.
+__device__ __forceinline__ void store_quad(const HaloParams& p, f32x4 v, bool ok, size_t pix, int n) {
+    if (ok && n < p.Nout) {
+        if (p.bias != nullptr) {                           // the bias has Nrows entries (a head: 150 of the 152 stored columns)
+            if (n + 3 < p.Nrows) {
+                v += *reinterpret_cast<const f32x4*>(p.bias + n);
             } else {
-                *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.out) + o) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < p.Nrows) v[e] += p.bias[n + e];
             }
+        }
+        const size_t o = pix * p.ldo + n;
+        if (p.accumulate) {
+            if (p.out_f32) {
+                v += *reinterpret_cast<const f32x4*>(static_cast<const float*>(p.out) + o);
+            } else {
+                const bf16x4 pv = *reinterpret_cast<const bf16x4*>(static_cast<const __bf16*>(p.out) + o);
+                v += f32x4{(float)pv[0], (float)pv[1], (float)pv[2], (float)pv[3]};
+            }
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];              // NaN stays NaN, like torch.relu
+        }
+        if (p.mask != nullptr) {
+            const bf16x4 mk = *reinterpret_cast<const bf16x4*>(p.mask + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (float)mk[e] > 0.f ? v[e] : 0.f;
+        }
+        if (p.out_f32) {
+            *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + o) = v;
+        } else {
+            *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.out) + o) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
         }
     }
 }
+
+// MFMA tile geometry of a wave's result.  M16 = v_mfma_f32_16x16x32_bf16 (on this chip the same FLOPs per cycle as 32x32x16 and a higher
+// sustained clock under load: MI355X_MICROARCH.md, DVFS give-back (7)), else v_mfma_f32_32x32x16_bf16.  With D^T = W x X^T a lane holds
+// pixel `lrow` of a tile and quads of four consecutive channels: M32 regs 4g..4g+3 = channels 8g + 4*lk + e (lk = lane / 32), M16 regs
+// 0..3 = channels 4*lk + e (lk = lane / 16).
+template <bool M16> struct Mfma {
+    static constexpr int MR = M16 ? 16 : 32;               // rows (pixels) = columns (channels) of a tile
+    static constexpr int NQ = M16 ? 1 : 4;                 // quads per lane and tile
+    static constexpr int KS = M16 ? 2 : 4;                 // k-steps per 64-channel stage
+    static constexpr int CPK = M16 ? 4 : 2;                // 16-byte chunks of a 128-byte row one k-step reads (= lane groups along k)
+    typedef typename std::conditional<M16, f32x4, f32x16>::type acc_t;
+    static __device__ __forceinline__ acc_t mma(const bf16x8 a, const bf16x8 b, const acc_t c) {
+        if constexpr (M16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 quad(const acc_t& c, int g) {
+        if constexpr (M16) return c;
+        else return f32x4{c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]};
+    }
+    static __device__ __forceinline__ int quad_ch(int g, int lk) { return M16 ? 4 * lk : 8 * g + 4 * lk; }
+};
 
 // Coalesced form of the epilogue for bf16 outputs without accumulation: the wave parks its (TM*32 pixels) x (TN*32 channels) result --
 // bias and ReLU applied, rounded to bf16 -- in a private LDS slot as [pixel][channel] rows (row stride +16 bytes: the 8-byte writes of
@@ -125,19 +144,20 @@ __device__ __forceinline__ void store_acc(const HaloParams& p, const f32x16& acc
 // per pixel and instruction instead of the 8-byte pieces of store_acc (measured on conv1_2: the scattered stores cost more than the
 // MFMAs).  The ReLU mask of a data gradient is applied on the way out (a select commutes with the rounding), read with the same 16-byte
 // pattern.  The same wave writes and reads its slot (LDS operations retire in order): no barrier inside.  pix_of(row, ok) -> pixel index.
-template <int TM, int TN, typename PixOf>
-__device__ __forceinline__ void store_tile_staged(const HaloParams& p, const f32x16 (&acc)[TN][TM], unsigned char* slot, int n_wave, int lane,
-                                                  PixOf pix_of) {
-    constexpr int RB = TN * 64, RS = RB + 16, LPR = RB / 16, RPI = 64 / LPR;      // row bytes, row stride, lanes per row, rows per instruction
-    const int lr = lane & 31, lh = lane >> 5;
+template <bool M16, int MT, int NT, typename PixOf>
+__device__ __forceinline__ void store_tile_staged(const HaloParams& p, const typename Mfma<M16>::acc_t (&acc)[NT][MT], unsigned char* slot, int n_wave,
+                                                  int lane, PixOf pix_of) {
+    typedef Mfma<M16> F;
+    constexpr int ROWS = MT * F::MR, RB = NT * F::MR * 2, RS = RB + 16, LPR = RB / 16, RPI = 64 / LPR;   // rows, row bytes, row stride, lanes per row, rows per instruction
+    const int lrow = lane & (F::MR - 1), lk = lane / F::MR;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = j * 32 + 8 * g + 4 * lh, n = n_wave + c;
-                f32x4 v = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
+            for (int g = 0; g < F::NQ; ++g) {
+                const int c = j * F::MR + F::quad_ch(g, lk), n = n_wave + c;
+                f32x4 v = F::quad(acc[j][i], g);
                 if (p.bias != nullptr) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -147,11 +167,11 @@ __device__ __forceinline__ void store_tile_staged(const HaloParams& p, const f32
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
                 }
-                *reinterpret_cast<bf16x4*>(slot + (i * 32 + lr) * RS + c * 2) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                *reinterpret_cast<bf16x4*>(slot + (i * F::MR + lrow) * RS + c * 2) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
             }
     __bf16* const out = static_cast<__bf16*>(p.out);
 #pragma unroll
-    for (int pass = 0; pass < TM * 32 / RPI; ++pass) {
+    for (int pass = 0; pass < ROWS / RPI; ++pass) {
         const int row = pass * RPI + lane / LPR, ch = (lane % LPR) * 8, n = n_wave + ch;
         bool ok;
         const size_t pix = pix_of(row, ok);
@@ -179,8 +199,10 @@ __device__ __forceinline__ void store_tile_staged(const HaloParams& p, const f32
 
 // TM x TN 32x32 accumulators per wave, WVM x WVN waves; MODE as above; PH = patch rows (modes 0, 1); APW = halo pieces
 // (8 rows = 1 KB each) per wave; ADBL: two halo buffers (the next chunk is prefetched while this one is multiplied)
-template <int TM, int TN, int WVM, int WVN, int MODE, int PH, int APW, bool ADBL>
+template <int TM, int TN, int WVM, int WVN, int MODE, int PH, int APW, bool ADBL, bool M16>
 __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(const HaloParams p) {
+    typedef Mfma<M16> F;
+    constexpr int MR = F::MR, MT = TM * 32 / MR, NT = TN * 32 / MR, KS = F::KS;
     static_assert(WVM * WVN == 8, "8 waves");
     constexpr int BM = WVM * TM * 32, BN = WVN * TN * 32;
     constexpr int PW = MODE == 1 ? 16 : 32;
@@ -200,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(const HaloParams p
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WVN, wn = wave % WVN;
-    const int lr = lane & 31, lh = lane >> 5;
+    const int lrow = lane & (MR - 1), lk = lane / MR;       // this lane's row of a fragment, its group along k
     const int nblk = p.tiles_m * p.tiles_n;
     const int lid = xcd_swizzle(blockIdx.x, nblk);
     const int tile_m = lid / p.tiles_n, tile_n = lid - tile_m * p.tiles_n;          // n fastest: neighbours share the halo in one L2
@@ -219,8 +241,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(const HaloParams p
     }
 
     // ---- LDS-DMA sources of the halo: piece q = wave + 8 i covers halo rows 8q .. 8q+7, lane -> (row 8q + lane/8, slot lane%8) ----
-    const __bf16* a_src[APW];
-    int a_step[APW];                       // 64 for a real pixel (advance by one chunk per chunk), 0 for a zero row
+    // (element offsets from p.x / p.w in 32 bits -- the host checks the tensors are below 2^31 elements -- NONE for a zero row: one
+    // register per piece instead of a pointer and a step)
+    constexpr unsigned NONE = 0xFFFFFFFFu;
+    unsigned a_off[APW];
     const __bf16* const zero = reinterpret_cast<const __bf16*>(g_zero_page);
 #pragma unroll
     for (int i = 0; i < APW; ++i) {
@@ -245,37 +269,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(const HaloParams p
             ok = h < HH * HW && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
         }
         const int c = pc ^ ((kappa >> 1) & 7);
-        a_src[i] = ok ? p.x + ((size_t)(n * p.H + y) * p.W + x) * p.ldx + c * 8 : zero + c * 8;
-        a_step[i] = ok ? 64 : 0;
+        a_off[i] = ok ? (unsigned)((n * p.H + y) * p.W + x) * (unsigned)p.ldx + c * 8 : NONE;
     }
     // ---- weight tile: piece q = wave * BPW + i covers rows 8q .. 8q+7 of the N tile ---------------------------------------------
-    const __bf16* b_src[BPW];
-    int b_mul[BPW];
+    unsigned b_off[BPW];
 #pragma unroll
     for (int i = 0; i < BPW; ++i) {
         const int row = (wave * BPW + i) * 8 + (lane >> 3), pc = lane & 7;
         const int c = pc ^ ((row >> 1) & 7);
-        const bool ok = n0 + row < p.Nrows;
-        b_src[i] = ok ? p.w + (size_t)(n0 + row) * 9 * p.K + c * 8 : zero + c * 8;
-        b_mul[i] = ok ? 1 : 0;
+        b_off[i] = n0 + row < p.Nrows ? (unsigned)(n0 + row) * 9u * (unsigned)p.K + c * 8 : NONE;
     }
     // A DMA that has nothing to fetch (no next chunk, no stage s+2) still runs, from the zero page into the slot it would have
     // filled: every wave then issues the same number of DMAs in every stage and all wait counts are compile-time constants.
     auto issue_a = [&](int i, int kc, int buf, bool real) {     // piece i of this wave, chunk kc -> halo buffer buf
-        const __bf16* src = real ? a_src[i] + kc * a_step[i] : zero;
+        const __bf16* src = (real && a_off[i] != NONE) ? p.x + (size_t)(a_off[i] + (unsigned)kc * 64u) : zero;
         __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), (lds_void*)(As + buf * A_BYTES + (wave + 8 * i) * 1024), 16, 0, 0);
     };
     auto issue_b = [&](int i, int s, int kc, int t, bool real) {   // piece i of this wave, stage s = kc * 9 + t -> ring slot s % 3
-        const __bf16* src = real ? b_src[i] + (t * p.K + kc * 64) * b_mul[i] : zero;
+        const __bf16* src = (real && b_off[i] != NONE) ? p.w + (size_t)(b_off[i] + (unsigned)(t * p.K + kc * 64)) : zero;
         __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), (lds_void*)(Bs + (s % NSLOT) * B_BYTES + (wave * BPW + i) * 1024), 16, 0, 0);
     };
 
     // ---- fragment addresses ------------------------------------------------------------------------------------------------
-    // pixel side: tile row m = (wm*TM + i)*32 + lr -> halo row of tap (0,0) and its swizzle key
-    int hbase[TM], kbase[TM];
+    // pixel side: tile row m = wm*TM*32 + i*MR + lrow -> halo row of tap (0,0) and its swizzle key
+    int hbase[MT], kbase[MT];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = (wm * TM + i) * 32 + lr;
+    for (int i = 0; i < MT; ++i) {
+        const int m = wm * TM * 32 + i * MR + lrow;
         if constexpr (MODE == 2) {
             hbase[i] = m;
             kbase[i] = m;
@@ -285,22 +305,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(const HaloParams p
             kbase[i] = px;
         }
     }
-    // weight side: row (wn*TN + j)*32 + lr; the 16-byte slot of k chunk 2ks + lh is constant over the stages
-    int w_off[TN][4];
+    // weight side: row wn*TN*32 + j*MR + lrow; the 16-byte slot of k chunk CPK*ks + lk is constant over the stages
+    int w_off[NT][KS];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int row = (wn * TN + j) * 32 + lr;
+    for (int j = 0; j < NT; ++j) {
+        const int row = wn * TN * 32 + j * MR + lrow;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) w_off[j][ks] = row * 128 + (((2 * ks + lh) ^ ((row >> 1) & 7)) << 4);
+        for (int ks = 0; ks < KS; ++ks) w_off[j][ks] = row * 128 + (((F::CPK * ks + lk) ^ ((row >> 1) & 7)) << 4);
     }
 
-    f32x16 acc[TN][TM];
+    typename F::acc_t acc[NT][MT];
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+            for (int r = 0; r < 4 * F::NQ; ++r) acc[j][i][r] = 0.f;
 
     const int KC = p.K >> 6, NS = KC * 9;
     const int row_pitch = MODE == 2 ? p.Wp : HW;
@@ -317,29 +337,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(const HaloParams p
     asm volatile("" ::: "memory");
 
     // tap (r, s2) reads halo row (py + dr) * pitch + (px + ds): forward dr = r, data gradient dr = 2 - r
-    int xrow[TM], xsw[TM];
+    int xrow[MT], xsw[MT];
     auto tap_setup = [&](int t) {
         const int r = t / 3, s2 = t - 3 * r;
         const int dr = p.flip ? 2 - r : r, ds = p.flip ? 2 - s2 : s2;
         const int hoff = dr * row_pitch + ds;
         const int koff = MODE == 2 ? hoff : ds;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < MT; ++i) {
             xrow[i] = (hbase[i] + hoff) * 128;
             xsw[i] = ((kbase[i] + koff) >> 1) & 7;
         }
     };
-    bf16x8 xf[2][TM], wf[2][TN];
+    // M32: two fragment sets (the reads of k-step ks+1 are requested before the MFMAs of k-step ks, and the next stage's first pixel
+    // fragments before the barrier).  M16 has twice the fragments per k-step (8 x 4 registers): one set -- the partner wave of the SIMD
+    // covers the read latency -- or the kernel spills.
+    constexpr int NSET = M16 ? 1 : 2;
+    bf16x8 xf[NSET][MT], wf[NSET][NT];
     auto load_x = [&](int set, const unsigned char* Ab, int ks) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) xf[set][i] = *reinterpret_cast<const bf16x8*>(Ab + xrow[i] + (((2 * ks + lh) ^ xsw[i]) << 4));
+        for (int i = 0; i < MT; ++i) xf[set][i] = *reinterpret_cast<const bf16x8*>(Ab + xrow[i] + (((F::CPK * ks + lk) ^ xsw[i]) << 4));
     };
     auto load_w = [&](int set, const unsigned char* Bb, int ks) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) wf[set][j] = *reinterpret_cast<const bf16x8*>(Bb + w_off[j][ks]);
+        for (int j = 0; j < NT; ++j) wf[set][j] = *reinterpret_cast<const bf16x8*>(Bb + w_off[j][ks]);
     };
     tap_setup(0);
-    load_x(0, As, 0);
+    if (NSET == 2) load_x(0, As, 0);
 
     // Stage = (chunk, tap): 4 k-steps of TM x TN MFMAs.  The fragments of k-step ks+1 are requested before the MFMAs of k-step ks, the
     // stage's DMA instructions sit BETWEEN the k-steps (an LDS-DMA holds the wave's issue port for ~100 cycles: issued in a block at the
@@ -355,26 +379,36 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(const HaloParams p
             const int s = kc * 9 + t;
             const unsigned char* Bb = Bs + (s % NSLOT) * B_BYTES;
             const int t2 = t + 2 >= 9 ? t + 2 - 9 : t + 2, kc2 = t + 2 >= 9 ? kc + 1 : kc;
-            load_w(0, Bb, 0);
+            if (NSET == 2) load_w(0, Bb, 0);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int cur = ks & 1, nxt = cur ^ 1;
-                if (ks < 3) {
-                    load_x(nxt, Ab, ks + 1);
-                    load_w(nxt, Bb, ks + 1);
+            for (int ks = 0; ks < KS; ++ks) {
+                const int cur = NSET == 2 ? (ks & 1) : 0, nxt = cur ^ 1;
+                if (NSET == 2) {
+                    if (ks < KS - 1) {
+                        load_x(nxt, Ab, ks + 1);
+                        load_w(nxt, Bb, ks + 1);
+                    }
+                } else {
+                    load_x(0, Ab, ks);
+                    load_w(0, Bb, ks);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (ks == 0) {
                     if (ADBL && t < APW) issue_a(t, kc + 1, (kc + 1) & 1, next_chunk);      // one halo piece of the next chunk per stage
-                } else if (ks - 1 < BPW) {
-                    issue_b(ks - 1, s + 2, kc2, t2, s + 2 < NS);
+                    if (KS == 1) {
+#pragma unroll
+                        for (int i = 0; i < BPW; ++i) issue_b(i, s + 2, kc2, t2, s + 2 < NS);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < BPW; ++i)
+                        if (i % (KS - 1) == ks - 1) issue_b(i, s + 2, kc2, t2, s + 2 < NS);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < NT; ++j)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][j], xf[cur][i], acc[j][i], 0, 0, 0);
+                    for (int i = 0; i < MT; ++i) acc[j][i] = F::mma(wf[cur][j], xf[cur][i], acc[j][i]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (!ADBL && t == 8) {
@@ -386,10 +420,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(const HaloParams p
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 tap_setup(0);
-                load_x(0, An, 0);
+                if (NSET == 2) load_x(0, An, 0);
             } else {
                 tap_setup(t == 8 ? 0 : t + 1);
-                load_x(0, t == 8 ? An : Ab, 0);               // (after the last stage: a read nobody uses)
+                if (NSET == 2) load_x(0, t == 8 ? An : Ab, 0);               // (after the last stage: a read nobody uses)
                 // all but what this stage issued has landed: stage s+1's weights, the halo pieces of earlier stages
                 wait_vm(((ADBL && t < APW) ? 1 : 0) + BPW);
                 __builtin_amdgcn_s_barrier();
@@ -417,16 +451,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(const HaloParams p
     constexpr int SLOT = TM * 32 * (TN * 64 + 16);            // bytes of a wave's staging slot
     if (!p.out_f32 && !p.accumulate && (p.ldo & 7) == 0 && 8 * SLOT <= (int)sizeof(lds)) {
         // (the last stage ended with a barrier: every wave is done with the halo and weight buffers, the slots reuse them)
-        store_tile_staged<TM, TN>(p, acc, lds + wave * SLOT, n0 + wn * TN * 32, lane,
-                                  [&](int row, bool& ok) { return pix_of_m(wm * TM * 32 + row, ok); });
+        store_tile_staged<M16, MT, NT>(p, acc, lds + wave * SLOT, n0 + wn * TN * 32, lane,
+                                       [&](int row, bool& ok) { return pix_of_m(wm * TM * 32 + row, ok); });
         return;
     }
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < MT; ++i) {
         bool ok;
-        const size_t pix = pix_of_m((wm * TM + i) * 32 + lr, ok);
+        const size_t pix = pix_of_m(wm * TM * 32 + i * MR + lrow, ok);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) store_acc(p, acc[j][i], ok, pix, n0 + (wn * TN + j) * 32 + 4 * lh);
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int g = 0; g < F::NQ; ++g) store_quad(p, F::quad(acc[j][i], g), ok, pix, n0 + wn * TN * 32 + j * MR + F::quad_ch(g, lk));
     }
 }
 
@@ -436,8 +472,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(const HaloParams p
 // once) and walks its share of the 8 x 32 patches with two halo buffers: the next patch's halo arrives by LDS-DMA while this one is
 // multiplied, nothing inside a patch needs a barrier (halo and filter are complete), one barrier per patch swaps the buffers, and the
 // stores of a patch drain under the next patch's MFMAs.  The layer is then bound by its HBM bytes (in + out = 0.74 GB at batch 32).
+template <bool M16>
 __global__ __launch_bounds__(512, 2) void conv3x3_bf16_k64_kernel(const HaloParams p) {
-    constexpr int TM = 2, WVN = 2, PH = 8, PW = 32, HW = PW + 2, HH = PH + 2;
+    typedef Mfma<M16> F;
+    constexpr int TM = 2, TN = 1, WVN = 2, PH = 8, PW = 32, HW = PW + 2, HH = PH + 2;
+    constexpr int MR = F::MR, MT = TM * 32 / MR, NT = TN * 32 / MR, KS = F::KS, NSTEP = 9 * KS;
     constexpr int NPIECE = (HH * HW + 7) / 8, A_BYTES = NPIECE * 1024, W_BYTES = 9 * 64 * 128, APW = (NPIECE + 7) / 8;
     static_assert(2 * A_BYTES + W_BYTES <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(128))) unsigned char lds[2 * A_BYTES + W_BYTES];
@@ -445,7 +484,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_k64_kernel(const HaloPara
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WVN, wn = wave % WVN;
-    const int lr = lane & 31, lh = lane >> 5;
+    const int lrow = lane & (MR - 1), lk = lane / MR;
     const __bf16* const zero = reinterpret_cast<const __bf16*>(g_zero_page);
     const int per_img = p.npw * p.nph, ntiles = p.tiles_m;
 
@@ -494,56 +533,65 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_k64_kernel(const HaloPara
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    int hbase[TM], kbase[TM];
+    int hbase[MT], kbase[MT];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = (wm * TM + i) * 32 + lr, py = m / PW, px = m - py * PW;
+    for (int i = 0; i < MT; ++i) {
+        const int m = wm * TM * 32 + i * MR + lrow, py = m / PW, px = m - py * PW;
         hbase[i] = py * HW + px;
         kbase[i] = px;
     }
-    const int wrow = wn * 32 + lr;
-    int w_off[4];
+    int w_off[NT][KS];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) w_off[ks] = wrow * 128 + (((2 * ks + lh) ^ ((wrow >> 1) & 7)) << 4);
+    for (int j = 0; j < NT; ++j) {
+        const int wrow = wn * 32 + j * MR + lrow;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) w_off[j][ks] = wrow * 128 + (((F::CPK * ks + lk) ^ ((wrow >> 1) & 7)) << 4);
+    }
 
     const unsigned lds_addr = (unsigned)(size_t)(lds_void*)lds;        // LDS byte address of the buffers (for the asm fragment reads)
     for (int it = 0; tile < ntiles; ++it, tile += gridDim.x) {
         const int next = tile + gridDim.x;
         int nimg = 0, noy0 = 0, nox0 = 0;
         if (next < ntiles) origin(next, nimg, noy0, nox0);
-        f32x16 acc[TM];
+        typename F::acc_t acc[NT][MT];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-        // 36 k-steps (9 taps x 4), fully unrolled; the fragments of step s + 3 are requested before the MFMAs of step s (four register
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4 * F::NQ; ++r) acc[j][i][r] = 0.f;
+        // 9 taps x KS k-steps, fully unrolled; the fragments of step s + LOOK are requested before the MFMAs of step s (LOOK + 1 register
         // sets, counted waits): with one step of lookahead every step waited ~200 cycles (eight waves' LDS traffic) for 64 cycles of MFMAs
-        constexpr int LOOK = 3;
-        bf16x8 xf[LOOK + 1][TM], wf[LOOK + 1];
+        constexpr int LOOK = M16 ? 1 : 3, RPS = MT + NT;               // reads per step
+        static_assert(RPS * LOOK <= 15, "lgkmcnt is a 4-bit counter");
+        bf16x8 xf[LOOK + 1][MT], wf[LOOK + 1][NT];
         const unsigned a_lds = lds_addr + (it & 1) * A_BYTES, w_lds = lds_addr + 2 * A_BYTES;
         auto load_step = [&](int set, int st) {
-            const int t = st >> 2, ks = st & 3;
+            const int t = st / KS, ks = st - t * KS;
             const int r = t / 3, s2 = t - 3 * r;
             const int dr = p.flip ? 2 - r : r, ds = p.flip ? 2 - s2 : s2;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                xf[set][i] = lds_read16(a_lds + (hbase[i] + dr * HW + ds) * 128 + (((2 * ks + lh) ^ (((kbase[i] + ds) >> 1) & 7)) << 4));
-            wf[set] = lds_read16(w_lds + t * 8192 + w_off[ks]);
+            for (int i = 0; i < MT; ++i)
+                xf[set][i] = lds_read16(a_lds + (hbase[i] + dr * HW + ds) * 128 + (((F::CPK * ks + lk) ^ (((kbase[i] + ds) >> 1) & 7)) << 4));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wf[set][j] = lds_read16(w_lds + t * 8192 + w_off[j][ks]);
         };
 #pragma unroll
         for (int st = 0; st < LOOK; ++st) load_step(st, st);
 #pragma unroll
-        for (int st = 0; st < 36; ++st) {
-            if (st + LOOK < 36) load_step((st + LOOK) % (LOOK + 1), st + LOOK);
+        for (int st = 0; st < NSTEP; ++st) {
+            if (st + LOOK < NSTEP) load_step((st + LOOK) % (LOOK + 1), st + LOOK);
             // the next patch's halo: one DMA per k-step at the start of the patch (an LDS-DMA holds the issue port ~100 cycles)
 #ifndef K64_NO_DMA
             if (st < APW && next < ntiles) issue_halo(st, nimg, noy0, nox0, (it & 1) ^ 1);
 #endif
-            if (st == 26) wait_vmcnt<0>();                    // ~5 taps after the last DMA and a whole patch after the last stores: nothing left to wait for
-            wait_lgkm_n(3 * (36 - 1 - st < LOOK ? 36 - 1 - st : LOOK));          // the reads of the steps after this one may stay in flight
+            if (st == NSTEP * 3 / 4) wait_vmcnt<0>();         // well after the last DMA and a whole patch after the last stores: nothing left to wait for
+            wait_lgkm_n(RPS * (NSTEP - 1 - st < LOOK ? NSTEP - 1 - st : LOOK));   // the reads of the steps after this one may stay in flight
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[st % (LOOK + 1)], xf[st % (LOOK + 1)][i], acc[i], 0, 0, 0);
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[j][i] = F::mma(wf[st % (LOOK + 1)][j], xf[st % (LOOK + 1)][i], acc[j][i]);
             __builtin_amdgcn_sched_barrier(0);
         }
         {
@@ -556,22 +604,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_k64_kernel(const HaloPara
             constexpr int SLOT = TM * 32 * (64 + 16);
             static_assert(8 * SLOT <= A_BYTES, "the eight staging slots reuse the halo buffer of the patch just multiplied");
 #ifdef K64_NO_STORE
-            if (acc[0][0] == 123.456f)                         // probe build: keep the accumulators alive, store nothing
+            if (acc[0][0][0] == 123.456f)                      // probe build: keep the accumulators alive, store nothing
 #endif
             if (!p.out_f32 && !p.accumulate && (p.ldo & 7) == 0) {
                 __builtin_amdgcn_s_barrier();                  // every wave has read its last fragment of this patch's halo
                 asm volatile("" ::: "memory");
-                f32x16 acc1[1][TM];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) acc1[0][i] = acc[i];
-                store_tile_staged<TM, 1>(p, acc1, lds + (it & 1) * A_BYTES + wave * SLOT, wn * 32, lane,
-                                         [&](int row, bool& ok) { return pix_of_m(wm * TM * 32 + row, ok); });
+                store_tile_staged<M16, MT, NT>(p, acc, lds + (it & 1) * A_BYTES + wave * SLOT, wn * 32, lane,
+                                               [&](int row, bool& ok) { return pix_of_m(wm * TM * 32 + row, ok); });
             } else {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
+                for (int i = 0; i < MT; ++i) {
                     bool ok;
-                    const size_t pix = pix_of_m((wm * TM + i) * 32 + lr, ok);
-                    store_acc(p, acc[i], ok, pix, wn * 32 + 4 * lh);
+                    const size_t pix = pix_of_m(wm * TM * 32 + i * MR + lrow, ok);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int g = 0; g < F::NQ; ++g) store_quad(p, F::quad(acc[j][i], g), ok, pix, wn * 32 + j * MR + F::quad_ch(g, lk));
                 }
             }
         }
@@ -584,9 +632,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_k64_kernel(const HaloPara
 int g_force_mode = -1;      // tuning aid: position space (0 / 1 / 2), -1 = by map size
 int g_force_bn = -1;        // tuning aid: 64 / 128, -1 = by channel count
 int g_k64 = 1;              // tuning aid: 0 = never the persistent K = 64 kernel
+// MFMA shape: 0 = 32x32x16 (default), 1 = 16x16x32 (ssd_tune_set_conv_bf16_mfma).  Measured interleaved on one device (tools/conv_bf16_bench.py,
+// batch 32): 631-637 vs 625-632 TFLOP/s over the forward layers, 686 vs 668-670 over the data gradients -- the kernels are not bound by MFMA
+// issue, so the higher clock the chip holds with the 16x16x32 shape (MI355X_MICROARCH.md) buys nothing here, and its twice-as-many fragment
+// registers cost the two-set read pipeline.
+int g_m16 = 0;
+
+template <int TM, int TN, int WVM, int WVN, int MODE, int PH, int APW, bool ADBL, bool M16>
+int launch_shape(HaloParams& p, hipStream_t st);
 
 template <int TM, int TN, int WVM, int WVN, int MODE, int PH, int APW, bool ADBL>
 int launch(HaloParams& p, hipStream_t st) {
+    if (g_m16) return launch_shape<TM, TN, WVM, WVN, MODE, PH, APW, ADBL, true>(p, st);
+    return launch_shape<TM, TN, WVM, WVN, MODE, PH, APW, ADBL, false>(p, st);
+}
+
+template <int TM, int TN, int WVM, int WVN, int MODE, int PH, int APW, bool ADBL, bool M16>
+int launch_shape(HaloParams& p, hipStream_t st) {
     constexpr int BM = WVM * TM * 32, BN = WVN * TN * 32;
     constexpr int PW = MODE == 1 ? 16 : 32;
     if (MODE == 2) {
@@ -602,7 +664,7 @@ int launch(HaloParams& p, hipStream_t st) {
         p.tiles_m = p.N * p.npw * p.nph;
     }
     p.tiles_n = ssd_cdiv(p.Nout, BN);
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<TM, TN, WVM, WVN, MODE, PH, APW, ADBL>), dim3(p.tiles_m * p.tiles_n), dim3(512), 0, st, p);
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<TM, TN, WVM, WVN, MODE, PH, APW, ADBL, M16>), dim3(p.tiles_m * p.tiles_n), dim3(512), 0, st, p);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
 }
@@ -619,7 +681,8 @@ int dispatch(HaloParams& p, hipStream_t st) {
         p.tiles_m = p.N * p.npw * p.nph;
         p.tiles_n = 1;
         const int blocks = p.tiles_m < 256 ? p.tiles_m : 256;                 // one persistent workgroup per CU
-        hipLaunchKernelGGL(conv3x3_bf16_k64_kernel, dim3(blocks), dim3(512), 0, st, p);
+        if (g_m16) hipLaunchKernelGGL(conv3x3_bf16_k64_kernel<true>, dim3(blocks), dim3(512), 0, st, p);
+        else hipLaunchKernelGGL(conv3x3_bf16_k64_kernel<false>, dim3(blocks), dim3(512), 0, st, p);
         SSD_CHECK_LAUNCH();
         return SSD_OK;
     }
@@ -643,6 +706,12 @@ extern "C" int ssd_tune_set_conv_bf16(int mode, int bn) {
     g_force_bn = bn;
     return SSD_OK;
 }
+// Tuning aid: MFMA shape of the bf16-tensor convolution kernels, 32 (v_mfma_f32_32x32x16_bf16, default) or 16 (v_mfma_f32_16x16x32_bf16).
+extern "C" int ssd_tune_set_conv_bf16_mfma(int rows) {
+    if (rows != 16 && rows != 32) return SSD_ERR_BAD_SHAPE;
+    g_m16 = rows == 16;
+    return SSD_OK;
+}
 // Tuning aid: 0 = conv1_2-shaped launches (K = 64, <= 64 output channels, 8 x 32 patches) on the general kernel instead of the persistent one.
 extern "C" int ssd_tune_set_conv_bf16_k64(int on) {
     g_k64 = on ? 1 : 0;
@@ -657,6 +726,7 @@ extern "C" int ssd_conv3x3_bf16(const void* x, int ldx, const void* w, int w_row
         ldo % 4 != 0 || w_rows <= 0)
         return SSD_ERR_BAD_SHAPE;
     if ((long)N * (H + 1) * (W + 2) >= (1L << 30)) return SSD_ERR_BAD_SHAPE;
+    if ((long)N * H * W * ldx >= (1L << 31) || (long)w_rows * 9 * K >= (1L << 31)) return SSD_ERR_BAD_SHAPE;      // 32-bit element offsets in the kernels
     if (!ssd_aligned16(x) || !ssd_aligned16(w) || !ssd_aligned16(out) || (bias && !ssd_aligned16(bias)) || (relu_mask && !ssd_aligned16(relu_mask)))
         return SSD_ERR_ALIGN;
     HaloParams p = {};

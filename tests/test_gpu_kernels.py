@@ -1221,8 +1221,9 @@ HALO_BF16_CASES = [
 ]
 
 
+@pytest.mark.parametrize("mfma", [16, 32])
 @pytest.mark.parametrize("case", HALO_BF16_CASES)
-def test_conv3x3_on_bf16_tensors_forward_and_data_gradient(case):
+def test_conv3x3_on_bf16_tensors_forward_and_data_gradient(case, mfma):
     """3x3 / s1 / p1 convolution with activations, gradients and weights in bf16 (f32 accumulate), every position space and both
     N tiles: forward (bias + ReLU, bf16 out; f32 out as the heads take it) and data gradient (mirrored taps, += an existing dx,
     ReLU mask from the bf16 activation) against torch-CPU f32 convolutions of the SAME bf16 operands.  f32 outputs within 2e-5
@@ -1237,6 +1238,7 @@ def test_conv3x3_on_bf16_tensors_forward_and_data_gradient(case):
     bias = torch.zeros(n_out)
     bias[:rows] = torch.randn(rows, generator=g)
     _lib.check(_lib.load().ssd_tune_set_conv_bf16(mode, bn), "tune")
+    _lib.check(_lib.load().ssd_tune_set_conv_bf16_mfma(mfma), "tune")          # both MFMA shapes (32x32x16 is the default)
     try:
         w_nchw = torch.zeros(n_out, k, 3, 3)
         w_nchw[:rows] = wt.float().reshape(rows, 3, 3, k).permute(0, 3, 1, 2)
@@ -1269,6 +1271,7 @@ def test_conv3x3_on_bf16_tensors_forward_and_data_gradient(case):
         assert bool((dx[act.to(dev) <= 0] == 0).all())
     finally:
         _lib.check(_lib.load().ssd_tune_set_conv_bf16(-1, -1), "tune")
+        _lib.check(_lib.load().ssd_tune_set_conv_bf16_mfma(32), "tune")
 
 
 @pytest.mark.parametrize("k,s,p,ceil,hw", POOLS)

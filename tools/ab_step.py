@@ -3,6 +3,7 @@ library switch (`ssd_tune_set_...`) or an attribute of the engine (`engine.<name
 
     python tools/ab_step.py ssd_tune_set_batched_units 0 1
     python tools/ab_step.py engine.first_fused 0 1
+    AB_CONV_DTYPE=bf16 python tools/ab_step.py ssd_tune_set_conv_bf16_k64 0 1        (the bf16-tensor mode)
 """
 import os
 import sys
@@ -23,6 +24,7 @@ def main():
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     net = Model.SSD_300().to(dev).train()
+    net.conv_dtype = os.environ.get("AB_CONV_DTYPE", "f32")
     tr = FlatSGDDataParallel(net, lr=1e-4)
     x, classes, boxes = bench.synth_batch(32, 1234, dev)
 
@@ -45,7 +47,7 @@ def main():
                 setattr(net._engine, fn[7:], type(getattr(net._engine, fn[7:]))(v))
                 net.invalidate_weight_cache()
             else:
-                _lib.check(getattr(lib, fn)(v), "tune")
+                _lib.check(getattr(lib, fn)(*([v] if fn != "ssd_tune_set_wgrad" else [-1, -1, v])), "tune")
             steps(2)
             res[v].append(steps(15))
     for v in vals:

@@ -12,6 +12,8 @@ bn = int(sys.argv[3]) if len(sys.argv) > 3 else -1
 _lib.check(_lib.load().ssd_tune_set_conv_bf16(mode, bn), "tune")
 if len(sys.argv) > 4:
     _lib.check(_lib.load().ssd_tune_set_conv_bf16_k64(int(sys.argv[4])), "tune")
+if len(sys.argv) > 5:
+    _lib.check(_lib.load().ssd_tune_set_conv_bf16_mfma(int(sys.argv[5])), "tune")
 dev = "cuda:0"
 LAYERS = [("conv1_2", 300, 64, 64), ("conv2_1", 150, 64, 128), ("conv2_2", 150, 128, 128), ("conv3_1", 75, 128, 256),
           ("conv3_2", 75, 256, 256), ("conv4_1", 38, 256, 512), ("conv4_2", 38, 512, 512), ("conv5_1", 19, 512, 512),
