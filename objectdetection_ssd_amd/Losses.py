@@ -143,16 +143,26 @@ def inference(l_, c_, index, top_k=200, phase='train', toDraw=True, min_score=0.
 inference.last_prior_ids = None
 
 
+def inference_batch_padded(l, c, sizes, top_k=200, min_score=0.2, iou_threshold=0.45):
+    """The batched decode as it leaves the device: (boxes (B,top_k,4) pixel xyxy, classes (B,top_k) int64, probs (B,top_k),
+    prior_ids (B,top_k) int32, count (B,) int32), rows i >= count[b] zero.  Four kernels + one memset, NO host synchronisation:
+    the primary form for a serving loop (slice on the host only when the detections are consumed there).  `sizes`: a (B,2) device
+    tensor of (img_w, img_h) is used as it is; anything else is uploaded."""
+    if not l.is_cuda:
+        raise RuntimeError("inference_batch_padded() runs on the gfx950 HIP kernels only (no CPU fallback)")
+    if torch.is_tensor(sizes) and sizes.is_cuda and sizes.dtype == torch.float32 and sizes.is_contiguous():
+        wh = sizes.reshape(-1, 2)
+    else:
+        wh = torch.as_tensor(sizes, dtype=torch.float32).reshape(-1, 2).to(l.device).contiguous()
+    pri, _ = _priors_on(l.device, l.shape[1])
+    return ops.decode_nms_batch(l.detach().float().contiguous(), c.detach().float().contiguous(), pri, wh, top_k, min_score, iou_threshold)
+
+
 def inference_batch(l, c, sizes, top_k=200, min_score=0.2, iou_threshold=0.45):
     """Batched `inference`: l (B,8732,4), c (B,8732,21), sizes = B (img_w, img_h)
-    pairs or a (B,2) tensor.  One kernel launch set and ONE host sync for the whole batch.  Returns a list of
+    pairs or a (B,2) tensor.  `inference_batch_padded` + ONE host sync (the counts) for the whole batch.  Returns a list of
     B tuples (boxes (K_i,4), classes (K_i,), probs (K_i,)); an image without detections gives ([], [], [])."""
-    if not l.is_cuda:
-        raise RuntimeError("inference_batch() runs on the gfx950 HIP kernels only (no CPU fallback)")
-    wh = torch.as_tensor(sizes, dtype=torch.float32).reshape(-1, 2).to(l.device).contiguous()
-    pri, _ = _priors_on(l.device, l.shape[1])
-    boxes, classes, probs, ids, count = ops.decode_nms_batch(l.detach().float().contiguous(), c.detach().float().contiguous(),
-                                                            pri, wh, top_k, min_score, iou_threshold)
+    boxes, classes, probs, ids, count = inference_batch_padded(l, c, sizes, top_k, min_score, iou_threshold)
     out = []
     for i, k in enumerate(count.tolist()):
         out.append(([], [], []) if k == 0 else (boxes[i, :k], classes[i, :k], probs[i, :k]))

@@ -1,16 +1,17 @@
 // Decode + softmax + per-class NMS + cross-class top-k for one image
 // (Losses.py:11-98 inference; Util.py:86-96 gcxgcy_to_cxcy, xywh_to_xyxy; Util.py:252-301 IoU).
 //
-//   D1 decode_softmax  thread per prior: box (cxcywh -> xyxy), class probabilities (class-major copy)
-//   D2 compact         block per class: candidates prob >= min_score -> 64-bit keys
-//                      (prob bits << 32 | ~prior index): descending key order = descending
-//                      prob, lower prior index first on ties (the CPU sort order)
+//   D1 decode_compact  thread per prior: box (cxcywh -> xyxy), class probabilities (the 21 scores of 256 priors staged through LDS:
+//                      coalesced reads), and straight away the candidates prob >= min_score of every class as 64-bit keys
+//                      (prob bits << 32 | ~prior index): descending key order = descending prob, lower prior index first on ties
+//                      (the CPU sort order).  Slots come from one atomic per (wave, class) -- ballot + prefix --
+//                      so the order inside keys[] varies from run to run; the ranks D3 computes from the unique keys do not.
 //   D3 rank_scatter    rank of every candidate = number of larger keys (keys are unique), so
 //                      the sort is a scatter; all classes and candidates in parallel
 //   D4 nms             block per class, greedy in sorted order, 64 rows at a time: suppression words by
 //                      wave ballot, in-chunk resolve by v_readlane, removed bitset in LDS
-//   D5 offsets/gather  class-major offsets and compact list of the kept boxes
-//   D6 topk_emit       if more than top_k survive: radix select of the top_k-th probability, ties in
+//   D5 topk_emit       class-major offsets and compact list of the kept boxes (first phase of the same block), then:
+//                      if more than top_k survive: radix select of the top_k-th probability, ties in
 //                      class-major order, rank of the selected entries in LDS; scale boxes by (w,h,w,h)
 // IoU uses the same contraction-free f32 sequence as the matcher.
 #include "common.h"
@@ -68,46 +69,50 @@ NmsWs carve(void* ws, int P, int C, int B) {
     return w;
 }
 
-__global__ void decode_softmax_kernel(const float* __restrict__ l_, const float* __restrict__ c_, const float* __restrict__ pri,
-                                      int P, int C, float* __restrict__ boxes, float* __restrict__ probs_t) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    const size_t img = blockIdx.z;                                  // one image per grid.z slice
-    l_ += img * P * 4; c_ += img * P * C; boxes += img * P * 4; probs_t += img * (size_t)(C - 1) * P;
-    const f32x4 g = *reinterpret_cast<const f32x4*>(l_ + (size_t)p * 4);
-    const f32x4 pr = *reinterpret_cast<const f32x4*>(pri + (size_t)p * 4);
-    // Util.py:89-91: g_c * p_wh / 10 + p_c ; exp(g_wh / 5) * p_wh
-    const float cx = g[0] * pr[2] / 10.f + pr[0], cy = g[1] * pr[3] / 10.f + pr[1];
-    const float w = expf(g[2] / 5.f) * pr[2], h = expf(g[3] / 5.f) * pr[3];
-    // Util.py:93-96: c - wh/2, c + wh/2
-    f32x4 b;
-    b[0] = cx - w / 2.f; b[1] = cy - h / 2.f; b[2] = cx + w / 2.f; b[3] = cy + h / 2.f;
-    *reinterpret_cast<f32x4*>(boxes + (size_t)p * 4) = b;
-    const float* x = c_ + (size_t)p * C;
-    float m = x[0];
-    for (int q = 1; q < C; ++q) m = fmaxf(m, x[q]);
-    float se = 0.f;
-    for (int q = 0; q < C; ++q) se += expf(x[q] - m);
-    for (int q = 0; q < C - 1; ++q) probs_t[(size_t)q * P + p] = expf(x[q] - m) / se;
-}
-
-__global__ __launch_bounds__(NB_T) void compact_kernel(const float* __restrict__ probs_t, int P, float min_score,
-                                                       uint64_t* __restrict__ keys, int32_t* __restrict__ cand_cnt) {
-    __shared__ int cnt;
-    const int c = blockIdx.x;
-    const size_t img = blockIdx.z, C1 = gridDim.x;
-    probs_t += img * C1 * P; keys += img * C1 * P; cand_cnt += img * (C1 + 1);
-    if (threadIdx.x == 0) cnt = 0;
+// grid = (ceil(P/256), 1, B).  cand_cnt[(C-1)+1 per image] must be zero on entry (hipMemsetAsync in front of the launch).
+__global__ __launch_bounds__(256) void decode_compact_kernel(const float* __restrict__ l_, const float* __restrict__ c_, const float* __restrict__ pri,
+                                                             int P, int C, float min_score, float* __restrict__ boxes, uint64_t* __restrict__ keys,
+                                                             int32_t* __restrict__ cand_cnt) {
+    extern __shared__ float sc[];                                   // [256][C] class scores of this block's priors
+    const int p0 = blockIdx.x * 256, tid = threadIdx.x, lane = tid & 63;
+    const int p = p0 + tid;
+    const size_t img = blockIdx.z;
+    const int C1 = C - 1;
+    l_ += img * P * 4; c_ += img * P * C; boxes += img * P * 4; keys += img * (size_t)C1 * P; cand_cnt += img * (C1 + 1);
+    const int rows = min(256, P - p0);
+    for (int e = tid; e < rows * C; e += 256) sc[e] = c_[(size_t)p0 * C + e];      // consecutive threads, consecutive floats
     __syncthreads();
-    for (int p = threadIdx.x; p < P; p += NB_T) {
-        const float v = probs_t[(size_t)c * P + p];
-        if (v >= min_score) {                                   // Losses.py:32 (NaN fails, as in torch)
-            const int pos = atomicAdd(&cnt, 1);
-            keys[(size_t)c * P + pos] = ((uint64_t)__float_as_uint(v) << 32) | (uint64_t)(0xffffffffu - (uint32_t)p);
+    const bool live = p < P;
+    float m = 0.f, se = 1.f;
+    if (live) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(l_ + (size_t)p * 4);
+        const f32x4 pr = *reinterpret_cast<const f32x4*>(pri + (size_t)p * 4);
+        // Util.py:89-91: g_c * p_wh / 10 + p_c ; exp(g_wh / 5) * p_wh
+        const float cx = g[0] * pr[2] / 10.f + pr[0], cy = g[1] * pr[3] / 10.f + pr[1];
+        const float w = expf(g[2] / 5.f) * pr[2], h = expf(g[3] / 5.f) * pr[3];
+        // Util.py:93-96: c - wh/2, c + wh/2
+        f32x4 b;
+        b[0] = cx - w / 2.f; b[1] = cy - h / 2.f; b[2] = cx + w / 2.f; b[3] = cy + h / 2.f;
+        *reinterpret_cast<f32x4*>(boxes + (size_t)p * 4) = b;
+        const float* x = sc + tid * C;                              // row stride C = 21 floats: odd, conflict-free
+        m = x[0];
+        for (int q = 1; q < C; ++q) m = fmaxf(m, x[q]);
+        se = 0.f;
+        for (int q = 0; q < C; ++q) se += expf(x[q] - m);
+    }
+    for (int q = 0; q < C1; ++q) {                                  // uniform trip count: the ballots need every lane
+        const float v = live ? expf(sc[tid * C + q] - m) / se : 0.f;
+        const bool hit = live && v >= min_score;                    // Losses.py:32 (NaN fails, as in torch)
+        const uint64_t mask = __ballot(hit);
+        if (mask == 0) continue;                                    // wave-uniform
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&cand_cnt[q], __popcll(mask));
+        base = __shfl(base, 0, 64);
+        if (hit) {
+            const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+            keys[(size_t)q * P + pos] = ((uint64_t)__float_as_uint(v) << 32) | (uint64_t)(0xffffffffu - (uint32_t)p);
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) cand_cnt[c] = cnt;
 }
 
 __global__ __launch_bounds__(256) void rank_scatter_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ cand_cnt,
@@ -256,34 +261,9 @@ __global__ __launch_bounds__(NB_T) void nms_kernel(const float* __restrict__ s_b
     if (tid == 0) kept_cnt[c] = running;
 }
 
-__global__ void offsets_kernel(const int32_t* __restrict__ kept_cnt, int C1, int32_t* __restrict__ offsets) {
-    kept_cnt += (size_t)blockIdx.z * (C1 + 1);
-    offsets += (size_t)blockIdx.z * (C1 + 2);
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        int o = 0;
-        for (int c = 0; c < C1; ++c) { offsets[c] = o; o += kept_cnt[c]; }
-        offsets[C1] = o;
-    }
-}
-
-// class-major compact list of the survivors: k_prob[offsets[c] + i], k_src = c*P + sorted position
-__global__ __launch_bounds__(256) void gather_kept_kernel(const float* __restrict__ s_prob, const int32_t* __restrict__ kept_pos,
-                                                          const int32_t* __restrict__ kept_cnt, const int32_t* __restrict__ offsets,
-                                                          int P, uint32_t* __restrict__ k_prob, int32_t* __restrict__ k_src) {
-    const int c = blockIdx.y;
-    const size_t img = blockIdx.z, C1 = gridDim.y;
-    s_prob += img * C1 * P; kept_pos += img * C1 * P; kept_cnt += img * (C1 + 1); offsets += img * (C1 + 2);
-    k_prob += img * C1 * P; k_src += img * C1 * P;
-    const int n = kept_cnt[c];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int src = c * P + kept_pos[(size_t)c * P + i];
-    k_prob[offsets[c] + i] = __float_as_uint(s_prob[src]);
-    k_src[offsets[c] + i] = src;
-}
-
 struct TopkArgs {
-    const float* s_boxes; const int32_t* s_idx; const uint32_t* k_prob; const int32_t* k_src; const int32_t* offsets;
+    const float* s_boxes; const int32_t* s_idx; const float* s_prob; const int32_t* kept_pos; const int32_t* kept_cnt;
+    uint32_t* k_prob; int32_t* k_src;           // scratch of this block: class-major compact list of the survivors (prob bits, c*P + sorted position)
     int P, C1, top_k; const float* wh;          // wh: (B,2) device array of (img_w, img_h)
     float* boxes; int64_t* classes; float* probs; int32_t* prior_ids; int32_t* count;
 };
@@ -295,7 +275,8 @@ struct TopkArgs {
 __global__ __launch_bounds__(NB_T) void topk_emit_kernel(TopkArgs a) {
     {
         const size_t img = blockIdx.z, K = (size_t)a.C1 * a.P;
-        a.s_boxes += img * K * 4; a.s_idx += img * K; a.k_prob += img * K; a.k_src += img * K; a.offsets += img * (a.C1 + 2);
+        a.s_boxes += img * K * 4; a.s_idx += img * K; a.k_prob += img * K; a.k_src += img * K;
+        a.s_prob += img * K; a.kept_pos += img * K; a.kept_cnt += img * (a.C1 + 1);
         a.wh += img * 2;
         a.boxes += img * a.top_k * 4; a.classes += img * a.top_k; a.probs += img * a.top_k; a.prior_ids += img * a.top_k; a.count += img;
     }
@@ -306,8 +287,26 @@ __global__ __launch_bounds__(NB_T) void topk_emit_kernel(TopkArgs a) {
     __shared__ int hist[256];
     __shared__ int wsum_gt[NB_T / 64], wsum_eq[NB_T / 64];
     __shared__ int bc[3];
+    __shared__ int offs[257];                                          // class-major exclusive offsets of the survivors (C1 <= 255)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int total = a.offsets[a.C1];
+    if (tid == 0) {
+        int o = 0;
+        for (int c = 0; c < a.C1; ++c) { offs[c] = o; o += a.kept_cnt[c]; }
+        offs[a.C1] = o;
+    }
+    __syncthreads();
+    const int total = offs[a.C1];
+    // the compact list (the two kernels offsets / gather_kept of the earlier version): written and read by this block only
+    for (int c = wave; c < a.C1; c += NB_T / 64) {
+        const int n = offs[c + 1] - offs[c];
+        for (int i = lane; i < n; i += 64) {
+            const int src = c * a.P + a.kept_pos[(size_t)c * a.P + i];
+            a.k_prob[offs[c] + i] = __float_as_uint(a.s_prob[src]);
+            a.k_src[offs[c] + i] = src;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
     auto emit = [&](int gpos, int slot) {
         const int src = a.k_src[gpos];
         const f32x4 b = *reinterpret_cast<const f32x4*>(a.s_boxes + (size_t)src * 4);
@@ -412,9 +411,9 @@ extern "C" int ssd_decode_nms_batch(const float* l_, const float* c_, const floa
     hipStream_t st = (hipStream_t)stream;
     const NmsWs w = carve(workspace, P, n_classes, B);
     const int C1 = n_classes - 1;
-    hipLaunchKernelGGL(decode_softmax_kernel, dim3(ssd_cdiv(P, 256), 1, B), dim3(256), 0, st, l_, c_, priors_cxcywh, P, n_classes, w.boxes, w.probs_t);
-    SSD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(compact_kernel, dim3(C1, 1, B), dim3(NB_T), 0, st, w.probs_t, P, min_score, w.keys, w.cand_cnt);
+    if (hipMemsetAsync(w.cand_cnt, 0, (size_t)n_classes * 4 * B, st) != hipSuccess) return SSD_ERR_LAUNCH;     // the candidate counters of decode_compact
+    hipLaunchKernelGGL(decode_compact_kernel, dim3(ssd_cdiv(P, 256), 1, B), dim3(256), (size_t)256 * n_classes * 4, st, l_, c_, priors_cxcywh, P,
+                       n_classes, min_score, w.boxes, w.keys, w.cand_cnt);
     SSD_CHECK_LAUNCH();
     hipLaunchKernelGGL(rank_scatter_kernel, dim3(ssd_cdiv(P, 256), C1, B), dim3(256), 0, st, w.keys, w.cand_cnt, w.boxes, P, w.s_boxes, w.s_prob, w.s_idx);
     SSD_CHECK_LAUNCH();
@@ -433,12 +432,7 @@ extern "C" int ssd_decode_nms_batch(const float* l_, const float* c_, const floa
     }
     hipLaunchKernelGGL(nms_kernel, dim3(C1, 1, B), dim3(NB_T), lds, st, w.s_boxes, w.cand_cnt, P, iou_threshold, CR, w.kept_pos, w.kept_cnt);
     SSD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(offsets_kernel, dim3(1, 1, B), dim3(64), 0, st, w.kept_cnt, C1, w.offsets);
-    SSD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gather_kept_kernel, dim3(ssd_cdiv(P, 256), C1, B), dim3(256), 0, st, w.s_prob, w.kept_pos, w.kept_cnt, w.offsets, P,
-                       w.k_prob, w.k_src);
-    SSD_CHECK_LAUNCH();
-    TopkArgs ta{w.s_boxes, w.s_idx, w.k_prob, w.k_src, w.offsets, P, C1, top_k, img_wh, boxes, classes, probs, prior_ids, count};
+    TopkArgs ta{w.s_boxes, w.s_idx, w.s_prob, w.kept_pos, w.kept_cnt, w.k_prob, w.k_src, P, C1, top_k, img_wh, boxes, classes, probs, prior_ids, count};
     hipLaunchKernelGGL(topk_emit_kernel, dim3(1, 1, B), dim3(NB_T), (size_t)top_k * 8, st, ta);
     SSD_CHECK_LAUNCH();
     return SSD_OK;

@@ -989,6 +989,27 @@ def test_loss_is_additive_over_images_at_full_batch():
     assert abs(s_loc - l_all.item()) <= 1e-5 * abs(l_all.item()) and abs(s_conf - c_all.item()) <= 1e-5 * abs(c_all.item())
 
 
+def test_padded_decode_is_the_list_form_without_the_sync():
+    """`inference_batch_padded` (device tensors + counts, no host synchronisation) row by row equals `inference_batch`; rows past the
+    count are zero; a device tensor of sizes is used as it is.  Two calls give identical results although the candidate keys land
+    in a different order every time (slots come from atomics): the ranks are computed from the unique keys."""
+    from objectdetection_ssd_amd import Losses
+    g = torch.Generator().manual_seed(77)
+    l = torch.randn(5, 8732, 4, generator=g).to(DEV)
+    c = (3 * torch.randn(5, 8732, 21, generator=g)).to(DEV)
+    c[3, :, :20] = -20.0                                                # an image without detections
+    sizes = torch.tensor([[500., 375.], [300., 300.], [640., 480.], [100., 100.], [375., 500.]], device=DEV)
+    b, k, p, ids, cnt = Losses.inference_batch_padded(l, c, sizes, top_k=150)
+    b2, k2, p2, ids2, cnt2 = Losses.inference_batch_padded(l, c, sizes, top_k=150)
+    assert torch.equal(b, b2) and torch.equal(k, k2) and torch.equal(p, p2) and torch.equal(ids, ids2) and torch.equal(cnt, cnt2)
+    outs = Losses.inference_batch(l, c, sizes.cpu(), top_k=150)
+    assert cnt.tolist()[3] == 0 and outs[3] == ([], [], [])
+    for i, n in enumerate(cnt.tolist()):
+        if n:
+            assert torch.equal(b[i, :n], outs[i][0]) and torch.equal(k[i, :n], outs[i][1]) and torch.equal(p[i, :n], outs[i][2])
+        assert bool((b[i, n:] == 0).all()) and bool((p[i, n:] == 0).all())
+
+
 def test_decode_output_invariants_at_full_batch():
     """32 images x 8732 priors through the batched decode: every kept score >= min_score, classes 0..19 in class-major order,
     scores descending inside a class, at most top_k rows, and no two kept boxes of one class overlap by >= the NMS threshold
