@@ -78,6 +78,12 @@ int ssd_conv2d_fwd_bf16(const float* x, const float* w_ohwi, const float* bias, 
                         const ssd_conv_geom* g, int relu, void* stream);
 int ssd_conv2d_dgrad_bf16(const float* dy, int ldy, const float* w_ihwo, int Co_pad, float* dx,
                           const float* relu_mask, int accumulate, const ssd_conv_geom* g, void* stream);
+/* ... with the split-K workspace of ssd_conv2d_igemm_workspace(g, direction) (may be NULL): small grids with a deep K loop -- the 10x10 ... 1x1
+ * maps of the aux blocks and heads -- are cut into K slices, reduced in slice order (reproducible) */
+int ssd_conv2d_fwd_bf16_ws(const float* x, const float* w_ohwi, const float* bias, float* y, int ldy, const ssd_conv_geom* g, int relu,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int ssd_conv2d_dgrad_bf16_ws(const float* dy, int ldy, const float* w_ihwo, int Co_pad, float* dx, const float* relu_mask, int accumulate,
+                             const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream);
 int ssd_conv2d_wgrad_bf16(const float* x, const float* dy, int ldy, float* dw_oihw, float* dbias,
                           const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream);
 int ssd_tune_set_igemm_bf16(int tile);   /* 0 = 256x128, 1 = 128x128, 2 = 128x64, 3 = 64x64, -1 = automatic */

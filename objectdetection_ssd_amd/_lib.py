@@ -54,6 +54,8 @@ SIGNATURES = {
     "ssd_conv2d_fwd_bf16": (_I, [_P, _P, _P, _P, _I, _G, _I, _P]),
     "ssd_conv2d_dgrad_bf16": (_I, [_P, _I, _P, _I, _P, _P, _I, _G, _P]),
     "ssd_conv2d_wgrad_bf16": (_I, [_P, _P, _I, _P, _P, _G, _P, _Z, _P]),
+    "ssd_conv2d_fwd_bf16_ws": (_I, [_P, _P, _P, _P, _I, _G, _I, _P, _Z, _P]),
+    "ssd_conv2d_dgrad_bf16_ws": (_I, [_P, _I, _P, _I, _P, _P, _I, _G, _P, _Z, _P]),
     "ssd_tune_set_igemm_bf16": (_I, [_I]),
     "ssd_weight_split_bf16x3": (_I, [_P, _P, _Z, _P]),
     "ssd_conv2d_fwd_x3": (_I, [_P, _P, _I, _P, _P, _I, _G, _I, _P]),

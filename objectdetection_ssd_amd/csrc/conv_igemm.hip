@@ -598,11 +598,14 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int kc = p.Ca / BK;
-    const int KT = T * kc;
+    // this block's K steps: all of them, or the blockIdx.y-th slice of a split-K launch (small grids with a deep K loop: the tiny maps of
+    // the aux blocks and heads -- one or two blocks walking 72 K steps were 60 us per layer, slower than the f32 path's split launches)
+    const int kt_begin = p.ksplit > 1 ? (int)blockIdx.y * p.kt_per_split : 0;
+    const int KT = p.ksplit > 1 ? min(T * kc - kt_begin, p.kt_per_split) : T * kc;
     f32x4 ra[A_ROWS], rb[B_ROWS];
-    int c_nxt = 0, r_nxt = 0, s_nxt = 0;
-    unsigned soff_a = 0, soff_b = 0;
-    tap_offsets(0, 0);
+    int c_nxt = kt_begin % kc, r_nxt = (kt_begin / kc) / p.S, s_nxt = (kt_begin / kc) % p.S;
+    unsigned soff_a = (unsigned)c_nxt * BK * 4, soff_b = (unsigned)kt_begin * BK * 4;
+    tap_offsets(r_nxt, s_nxt);
     auto issue_loads = [&]() {
 #pragma unroll
         for (int j = 0; j < A_ROWS; ++j) ra[j] = buf_load16(srd_a, voff_a[j], soff_a);
@@ -658,6 +661,21 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmParams p) {
         }
     }
 
+    if (p.ksplit > 1) {                                   // uniform: raw partial tile, finished by splitk_reduce_kernel
+        float* slab = p.slab + (size_t)blockIdx.y * p.M * p.Nout;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + (wn * TN + j) * 32 + lr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (n < p.Nout && m < p.M) slab[(size_t)m * p.Nout + n] = acc[i][j][r];
+                }
+            }
+        return;
+    }
     igemm_epilogue<BM, TM, TN>(p, acc, m0, n0, wm, wn, lr, lh);
 }
 
@@ -1119,25 +1137,44 @@ int launch_igemm_bf16(IgemmParams& p, hipStream_t st) {
     p.tiles_n = ssd_cdiv(p.Nout, BN);
     p.rcp_howo = 1.0f / (float)(p.Ho * p.Wo);
     p.rcp_wo = 1.0f / (float)p.Wo;
-    hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, WM, WN>), dim3(p.tiles_m * p.tiles_n, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, st, p);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
 }
 
-int dispatch_igemm_bf16(IgemmParams& p, hipStream_t st) {
+int plan_ksplit(int M, int Nout, int Ca, int taps);
+
+int dispatch_igemm_bf16(IgemmParams& p, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0) {
     int t = g_bf16_tile;
+    p.ksplit = 1;
     if (t < 0) {
         // measured (tools/conv_bench.py bf16): 128x128 wins once it yields >= ~300 blocks (300-620 TFLOP/s),
         // 128x64 for the 64-channel outputs, 64x64 for the small maps
         const long b128 = (long)ssd_cdiv(p.M, 128) * ssd_cdiv(p.Nout, 128);
         t = p.Nout <= 64 ? 2 : (b128 >= 300 ? 1 : 3);
     }
-    switch (t) {
-        case 0: return launch_igemm_bf16<256, 128, 4, 1>(p, st);
-        case 1: return launch_igemm_bf16<128, 128, 2, 2>(p, st);
-        case 2: return launch_igemm_bf16<128, 64, 4, 1>(p, st);
-        default: return launch_igemm_bf16<64, 64, 2, 2>(p, st);
+    if (t == 3 && ws != nullptr) {                              // 64 x 64 tiles on a small grid with a deep K loop: K slices + the f32 path's reduction
+        const int k = plan_ksplit(p.M, p.Nout, p.Ca, p.R * p.S);
+        if (k > 1 && (size_t)k * p.M * p.Nout * sizeof(float) <= ws_bytes) {
+            p.ksplit = k;
+            p.kt_per_split = ssd_cdiv(p.R * p.S * (p.Ca / BK), k);
+            p.slab = static_cast<float*>(ws);
+        }
     }
+    int e;
+    switch (t) {
+        case 0: e = launch_igemm_bf16<256, 128, 4, 1>(p, st); break;
+        case 1: e = launch_igemm_bf16<128, 128, 2, 2>(p, st); break;
+        case 2: e = launch_igemm_bf16<128, 64, 4, 1>(p, st); break;
+        default: e = launch_igemm_bf16<64, 64, 2, 2>(p, st); break;
+    }
+    if (e != SSD_OK || p.ksplit <= 1) return e;
+    const size_t total = (size_t)p.M * p.Nout;
+    const int rb = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, st, p.slab, p.ksplit, p.M, p.Nout, p.ldo, p.bias, p.out, p.mask,
+                       p.relu, p.accumulate);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
 }
 
 int check_geom(const ssd_conv_geom* g) {
@@ -1173,7 +1210,7 @@ static int conv2d_fwd_impl(const float* x, const float* w_ohwi, const float* bia
     p.Nout = g->Co; p.Nrows = g->Co; p.ldo = ldy; p.R = g->R; p.S = g->S;
     p.sm = g->stride; p.sd = 1; p.off = -g->pad; p.dstep = g->dil;
     p.M = g->N * g->Ho * g->Wo; p.relu = relu; p.accumulate = accumulate;
-    return bf16 ? dispatch_igemm_bf16(p, (hipStream_t)stream) : dispatch_igemm(p, (hipStream_t)stream, ws, ws_bytes);
+    return bf16 ? dispatch_igemm_bf16(p, (hipStream_t)stream, ws, ws_bytes) : dispatch_igemm(p, (hipStream_t)stream, ws, ws_bytes);
 }
 
 // Workspace the split-K path of ssd_conv2d_fwd_ws (direction 0) / ssd_conv2d_dgrad_ws (direction 1) wants for this
@@ -1209,6 +1246,12 @@ extern "C" int ssd_conv2d_fwd_accum_bf16(const float* x, const float* w_ohwi, co
 extern "C" int ssd_conv2d_fwd(const float* x, const float* w_ohwi, const float* bias, float* y, int ldy,
                               const ssd_conv_geom* g, int relu, void* stream) {
     return conv2d_fwd_impl(x, w_ohwi, bias, y, ldy, g, relu, stream, false);
+}
+// bf16-operand kernels with the split-K workspace of ssd_conv2d_igemm_workspace (same plan as the f32 kernels: small grids, deep K)
+extern "C" int ssd_conv2d_fwd_bf16_ws(const float* x, const float* w_ohwi, const float* bias, float* y, int ldy, const ssd_conv_geom* g,
+                                      int relu, void* workspace, size_t workspace_bytes, void* stream) {
+    if (workspace != nullptr && !ssd_aligned16(workspace)) return SSD_ERR_ALIGN;
+    return conv2d_fwd_impl(x, w_ohwi, bias, y, ldy, g, relu, stream, true, 0, workspace, workspace_bytes);
 }
 extern "C" int ssd_conv2d_fwd_bf16(const float* x, const float* w_ohwi, const float* bias, float* y, int ldy,
                                    const ssd_conv_geom* g, int relu, void* stream) {
@@ -1249,7 +1292,7 @@ static int conv2d_dgrad_impl(const float* dy, int ldy, const float* w_ihwo, int 
         p.stamps = nullptr;
         return launch_igemm<64, 64, 2, 2, 1, false, true>(p, (hipStream_t)stream);
     }
-    return bf16 ? dispatch_igemm_bf16(p, (hipStream_t)stream) : dispatch_igemm(p, (hipStream_t)stream, ws, ws_bytes);
+    return bf16 ? dispatch_igemm_bf16(p, (hipStream_t)stream, ws, ws_bytes) : dispatch_igemm(p, (hipStream_t)stream, ws, ws_bytes);
 }
 
 extern "C" int ssd_tune_set_dgrad_parity(int on) {
@@ -1270,6 +1313,11 @@ extern "C" int ssd_conv2d_dgrad(const float* dy, int ldy, const float* w_ihwo, i
 extern "C" int ssd_conv2d_dgrad_bf16(const float* dy, int ldy, const float* w_ihwo, int Co_pad, float* dx,
                                      const float* relu_mask, int accumulate, const ssd_conv_geom* g, void* stream) {
     return conv2d_dgrad_impl(dy, ldy, w_ihwo, Co_pad, dx, relu_mask, accumulate, g, stream, true);
+}
+extern "C" int ssd_conv2d_dgrad_bf16_ws(const float* dy, int ldy, const float* w_ihwo, int Co_pad, float* dx, const float* relu_mask,
+                                        int accumulate, const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream) {
+    if (workspace != nullptr && !ssd_aligned16(workspace)) return SSD_ERR_ALIGN;
+    return conv2d_dgrad_impl(dy, ldy, w_ihwo, Co_pad, dx, relu_mask, accumulate, g, stream, true, workspace, workspace_bytes);
 }
 extern "C" int ssd_tune_set_igemm_bf16(int tile) {
     if (tile < -1 || tile > 3) return SSD_ERR_BAD_SHAPE;

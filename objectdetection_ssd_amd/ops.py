@@ -217,12 +217,12 @@ def conv2d_fwd(x: torch.Tensor, w_ohwi: torch.Tensor, bias: Optional[torch.Tenso
             check(rc, "conv3x3_halo_fwd_bf16")
             return out
     lib = _lib.load()
-    if bf16:
-        check(lib.ssd_conv2d_fwd_bf16(x.data_ptr(), w_ohwi.data_ptr(), _ptr(bias), out.data_ptr(), ld, C.byref(g), int(relu), _stream()),
-              "conv2d_fwd_bf16")
-        return out
     nbytes = lib.ssd_conv2d_igemm_workspace(C.byref(g), 0)             # > 0 only for small grids with a deep K loop
     ws = workspace(nbytes, x.device, "igemm") if nbytes else None
+    if bf16:
+        check(lib.ssd_conv2d_fwd_bf16_ws(x.data_ptr(), w_ohwi.data_ptr(), _ptr(bias), out.data_ptr(), ld, C.byref(g), int(relu), _ptr(ws),
+                                         ws.numel() if ws is not None else 0, _stream()), "conv2d_fwd_bf16")
+        return out
     check(lib.ssd_conv2d_fwd_ws(x.data_ptr(), w_ohwi.data_ptr(), _ptr(bias), out.data_ptr(), ld, C.byref(g), int(relu), _ptr(ws),
                                 ws.numel() if ws is not None else 0, _stream()), "conv2d_fwd")
     return out
@@ -258,12 +258,12 @@ def conv2d_dgrad(dy: torch.Tensor, w_ihwo: torch.Tensor, g: ConvGeom, dx: Option
             check(rc, "conv3x3_halo_dgrad_bf16")
             return dx
     lib = _lib.load()
-    if bf16:
-        check(lib.ssd_conv2d_dgrad_bf16(dy.data_ptr(), co_pad, w_ihwo.data_ptr(), co_pad, dx.data_ptr(), _ptr(relu_mask), int(accumulate),
-                                        C.byref(g), _stream()), "conv2d_dgrad_bf16")
-        return dx
     nbytes = lib.ssd_conv2d_igemm_workspace(C.byref(g), 1)
     ws = workspace(nbytes, dy.device, "igemm") if nbytes else None
+    if bf16:
+        check(lib.ssd_conv2d_dgrad_bf16_ws(dy.data_ptr(), co_pad, w_ihwo.data_ptr(), co_pad, dx.data_ptr(), _ptr(relu_mask), int(accumulate),
+                                           C.byref(g), _ptr(ws), ws.numel() if ws is not None else 0, _stream()), "conv2d_dgrad_bf16")
+        return dx
     check(lib.ssd_conv2d_dgrad_ws(dy.data_ptr(), co_pad, w_ihwo.data_ptr(), co_pad, dx.data_ptr(), _ptr(relu_mask), int(accumulate),
                                   C.byref(g), _ptr(ws), ws.numel() if ws is not None else 0, _stream()), "conv2d_dgrad")
     return dx
