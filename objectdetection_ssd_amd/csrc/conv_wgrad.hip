@@ -413,8 +413,12 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const WgradParams
     constexpr unsigned ES = IN_BF16 ? 2u : 4u;                  // bytes per element of x / dy
     constexpr int BT = 64, CHUNKS = 16, RPP = 16;
     constexpr int PADX = TAPS == 9 ? DIL : 0;
-    constexpr int HHd = PH + 2 * PADX, HWd = PW + 2 * PADX, HPIXd = HHd * HWd, XP = (HPIXd + RPP - 1) / RPP;
-    __shared__ __attribute__((aligned(16))) __bf16 Ys[PH * PW * LDT];
+    // TAPS = 1: a "patch" is 128 CONSECUTIVE pixels of the flattened batch (no 2-D structure to respect, no halo): 8 k-steps = 8 MFMAs per
+    // wave between two barriers instead of the 2 a 32-pixel patch gives a single tap (fc7: 0.22 ms at 112 TFLOP/s with 32-pixel patches)
+    constexpr int NPP = TAPS == 1 ? 128 : PH * PW;             // pixels per patch
+    constexpr int YP = NPP / RPP, KSTEPS = NPP / 16;
+    constexpr int HHd = PH + 2 * PADX, HWd = PW + 2 * PADX, HPIXd = TAPS == 1 ? NPP : HHd * HWd, XP = (HPIXd + RPP - 1) / RPP;
+    __shared__ __attribute__((aligned(16))) __bf16 Ys[NPP * LDT];
     __shared__ __attribute__((aligned(16))) __bf16 Xs[HPIXd * LDT];
     __shared__ float bias_red[256 * 4];
 
@@ -430,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const WgradParams
     const int co0 = tile_co * BT, ci0 = tile_ci * BT;
     const int npw = (p.Wo + PW - 1) / PW, nph = (p.Ho + PH - 1) / PH;
     const int per_img = npw * nph;
-    const int npatch = per_img * (p.M / (p.Ho * p.Wo));
+    const int npatch = TAPS == 1 ? (p.M + NPP - 1) / NPP : per_img * (p.M / (p.Ho * p.Wo));
     const int pb = split * p.m_per_split;
     const int pe = min(npatch, pb + p.m_per_split);
 
@@ -444,9 +448,9 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const WgradParams
     const __amdgpu_buffer_rsrc_t srd_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t srd_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
 
-    int ypy[2], ypx[2], xhy[XP], xhx[XP];
+    int ypy[YP], ypx[YP], xhy[XP], xhx[XP];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { const int q = prow + RPP * j; ypy[j] = q / PW; ypx[j] = q % PW; }
+    for (int j = 0; j < YP; ++j) { const int q = prow + RPP * j; ypy[j] = q / PW; ypx[j] = q % PW; }
 #pragma unroll
     for (int j = 0; j < XP; ++j) { const int q = prow + RPP * j; xhy[j] = q / HWd; xhx[j] = q % HWd; }
 
@@ -458,17 +462,27 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const WgradParams
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     typedef typename std::conditional<IN_BF16, u32x2, f32x4>::type raw_t;      // four channels as they come from memory
-    raw_t ry[2], rx[XP];
+    raw_t ry[YP], rx[XP];
     auto load4 = [](__amdgpu_buffer_rsrc_t srd, unsigned voff) -> raw_t {
         if constexpr (IN_BF16) return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(srd, (int)voff, 0, 0));
         else return buf_load16(srd, voff, 0);
     };
 
     auto issue_loads = [&](int patch) {
+        if constexpr (TAPS == 1) {                             // pixel m = patch * 128 + row: the same row of dy and of x (1x1, stride 1, no padding)
+#pragma unroll
+            for (int j = 0; j < YP; ++j) {
+                const int m = patch * NPP + prow + RPP * j;
+                const bool ok = m < p.M;
+                ry[j] = load4(srd_y, ok && y_col_ok ? (unsigned)m * ldy4 + y_col : OOB);
+                rx[j] = load4(srd_x, ok && x_col_ok ? (unsigned)m * ci4 + x_col : OOB);
+            }
+            return;
+        }
         const int n = patch / per_img, rem = patch - n * per_img;
         const int oh0 = (rem / npw) * PH, ow0 = (rem % npw) * PW;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < YP; ++j) {
             const int oh = oh0 + ypy[j], ow = ow0 + ypx[j];
             const bool ok = y_col_ok && oh < p.Ho && ow < p.Wo;
             const unsigned v = ok ? (unsigned)((n * p.Ho + oh) * p.Wo + ow) * ldy4 + y_col : OOB;
@@ -488,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const WgradParams
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < YP; ++j) {
             const bf16x4 b = to_bf16(ry[j]);
             *reinterpret_cast<bf16x4*>(&Ys[(prow + RPP * j) * LDT + chunk * 4]) = b;
             if (do_bias) {                                    // bias gradient: f32 sums of dy as it is stored
@@ -509,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const WgradParams
             const bool more = patch + 1 < pe;
             if (more) issue_loads(patch + 1);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < KSTEPS; ++ks) {
                 // k = 8*lh + j  <->  patch pixel (py = 2ks + lh, px = j)
                 const bf16x8 a = tr_frag(Ys, (2 * ks + lh) * PW, wm * 32, lane);
                 if constexpr (TAPS == 9) {
@@ -642,7 +656,8 @@ WgradPlan plan_wgrad(const ssd_conv_geom* g, bool bf16 = false) {
         pl.bt = 64; pl.nbuf = 1;
         pl.tiles_co = ssd_cdiv(g->Co, 64);
         pl.tiles_ci = ssd_cdiv(g->Ci, 64);
-        const int npatch = g->N * ssd_cdiv(g->Ho, SHAPES[pl.shape][0]) * ssd_cdiv(g->Wo, SHAPES[pl.shape][1]);
+        const int npatch = (bf16 && g->R == 1) ? ssd_cdiv(M, 128)                    // the bf16 patch kernel's 1x1 form: 128 consecutive pixels
+                                               : g->N * ssd_cdiv(g->Ho, SHAPES[pl.shape][0]) * ssd_cdiv(g->Wo, SHAPES[pl.shape][1]);
         const int per_split = pl.tiles_co * pl.tiles_ci;
         const int bpc = g_force_blocks_per_cu > 0 ? g_force_blocks_per_cu : 2;       // exactly the 2 resident blocks per CU: no tail round
         int ns = ssd_cdiv(256 * bpc, per_split);
