@@ -265,6 +265,22 @@ int ssd_tune_set_wino_fused(int mode);
  * generic 64 x 64 implicit-GEMM kernel.  1: wherever K % 32 == 0 and K >= 64; -1 (default) / 0: never -- measured no faster (both kernels
  * sit at the device's sustained f32 MFMA rate); kept, tested bit-identical, as the evidence for that statement. */
 int ssd_tune_set_gemm_nt(int mode);
+/* f32 plane GEMMs on the bf16 MFMA from three exact bf16 limbs per operand (csrc/gemm_x3.hip; the Winograd-domain products of the
+ * 3x3 layers, Model.py:135-156): out[b][m][n] = sum_k a[b][m][k] * w[b][n][k].  The filter planes are split once
+ * (ssd_gemm_x3_split_weights: w [nbatch][rows][K] f32 -> w3, ssd_gemm_x3_weights_bytes(rows, K, nbatch) bytes); K % 16 == 0, n_rows >= N.
+ * ssd_gemm_planes_f32: the same product on the f32 MFMA (K % 32 == 0), the kernel the x3 form replaces -- both are public for the
+ * parity test and tools/gemm_x3_bench.py. */
+/* ssd_wino_uses_x3(mo, K): 1 if the F(4x4) plane GEMMs of reduction length K run the three-limb form -- the transformed filter of such
+ * a layer (U_fwd: K = Ci; U_bwd: K = Co_pad) is then NOT [36][rows][K] f32 but [36][K/16][3][pad128(rows)][16] bf16 limbs
+ * (ssd_gemm_x3_weights_bytes(rows, K, 36) bytes, zero-initialised by the caller: padding rows are never written), both from
+ * ssd_wino_weights and from a kind-0 weight job with bit 0 (out_fwd) / bit 1 (out_bwd) of pad0 set.  ssd_tune_set_wino_x3(0 | 1 | -1):
+ * off / on / the default (environment SSD_WINO_X3, on unless "0"); filters transformed under one setting must not be used under another. */
+int ssd_wino_uses_x3(int mo, int K);
+int ssd_tune_set_wino_x3(int on);
+size_t ssd_gemm_x3_weights_bytes(int rows, int K, int nbatch);
+int ssd_gemm_x3_split_weights(const float* w, void* w3, int rows, int K, int nbatch, void* stream);
+int ssd_gemm_planes_x3(const float* a, const void* w3, float* out, int M, int K, int N, int n_rows, int nbatch, void* stream);
+int ssd_gemm_planes_f32(const float* a, const float* w, float* out, int M, int K, int N, int n_rows, int nbatch, void* stream);
 int ssd_has_experimental(void);           /* 1 if built with SSD_EXPERIMENTAL: gemm_nt.hip and wino4_full_kernel (both off by default, forced by ssd_tune_set_gemm_nt(1) / ssd_tune_set_wino_full(1)) are present */
 /* The whole convolution (input transform too) in one kernel where the reduction length is 64 (128 when forced): -1 automatic, 0 never, 1 force.
  * ssd_conv3x3_wino_uses_full tells the caller whether a geometry's forward (0) / data gradient from dy (1) takes that kernel -- it then

@@ -285,7 +285,7 @@ class _Engine:
 
     def _wino_weights(self, key: str, tensors, co_pad: int):
         """Cached Winograd-domain filters (U_fwd [16][Co][Ci], U_bwd [16][Ci][co_pad]), refreshed when a parameter changes."""
-        sig = tuple((t.data_ptr(), t._version) for t in tensors)
+        sig = tuple((t.data_ptr(), t._version) for t in tensors) + (ops.wino_x3(4, 256),)     # + the GEMM form the filters were laid out for
         ent = self._wcache.get("wino:" + key)
         if ent is None or ent[0] != sig:
             w = tensors[0] if len(tensors) == 1 else torch.cat(list(tensors), 0)
@@ -333,7 +333,8 @@ class _Engine:
         """Fill the weight cache for a training step with one launch.  The output buffers persist across steps (rewritten in place, on the
         caller's stream, after the previous step's last use); the job table is rebuilt only when a parameter's storage or the input
         size changes."""
-        sig = (x.shape[2], x.shape[3], self.wino, self.WINO_TILE, self.WINO_MIN_CI, self.WINO_MIN_HW, self.bf16, self.bf16_tensors) + tuple(P[n].data_ptr() for n in self.names)
+        sig = (x.shape[2], x.shape[3], self.wino, self.WINO_TILE, self.WINO_MIN_CI, self.WINO_MIN_HW, self.bf16, self.bf16_tensors,
+               ops.wino_x3(4, 256)) + tuple(P[n].data_ptr() for n in self.names)
         if self._wtable is None or self._wtable[0] != sig:
             jobs, entries = [], []
             bs, hw, dev = x.shape[0], {"x": (x.shape[2], x.shape[3])}, x.device
@@ -377,8 +378,8 @@ class _Engine:
                         jobs.append(dict(job, kind=3, co_pad=co_all, pad1=ops.pad64(co_all), out_fwd=wf, out_bwd=wb))
                         entries.append((op["p"], "b16", tensors, (wf, wb)))
                     elif self._wino_ok(g) and self.WINO_TILE == 4:
-                        uf = torch.empty((36, co_all, g.Ci), device=dev, dtype=torch.float32)
-                        ub = torch.empty((36, g.Ci, co_pad), device=dev, dtype=torch.float32)
+                        uf = ops.wino_filter_alloc(4, co_all, g.Ci, dev)
+                        ub = ops.wino_filter_alloc(4, g.Ci, co_pad, dev)
                         jobs.append(dict(job, kind=0, out_fwd=uf, out_bwd=ub))
                         entries.append((op["p"], "wino", tensors, (uf, ub)))
                     elif self._wino_ok(g):
@@ -396,7 +397,7 @@ class _Engine:
             if what == "b16":
                 self._wcache["b16:" + key] = (lsig, bufs[0], bufs[1])
             elif what == "wino":
-                self._wcache["wino:" + key] = (lsig, bufs[0], bufs[1])
+                self._wcache["wino:" + key] = (lsig + (ops.wino_x3(4, 256),), bufs[0], bufs[1])
             elif what == "layout":
                 self._wcache[key] = [lsig, None, bufs[0], bufs[1]]
             else:

@@ -77,6 +77,12 @@ SIGNATURES = {
     "ssd_tune_set_conv_bf16": (_I, [_I, _I]),
     "ssd_tune_set_conv_bf16_k64": (_I, [_I]),
     "ssd_tune_set_conv_bf16_mfma": (_I, [_I]),
+    "ssd_wino_uses_x3": (_I, [_I, _I]),
+    "ssd_tune_set_wino_x3": (_I, [_I]),
+    "ssd_gemm_x3_weights_bytes": (_Z, [_I, _I, _I]),
+    "ssd_gemm_x3_split_weights": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ssd_gemm_planes_x3": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ssd_gemm_planes_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ssd_has_experimental": (_I, []),
     "ssd_conv3x3_wgrad_bf16t": (_I, [_P, _P, _I, _P, _P, _G, _P, _Z, _P]),
     "ssd_conv1_first_fwd_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),

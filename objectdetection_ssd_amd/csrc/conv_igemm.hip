@@ -1434,6 +1434,12 @@ __attribute__((visibility("hidden"))) int ssd_internal_gemm_batched(const float*
     return launch_igemm<64, 64, 2, 2, 1, true>(p, st);
 }
 
+extern "C" int ssd_gemm_planes_f32(const float* a, const float* w, float* out, int M, int K, int N, int n_rows, int nbatch, void* stream) {
+    if (!a || !w || !out) return SSD_ERR_NULL;
+    if (!ssd_aligned16(a) || !ssd_aligned16(w) || !ssd_aligned16(out)) return SSD_ERR_ALIGN;
+    return ssd_internal_gemm_batched(a, w, out, M, K, N, n_rows, nbatch, (size_t)M * K, (size_t)n_rows * K, 1, (hipStream_t)stream);
+}
+
 // Measurement aid (bench.py): time every batched Winograd GEMM launch by itself, so that the kernel's own rate can be held
 // against its rocprof row.  begin() creates the events on first use and arms the recorder; collect() (after the caller has
 // synchronised) returns up to `max` (milliseconds, executed FLOPs) pairs in launch order and disarms it.

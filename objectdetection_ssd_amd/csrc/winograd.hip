@@ -7,10 +7,13 @@
 //   W4 output    y = A^T m A (+ bias, ReLU | + previous dx, ReLU mask), the two rows / columns of each tile
 // The transforms are exact in binary arithmetic up to the usual rounding of their additions (factors 1, 1/2, 1/4); the result
 // differs from the direct sum at the 1e-6 level.  V and M live in a caller-provided workspace (16 planes each).
+#include <cstdlib>
 #include "common.h"
 
 int ssd_internal_gemm_batched(const float* a, const float* w, float* out, int M, int K, int N, int n_rows, int nbatch,
                               size_t batch_a_elems, size_t batch_w_elems, int ksplit, hipStream_t st);
+int ssd_internal_gemm_batched_x3(const float* a, const void* w3, float* out, int M, int K, int N, int n_rows, int nbatch, size_t batch_a_elems,
+                                 hipStream_t st);
 int ssd_internal_wino4_gemm_out(const float* V, const float* U, int tiles, int K, int Nrows, int Nout, float* out, int ldo, int Cvalid,
                                 const float* bias, const float* mask, const unsigned long long* mask_bits, int relu, int accumulate, int H,
                                 int W, int TH, int TW, float* yp, uint8_t* am, int Ho, int Wo, hipStream_t st);
@@ -359,7 +362,25 @@ __device__ constexpr float W4_G[6][3] = {{0.25f, 0, 0}, {-1.f / 6, -1.f / 6, -1.
                                          {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0, 0, 1}};
 __device__ constexpr float W4_AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
 
-__global__ void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Co, int Ci, int Nrows, int K, int mode) {
+// One element (plane p, row n, column k) of a transformed filter.  x3 = 0: U [36][Nrows][K] f32.  x3 = 1: the three exact bf16 limbs of
+// the value in the layout of csrc/gemm_x3.hip, [36][K/16][3][pad128(Nrows)][16] bf16 (rows beyond Nrows: never written, zero from the
+// allocation).
+__device__ __forceinline__ void store_u(float* __restrict__ U, int x3, int p, int n, int k, int Nrows, int K, float v) {
+    if (!x3) {
+        U[((size_t)p * Nrows + n) * K + k] = v;
+        return;
+    }
+    const __bf16 h = (__bf16)v;                       // round-to-nearest limbs; both residuals are exact (gemm_x3.hip)
+    const float r1 = v - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const size_t limb = (size_t)((Nrows + 127) / 128 * 128) * 16;
+    __bf16* d = reinterpret_cast<__bf16*>(U) + ((size_t)p * (K >> 4) + (k >> 4)) * 3 * limb + (size_t)n * 16 + (k & 15);
+    d[0] = h;
+    d[limb] = m;
+    d[2 * limb] = (__bf16)(r1 - (float)m);
+}
+
+__global__ void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Co, int Ci, int Nrows, int K, int mode, int x3) {
     const size_t total = (size_t)Nrows * K;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int k = (int)(i % K), n = (int)(i / K);
@@ -379,7 +400,7 @@ __global__ void wino4_weight_kernel(const float* __restrict__ w, float* __restri
         for (int a = 0; a < 6; ++a)
 #pragma unroll
             for (int b = 0; b < 6; ++b)
-                U[((size_t)(a * 6 + b) * Nrows + n) * K + k] = W4_G[b][0] * t[a][0] + W4_G[b][1] * t[a][1] + W4_G[b][2] * t[a][2];
+                store_u(U, x3, a * 6 + b, n, k, Nrows, K, W4_G[b][0] * t[a][0] + W4_G[b][1] * t[a][1] + W4_G[b][2] * t[a][2]);
     }
 }
 
@@ -938,11 +959,23 @@ inline bool use_full(int mo, int K, int Nout) {
     // to scratch.  Off unless forced; kept as the correct, tested starting point for an LDS-DMA filter ring beside a 16-channel V pass.
     return g_full == 1;
 }
+// The 36 plane GEMMs of an F(4x4) layer on the bf16 MFMA from three exact bf16 limbs per operand (csrc/gemm_x3.hip) instead of the f32 MFMA:
+// long reductions only (K >= 256: the layers whose GEMMs are MFMA-bound; at K <= 128 the fused GEMM + output transform kernel wins and
+// the planes, not the MFMA, bound the layer).  The filters of such a layer are kept as limb planes (store_u), so the rule must not
+// change between a layer's filter transform and its convolutions: ops.py checks the filter tensor's dtype against it on every call.
+int g_wino_x3 = -1;                // ssd_tune_set_wino_x3: -1 = environment SSD_WINO_X3 (default on), 0 off, 1 on
+inline bool use_x3(int mo, int K) {
+    if (g_wino_x3 < 0) {
+        const char* e = getenv("SSD_WINO_X3");
+        g_wino_x3 = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
+    return g_wino_x3 == 1 && mo == 4 && K >= 256 && K % 16 == 0;
+}
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 // GEMMs + output transform in one kernel (wino_fused.hip)?  It removes the write and the read-back of the M planes; what it costs is
 // MFMA efficiency on long reductions (one workgroup per CU, 16x16x4 MFMAs).
 inline bool use_fused(int mo, int K, int Nout) {
-    if (mo != 4 || (K != 64 && K != 128 && K != 256) || g_fused == 0) return false;
+    if (mo != 4 || (K != 64 && K != 128 && K != 256) || g_fused == 0 || use_x3(mo, K)) return false;
     if (g_fused == 1) return true;
     return K <= 128;                   // measured at batch 32 (tools/wino_bench.py): conv1_2 forward 1.52 -> 1.14 ms, dgrad 1.26 -> 0.94, conv2_1 forward 0.67 -> 0.50
 }
@@ -1017,7 +1050,11 @@ int wino_conv(int mo, const float* in, int Cin, const float* U, int U_rows, floa
         return ssd_internal_wino4_gemm_out(V, U, (int)tiles, Cin, U_rows, Cout, out, ldo, Cvalid, bias, mask, mask_bits, relu, accumulate, H, W, TH, TW,
                                            pooled ? pooled->y : nullptr, pooled ? pooled->argmax : nullptr, pooled ? pooled->Ho : 0,
                                            pooled ? pooled->Wo : 0, st);
-    if (int e = ssd_internal_gemm_batched(V, U, Mx, (int)tiles, Cin, Cout, U_rows, P, tiles * Cin, (size_t)U_rows * Cin, 1, st)) return e;
+    if (use_x3(mo, Cin)) {
+        if (int e = ssd_internal_gemm_batched_x3(V, U, Mx, (int)tiles, Cin, Cout, U_rows, P, tiles * Cin, st)) return e;
+    } else if (int e = ssd_internal_gemm_batched(V, U, Mx, (int)tiles, Cin, Cout, U_rows, P, tiles * Cin, (size_t)U_rows * Cin, 1, st)) {
+        return e;
+    }
     if (pooled != nullptr)
         hipLaunchKernelGGL(wino4_output_pool_kernel, dim3(grid_for(tiles * (Cout / 4))), dim3(256), 0, st, Mx, pooled->y, pooled->argmax, N, H, W,
                            Cout, TH, TW, bias, pooled->Ho, pooled->Wo);
@@ -1045,12 +1082,12 @@ extern "C" int ssd_wino_weights(const float* w_oihw, float* U_fwd, float* U_bwd,
     hipStream_t st = (hipStream_t)stream;
     if (U_fwd) {
         if (mo == 2) hipLaunchKernelGGL(wino_weight_kernel, dim3(grid_for((size_t)Co * Ci)), dim3(256), 0, st, w_oihw, U_fwd, Co, Ci, Co, Ci, 0);
-        else hipLaunchKernelGGL(wino4_weight_kernel, dim3(grid_for((size_t)Co * Ci)), dim3(256), 0, st, w_oihw, U_fwd, Co, Ci, Co, Ci, 0);
+        else hipLaunchKernelGGL(wino4_weight_kernel, dim3(grid_for((size_t)Co * Ci)), dim3(256), 0, st, w_oihw, U_fwd, Co, Ci, Co, Ci, 0, (int)use_x3(4, Ci));
         SSD_CHECK_LAUNCH();
     }
     if (U_bwd) {
         if (mo == 2) hipLaunchKernelGGL(wino_weight_kernel, dim3(grid_for((size_t)Ci * Co_pad)), dim3(256), 0, st, w_oihw, U_bwd, Co, Ci, Ci, Co_pad, 1);
-        else hipLaunchKernelGGL(wino4_weight_kernel, dim3(grid_for((size_t)Ci * Co_pad)), dim3(256), 0, st, w_oihw, U_bwd, Co, Ci, Ci, Co_pad, 1);
+        else hipLaunchKernelGGL(wino4_weight_kernel, dim3(grid_for((size_t)Ci * Co_pad)), dim3(256), 0, st, w_oihw, U_bwd, Co, Ci, Ci, Co_pad, 1, (int)use_x3(4, Co_pad));
         SSD_CHECK_LAUNCH();
     }
     return SSD_OK;
@@ -1160,6 +1197,12 @@ WinoWgradPlan wino_wgrad_plan(const ssd_conv_geom* g, int ldy, int mo) {
     return w;
 }
 }  // namespace
+
+extern "C" int ssd_tune_set_wino_x3(int on) {
+    g_wino_x3 = on < 0 ? -1 : (on != 0);
+    return SSD_OK;
+}
+extern "C" int ssd_wino_uses_x3(int mo, int K) { return use_x3(mo, K) ? 1 : 0; }
 
 extern "C" int ssd_tune_set_wino_bias_tail(int on) {
     g_bias_tail = on != 0;
@@ -1515,11 +1558,12 @@ __global__ __launch_bounds__(256) void weight_jobs_kernel(const ssd_weight_job* 
             for (int s = 0; s < 3; ++s) t[a][s] = W4_G[a][0] * g[0][s] + W4_G[a][1] * g[1][s] + W4_G[a][2] * g[2][s];
         float* U = fwd ? j.out_fwd : j.out_bwd;
         if (fwd && j.out_fwd == nullptr) return;
+        const int x3 = (j.pad0 >> (fwd ? 0 : 1)) & 1;         // pad0 bit 0 / 1: out_fwd / out_bwd hold limb planes (ssd_wino_uses_x3 of their K)
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
             for (int b = 0; b < 6; ++b)
-                U[((size_t)(a * 6 + b) * Nrows + n) * K + k] = W4_G[b][0] * t[a][0] + W4_G[b][1] * t[a][1] + W4_G[b][2] * t[a][2];
+                store_u(U, x3, a * 6 + b, n, k, Nrows, K, W4_G[b][0] * t[a][0] + W4_G[b][1] * t[a][1] + W4_G[b][2] * t[a][2]);
     } else if (j.kind == 1) {                        // OHWI [co_pad][T][Ci] and IHWO [Ci][T][co_pad]
         const size_t total = (size_t)j.co_pad * T * Ci;
         if (i < total) {

@@ -817,16 +817,49 @@ def photometric_u8(arena: torch.Tensor, descs, photo) -> None:
 
 
 # ---- Winograd F(mo x mo, 3x3), mo = 2 or 4 --------------------------------------------------------
+def wino_x3(mo: int, K: int) -> bool:
+    """True if the F(4x4) plane GEMMs of reduction length K multiply three bf16 limbs per f32 operand (csrc/gemm_x3.hip); the layer's
+    transformed filter is then a bf16 limb tensor (`wino_filter_alloc`)."""
+    return bool(_lib.load().ssd_wino_uses_x3(mo, K))
+
+
+def wino_filter_alloc(mo: int, rows: int, K: int, device) -> torch.Tensor:
+    """Destination of a transformed filter with `rows` output rows and reduction length K: (P, rows, K) f32, or -- where `wino_x3` --
+    the limb planes (P, K/16, 3, pad128(rows), 16) bf16, zero-filled (the padding rows are never written)."""
+    P = (mo + 2) ** 2
+    if wino_x3(mo, K):
+        return torch.zeros((P, K // 16, 3, (rows + 127) // 128 * 128, 16), device=device, dtype=torch.bfloat16)
+    return torch.empty((P, rows, K), device=device, dtype=torch.float32)
+
+
+def _wino_filter(u: torch.Tensor, name: str, rows: int, K: Optional[int]) -> int:
+    """Check a transformed filter against its geometry and the library's current GEMM form; returns K."""
+    mo = _wino_mo(u)
+    if u.dtype == torch.bfloat16:
+        _req(u, name, torch.bfloat16)
+        k = u.shape[1] * 16
+        ok = u.dim() == 5 and tuple(u.shape[2:]) == (3, (rows + 127) // 128 * 128, 16) and (K is None or k == K)
+    else:
+        _req(u, name)
+        k = u.shape[2] if u.dim() == 3 else -1
+        ok = u.dim() == 3 and u.shape[1] == rows and (K is None or k == K)
+    if not ok:
+        raise ValueError(f"{name}: shape does not match the geometry")
+    if (u.dtype == torch.bfloat16) != wino_x3(mo, k):
+        raise ValueError(f"{name}: transformed under another ssd_tune_set_wino_x3 setting than the one in force")
+    return k
+
+
 def wino_weights(w_oihw: torch.Tensor, co_pad: Optional[int] = None, want_bwd: bool = True, mo: int = 2):
-    """(Co,Ci,3,3) -> U_fwd (P,Co,Ci) and, if asked, U_bwd (P,Ci,co_pad), P = (mo+2)^2, for conv2d_fwd_wino / conv2d_dgrad_wino."""
+    """(Co,Ci,3,3) -> U_fwd (P,Co,Ci) and, if asked, U_bwd (P,Ci,co_pad), P = (mo+2)^2, for conv2d_fwd_wino / conv2d_dgrad_wino
+    (either may be a limb tensor instead: `wino_filter_alloc`)."""
     _req(w_oihw, "weight")
     co, ci, r, s = w_oihw.shape
     if (r, s) != (3, 3) or mo not in (2, 4):
         raise ValueError("Winograd needs 3x3 filters and mo in (2, 4)")
     co_pad = pad32(co) if co_pad is None else co_pad
-    P = (mo + 2) ** 2
-    uf = torch.empty((P, co, ci), device=w_oihw.device, dtype=torch.float32)
-    ub = torch.empty((P, ci, co_pad), device=w_oihw.device, dtype=torch.float32) if want_bwd else None
+    uf = wino_filter_alloc(mo, co, ci, w_oihw.device)
+    ub = wino_filter_alloc(mo, ci, co_pad, w_oihw.device) if want_bwd else None
     check(_lib.load().ssd_wino_weights(w_oihw.data_ptr(), uf.data_ptr(), _ptr(ub), co, ci, co_pad, mo, _stream()), "wino_weights")
     return uf, ub
 
@@ -861,9 +894,10 @@ def conv2d_fwd_wino(x: torch.Tensor, u_fwd: torch.Tensor, bias: Optional[torch.T
                     ld: Optional[int] = None, keep_planes: bool = False, want_bits: bool = False):
     """keep_planes: also return the transformed input (F(4x4) only) for `conv2d_wgrad_wino(..., planes=)` -> (y, planes);
     want_bits (with keep_planes): also the bit mask x > 0 for `conv2d_dgrad_wino(..., bits=)` -> (y, planes, bits)."""
-    _req(x, "x"); _req(u_fwd, "u_fwd")
+    _req(x, "x")
     mo = _wino_mo(u_fwd)
-    if tuple(x.shape) != (g.N, g.H, g.W, g.Ci) or tuple(u_fwd.shape[1:]) != (g.Co, g.Ci):
+    _wino_filter(u_fwd, "u_fwd", g.Co, g.Ci)
+    if tuple(x.shape) != (g.N, g.H, g.W, g.Ci):
         raise ValueError("conv2d_fwd_wino: shapes do not match the geometry")
     if bias is not None:
         _req(bias, "bias")
@@ -894,10 +928,11 @@ def conv2d_fwd_wino_pool(x: torch.Tensor, u_fwd: torch.Tensor, bias: Optional[to
                          want_argmax: bool = True, keep_planes: bool = False, want_bits: bool = False):
     """conv3x3 -> ReLU -> max pool 2x2 / stride 2 in one pass (F(4x4,3x3) filters): (pooled y, argmax or None), the pair
     `conv2d_fwd_wino(relu=True)` + `maxpool_fwd(2, 2, 0)` returns, without the full-resolution activation in between."""
-    _req(x, "x"); _req(u_fwd, "u_fwd")
+    _req(x, "x")
     if _wino_mo(u_fwd) != 4:
         raise ValueError("conv2d_fwd_wino_pool: needs F(4x4,3x3) filters")
-    if tuple(x.shape) != (g.N, g.H, g.W, g.Ci) or tuple(u_fwd.shape[1:]) != (g.Co, g.Ci) or g.Co % 4 != 0:
+    _wino_filter(u_fwd, "u_fwd", g.Co, g.Ci)
+    if tuple(x.shape) != (g.N, g.H, g.W, g.Ci) or g.Co % 4 != 0:
         raise ValueError("conv2d_fwd_wino_pool: shapes do not match the geometry")
     if bias is not None:
         _req(bias, "bias")
@@ -924,17 +959,16 @@ def conv2d_dgrad_wino(dy: Optional[torch.Tensor], u_bwd: torch.Tensor, g: ConvGe
     """planes: B^T dy B as `conv2d_wgrad_wino(..., dgrad_planes=True)` left it ((36, tiles, Co_pad), F(4x4)); dy is then not read.
     bits (with planes): the ReLU mask as the forward's input transform left it (`conv2d_fwd_wino(..., want_bits=True)`), applied
     instead of relu_mask."""
-    _req(u_bwd, "u_bwd")
     mo = _wino_mo(u_bwd)
-    co_pad = u_bwd.shape[2]
+    co_pad = _wino_filter(u_bwd, "u_bwd", g.Ci, None)
     dev = u_bwd.device
     if planes is not None:
         _req(planes, "planes")
-        if mo != 4 or tuple(planes.shape) != (36, wino_planes_shape(g)[1], co_pad) or u_bwd.shape[1] != g.Ci:
+        if mo != 4 or tuple(planes.shape) != (36, wino_planes_shape(g)[1], co_pad):
             raise ValueError("conv2d_dgrad_wino: planes do not match the geometry")
     else:
         _req(dy, "dy")
-        if dy.numel() != g.N * g.H * g.W * co_pad or u_bwd.shape[1] != g.Ci:
+        if dy.numel() != g.N * g.H * g.W * co_pad:
             raise ValueError("conv2d_dgrad_wino: shapes do not match the geometry")
     if dx is None:
         if accumulate:
@@ -1083,7 +1117,7 @@ class WeightTable:
         for a, j in zip(arr, jobs):
             for t in (j["w0"], j.get("w1"), j.get("out_fwd"), j.get("out_bwd")):
                 if t is not None:
-                    _req(t, "weight job tensor", t.dtype if (j["kind"] == 3 and t.dtype == torch.bfloat16) else torch.float32)
+                    _req(t, "weight job tensor", t.dtype if (j["kind"] in (0, 3) and t.dtype == torch.bfloat16) else torch.float32)
                     self.keep.append(t)
             a.w0 = j["w0"].data_ptr()
             a.w1 = j["w1"].data_ptr() if j.get("w1") is not None else j["w0"].data_ptr()
@@ -1091,6 +1125,8 @@ class WeightTable:
             a.out_bwd = _ptr(j.get("out_bwd"))
             a.co0, a.co, a.ci, a.taps, a.co_pad, a.kind = j["co0"], j["co"], j["ci"], j["taps"], j["co_pad"], j["kind"]
             a.pad1 = j.get("pad1", 0)
+            if j["kind"] == 0:                 # Winograd filters: which outputs are limb tensors (wino_filter_alloc)
+                a.pad0 = sum(bit for bit, key in ((1, "out_fwd"), (2, "out_bwd")) if j.get(key) is not None and j[key].dtype == torch.bfloat16)
             nb = lib.ssd_weight_job_blocks(C.byref(a))
             if nb <= 0:
                 raise ValueError("bad weight job")

@@ -1013,6 +1013,51 @@ def test_winograd_plane_gemm_128_tile_dma_kernel_equals_generic_kernel(case):
     _close(out[1][1], _nhwc(x64.grad), what=f"dgrad vs f64 {case}")
 
 
+X3_GEMM_CASES = [  # M, K, N, planes: full tiles; ragged rows and a cut column tile; fewer rows than a tile, N just over one tile; deep K
+    (384, 256, 256, 3), (1000, 512, 100, 2), (129, 256, 130, 1), (64, 1024, 512, 2), (3200, 512, 512, 1),
+]
+
+
+@pytest.mark.parametrize("case", X3_GEMM_CASES)
+def test_plane_gemm_from_three_bf16_limbs_is_as_exact_as_the_f32_mfma(case):
+    """csrc/gemm_x3.hip: out[b] = a[b] * w[b]^T with every f32 operand split exactly into three bf16 limbs and six limb products per block
+    on the bf16 MFMA (f32 accumulate).  Against an f64 product it must be no worse than the f32-MFMA kernel it replaces (the dropped
+    limb products are <= 2^-24 relative), on operands with a wide dynamic range, and rows / columns outside M x N must stay untouched."""
+    from objectdetection_ssd_amd import _lib
+    lib = _lib.load()
+    M, K, N, P = case
+    dev = _dev()
+    gen = torch.Generator().manual_seed(M + K + N)
+    a = torch.randn(P, M, K, generator=gen) * torch.exp(2.0 * torch.randn(P, M, K, generator=gen))
+    w = torch.randn(P, N, K, generator=gen) * torch.exp(2.0 * torch.randn(P, N, K, generator=gen)) / K ** 0.5
+    a[0, 0, :8] = 0.0
+    w[0, 0, 3] = 0.0
+    ad, wd = a.to(dev), w.to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    w3 = torch.zeros(lib.ssd_gemm_x3_weights_bytes(N, K, P), dtype=torch.uint8, device=dev)
+    assert w3.numel() == P * K * ((N + 127) // 128 * 128) * 6
+    _lib.check(lib.ssd_gemm_x3_split_weights(wd.data_ptr(), w3.data_ptr(), N, K, P, st), "split")
+    # the three limbs add up to the weight exactly
+    lim = w3.view(torch.bfloat16).view(P, K // 16, 3, -1, 16).float()
+    back = lim.sum(2)[:, :, :N, :].permute(0, 2, 1, 3).reshape(P, N, K)
+    assert torch.equal(back.cpu(), w), "hi + mid + lo != w"
+    assert float(lim[:, :, :, N:, :].abs().max()) == 0.0 if lim.shape[3] > N else True
+    guard = 7.0
+    o3 = torch.full((P, M, N), guard, device=dev)
+    o32 = torch.full((P, M, N), guard, device=dev)
+    _lib.check(lib.ssd_gemm_planes_x3(ad.data_ptr(), w3.data_ptr(), o3.data_ptr(), M, K, N, N, P, st), "x3")
+    _lib.check(lib.ssd_gemm_planes_f32(ad.data_ptr(), wd.data_ptr(), o32.data_ptr(), M, K, N, N, P, st), "f32")
+    ref = torch.bmm(a.double(), w.double().transpose(1, 2))
+    scale = torch.bmm(a.double().abs(), w.double().abs().transpose(1, 2))            # sum_k |a||w|: what an f32 sum's error is relative to
+    e3 = float(((o3.cpu().double() - ref).abs() / scale.clamp_min(1e-300)).max())
+    e32 = float(((o32.cpu().double() - ref).abs() / scale.clamp_min(1e-300)).max())
+    r3 = float((o3.cpu().double() - ref).norm() / ref.norm())
+    r32 = float((o32.cpu().double() - ref).norm() / ref.norm())
+    # measured: 2.4e-7 ... 3.7e-7 against 2.6e-7 ... 4.1e-7 of the f32 MFMA (which rounds once per product block, the limb form six times)
+    assert r3 <= 1e-6 and r3 <= 1.5 * r32 + 1e-9, (r3, r32)
+    assert e3 <= 2.0 * e32 + 1e-9 and e3 <= 2e-6, (e3, e32)
+
+
 DILATED_CASES = [  # n, h, w, ci, co, dilation: fc6's shape class, odd maps, lattices of unequal size, a map smaller than the dilation
     (2, 19, 19, 64, 96, 4), (1, 10, 13, 32, 64, 2), (2, 7, 5, 32, 32, 3), (1, 3, 3, 32, 32, 4), (1, 23, 17, 32, 40, 4), (32, 19, 19, 512, 1024, 4),
 ]

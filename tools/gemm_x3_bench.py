@@ -1,0 +1,57 @@
+"""Plane GEMMs of the Winograd layers: f32 MFMA kernel vs the three-limb bf16 MFMA kernel (csrc/gemm_x3.hip), same operands.
+
+    python tools/gemm_x3_bench.py            # the batch-32 shapes of conv3_2, conv4_2, conv5_2, fc6, c_4
+Prints per shape: ms and TFLOP/s (f32-equivalent: 2*M*K*N*P) of both, and the relative L2 error of each against an f64 product
+of plane 0.
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from objectdetection_ssd_amd import _lib  # noqa: E402
+
+SHAPES = [("conv3_2", 32 * 19 * 19, 256, 256, 36), ("conv4_2", 32 * 10 * 10, 512, 512, 36), ("conv5_2", 32 * 5 * 5, 512, 512, 36),
+          ("fc6", 32 * 8 * 8, 512, 1024, 36), ("c_4", 32 * 10 * 10, 512, 100, 36), ("dgrad conv3_1", 32 * 19 * 19, 256, 128, 36)]
+
+
+def main():
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    for name, M, K, N, P in SHAPES:
+        g = torch.Generator(device="cpu").manual_seed(1)
+        a = torch.randn(P, M, K, generator=g).to(dev)
+        w = (torch.randn(P, N, K, generator=g) / K ** 0.5).to(dev)
+        o32 = torch.empty(P, M, N, device=dev)
+        ox3 = torch.empty(P, M, N, device=dev)
+        w3 = torch.empty(lib.ssd_gemm_x3_weights_bytes(N, K, P), dtype=torch.uint8, device=dev)
+        _lib.check(lib.ssd_gemm_x3_split_weights(w.data_ptr(), w3.data_ptr(), N, K, P, st), "split")
+        f32 = lambda: _lib.check(lib.ssd_gemm_planes_f32(a.data_ptr(), w.data_ptr(), o32.data_ptr(), M, K, N, N, P, st), "f32")   # noqa: E731
+        x3 = lambda: _lib.check(lib.ssd_gemm_planes_x3(a.data_ptr(), w3.data_ptr(), ox3.data_ptr(), M, K, N, N, P, st), "x3")    # noqa: E731
+        res = {}
+        for tag, fn in (("f32", f32), ("x3", x3)):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            res[tag] = e0.elapsed_time(e1) / 10
+        ref = a[0].double() @ w[0].double().T
+        err = {t: float((o[0].double() - ref).norm() / ref.norm()) for t, o in (("f32", o32), ("x3", ox3))}
+        last = P - 1
+        ref2 = a[last].double() @ w[last].double().T
+        err2 = float((ox3[last].double() - ref2).norm() / ref2.norm())
+        fl = 2.0 * M * K * N * P
+        print(f"{name:14s} M={M:6d} K={K:4d} N={N:4d}  f32 {res['f32']:.3f} ms {fl / res['f32'] / 1e9:7.1f} TF/s   x3 {res['x3']:.3f} ms "
+              f"{fl / res['x3'] / 1e9:7.1f} TF/s (executed bf16 {6 * fl / res['x3'] / 1e9:7.1f})   err f32 {err['f32']:.2e} x3 {err['x3']:.2e} / {err2:.2e}",
+              flush=True)
+
+
+if __name__ == "__main__":
+    main()
