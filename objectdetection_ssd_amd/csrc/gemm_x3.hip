@@ -14,6 +14,7 @@
 // thread and step, a step ahead), split in registers (~44 VALU instructions: v_cvt_pk_bf16_f32 / shift / and / sub) and written as three 16-byte LDS
 // stores.  LDS rows are 32 bytes (16 k); the two 16-byte halves of row r are swapped when bit 3 of r is set, so that the 16 lanes
 // of a ds_read_b128 group hit 16 different 16-byte slots (MI355X_MICROARCH.md LDS table).
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -91,10 +92,13 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
     const size_t limb_elems = (size_t)p.rows_pad * 16;
     const __bf16* b_src = p.w3 + (size_t)b * NK * 3 * limb_elems + (size_t)(n0 + brow) * 16 + bhalf * 8;
 
-    f32x4 ra0, ra1;
-    auto load_a = [&](int ks) {
-        ra0 = buf_load16(srd_a, voff_a, (unsigned)ks * 64u);
-        ra1 = buf_load16(srd_a, voff_a + 16u, (unsigned)ks * 64u);
+    // two register sets for the raw activation rows: the loads of step s + 2 are issued at the start of step s, the split of
+    // step s + 1's rows (issued a step earlier) runs in the shadow of step s's MFMAs
+    f32x4 ra[2][2];
+    auto load_a = [&](int ks, int set) {          // beyond the last step: out-of-range offsets (zeros, no traffic) keep vmcnt uniform
+        const unsigned v = ks < NK ? voff_a : OOB;
+        ra[set][0] = buf_load16(srd_a, v, (unsigned)ks * 64u);
+        ra[set][1] = buf_load16(srd_a, v + 16u, (unsigned)ks * 64u);
     };
     auto dma_b = [&](int ks, int stage) {
         const __bf16* s = b_src + (size_t)ks * 3 * limb_elems;
@@ -102,14 +106,6 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(s + pl * limb_elems), (lds_void*)(d + pl * X3_LIMB), 16, 0, 0);
-    };
-    auto store_a = [&](int stage) {
-        u32x4 hi, mid, lo;
-        split8(ra0, ra1, hi, mid, lo);
-        unsigned char* d = lds + stage * X3_STAGE + a_wr;
-        *reinterpret_cast<u32x4*>(d) = hi;
-        *reinterpret_cast<u32x4*>(d + X3_LIMB) = mid;
-        *reinterpret_cast<u32x4*>(d + 2 * X3_LIMB) = lo;
     };
 
     f32x16 acc[2][2];
@@ -123,48 +119,258 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
     const unsigned frag = lr * 32 + ((lh ^ ((lr >> 3) & 1)) << 4);
     const unsigned a_rd = wm * 64 * 32 + frag, b_rd = X3_OPER + wn * 64 * 32 + frag;
 
-    load_a(0);
-    dma_b(0, 0);
-    store_a(0);                                   // (the compiler waits for ra0 / ra1 here)
-    if (NK > 1) {
-        load_a(1);
-        dma_b(1, 1);
-        wait_vmcnt<5>();                          // stage 0's weights have landed; stage 1's loads stay in flight
-    } else {
-        wait_vmcnt<0>();
-    }
-    __syncthreads();
-    for (int ks = 0; ks < NK; ++ks) {
-        const unsigned char* st = lds + (ks & 1) * X3_STAGE;
+    // one step on LDS stage PH: 12 fragment reads, then 24 MFMAs (product-major, smallest limb products first) with the split of the
+    // other register set's rows placed by hand between them -- one stage (<= 4 VALU instructions) of one pair per MFMA, pinned by
+    // sched_barrier: a 32-cycle v_mfma_f32_32x32x16_bf16 hides up to five 4-cycle instructions -- and the three LDS stores at the end
+    auto step = [&](auto ph_tag) {
+        constexpr int PH = decltype(ph_tag)::value;
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        const unsigned char* st = lds + PH * X3_STAGE;
         bf16x8 af[3][2], bf[3][2];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int g = 0; g < 3; ++g)                // in the order the products need them
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                af[pl][i] = *reinterpret_cast<const bf16x8*>(st + a_rd + pl * X3_LIMB + i * 1024);
-                bf[pl][i] = *reinterpret_cast<const bf16x8*>(st + b_rd + pl * X3_LIMB + i * 1024);
+                const int pa = g == 0 ? 2 : (g == 1 ? 0 : 1), pb = g == 0 ? 0 : (g == 1 ? 2 : 1);
+                af[pa][i] = *reinterpret_cast<const bf16x8*>(st + a_rd + pa * X3_LIMB + i * 1024);
+                bf[pb][i] = *reinterpret_cast<const bf16x8*>(st + b_rd + pb * X3_LIMB + i * 1024);
             }
-        // product-major: four independent accumulators between two MFMAs of one chain; smallest terms first
-#define X3_MMA(PA, PB)                                                                                              \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                        \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA][i], bf[PB][j], acc[i][j], 0, 0, 0);
-        X3_MMA(2, 0)
-        X3_MMA(0, 2)
-        X3_MMA(1, 1)
-        X3_MMA(1, 0)
-        X3_MMA(0, 1)
-        X3_MMA(0, 0)
-#undef X3_MMA
-        if (ks + 1 < NK) store_a((ks + 1) & 1);   // the other stage: last read a step ago, a barrier since
-        wait_vmcnt<0>();                          // the weights of step ks + 1
-        __syncthreads();
-        if (ks + 2 < NK) {
-            load_a(ks + 2);
-            dma_b(ks + 2, ks & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 v0 = ra[PH ^ 1][0], v1 = ra[PH ^ 1][1];
+        const float xa[4] = {v0[0], v0[2], v1[0], v1[2]}, xb[4] = {v0[1], v0[3], v1[1], v1[3]};
+        unsigned hi[4], mid[4], lo[4];
+        float r1a[4], r1b[4];
+#pragma unroll
+        for (int q = 0; q < 24; ++q) {
+            const int pr = q >> 2, i = (q >> 1) & 1, j = q & 1;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[pr]][i], bf[PB[pr]][j], acc[i][j], 0, 0, 0);
+            if (q >= 2 && q < 22) {                // (the first MFMAs wait for the fragments anyway)
+                const int e = (q - 2) / 5, sg = (q - 2) % 5;
+                // (the empty asm pins each stage's results where they are written: pure arithmetic would otherwise sink, at IR level,
+                // past every MFMA to its only use, the LDS stores)
+                if (sg == 0) { hi[e] = pack_rne(xa[e], xb[e]); asm volatile("" : "+v"(hi[e])); }
+                if (sg == 1) {
+                    r1a[e] = xa[e] - __uint_as_float(hi[e] << 16); r1b[e] = xb[e] - __uint_as_float(hi[e] & 0xffff0000u);
+                    asm volatile("" : "+v"(r1a[e]), "+v"(r1b[e]));
+                }
+                if (sg == 2) { mid[e] = pack_rne(r1a[e], r1b[e]); asm volatile("" : "+v"(mid[e])); }
+                if (sg == 3) {
+                    r1a[e] -= __uint_as_float(mid[e] << 16); r1b[e] -= __uint_as_float(mid[e] & 0xffff0000u);
+                    asm volatile("" : "+v"(r1a[e]), "+v"(r1b[e]));
+                }
+                if (sg == 4) { lo[e] = pack_rne(r1a[e], r1b[e]); asm volatile("" : "+v"(lo[e])); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        unsigned char* d = lds + (PH ^ 1) * X3_STAGE + a_wr;       // the other stage: last read a step ago, a barrier since
+        *reinterpret_cast<u32x4*>(d) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+        *reinterpret_cast<u32x4*>(d + X3_LIMB) = u32x4{mid[0], mid[1], mid[2], mid[3]};
+        *reinterpret_cast<u32x4*>(d + 2 * X3_LIMB) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+    };
+
+    // prologue: stage 0 complete, stage 1's weights and the rows of steps 1 and 2 in flight
+    dma_b(0, 0);
+    load_a(0, 0);
+    load_a(1, 1);
+    {
+        u32x4 hi, mid, lo;
+        split8(ra[0][0], ra[0][1], hi, mid, lo);  // (the compiler waits for set 0 here)
+        unsigned char* d = lds + a_wr;
+        *reinterpret_cast<u32x4*>(d) = hi;
+        *reinterpret_cast<u32x4*>(d + X3_LIMB) = mid;
+        *reinterpret_cast<u32x4*>(d + 2 * X3_LIMB) = lo;
     }
+    dma_b(1, 1);
+    load_a(2, 0);
+    wait_vmcnt<7>();                              // issue order: B(0), A(0), A(1), B(1), A(2): everything up to A(0) has landed
+    __syncthreads();
+    for (int ks = 0; ks < NK; ks += 2) {          // NK is even (K % 32 == 0)
+        step(std::integral_constant<int, 0>{});   // step ks: reads stage 0, writes A(ks + 1) into stage 1
+        wait_vmcnt<2>();                          // B(ks + 1) has landed; the two row loads issued after it stay in flight
+        __syncthreads();
+        if (ks + 2 < NK) dma_b(ks + 2, 0);
+        load_a(ks + 3, 1);
+        step(std::integral_constant<int, 1>{});   // step ks + 1
+        wait_vmcnt<2>();
+        __syncthreads();
+        if (ks + 3 < NK) dma_b(ks + 3, 1);
+        load_a(ks + 4, 0);
+    }
+    wait_vmcnt<0>();
 
     float* out = p.out + (size_t)b * p.batch_out;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+                if (m < p.M && n < p.N) out[(size_t)m * p.N + n] = acc[i][j][r];
+            }
+        }
+}
+
+// ---- TN form: out[b][split][m][n] = sum_k a[b][k][m] * c[b][k][n]  (the Winograd weight gradient: a = transformed dy planes [tiles][ldy],
+// c = transformed input planes [tiles][Ci], k = tiles; split-K over `ksplit` slices of the tile range) ------------------------------------
+// Both operands are activations, both are split in the kernel: per 16-tile step a thread loads 8 consecutive channels of one tile row of
+// each operand (2 x 2 16-byte loads, 512-byte rows: coalesced), two steps ahead into one of two register sets, splits them in the
+// shadow of the step's 24 MFMAs and stores six 16-byte limb rows.  LDS images are [16 tiles][128 channels] bf16 per limb, plain 256-byte
+// rows with the 16-byte chunk ch of row r at ch ^ (((r & 3) << 2) | ((r >> 2) & 3)) (cdna_hip_programming.md T10, image (b): conflict-
+// free for the transposing read); the MFMA operands -- 8 consecutive TILES of one channel per lane -- come from ds_read_b64_tr_b16.
+struct TnX3Params {
+    const float* a; const float* c; float* out;
+    int M, N, K, lda, ldc, tiles_m, tiles_n, ksplit, ksteps_per_split, groups;      // K steps of 16; groups = problems x ksplit
+    size_t batch_a, batch_c;
+    unsigned a_bytes, c_bytes;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* p0, const unsigned char* p1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(const TnX3Params p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * X3_STAGE];       // stage = A limbs (3 x 4 KB) + C limbs (3 x 4 KB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+    // every XCD walks a contiguous range of (group, tile) ids: the output tiles of one (problem, K slice), which share the operand
+    // panels, run on one XCD next to each other in time
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int sid = xcd_swizzle(blockIdx.x, nblk * p.groups);
+    const int grp = sid / nblk, lid = sid - grp * nblk;
+    const int m0 = (lid / p.tiles_n) * 128, n0 = (lid % p.tiles_n) * 128;
+    const int by = grp % p.ksplit, bz = grp / p.ksplit;
+    const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a + (size_t)bz * p.batch_a), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.c + (size_t)bz * p.batch_c), 0, (int)p.c_bytes, 0x00020000);
+    const int ksteps = (p.K + 15) >> 4;
+    const int kt_begin = by * p.ksteps_per_split;
+    const int KT = min(ksteps - kt_begin, p.ksteps_per_split);                      // (an odd count runs one more step on zero rows)
+
+    // loads / LDS stores: thread -> (tile row t of the step, 16-byte chunk ch = 8 channels)
+    const int trow = tid >> 4, ch = tid & 15;
+    const bool ok_a = m0 + ch * 8 < p.lda, ok_c = n0 + ch * 8 < p.ldc;           // lda, ldc are multiples of 4: a chunk may be half valid
+    const bool ok_a2 = m0 + ch * 8 + 4 < p.lda, ok_c2 = n0 + ch * 8 + 4 < p.ldc;
+    const unsigned wr = 256 * trow + 16 * (ch ^ (((trow & 3) << 2) | ((trow >> 2) & 3)));
+    f32x4 ra[2][4];                                                                 // [register set][a lo, a hi, c lo, c hi]
+    auto load = [&](int kt, int set) {
+        const size_t k = (size_t)(kt_begin + kt) * 16 + trow;
+        const bool in = kt < KT && k < (size_t)p.K;
+        const unsigned va = (unsigned)((k * p.lda + m0 + ch * 8) * 4), vc = (unsigned)((k * p.ldc + n0 + ch * 8) * 4);
+        ra[set][0] = buf_load16(srd_a, in && ok_a ? va : OOB, 0);
+        ra[set][1] = buf_load16(srd_a, in && ok_a2 ? va + 16u : OOB, 0);
+        ra[set][2] = buf_load16(srd_c, in && ok_c ? vc : OOB, 0);
+        ra[set][3] = buf_load16(srd_c, in && ok_c2 ? vc + 16u : OOB, 0);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposed fragment reads: lane 4q+p of a 16-lane group supplies row r0 + q, chunk c0 + (p >> 1), half p & 1 of its 4 x 16 block;
+    // groups 0 / 1 of a half-wave take channels 0..15 / 16..31 of the 32-wide MFMA tile, the upper half-wave the tiles k = 8..15
+    unsigned rd[2][2][2];                                                           // [operand][MFMA tile i][rows +0 / +4]
+    {
+        const int q = (lane & 15) >> 2, pp = lane & 3, g16 = (lane >> 4) & 1;
+#pragma unroll
+        for (int op = 0; op < 2; ++op)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = 8 * lh + 4 * h + q;
+                    const int c = (op == 0 ? wm : wn) * 8 + i * 4 + g16 * 2 + (pp >> 1);
+                    rd[op][i][h] = op * X3_OPER + 256 * row + 16 * (c ^ (((row & 3) << 2) | ((row >> 2) & 3))) + 8 * (pp & 1);
+                }
+    }
+
+    auto step = [&](auto ph_tag) {
+        constexpr int PH = decltype(ph_tag)::value;
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        const unsigned char* st = lds + PH * X3_STAGE;
+        bf16x8 af[3][2], bf[3][2];
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int pa = g == 0 ? 2 : (g == 1 ? 0 : 1), pb = g == 0 ? 0 : (g == 1 ? 2 : 1);
+                af[pa][i] = tr_pair(st + rd[0][i][0] + pa * X3_LIMB, st + rd[0][i][1] + pa * X3_LIMB);
+                bf[pb][i] = tr_pair(st + rd[1][i][0] + pb * X3_LIMB, st + rd[1][i][1] + pb * X3_LIMB);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        float xa[8], xb[8];                                                          // eight pairs: a chunk (4), c chunk (4)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            xa[2 * v] = ra[PH ^ 1][v][0]; xb[2 * v] = ra[PH ^ 1][v][1];
+            xa[2 * v + 1] = ra[PH ^ 1][v][2]; xb[2 * v + 1] = ra[PH ^ 1][v][3];
+        }
+        unsigned hi[8], mid[8], lo[8];
+        float r1a[8], r1b[8];
+        auto stage = [&](int sidx) {                                                  // 40 stages: pair e = sidx / 5, stage sidx % 5
+            const int e = sidx / 5, sg = sidx % 5;
+            if (sg == 0) { hi[e] = pack_rne(xa[e], xb[e]); asm volatile("" : "+v"(hi[e])); }
+            if (sg == 1) {
+                r1a[e] = xa[e] - __uint_as_float(hi[e] << 16); r1b[e] = xb[e] - __uint_as_float(hi[e] & 0xffff0000u);
+                asm volatile("" : "+v"(r1a[e]), "+v"(r1b[e]));
+            }
+            if (sg == 2) { mid[e] = pack_rne(r1a[e], r1b[e]); asm volatile("" : "+v"(mid[e])); }
+            if (sg == 3) {
+                r1a[e] -= __uint_as_float(mid[e] << 16); r1b[e] -= __uint_as_float(mid[e] & 0xffff0000u);
+                asm volatile("" : "+v"(r1a[e]), "+v"(r1b[e]));
+            }
+            if (sg == 4) { lo[e] = pack_rne(r1a[e], r1b[e]); asm volatile("" : "+v"(lo[e])); }
+        };
+#pragma unroll
+        for (int q = 0; q < 24; ++q) {
+            const int pr = q >> 2, i = (q >> 1) & 1, j = q & 1;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[pr]][i], bf[PB[pr]][j], acc[i][j], 0, 0, 0);
+            if (q >= 2 && q < 20) { stage(2 * (q - 2)); stage(2 * (q - 2) + 1); }     // 36 stages, two per MFMA ...
+            if (q >= 20) stage(36 + (q - 20));                                        // ... and the last four
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        unsigned char* d = lds + (PH ^ 1) * X3_STAGE + wr;
+        *reinterpret_cast<u32x4*>(d) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+        *reinterpret_cast<u32x4*>(d + X3_LIMB) = u32x4{mid[0], mid[1], mid[2], mid[3]};
+        *reinterpret_cast<u32x4*>(d + 2 * X3_LIMB) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+        *reinterpret_cast<u32x4*>(d + X3_OPER) = u32x4{hi[4], hi[5], hi[6], hi[7]};
+        *reinterpret_cast<u32x4*>(d + X3_OPER + X3_LIMB) = u32x4{mid[4], mid[5], mid[6], mid[7]};
+        *reinterpret_cast<u32x4*>(d + X3_OPER + 2 * X3_LIMB) = u32x4{lo[4], lo[5], lo[6], lo[7]};
+    };
+
+    load(0, 0);
+    load(1, 1);
+    {
+        u32x4 h, m, l;
+        unsigned char* d = lds + wr;
+        split8(ra[0][0], ra[0][1], h, m, l);          // (the compiler waits for set 0 here)
+        *reinterpret_cast<u32x4*>(d) = h; *reinterpret_cast<u32x4*>(d + X3_LIMB) = m; *reinterpret_cast<u32x4*>(d + 2 * X3_LIMB) = l;
+        split8(ra[0][2], ra[0][3], h, m, l);
+        *reinterpret_cast<u32x4*>(d + X3_OPER) = h; *reinterpret_cast<u32x4*>(d + X3_OPER + X3_LIMB) = m;
+        *reinterpret_cast<u32x4*>(d + X3_OPER + 2 * X3_LIMB) = l;
+    }
+    load(2, 0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; kt += 2) {
+        step(std::integral_constant<int, 0>{});       // step kt: reads stage 0, splits set 1 (step kt + 1) into stage 1
+        __syncthreads();
+        load(kt + 3, 1);
+        step(std::integral_constant<int, 1>{});       // step kt + 1
+        __syncthreads();
+        load(kt + 4, 0);
+    }
+
+    float* out = p.out + ((size_t)bz * p.ksplit + by) * p.M * p.N;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -208,13 +414,13 @@ __global__ __launch_bounds__(256) void split_weights_x3_kernel(const float* __re
 }  // namespace
 
 extern "C" size_t ssd_gemm_x3_weights_bytes(int rows, int K, int nbatch) {
-    if (rows <= 0 || K <= 0 || K % 16 != 0 || nbatch <= 0) return 0;
+    if (rows <= 0 || K <= 0 || K % 32 != 0 || nbatch <= 0) return 0;
     return (size_t)nbatch * K * ssd_cdiv(rows, 128) * 128 * 3 * 2;
 }
 
 extern "C" int ssd_gemm_x3_split_weights(const float* w, void* w3, int rows, int K, int nbatch, void* stream) {
     if (!w || !w3) return SSD_ERR_NULL;
-    if (rows <= 0 || K <= 0 || K % 16 != 0 || nbatch <= 0) return SSD_ERR_BAD_SHAPE;
+    if (rows <= 0 || K <= 0 || K % 32 != 0 || nbatch <= 0) return SSD_ERR_BAD_SHAPE;
     if (!ssd_aligned16(w) || !ssd_aligned16(w3)) return SSD_ERR_ALIGN;
     const int rows_pad = ssd_cdiv(rows, 128) * 128;
     const size_t total = (size_t)nbatch * (K / 16) * rows_pad, blocks = (total + 255) / 256;
@@ -227,7 +433,7 @@ extern "C" int ssd_gemm_x3_split_weights(const float* w, void* w3, int rows, int
 // Internal (not part of the C ABI): the x3 form of ssd_internal_gemm_batched (conv_igemm.hip); w3 from ssd_gemm_x3_split_weights
 __attribute__((visibility("hidden"))) int ssd_internal_gemm_batched_x3(const float* a, const void* w3, float* out, int M, int K, int N, int n_rows,
                                                                         int nbatch, size_t batch_a_elems, hipStream_t st) {
-    if (K % 16 != 0 || M <= 0 || N <= 0 || n_rows <= 0 || ssd_cdiv(n_rows, 128) * 128 < N || nbatch <= 0) return SSD_ERR_BAD_SHAPE;
+    if (K % 32 != 0 || M <= 0 || N <= 0 || n_rows <= 0 || ssd_cdiv(n_rows, 128) * 128 < N || nbatch <= 0) return SSD_ERR_BAD_SHAPE;
     if ((size_t)M * K * 4 >= 0xF0000000ull) return SSD_ERR_BAD_SHAPE;
     GemmX3Params p{};
     p.a = a; p.w3 = static_cast<const __bf16*>(w3); p.out = out;
@@ -237,6 +443,28 @@ __attribute__((visibility("hidden"))) int ssd_internal_gemm_batched_x3(const flo
     const size_t nblk = (size_t)p.tiles_m * p.tiles_n * nbatch;
     if (nblk >= (1ull << 31)) return SSD_ERR_BAD_SHAPE;
     hipLaunchKernelGGL(gemm_planes_x3_kernel, dim3((unsigned)nblk), dim3(256), 0, st, p);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
+// Internal: TN split-K plane GEMMs from limbs; out[b][split][M][N] raw partial sums, K steps of 16 rows, `ksplit` slices of
+// `ksteps_per_split` steps each (ksplit * ksteps_per_split >= ceil(K / 16))
+__attribute__((visibility("hidden"))) int ssd_internal_gemm_tn_x3(const float* a, const float* c, float* out, int M, int N, int K, int lda, int ldc,
+                                                                   int nbatch, int ksplit, int ksteps_per_split, size_t batch_a, size_t batch_c,
+                                                                   hipStream_t st) {
+    if (M <= 0 || N <= 0 || K <= 0 || lda % 4 != 0 || ldc % 4 != 0 || nbatch <= 0 || ksplit < 1 || ksteps_per_split < 1) return SSD_ERR_BAD_SHAPE;
+    if ((size_t)ksplit * ksteps_per_split * 16 < (size_t)K) return SSD_ERR_BAD_SHAPE;
+    if (batch_a * 4 >= 0xF0000000ull || batch_c * 4 >= 0xF0000000ull) return SSD_ERR_BAD_SHAPE;
+    TnX3Params q{};
+    q.a = a; q.c = c; q.out = out;
+    q.M = M; q.N = N; q.K = K; q.lda = lda; q.ldc = ldc;
+    q.tiles_m = ssd_cdiv(M, 128); q.tiles_n = ssd_cdiv(N, 128);
+    q.ksplit = ksplit; q.ksteps_per_split = ksteps_per_split; q.groups = nbatch * ksplit;
+    q.batch_a = batch_a; q.batch_c = batch_c;
+    q.a_bytes = (unsigned)((size_t)K * lda * 4); q.c_bytes = (unsigned)((size_t)K * ldc * 4);
+    const size_t nblk = (size_t)q.tiles_m * q.tiles_n * q.groups;
+    if (nblk >= (1ull << 31)) return SSD_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(gemm_tn_x3_kernel, dim3((unsigned)nblk), dim3(256), 0, st, q);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
 }

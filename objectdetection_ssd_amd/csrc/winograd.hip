@@ -14,6 +14,8 @@ int ssd_internal_gemm_batched(const float* a, const float* w, float* out, int M,
                               size_t batch_a_elems, size_t batch_w_elems, int ksplit, hipStream_t st);
 int ssd_internal_gemm_batched_x3(const float* a, const void* w3, float* out, int M, int K, int N, int n_rows, int nbatch, size_t batch_a_elems,
                                  hipStream_t st);
+int ssd_internal_gemm_tn_x3(const float* a, const float* c, float* out, int M, int N, int K, int lda, int ldc, int nbatch, int ksplit,
+                            int ksteps_per_split, size_t batch_a, size_t batch_c, hipStream_t st);
 int ssd_internal_wino4_gemm_out(const float* V, const float* U, int tiles, int K, int Nrows, int Nout, float* out, int ldo, int Cvalid,
                                 const float* bias, const float* mask, const unsigned long long* mask_bits, int relu, int accumulate, int H,
                                 int W, int TH, int TW, float* yp, uint8_t* am, int Ho, int Wo, hipStream_t st);
@@ -1167,9 +1169,16 @@ namespace {
 constexpr int COLSUM_BLOCKS = 512;
 constexpr int DY_BIAS_BLOCKS = 2048;      // >= COLSUM_BLOCKS: rows of the bias-gradient partial buffer
 int g_wgrad_tn = 1;               // F(4x4) weight gradient on untransposed planes + the TN GEMM (0: transposed planes + the NT GEMM)
-struct WinoWgradPlan { int TH, TW, Tpad, ks, cdy, P; size_t tiles, yb, vb, zb, pb; LatPlan lp; };
+struct WinoWgradPlan { int TH, TW, Tpad, ks, cdy, P, x3; size_t tiles, yb, vb, zb, pb; LatPlan lp; };
+// The 36 TN GEMMs dU = dY^T V of an F(4x4) layer from three bf16 limbs per operand (gemm_x3.hip, 128 x 128 tiles): where both channel
+// counts fill the tiles (padding <= 25 %: the trunk from conv2_2 on and fc6; the heads' 100 / 150 rows stay on the 64 x 64 f32 kernel)
+inline bool use_x3_tn(const ssd_conv_geom* g, int mo) {
+    return use_x3(mo, 256) && g_wgrad_tn && g->Co >= 128 && g->Ci >= 128 && (g->Co + 127) / 128 * 128 * 4 <= g->Co * 5 &&
+           (g->Ci + 127) / 128 * 128 * 4 <= g->Ci * 5;
+}
 WinoWgradPlan wino_wgrad_plan(const ssd_conv_geom* g, int ldy, int mo) {
     WinoWgradPlan w;
+    w.x3 = use_x3_tn(g, mo) ? 1 : 0;
     w.P = (mo + 2) * (mo + 2);
     w.lp = lat_plan(g->H, g->W, mo == 4 ? g->dil : 1);
     w.TH = mo == 4 ? w.lp.TH : (g->H + mo - 1) / mo; w.TW = mo == 4 ? w.lp.TW : (g->W + mo - 1) / mo;
@@ -1190,11 +1199,44 @@ WinoWgradPlan wino_wgrad_plan(const ssd_conv_geom* g, int ldy, int mo) {
         const int k2 = (ksteps + per - 1) / per;
         if ((k2 & 1) == 0) w.ks = k2;
     }
+    if (w.x3) {
+        // one round of resident blocks (3 per CU): as many K slices as keep the grid within 768 blocks, an even count (partial sums
+        // are written and read back: no more slices than that), at least 8 steps of 16 tiles each
+        const int bp128 = ((g->Co + 127) / 128) * ((g->Ci + 127) / 128) * w.P, steps16 = (int)((w.tiles + 15) / 16);
+        int k3 = 768 / bp128;
+        if (k3 > 1) k3 &= ~1;
+        if (k3 > steps16 / 8) k3 = steps16 / 8;
+        if (k3 < 1) k3 = 1;
+        const int per3 = (steps16 + k3 - 1) / k3;
+        w.ks = (steps16 + per3 - 1) / per3;
+    }
     w.yb = align256((size_t)w.P * ldy * w.Tpad * 4);
     w.vb = align256((size_t)w.P * g->Ci * w.Tpad * 4);
     w.zb = align256((size_t)w.P * w.ks * g->Co * g->Ci * 4);
     w.pb = align256((size_t)DY_BIAS_BLOCKS * ldy * 4);
     return w;
+}
+// the split-K TN GEMMs of the F(4x4) weight gradient: Zs[plane][slice][Co][Ci] = (slice of) Y[plane]^T V[plane]
+int launch_wgrad_tn(const float* Y, const float* V, float* Zs, const ssd_conv_geom* g, int ldy, const WinoWgradPlan& w, hipStream_t st) {
+    if (w.x3) {
+        const int steps16 = (int)((w.tiles + 15) / 16);
+        return ssd_internal_gemm_tn_x3(Y, V, Zs, g->Co, g->Ci, (int)w.tiles, ldy, g->Ci, w.P, w.ks, (steps16 + w.ks - 1) / w.ks, w.tiles * ldy,
+                                       w.tiles * g->Ci, st);
+    }
+    TnParams q;
+    q.a = Y; q.b = V; q.out = Zs;
+    q.M = g->Co; q.N = g->Ci; q.K = (int)w.tiles; q.lda = ldy; q.ldb = g->Ci;
+    q.tiles_m = (g->Co + 63) / 64; q.tiles_n = (g->Ci + 63) / 64;
+    const int ksteps = (q.K + 31) / 32;
+    q.ksplit = w.ks;
+    q.ksteps_per_split = (ksteps + w.ks - 1) / w.ks;
+    q.batch_a = w.tiles * ldy; q.batch_b = w.tiles * g->Ci;
+    if (q.batch_a * 4 >= 0xFFFFFFF0ull || q.batch_b * 4 >= 0xFFFFFFF0ull) return SSD_ERR_BAD_SHAPE;
+    q.a_bytes = (unsigned)(q.batch_a * 4); q.b_bytes = (unsigned)(q.batch_b * 4);
+    q.groups = w.P * w.ks;
+    hipLaunchKernelGGL(wino_gemm_tn_kernel, dim3((unsigned)(q.tiles_m * q.tiles_n * ((q.groups + 7) / 8) * 8)), dim3(256), 0, st, q);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
 }
 }  // namespace
 
@@ -1335,19 +1377,7 @@ int wino_wgrad(const float* x, const float* planes, const float* dy, int ldy, fl
             hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(w.tiles * (g->Ci / 4))), dim3(256), 0, st, x, Vt, g->N, g->H, g->W, g->Ci, w.TH,
                                w.TW, static_cast<unsigned long long*>(nullptr), w.lp.lat);
         SSD_CHECK_LAUNCH();
-        TnParams q;
-        q.a = Yt; q.b = planes != nullptr ? planes : Vt; q.out = Zs;
-        q.M = g->Co; q.N = g->Ci; q.K = (int)w.tiles; q.lda = ldy; q.ldb = g->Ci;
-        q.tiles_m = (g->Co + 63) / 64; q.tiles_n = (g->Ci + 63) / 64;
-        const int ksteps = (q.K + 31) / 32;
-        q.ksplit = w.ks;
-        q.ksteps_per_split = (ksteps + w.ks - 1) / w.ks;
-        q.batch_a = w.tiles * ldy; q.batch_b = w.tiles * g->Ci;
-        if (q.batch_a * 4 >= 0xFFFFFFF0ull || q.batch_b * 4 >= 0xFFFFFFF0ull) return SSD_ERR_BAD_SHAPE;
-        q.a_bytes = (unsigned)(q.batch_a * 4); q.b_bytes = (unsigned)(q.batch_b * 4);
-        q.groups = w.P * w.ks;
-        hipLaunchKernelGGL(wino_gemm_tn_kernel, dim3((unsigned)(q.tiles_m * q.tiles_n * ((q.groups + 7) / 8) * 8)), dim3(256), 0, st, q);
-        SSD_CHECK_LAUNCH();
+        if (int e = launch_wgrad_tn(Yt, planes != nullptr ? planes : Vt, Zs, g, ldy, w, st)) return e;
     } else if (mo == 2) {
         hipLaunchKernelGGL(wino_xform_t_kernel<1>, gyd, dim3(256), 0, st, dy, Yt, g->N, g->H, g->W, ldy, w.TH, w.TW, w.Tpad);
         hipLaunchKernelGGL(wino_xform_t_kernel<0>, gxd, dim3(256), 0, st, x, Vt, g->N, g->H, g->W, g->Ci, w.TH, w.TW, w.Tpad);
@@ -1491,19 +1521,7 @@ extern "C" int ssd_wino4_wgrad_gemm(const float* wgrad_planes, const float* x_pl
     if (workspace_bytes < w.zb) return SSD_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float* Zs = static_cast<float*>(workspace);
-    TnParams q;
-    q.a = wgrad_planes; q.b = x_planes; q.out = Zs;
-    q.M = g->Co; q.N = g->Ci; q.K = (int)w.tiles; q.lda = ldy; q.ldb = g->Ci;
-    q.tiles_m = (g->Co + 63) / 64; q.tiles_n = (g->Ci + 63) / 64;
-    const int ksteps = (q.K + 31) / 32;
-    q.ksplit = w.ks;
-    q.ksteps_per_split = (ksteps + w.ks - 1) / w.ks;
-    q.batch_a = w.tiles * ldy; q.batch_b = w.tiles * g->Ci;
-    if (q.batch_a * 4 >= 0xFFFFFFF0ull || q.batch_b * 4 >= 0xFFFFFFF0ull) return SSD_ERR_BAD_SHAPE;
-    q.a_bytes = (unsigned)(q.batch_a * 4); q.b_bytes = (unsigned)(q.batch_b * 4);
-    q.groups = w.P * w.ks;
-    hipLaunchKernelGGL(wino_gemm_tn_kernel, dim3((unsigned)(q.tiles_m * q.tiles_n * ((q.groups + 7) / 8) * 8)), dim3(256), 0, st, q);
-    SSD_CHECK_LAUNCH();
+    if (int e = launch_wgrad_tn(wgrad_planes, x_planes, Zs, g, ldy, w, st)) return e;
     const size_t total = (size_t)g->Co * g->Ci;
     int ks_left = w.ks;
     if (w.ks > 1 && total / 4 < 65536) {

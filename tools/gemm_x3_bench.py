@@ -11,7 +11,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from objectdetection_ssd_amd import _lib  # noqa: E402
+from objectdetection_ssd_amd import _lib, ops  # noqa: E402
 
 SHAPES = [("conv3_2", 32 * 19 * 19, 256, 256, 36), ("conv4_2", 32 * 10 * 10, 512, 512, 36), ("conv5_2", 32 * 5 * 5, 512, 512, 36),
           ("fc6", 32 * 8 * 8, 512, 1024, 36), ("c_4", 32 * 10 * 10, 512, 100, 36), ("dgrad conv3_1", 32 * 19 * 19, 256, 128, 36)]
@@ -37,11 +37,14 @@ def main():
                 fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(10):
+            pa = ops.clock_probe(dev)
+            for _ in range(20):
                 fn()
+            pb = ops.clock_probe(dev)
             e1.record()
             torch.cuda.synchronize()
-            res[tag] = e0.elapsed_time(e1) / 10
+            res[tag] = e0.elapsed_time(e1) / 20
+            res[tag + "_mhz"] = ops.shader_mhz(pa, pb)
         ref = a[0].double() @ w[0].double().T
         err = {t: float((o[0].double() - ref).norm() / ref.norm()) for t, o in (("f32", o32), ("x3", ox3))}
         last = P - 1
@@ -49,7 +52,7 @@ def main():
         err2 = float((ox3[last].double() - ref2).norm() / ref2.norm())
         fl = 2.0 * M * K * N * P
         print(f"{name:14s} M={M:6d} K={K:4d} N={N:4d}  f32 {res['f32']:.3f} ms {fl / res['f32'] / 1e9:7.1f} TF/s   x3 {res['x3']:.3f} ms "
-              f"{fl / res['x3'] / 1e9:7.1f} TF/s (executed bf16 {6 * fl / res['x3'] / 1e9:7.1f})   err f32 {err['f32']:.2e} x3 {err['x3']:.2e} / {err2:.2e}",
+              f"{fl / res['x3'] / 1e9:7.1f} TF/s (executed bf16 {6 * fl / res['x3'] / 1e9:7.1f})   err f32 {err['f32']:.2e} x3 {err['x3']:.2e} / {err2:.2e}  clock f32 {res['f32_mhz']:.0f} x3 {res['x3_mhz']:.0f} MHz",
               flush=True)
 
 
