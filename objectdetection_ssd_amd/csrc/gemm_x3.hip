@@ -100,6 +100,14 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
         ra[set][0] = buf_load16(srd_a, v, (unsigned)ks * 64u);
         ra[set][1] = buf_load16(srd_a, v + 16u, (unsigned)ks * 64u);
     };
+    // Sign dither.  The bf16 MFMA's internal sum is truncated, not rounded: against f64 the result carries a bias of about -1.7e-10 of
+    // its magnitude per MFMA of the chain, always downwards (tools/x3_bias_probe.py: -3.3e-8 at K = 512, -1.3e-7 at K = 2048, the same
+    // for positive, negative and mixed data; the f32 MFMA: < 1e-9).  That is 1/10 of the random rounding error of one product, but it
+    // is coherent: through the Winograd output transform and ten layers of backward it sums where rounding errors average out.
+    // So row m of the activation operand enters with sign s(m) = +-1 (bit 31 of the raw f32 words, before the split: limbs of -x are
+    // minus the limbs of x) and the finished row is multiplied by s(m) again: the bias of an output element keeps its size but takes
+    // the sign s(m), s(m) = (-1)^(bit 2 ^ bit 5 of m): zero mean over any 8 consecutive rows.
+    const unsigned a_sign = (unsigned)(((arow >> 2) ^ (arow >> 5)) & 1) << 31;
     auto dma_b = [&](int ks, int stage) {
         const __bf16* s = b_src + (size_t)ks * 3 * limb_elems;
         unsigned char* d = lds + stage * X3_STAGE + X3_OPER + wave * 1024;
@@ -137,7 +145,12 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
             }
         __builtin_amdgcn_sched_barrier(0);
         const f32x4 v0 = ra[PH ^ 1][0], v1 = ra[PH ^ 1][1];
-        const float xa[4] = {v0[0], v0[2], v1[0], v1[2]}, xb[4] = {v0[1], v0[3], v1[1], v1[3]};
+        float xa[4] = {v0[0], v0[2], v1[0], v1[2]}, xb[4] = {v0[1], v0[3], v1[1], v1[3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            xa[e] = __uint_as_float(__float_as_uint(xa[e]) ^ a_sign);
+            xb[e] = __uint_as_float(__float_as_uint(xb[e]) ^ a_sign);
+        }
         unsigned hi[4], mid[4], lo[4];
         float r1a[4], r1b[4];
 #pragma unroll
@@ -174,7 +187,13 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
     load_a(1, 1);
     {
         u32x4 hi, mid, lo;
-        split8(ra[0][0], ra[0][1], hi, mid, lo);  // (the compiler waits for set 0 here)
+        f32x4 s0 = ra[0][0], s1 = ra[0][1];       // (the compiler waits for set 0 here)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s0[e] = __uint_as_float(__float_as_uint(s0[e]) ^ a_sign);
+            s1[e] = __uint_as_float(__float_as_uint(s1[e]) ^ a_sign);
+        }
+        split8(s0, s1, hi, mid, lo);
         unsigned char* d = lds + a_wr;
         *reinterpret_cast<u32x4*>(d) = hi;
         *reinterpret_cast<u32x4*>(d + X3_LIMB) = mid;
@@ -206,8 +225,9 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
             const int n = n0 + wn * 64 + j * 32 + lr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
-                if (m < p.M && n < p.N) out[(size_t)m * p.N + n] = acc[i][j][r];
+                const int m = m0 + wm * 64 + i * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);       // bits 2 and 5 of m: lh and i
+                const float v = ((lh ^ i) & 1) ? -acc[i][j][r] : acc[i][j][r];               // the row's sign s(m) again
+                if (m < p.M && n < p.N) out[(size_t)m * p.N + n] = v;
             }
         }
 }
@@ -259,6 +279,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(const TnX3Params p) 
     const bool ok_a = m0 + ch * 8 < p.lda, ok_c = n0 + ch * 8 < p.ldc;           // lda, ldc are multiples of 4: a chunk may be half valid
     const bool ok_a2 = m0 + ch * 8 + 4 < p.lda, ok_c2 = n0 + ch * 8 + 4 < p.ldc;
     const unsigned wr = 256 * trow + 16 * (ch ^ (((trow & 3) << 2) | ((trow >> 2) & 3)));
+    // sign dither (see gemm_planes_x3_kernel): channel m of the a operand enters with s(m) = (-1)^(bit 3 ^ bit 6 of m) -- constant over a
+    // thread's 8 channels -- and row m of the result is multiplied by s(m) again: the truncation bias of the bf16 MFMA chain, always
+    // downwards, becomes zero-mean over the rows
+    const unsigned a_sign = (unsigned)((ch ^ (ch >> 3)) & 1) << 31;
     f32x4 ra[2][4];                                                                 // [register set][a lo, a hi, c lo, c hi]
     auto load = [&](int kt, int set) {
         const size_t k = (size_t)(kt_begin + kt) * 16 + trow;
@@ -312,8 +336,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(const TnX3Params p) 
         float xa[8], xb[8];                                                          // eight pairs: a chunk (4), c chunk (4)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            xa[2 * v] = ra[PH ^ 1][v][0]; xb[2 * v] = ra[PH ^ 1][v][1];
-            xa[2 * v + 1] = ra[PH ^ 1][v][2]; xb[2 * v + 1] = ra[PH ^ 1][v][3];
+            const unsigned sg = v < 2 ? a_sign : 0u;                                 // the sign dither of the a operand's channel group
+            xa[2 * v] = __uint_as_float(__float_as_uint(ra[PH ^ 1][v][0]) ^ sg); xb[2 * v] = __uint_as_float(__float_as_uint(ra[PH ^ 1][v][1]) ^ sg);
+            xa[2 * v + 1] = __uint_as_float(__float_as_uint(ra[PH ^ 1][v][2]) ^ sg); xb[2 * v + 1] = __uint_as_float(__float_as_uint(ra[PH ^ 1][v][3]) ^ sg);
         }
         unsigned hi[8], mid[8], lo[8];
         float r1a[8], r1b[8];
@@ -353,7 +378,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(const TnX3Params p) 
     {
         u32x4 h, m, l;
         unsigned char* d = lds + wr;
-        split8(ra[0][0], ra[0][1], h, m, l);          // (the compiler waits for set 0 here)
+        f32x4 s0 = ra[0][0], s1 = ra[0][1];           // (the compiler waits for set 0 here)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s0[e] = __uint_as_float(__float_as_uint(s0[e]) ^ a_sign);
+            s1[e] = __uint_as_float(__float_as_uint(s1[e]) ^ a_sign);
+        }
+        split8(s0, s1, h, m, l);
         *reinterpret_cast<u32x4*>(d) = h; *reinterpret_cast<u32x4*>(d + X3_LIMB) = m; *reinterpret_cast<u32x4*>(d + 2 * X3_LIMB) = l;
         split8(ra[0][2], ra[0][3], h, m, l);
         *reinterpret_cast<u32x4*>(d + X3_OPER) = h; *reinterpret_cast<u32x4*>(d + X3_OPER + X3_LIMB) = m;
@@ -378,8 +409,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(const TnX3Params p) 
             const int n = n0 + wn * 64 + j * 32 + lr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
-                if (m < p.M && n < p.N) out[(size_t)m * p.N + n] = acc[i][j][r];
+                const int m = m0 + wm * 64 + i * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);       // bits 3 and 6 of m: bit 0 of r >> 2, and wm
+                const float v = (((r >> 2) ^ wm) & 1) ? -acc[i][j][r] : acc[i][j][r];
+                if (m < p.M && n < p.N) out[(size_t)m * p.N + n] = v;
             }
         }
 }

@@ -363,6 +363,11 @@ __device__ constexpr float W4_BT[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1,
 __device__ constexpr float W4_G[6][3] = {{0.25f, 0, 0}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
                                          {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0, 0, 1}};
 __device__ constexpr float W4_AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+// one row of G against three values, as an explicit product + two fused multiply-adds: the filter transform is written in three
+// kernels (per layer, job table, limb rows) whose results must agree bit for bit, whatever the compiler would contract in each
+__device__ __forceinline__ float w4_g_dot(int row, float x0, float x1, float x2) {
+    return __builtin_fmaf(W4_G[row][2], x2, __builtin_fmaf(W4_G[row][1], x1, W4_G[row][0] * x0));
+}
 
 // One element (plane p, row n, column k) of a transformed filter.  x3 = 0: U [36][Nrows][K] f32.  x3 = 1: the three exact bf16 limbs of
 // the value in the layout of csrc/gemm_x3.hip, [36][K/16][3][pad128(Nrows)][16] bf16 (rows beyond Nrows: never written, zero from the
@@ -397,12 +402,12 @@ __global__ void wino4_weight_kernel(const float* __restrict__ w, float* __restri
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) t[a][s] = W4_G[a][0] * g[0][s] + W4_G[a][1] * g[1][s] + W4_G[a][2] * g[2][s];
+            for (int s = 0; s < 3; ++s) t[a][s] = w4_g_dot(a, g[0][s], g[1][s], g[2][s]);
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
             for (int b = 0; b < 6; ++b)
-                store_u(U, x3, a * 6 + b, n, k, Nrows, K, W4_G[b][0] * t[a][0] + W4_G[b][1] * t[a][1] + W4_G[b][2] * t[a][2]);
+                store_u(U, x3, a * 6 + b, n, k, Nrows, K, w4_g_dot(b, t[a][0], t[a][1], t[a][2]));
     }
 }
 
@@ -1557,11 +1562,55 @@ __global__ __launch_bounds__(256) void weight_jobs_kernel(const ssd_weight_job* 
         return co < j.co0 ? j.w0[((size_t)co * Ci + ci) * T + t] : j.w1[((size_t)(co - j.co0) * Ci + ci) * T + t];
     };
     if (j.kind == 0) {                               // Winograd F(4x4,3x3): thread = (n, k) of U_fwd [36][Co][Ci] or of U_bwd [36][Ci][co_pad]
+        // pad0 bit 0 / 1: out_fwd / out_bwd hold limb planes (ssd_wino_uses_x3 of their K): there a thread transforms 8 consecutive k of
+        // one row and writes each plane's limbs as three 16-byte stores
+        const int x3f = j.pad0 & 1, x3b = (j.pad0 >> 1) & 1;
         const size_t nf = (size_t)Co * Ci, nb = (size_t)Ci * j.co_pad;
-        const bool fwd = i < nf;
-        if (!fwd && (j.out_bwd == nullptr || i - nf >= nb)) return;
-        const size_t e = fwd ? i : i - nf;
+        const size_t tf = x3f ? nf / 8 : nf, tb = j.out_bwd == nullptr ? 0 : (x3b ? nb / 8 : nb);
+        const bool fwd = i < tf;
+        if (!fwd && i - tf >= tb) return;
+        if (fwd && j.out_fwd == nullptr) return;
+        const size_t e = fwd ? i : i - tf;
         const int Nrows = fwd ? Co : Ci, K = fwd ? Ci : j.co_pad;
+        float* U = fwd ? j.out_fwd : j.out_bwd;
+        if (fwd ? x3f : x3b) {
+            const int K8 = K >> 3, k8 = (int)(e % K8) * 8, n = (int)(e / K8);
+            float g[8][9];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int co = fwd ? n : k8 + q, ci = fwd ? k8 + q : n;
+#pragma unroll
+                for (int t9 = 0; t9 < 9; ++t9) g[q][t9] = co < Co ? src(co, ci, fwd ? t9 : 8 - t9) : 0.f;
+            }
+            const size_t limb = (size_t)((Nrows + 127) / 128 * 128) * 16;
+            __bf16* base = reinterpret_cast<__bf16*>(U) + (size_t)(k8 >> 4) * 3 * limb + (size_t)n * 16 + (k8 & 15);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                float t[8][3];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int s2 = 0; s2 < 3; ++s2) t[q][s2] = w4_g_dot(a, g[q][s2], g[q][3 + s2], g[q][6 + s2]);
+#pragma unroll
+                for (int b = 0; b < 6; ++b) {
+                    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+                    bf16x8 h, m, l;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float v = w4_g_dot(b, t[q][0], t[q][1], t[q][2]);
+                        h[q] = (__bf16)v;                 // round-to-nearest limbs; both residuals are exact (gemm_x3.hip)
+                        const float r1 = v - (float)h[q];
+                        m[q] = (__bf16)r1;
+                        l[q] = (__bf16)(r1 - (float)m[q]);
+                    }
+                    __bf16* d = base + (size_t)(a * 6 + b) * (K >> 4) * 3 * limb;
+                    *reinterpret_cast<bf16x8*>(d) = h;
+                    *reinterpret_cast<bf16x8*>(d + limb) = m;
+                    *reinterpret_cast<bf16x8*>(d + 2 * limb) = l;
+                }
+            }
+            return;
+        }
         const int k = (int)(e % K), n = (int)(e / K);
         const int co = fwd ? n : k, ci = fwd ? k : n;
         float g[3][3];
@@ -1573,15 +1622,12 @@ __global__ __launch_bounds__(256) void weight_jobs_kernel(const ssd_weight_job* 
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) t[a][s] = W4_G[a][0] * g[0][s] + W4_G[a][1] * g[1][s] + W4_G[a][2] * g[2][s];
-        float* U = fwd ? j.out_fwd : j.out_bwd;
-        if (fwd && j.out_fwd == nullptr) return;
-        const int x3 = (j.pad0 >> (fwd ? 0 : 1)) & 1;         // pad0 bit 0 / 1: out_fwd / out_bwd hold limb planes (ssd_wino_uses_x3 of their K)
+            for (int s = 0; s < 3; ++s) t[a][s] = w4_g_dot(a, g[0][s], g[1][s], g[2][s]);
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
             for (int b = 0; b < 6; ++b)
-                store_u(U, x3, a * 6 + b, n, k, Nrows, K, W4_G[b][0] * t[a][0] + W4_G[b][1] * t[a][1] + W4_G[b][2] * t[a][2]);
+                U[((size_t)(a * 6 + b) * Nrows + n) * K + k] = w4_g_dot(b, t[a][0], t[a][1], t[a][2]);
     } else if (j.kind == 1) {                        // OHWI [co_pad][T][Ci] and IHWO [Ci][T][co_pad]
         const size_t total = (size_t)j.co_pad * T * Ci;
         if (i < total) {
@@ -1623,7 +1669,8 @@ __global__ __launch_bounds__(256) void weight_jobs_kernel(const ssd_weight_job* 
 extern "C" int ssd_weight_job_blocks(const ssd_weight_job* job) {
     if (!job || job->co <= 0 || job->ci <= 0) return -1;
     size_t elems;
-    if (job->kind == 0) elems = (size_t)job->co * job->ci + (job->out_bwd ? (size_t)job->ci * job->co_pad : 0);
+    if (job->kind == 0)          // threads: one per element, or per 8 elements of a limb-plane output (pad0 bit 0: out_fwd, bit 1: out_bwd)
+        elems = (size_t)job->co * job->ci / ((job->pad0 & 1) ? 8 : 1) + (job->out_bwd ? (size_t)job->ci * job->co_pad / ((job->pad0 & 2) ? 8 : 1) : 0);
     else if (job->kind == 1) elems = (size_t)job->co_pad * job->taps * job->ci * (job->out_bwd ? 2 : 1);
     else if (job->kind == 2) elems = (size_t)job->co * 32;
     else if (job->kind == 3) elems = (size_t)job->co_pad * job->taps * job->ci + (job->out_bwd ? (size_t)job->ci * job->taps * job->pad1 : 0);

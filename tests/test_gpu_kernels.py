@@ -909,10 +909,34 @@ def test_weight_job_table_equals_the_per_layer_transforms_bit_for_bit():
         dict(kind=1, w0=w_fc6, co0=64, co=64, ci=32, taps=9, co_pad=64, out_fwd=e(64, 9, 32), out_bwd=None),
         dict(kind=2, w0=w_first, co0=64, co=64, ci=3, taps=9, co_pad=64, out_fwd=e(64, 1, 32)),
     ]
+    # limb-plane outputs (reduction length >= 256 under the default ssd_tune_set_wino_x3): forward only, backward only, both
+    w_xa, w_xb, w_xc = rnd(160, 256, 3, 3), rnd(256, 64, 3, 3), rnd(288, 256, 3, 3)
+    for wq, cp in ((w_xa, 160), (w_xb, 256), (w_xc, 288)):
+        co_, ci_ = wq.shape[0], wq.shape[1]
+        jobs.append(dict(kind=0, w0=wq, co0=co_, co=co_, ci=ci_, taps=9, co_pad=cp, out_fwd=ops.wino_filter_alloc(4, co_, ci_, dev),
+                         out_bwd=ops.wino_filter_alloc(4, ci_, cp, dev)))
+    assert [jb["out_fwd"].dtype == torch.bfloat16 for jb in jobs[6:]] == [True, False, True]
+    assert [jb["out_bwd"].dtype == torch.bfloat16 for jb in jobs[6:]] == [False, True, True]
     table = ops.WeightTable(jobs, dev)
-    assert table.njobs == 6 and table.total_blocks > 6
+    assert table.njobs == 9 and table.total_blocks > 9
     table.run()
     torch.cuda.synchronize()
+    for jb, cp in zip(jobs[6:], (160, 256, 288)):
+        uf, ub = ops.wino_weights(jb["w0"], co_pad=cp, mo=4)
+        assert uf.dtype == jb["out_fwd"].dtype and ub.dtype == jb["out_bwd"].dtype
+        assert torch.equal(jb["out_fwd"].view(torch.int16) if uf.dtype == torch.bfloat16 else jb["out_fwd"],
+                           uf.view(torch.int16) if uf.dtype == torch.bfloat16 else uf)
+        assert torch.equal(jb["out_bwd"].view(torch.int16) if ub.dtype == torch.bfloat16 else jb["out_bwd"],
+                           ub.view(torch.int16) if ub.dtype == torch.bfloat16 else ub)
+    # the limbs of a filter plane add up to the f32 transform: hi + mid + lo == U exactly
+    lib = __import__("objectdetection_ssd_amd._lib", fromlist=["load"]).load()
+    try:
+        assert lib.ssd_tune_set_wino_x3(0) == 0
+        uf32, _ = ops.wino_weights(w_xc, co_pad=288, mo=4)
+    finally:
+        assert lib.ssd_tune_set_wino_x3(-1) == 0
+    lim = jobs[8]["out_fwd"].float().sum(2)[:, :, :288, :].permute(0, 2, 1, 3).reshape(36, 288, 256)
+    assert torch.equal(lim, uf32)
     uf, ub = ops.wino_weights(w_wino, co_pad=128, mo=4)
     assert torch.equal(jobs[0]["out_fwd"], uf) and torch.equal(jobs[0]["out_bwd"], ub)
     uf, ub = ops.wino_weights(headw, co_pad=160, mo=4)
