@@ -40,6 +40,7 @@ struct NmsWs {
     float* s_prob;       // [C-1][P]
     int32_t* s_idx;      // [C-1][P]
     int32_t* kept_pos;   // [C-1][P] sorted positions of kept boxes, in order
+    uint32_t* kept_prob; // [C-1][P] probability bits of the kept boxes, in the same order
     int32_t* kept_cnt;   // [C-1]
     int32_t* offsets;    // [C] class-major exclusive offsets, [C-1] = total
     uint32_t* k_prob;    // [(C-1)*P] prob bits of the kept boxes, class-major
@@ -61,6 +62,7 @@ NmsWs carve(void* ws, int P, int C, int B) {
     w.s_prob = reinterpret_cast<float*>(b + o); o += up(K * 4);
     w.s_idx = reinterpret_cast<int32_t*>(b + o); o += up(K * 4);
     w.kept_pos = reinterpret_cast<int32_t*>(b + o); o += up(K * 4);
+    w.kept_prob = reinterpret_cast<uint32_t*>(b + o); o += up(K * 4);
     w.kept_cnt = reinterpret_cast<int32_t*>(b + o); o += up((size_t)C * 4 * B);
     w.offsets = reinterpret_cast<int32_t*>(b + o); o += up((size_t)(C + 1) * 4 * B);
     w.k_prob = reinterpret_cast<uint32_t*>(b + o); o += up(K * 4);
@@ -154,16 +156,43 @@ __global__ __launch_bounds__(256) void rank_scatter_kernel(const uint64_t* __res
 //      (v_readlane), giving the chunk's keep mask;
 //   C  the kept rows' words are OR-ed into the removed bitset of all later columns.
 // All state (removed bitset, CR x n/64 words) lives in LDS; no n x n matrix ever reaches memory.
-__global__ __launch_bounds__(NB_T) void nms_kernel(const float* __restrict__ s_boxes, const int32_t* __restrict__ cand_cnt, int P,
-                                                   float thr, int CR, int32_t* __restrict__ kept_pos, int32_t* __restrict__ kept_cnt) {
+//
+// The test IoU >= thr is the reference's float sequence inter / ((a1 + a2) - inter) >= thr (Util.py:252-301, Losses.py:51) bit for
+// bit, but the IEEE division (~12 dependent instructions) is only executed where it can matter: with t = thr * union and
+// d = inter - t, |d| > 1e-5 t decides the comparison whatever the two roundings (each <= 6e-8 relative) do, so a wave divides only
+// when one of its lanes lies within 1e-5 of the threshold (or the union is not a normal positive number).  Four rows are tested per
+// pass -- four independent dependency chains per lane -- and the areas are computed once per box, not once per pair.
+__device__ __forceinline__ float hw_max(float x, float y) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ float hw_min(float x, float y) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+struct IouTest { float inter, uni, d; bool sure; };
+__device__ __forceinline__ IouTest iou_test(const f32x4 a, float area_a, const f32x4 b, float area_b, float thr) {
+    IouTest r;
+    // v_max / v_min as they are: fmaxf / fminf would first canonicalise each of the eight inputs (signalling-NaN semantics), eight more
+    // instructions per test.  A NaN coordinate makes its box's area NaN, so the test ends in the exact path and is false either way.
+    const float lx = hw_max(a[0], b[0]), ly = hw_max(a[1], b[1]);
+    const float hx = hw_min(a[2], b[2]), hy = hw_min(a[3], b[3]);
+    const float dx = hw_max(hx - lx, 0.f), dy = hw_max(hy - ly, 0.f);
+    r.inter = dx * dy;
+    r.uni = (area_a + area_b) - r.inter;
+    const float t = thr * r.uni;
+    r.d = r.inter - t;
+    r.sure = fabsf(r.d) > 1e-5f * t && t > 1e-20f;                           // false for NaN / infinity anywhere, for empty boxes and for thr <= 0
+    return r;
+}
+
+__global__ __launch_bounds__(NB_T) void nms_kernel(const float* __restrict__ s_boxes, const float* __restrict__ s_prob,
+                                                   const int32_t* __restrict__ cand_cnt, int P, float thr, int CR,
+                                                   int32_t* __restrict__ kept_pos, uint32_t* __restrict__ kept_prob, int32_t* __restrict__ kept_cnt) {
     extern __shared__ __attribute__((aligned(16))) uint64_t sm64[];
     __shared__ int wave_tot[NB_T / 64];
     __shared__ int running;
     __shared__ uint64_t s_keep;
-    __shared__ __attribute__((aligned(16))) float rowbox[64 * 4];
-    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) float rowbox[64 * 8];            // box + area per row of the chunk
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // provably uniform: the item / row bookkeeping below stays on the scalar unit
     const size_t img = blockIdx.z, C1 = gridDim.x;
-    s_boxes += img * C1 * P * 4; cand_cnt += img * (C1 + 1); kept_pos += img * C1 * P; kept_cnt += img * (C1 + 1);
+    s_boxes += img * C1 * P * 4; s_prob += img * C1 * P; cand_cnt += img * (C1 + 1);
+    kept_pos += img * C1 * P; kept_prob += img * C1 * P; kept_cnt += img * (C1 + 1);
     const int n = cand_cnt[c];
     const int nw = (n + 63) >> 6, nwcap = (P + 63) >> 6;
     uint64_t* removed = sm64;                 // [nwcap]
@@ -175,31 +204,64 @@ __global__ __launch_bounds__(NB_T) void nms_kernel(const float* __restrict__ s_b
         const int R = base >> 6, bit0 = base & 63;
         const int span = nw - R;
         // ---- A ------------------------------------------------------------------------------------------
-        // the chunk's row boxes go to LDS once; a wave item = (column word w, group of CR/4 rows): every lane
-        // loads its column box once and tests it against the rows (LDS broadcast), one ballot per row
+        // the chunk's row boxes (+ areas) go to LDS once; a wave item = (column word w, group of CR/4 rows): every lane
+        // loads its column box once and tests it against the rows (LDS broadcast), four rows per pass, one ballot per row
         const uint64_t rem_start = removed[R];
         if (tid < CR) {
             const int i = base + tid;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (i < n) v = *reinterpret_cast<const f32x4*>(bx + (size_t)i * 4);
-            *reinterpret_cast<f32x4*>(rowbox + tid * 4) = v;
+            *reinterpret_cast<f32x4*>(rowbox + tid * 8) = v;
+            rowbox[tid * 8 + 4] = (v[2] - v[0]) * (v[3] - v[1]);
         }
         __syncthreads();
+        const uint64_t dead = (rem_start >> bit0) | (n - base >= CR ? 0ull : (~0ull << (n - base)));       // bit r: row base + r needs no words
         const int RG = CR >> 2;
+#ifndef NMS_PROBE_NO_A                         // timing probes (tools/nms_probe.sh): a phase compiled out, results meaningless
         for (int item = wave; item < 4 * span; item += NB_T / 64) {
             const int w = R + (item >> 2), r0 = (item & 3) * RG;
             const int j = (w << 6) + lane;
             f32x4 b = {0.f, 0.f, 0.f, 0.f};
             if (j < n) b = *reinterpret_cast<const f32x4*>(bx + (size_t)j * 4);
-            for (int r = r0; r < r0 + RG; ++r) {
-                const int i = base + r;
-                if (i >= n || ((rem_start >> (bit0 + r)) & 1ull)) continue;      // uniform per wave
-                const f32x4 a = *reinterpret_cast<const f32x4*>(rowbox + r * 4);
-                const bool hit = j < n && j > i && iou_boxes(a, b) >= thr;       // Losses.py:51 (NaN >= thr is false)
-                const uint64_t m = __ballot(hit);
-                if (lane == 0) chunk[r * nw + w] = m;
+            const float area_b = (b[2] - b[0]) * (b[3] - b[1]);
+            uint64_t col_ok = n - (w << 6) >= 64 ? ~0ull : ~(~0ull << (n - (w << 6)));                         // lanes with j < n
+            const bool diag = w == R;                                                                          // (uniform) the word that holds the rows themselves
+            // the rows of this item that still need their words, four at a time whatever their positions (scalar bit scan): a row
+            // removed before this chunk costs nothing, and the four tests of a pass are independent instruction chains
+            uint64_t todo = ~dead & ((RG == 64 ? ~0ull : ((1ull << RG) - 1ull)) << r0);
+            while (todo != 0ull) {
+                int rq[4];
+                const int cnt = min(4, __popcll(todo));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    rq[q] = todo != 0ull ? __builtin_ctzll(todo) : rq[0];                                      // (short pass: row rq[0] again, harmless)
+                    todo &= todo - 1ull;
+                }
+                IouTest t4[4];
+                uint64_t gt[4], sure = thr > 0.f ? ~0ull : 0ull;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                                                                  // every comparison lands in a scalar mask
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(rowbox + rq[q] * 8);
+                    t4[q] = iou_test(a, rowbox[rq[q] * 8 + 4], b, area_b, thr);
+                    gt[q] = __ballot(t4[q].d > 0.f);
+                    sure &= __ballot(t4[q].sure);
+                }
+                if (sure != ~0ull) {                                                                           // rare: the exact reference expression
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) gt[q] = __ballot(t4[q].inter / t4[q].uni >= thr);              // Losses.py:51 (NaN >= thr is false)
+                }
+                uint64_t mine = 0;
+                int myr = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint64_t m = gt[q] & col_ok;
+                    if (diag) m &= bit0 + rq[q] == 63 ? 0ull : (~0ull << (bit0 + rq[q] + 1));                  // j > i
+                    if (lane == q) { mine = m; myr = rq[q]; }
+                }
+                if (lane < cnt) chunk[myr * nw + w] = mine;
             }
         }
+#endif
         __syncthreads();
         // ---- B ------------------------------------------------------------------------------------------
         if (wave == 0) {
@@ -208,15 +270,19 @@ __global__ __launch_bounds__(NB_T) void nms_kernel(const float* __restrict__ s_b
             const uint64_t d = live ? chunk[lane * nw + R] : 0ull;
             const unsigned dlo = (unsigned)d, dhi = (unsigned)(d >> 32);
             uint64_t rem = rem_start, keep = 0;
-            for (int r = 0; r < CR; ++r) {
-                if (base + r >= n) break;
+#ifndef NMS_PROBE_NO_B
+            // rows still standing (aligned to the chunk: bit r = row base + r); each kept row removes what its diagonal word names
+            uint64_t avail = ~(rem_start >> bit0) & (CR == 64 ? ~0ull : ((1ull << CR) - 1ull));
+            if (n - base < CR) avail &= ~(~0ull << (n - base));
+            while (avail != 0ull) {                                   // one pass per KEPT row (scalar: find-first-set, two v_readlane, and-not, or)
+                const int r = __builtin_ctzll(avail);
                 const uint64_t row = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)dhi, r) << 32) |
                                      (uint64_t)(unsigned)__builtin_amdgcn_readlane((int)dlo, r);
-                if (!((rem >> (bit0 + r)) & 1ull)) {
-                    keep |= 1ull << r;
-                    rem |= row;
-                }
+                keep |= 1ull << r;
+                rem |= row;
+                avail &= ~((row >> bit0) | (1ull << r));
             }
+#endif
             if (lane == 0) {
                 removed[R] = rem;
                 s_keep = keep;
@@ -225,15 +291,20 @@ __global__ __launch_bounds__(NB_T) void nms_kernel(const float* __restrict__ s_b
         __syncthreads();
         // ---- C ------------------------------------------------------------------------------------------
         const uint64_t keep = s_keep;
-        for (int w = R + 1 + tid; w < nw; w += NB_T) {
-            uint64_t acc = 0;
-            for (int r = 0; r < CR; ++r)
-                if ((keep >> r) & 1ull) acc |= chunk[r * nw + w];
-            removed[w] |= acc;
+#ifndef NMS_PROBE_NO_C
+        for (int w = R + 1 + wave; w < nw; w += NB_T / 64) {          // a wave per later word: lane r brings row r's word if the row was kept
+            uint64_t v = (lane < CR && ((keep >> lane) & 1ull)) ? chunk[lane * nw + w] : 0ull;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned lo = __shfl_xor((unsigned)v, o, 64), hi = __shfl_xor((unsigned)(v >> 32), o, 64);
+                v |= ((uint64_t)hi << 32) | lo;
+            }
+            if (lane == 0) removed[w] |= v;
         }
+#endif
         __syncthreads();
     }
-    // ---- ordered compaction of the survivors ------------------------------------------------------------------
+    // ---- ordered compaction of the survivors (sorted position + probability bits, for the top-k block) -----------------
     if (tid == 0) running = 0;
     __syncthreads();
     for (int j0 = 0; j0 < n; j0 += NB_T) {
@@ -249,7 +320,10 @@ __global__ __launch_bounds__(NB_T) void nms_kernel(const float* __restrict__ s_b
         __syncthreads();
         int off = running;
         for (int w = 0; w < wave; ++w) off += wave_tot[w];
-        if (keep) kept_pos[(size_t)c * P + off + incl - 1] = j;
+        if (keep) {
+            kept_pos[(size_t)c * P + off + incl - 1] = j;
+            kept_prob[(size_t)c * P + off + incl - 1] = __float_as_uint(s_prob[(size_t)c * P + j]);
+        }
         __syncthreads();
         if (tid == 0) {
             int t = 0;
@@ -262,7 +336,7 @@ __global__ __launch_bounds__(NB_T) void nms_kernel(const float* __restrict__ s_b
 }
 
 struct TopkArgs {
-    const float* s_boxes; const int32_t* s_idx; const float* s_prob; const int32_t* kept_pos; const int32_t* kept_cnt;
+    const float* s_boxes; const int32_t* s_idx; const uint32_t* kept_prob; const int32_t* kept_pos; const int32_t* kept_cnt;
     uint32_t* k_prob; int32_t* k_src;           // scratch of this block: class-major compact list of the survivors (prob bits, c*P + sorted position)
     int P, C1, top_k; const float* wh;          // wh: (B,2) device array of (img_w, img_h)
     float* boxes; int64_t* classes; float* probs; int32_t* prior_ids; int32_t* count;
@@ -276,7 +350,7 @@ __global__ __launch_bounds__(NB_T) void topk_emit_kernel(TopkArgs a) {
     {
         const size_t img = blockIdx.z, K = (size_t)a.C1 * a.P;
         a.s_boxes += img * K * 4; a.s_idx += img * K; a.k_prob += img * K; a.k_src += img * K;
-        a.s_prob += img * K; a.kept_pos += img * K; a.kept_cnt += img * (a.C1 + 1);
+        a.kept_prob += img * K; a.kept_pos += img * K; a.kept_cnt += img * (a.C1 + 1);
         a.wh += img * 2;
         a.boxes += img * a.top_k * 4; a.classes += img * a.top_k; a.probs += img * a.top_k; a.prior_ids += img * a.top_k; a.count += img;
     }
@@ -296,14 +370,18 @@ __global__ __launch_bounds__(NB_T) void topk_emit_kernel(TopkArgs a) {
     }
     __syncthreads();
     const int total = offs[a.C1];
-    // the compact list (the two kernels offsets / gather_kept of the earlier version): written and read by this block only
-    for (int c = wave; c < a.C1; c += NB_T / 64) {
-        const int n = offs[c + 1] - offs[c];
-        for (int i = lane; i < n; i += 64) {
-            const int src = c * a.P + a.kept_pos[(size_t)c * a.P + i];
-            a.k_prob[offs[c] + i] = __float_as_uint(a.s_prob[src]);
-            a.k_src[offs[c] + i] = src;
+    // the compact class-major list (the two kernels offsets / gather_kept of the earlier version): written and read by this block only;
+    // one entry per thread and pass, its class found by bisection of the 21 offsets (20 classes over 16 waves was two rounds of
+    // dependent loads for the last four classes)
+    for (int g = tid; g < total; g += NB_T) {
+        int lo = 0, hi = a.C1 - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (offs[mid] <= g) lo = mid; else hi = mid - 1;
         }
+        const int src = lo * a.P + (g - offs[lo]);
+        a.k_prob[g] = a.kept_prob[src];
+        a.k_src[g] = lo * a.P + a.kept_pos[src];
     }
     __threadfence_block();
     __syncthreads();
@@ -430,9 +508,10 @@ extern "C" int ssd_decode_nms_batch(const float* l_, const float* c_, const floa
             raised = true;
         }
     }
-    hipLaunchKernelGGL(nms_kernel, dim3(C1, 1, B), dim3(NB_T), lds, st, w.s_boxes, w.cand_cnt, P, iou_threshold, CR, w.kept_pos, w.kept_cnt);
+    hipLaunchKernelGGL(nms_kernel, dim3(C1, 1, B), dim3(NB_T), lds, st, w.s_boxes, w.s_prob, w.cand_cnt, P, iou_threshold, CR, w.kept_pos, w.kept_prob,
+                       w.kept_cnt);
     SSD_CHECK_LAUNCH();
-    TopkArgs ta{w.s_boxes, w.s_idx, w.s_prob, w.kept_pos, w.kept_cnt, w.k_prob, w.k_src, P, C1, top_k, img_wh, boxes, classes, probs, prior_ids, count};
+    TopkArgs ta{w.s_boxes, w.s_idx, w.kept_prob, w.kept_pos, w.kept_cnt, w.k_prob, w.k_src, P, C1, top_k, img_wh, boxes, classes, probs, prior_ids, count};
     hipLaunchKernelGGL(topk_emit_kernel, dim3(1, 1, B), dim3(NB_T), (size_t)top_k * 8, st, ta);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
