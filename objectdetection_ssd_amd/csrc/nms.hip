@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void rank_scatter_kernel(const uint64_t* __res
 // pass -- four independent dependency chains per lane -- and the areas are computed once per box, not once per pair.
 __device__ __forceinline__ float hw_max(float x, float y) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
 __device__ __forceinline__ float hw_min(float x, float y) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
-struct IouTest { float inter, uni, d; bool sure; };
+struct IouTest { float inter, uni, d, t; };
 __device__ __forceinline__ IouTest iou_test(const f32x4 a, float area_a, const f32x4 b, float area_b, float thr) {
     IouTest r;
     // v_max / v_min as they are: fmaxf / fminf would first canonicalise each of the eight inputs (signalling-NaN semantics), eight more
@@ -174,17 +174,17 @@ __device__ __forceinline__ IouTest iou_test(const f32x4 a, float area_a, const f
     const float dx = hw_max(hx - lx, 0.f), dy = hw_max(hy - ly, 0.f);
     r.inter = dx * dy;
     r.uni = (area_a + area_b) - r.inter;
-    const float t = thr * r.uni;
-    r.d = r.inter - t;
-    r.sure = fabsf(r.d) > 1e-5f * t && t > 1e-20f;                           // false for NaN / infinity anywhere, for empty boxes and for thr <= 0
+    r.t = thr * r.uni;
+    r.d = r.inter - r.t;           // decided where |d| > 1e-5 t and t > 1e-20: false for NaN / infinity anywhere, for empty boxes and for thr <= 0
     return r;
 }
 
-__global__ __launch_bounds__(NB_T) void nms_kernel(const float* __restrict__ s_boxes, const float* __restrict__ s_prob,
-                                                   const int32_t* __restrict__ cand_cnt, int P, float thr, int CR,
+template <int NT>
+__global__ __launch_bounds__(NT) void nms_kernel(const float* __restrict__ s_boxes, const float* __restrict__ s_prob,
+                                                   const int32_t* __restrict__ cand_cnt, int P, float thr, int chunk_words,
                                                    int32_t* __restrict__ kept_pos, uint32_t* __restrict__ kept_prob, int32_t* __restrict__ kept_cnt) {
     extern __shared__ __attribute__((aligned(16))) uint64_t sm64[];
-    __shared__ int wave_tot[NB_T / 64];
+    __shared__ int wave_tot[NT / 64];
     __shared__ int running;
     __shared__ uint64_t s_keep;
     __shared__ __attribute__((aligned(16))) float rowbox[64 * 8];            // box + area per row of the chunk
@@ -196,9 +196,10 @@ __global__ __launch_bounds__(NB_T) void nms_kernel(const float* __restrict__ s_b
     const int n = cand_cnt[c];
     const int nw = (n + 63) >> 6, nwcap = (P + 63) >> 6;
     uint64_t* removed = sm64;                 // [nwcap]
-    uint64_t* chunk = sm64 + nwcap;           // [CR][nw]
+    uint64_t* chunk = sm64 + nwcap;           // [CR][nw]: 64 rows at a time where the class's own word count lets them fit, else 32
+    const int CR = 64 * nw <= chunk_words ? 64 : 32;
     const float* bx = s_boxes + (size_t)c * P * 4;
-    for (int w = tid; w < nw; w += NB_T) removed[w] = 0;
+    for (int w = tid; w < nw; w += NT) removed[w] = 0;
     __syncthreads();
     for (int base = 0; base < n; base += CR) {
         const int R = base >> 6, bit0 = base & 63;
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(NB_T) void nms_kernel(const float* __restrict__ s_b
         const uint64_t dead = (rem_start >> bit0) | (n - base >= CR ? 0ull : (~0ull << (n - base)));       // bit r: row base + r needs no words
         const int RG = CR >> 2;
 #ifndef NMS_PROBE_NO_A                         // timing probes (tools/nms_probe.sh): a phase compiled out, results meaningless
-        for (int item = wave; item < 4 * span; item += NB_T / 64) {
+        for (int item = wave; item < 4 * span; item += NT / 64) {
             const int w = R + (item >> 2), r0 = (item & 3) * RG;
             const int j = (w << 6) + lane;
             f32x4 b = {0.f, 0.f, 0.f, 0.f};
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(NB_T) void nms_kernel(const float* __restrict__ s_b
                     const f32x4 a = *reinterpret_cast<const f32x4*>(rowbox + rq[q] * 8);
                     t4[q] = iou_test(a, rowbox[rq[q] * 8 + 4], b, area_b, thr);
                     gt[q] = __ballot(t4[q].d > 0.f);
-                    sure &= __ballot(t4[q].sure);
+                    sure &= __ballot(fabsf(t4[q].d) > 1e-5f * t4[q].t) & __ballot(t4[q].t > 1e-20f);
                 }
                 if (sure != ~0ull) {                                                                           // rare: the exact reference expression
 #pragma unroll
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(NB_T) void nms_kernel(const float* __restrict__ s_b
         // ---- C ------------------------------------------------------------------------------------------
         const uint64_t keep = s_keep;
 #ifndef NMS_PROBE_NO_C
-        for (int w = R + 1 + wave; w < nw; w += NB_T / 64) {          // a wave per later word: lane r brings row r's word if the row was kept
+        for (int w = R + 1 + wave; w < nw; w += NT / 64) {          // a wave per later word: lane r brings row r's word if the row was kept
             uint64_t v = (lane < CR && ((keep >> lane) & 1ull)) ? chunk[lane * nw + w] : 0ull;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(NB_T) void nms_kernel(const float* __restrict__ s_b
     // ---- ordered compaction of the survivors (sorted position + probability bits, for the top-k block) -----------------
     if (tid == 0) running = 0;
     __syncthreads();
-    for (int j0 = 0; j0 < n; j0 += NB_T) {
+    for (int j0 = 0; j0 < n; j0 += NT) {
         const int j = j0 + tid;
         const int keep = (j < n && !((removed[j >> 6] >> (j & 63)) & 1ull)) ? 1 : 0;
         int incl = keep;
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(NB_T) void nms_kernel(const float* __restrict__ s_b
         __syncthreads();
         if (tid == 0) {
             int t = 0;
-            for (int w = 0; w < NB_T / 64; ++w) t += wave_tot[w];
+            for (int w = 0; w < NT / 64; ++w) t += wave_tot[w];
             running += t;
         }
         __syncthreads();
@@ -495,21 +496,31 @@ extern "C" int ssd_decode_nms_batch(const float* l_, const float* c_, const floa
     SSD_CHECK_LAUNCH();
     hipLaunchKernelGGL(rank_scatter_kernel, dim3(ssd_cdiv(P, 256), C1, B), dim3(256), 0, st, w.keys, w.cand_cnt, w.boxes, P, w.s_boxes, w.s_prob, w.s_idx);
     SSD_CHECK_LAUNCH();
+    // Block size and LDS by batch: a single image is a latency problem (20 workgroups on 256 CUs: 16 waves each, 64-row chunks whatever
+    // the candidate count); a batch is a throughput problem -- 8-wave workgroups with a 37 KB chunk buffer fit four to a CU, so up to
+    // 1024 (image, class) problems are resident at once instead of two rounds of 512 (64-row chunks up to 4608 candidates per class).
     const int nwcap = (P + 63) / 64;
-    int CR = 64;
-    size_t lds = (size_t)(1 + CR) * nwcap * 8;
-    if (lds > 140 * 1024) { CR = 32; lds = (size_t)(1 + CR) * nwcap * 8; }
-    if (lds > 140 * 1024) return SSD_ERR_BAD_SHAPE;
+    const bool wide = (size_t)C1 * B <= 128;
+    int chunk_words = wide ? 64 * nwcap : (32 * nwcap > 4608 ? 32 * nwcap : 4608);
+    const int cap_words = 140 * 1024 / 8 - nwcap;                  // (SSD512's 24564 priors: 64-row chunks up to 4 480 candidates of a class)
+    if (chunk_words > cap_words) chunk_words = cap_words;
+    if (chunk_words < 32 * nwcap) return SSD_ERR_BAD_SHAPE;
+    const size_t lds = (size_t)(nwcap + chunk_words) * 8;
     if (lds > 48 * 1024) {
         static bool raised = false;
         if (!raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
                 return SSD_ERR_LAUNCH;
             raised = true;
         }
     }
-    hipLaunchKernelGGL(nms_kernel, dim3(C1, 1, B), dim3(NB_T), lds, st, w.s_boxes, w.s_prob, w.cand_cnt, P, iou_threshold, CR, w.kept_pos, w.kept_prob,
-                       w.kept_cnt);
+    if (wide)
+        hipLaunchKernelGGL(nms_kernel<1024>, dim3(C1, 1, B), dim3(1024), lds, st, w.s_boxes, w.s_prob, w.cand_cnt, P, iou_threshold, chunk_words, w.kept_pos,
+                           w.kept_prob, w.kept_cnt);
+    else
+        hipLaunchKernelGGL(nms_kernel<512>, dim3(C1, 1, B), dim3(512), lds, st, w.s_boxes, w.s_prob, w.cand_cnt, P, iou_threshold, chunk_words, w.kept_pos,
+                           w.kept_prob, w.kept_cnt);
     SSD_CHECK_LAUNCH();
     TopkArgs ta{w.s_boxes, w.s_idx, w.kept_prob, w.kept_pos, w.kept_cnt, w.k_prob, w.k_src, P, C1, top_k, img_wh, boxes, classes, probs, prior_ids, count};
     hipLaunchKernelGGL(topk_emit_kernel, dim3(1, 1, B), dim3(NB_T), (size_t)top_k * 8, st, ta);
