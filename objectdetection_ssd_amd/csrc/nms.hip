@@ -97,22 +97,43 @@ __global__ __launch_bounds__(256) void decode_compact_kernel(const float* __rest
         b[0] = cx - w / 2.f; b[1] = cy - h / 2.f; b[2] = cx + w / 2.f; b[3] = cy + h / 2.f;
         *reinterpret_cast<f32x4*>(boxes + (size_t)p * 4) = b;
         const float* x = sc + tid * C;                              // row stride C = 21 floats: odd, conflict-free
+        float* xw = sc + tid * C;
         m = x[0];
         for (int q = 1; q < C; ++q) m = fmaxf(m, x[q]);
         se = 0.f;
-        for (int q = 0; q < C; ++q) se += expf(x[q] - m);
+        for (int q = 0; q < C; ++q) {                               // exp(x - max) is kept in place of x: the second pass divides, it does
+            const float e = expf(x[q] - m);                         // not exponentiate again (same value, 21 expf per prior instead of 41)
+            xw[q] = e;
+            se += e;
+        }
     }
-    for (int q = 0; q < C1; ++q) {                                  // uniform trip count: the ballots need every lane
-        const float v = live ? expf(sc[tid * C + q] - m) / se : 0.f;
-        const bool hit = live && v >= min_score;                    // Losses.py:32 (NaN fails, as in torch)
-        const uint64_t mask = __ballot(hit);
-        if (mask == 0) continue;                                    // wave-uniform
+    // Candidates, 32 classes at a time: every lane collects its hit bits (the probability replaces exp in LDS), lane k then owns class
+    // q0 + k -- counts the wave's hits of that class and takes the wave's slots with ONE atomic -- so a wave waits for one atomic round
+    // trip per 32 classes instead of one per class (20 dependent returns were most of this kernel's time).
+    for (int q0 = 0; q0 < C1; q0 += 32) {
+        const int nq = min(32, C1 - q0);
+        unsigned hits = 0;
+        for (int k = 0; k < nq; ++k) {
+            const float v = live ? sc[tid * C + q0 + k] / se : 0.f;
+            if (live) sc[tid * C + q0 + k] = v;
+            hits |= (live && v >= min_score ? 1u : 0u) << k;        // Losses.py:32 (NaN fails, as in torch)
+        }
+        int cnt = 0;
+        for (int k = 0; k < nq; ++k) {                              // uniform trip count: the ballots need every lane
+            const int pc = __popcll(__ballot((hits >> k) & 1u));
+            if (lane == k) cnt = pc;
+        }
         int base = 0;
-        if (lane == 0) base = atomicAdd(&cand_cnt[q], __popcll(mask));
-        base = __shfl(base, 0, 64);
-        if (hit) {
-            const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
-            keys[(size_t)q * P + pos] = ((uint64_t)__float_as_uint(v) << 32) | (uint64_t)(0xffffffffu - (uint32_t)p);
+        if (cnt > 0) base = atomicAdd(&cand_cnt[q0 + lane], cnt);
+        for (int k = 0; k < nq; ++k) {
+            const uint64_t mask = __ballot((hits >> k) & 1u);
+            if (mask == 0) continue;                                // wave-uniform
+            const int b0 = __shfl(base, k, 64);
+            if ((hits >> k) & 1u) {
+                const int pos = b0 + __popcll(mask & ((1ull << lane) - 1ull));
+                const float v = sc[tid * C + q0 + k];
+                keys[(size_t)(q0 + k) * P + pos] = ((uint64_t)__float_as_uint(v) << 32) | (uint64_t)(0xffffffffu - (uint32_t)p);
+            }
         }
     }
 }
@@ -339,7 +360,7 @@ __global__ __launch_bounds__(NT) void nms_kernel(const float* __restrict__ s_box
 struct TopkArgs {
     const float* s_boxes; const int32_t* s_idx; const uint32_t* kept_prob; const int32_t* kept_pos; const int32_t* kept_cnt;
     uint32_t* k_prob; int32_t* k_src;           // scratch of this block: class-major compact list of the survivors (prob bits, c*P + sorted position)
-    int P, C1, top_k; const float* wh;          // wh: (B,2) device array of (img_w, img_h)
+    int P, C1, top_k, kp_cap; const float* wh;  // kp_cap: survivors whose probability bits fit the block's LDS; wh: (B,2) device array of (img_w, img_h)
     float* boxes; int64_t* classes; float* probs; int32_t* prior_ids; int32_t* count;
 };
 
@@ -364,13 +385,34 @@ __global__ __launch_bounds__(NB_T) void topk_emit_kernel(TopkArgs a) {
     __shared__ int bc[3];
     __shared__ int offs[257];                                          // class-major exclusive offsets of the survivors (C1 <= 255)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) {
-        int o = 0;
-        for (int c = 0; c < a.C1; ++c) { offs[c] = o; o += a.kept_cnt[c]; }
-        offs[a.C1] = o;
+    if (wave == 0) {                                                    // exclusive scan of the per-class counts (C1 <= 255: four per lane)
+        int cnt[4], s4 = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = lane * 4 + e;
+            cnt[e] = c < a.C1 ? a.kept_cnt[c] : 0;
+            s4 += cnt[e];
+        }
+        int incl = s4;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        int o = incl - s4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = lane * 4 + e;
+            if (c <= a.C1) offs[c] = o;
+            o += cnt[e];
+        }
     }
     __syncthreads();
     const int total = offs[a.C1];
+    // the survivors' probability bits stay in LDS for the six passes below when they fit (else they are read back from k_prob)
+    uint32_t* kp_lds = reinterpret_cast<uint32_t*>(smem) + 2 * a.top_k;
+    const bool in_lds = total <= a.kp_cap;
+    auto kp = [&](int g) -> uint32_t { return in_lds ? kp_lds[g] : a.k_prob[g]; };
     // the compact class-major list (the two kernels offsets / gather_kept of the earlier version): written and read by this block only;
     // one entry per thread and pass, its class found by bisection of the 21 offsets (20 classes over 16 waves was two rounds of
     // dependent loads for the last four classes)
@@ -381,7 +423,8 @@ __global__ __launch_bounds__(NB_T) void topk_emit_kernel(TopkArgs a) {
             if (offs[mid] <= g) lo = mid; else hi = mid - 1;
         }
         const int src = lo * a.P + (g - offs[lo]);
-        a.k_prob[g] = a.kept_prob[src];
+        const uint32_t u = a.kept_prob[src];
+        if (in_lds) kp_lds[g] = u; else a.k_prob[g] = u;
         a.k_src[g] = lo * a.P + a.kept_pos[src];
     }
     __threadfence_block();
@@ -393,7 +436,7 @@ __global__ __launch_bounds__(NB_T) void topk_emit_kernel(TopkArgs a) {
         o[0] = b[0] * img_w; o[1] = b[1] * img_h; o[2] = b[2] * img_w; o[3] = b[3] * img_h;    // Losses.py:89
         *reinterpret_cast<f32x4*>(a.boxes + (size_t)slot * 4) = o;
         a.classes[slot] = src / a.P;
-        a.probs[slot] = __uint_as_float(a.k_prob[gpos]);
+        a.probs[slot] = __uint_as_float(kp(gpos));
         a.prior_ids[slot] = a.s_idx[src];
     };
     if (tid == 0) *a.count = total > a.top_k ? a.top_k : total;
@@ -408,18 +451,30 @@ __global__ __launch_bounds__(NB_T) void topk_emit_kernel(TopkArgs a) {
         for (int b = tid; b < 256; b += NB_T) hist[b] = 0;
         __syncthreads();
         for (int g = tid; g < total; g += NB_T) {
-            const uint32_t u = a.k_prob[g];
+            const uint32_t u = kp(g);
             if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1);
         }
         __syncthreads();
-        if (tid == 0) {
-            int rem = remaining, d = 255;
-            for (; d > 0; --d) {
-                if (hist[d] >= rem) break;
-                rem -= hist[d];
+        if (wave == 0) {              // the digit d with count(digits > d) < remaining <= count(digits >= d): suffix sums over four bins per lane
+            const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            const int s4 = h0 + h1 + h2 + h3;
+            int suf = s4;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_down(suf, o, 64);
+                if (lane + o < 64) suf += t;
             }
-            bc[0] = d;
-            bc[1] = rem;
+            const int above = suf - s4;
+            if (above < remaining && suf >= remaining) {              // exactly one lane
+                int r = remaining - above, d = 4 * lane + 3;
+                if (h3 < r) { r -= h3; d = 4 * lane + 2; if (h2 < r) { r -= h2; d = 4 * lane + 1; if (h1 < r) { r -= h1; d = 4 * lane; } } }
+                bc[0] = d;
+                bc[1] = r;
+            }
+            if (lane == 0 && suf < remaining) {                       // fewer matching entries than asked for (cannot happen: total > top_k)
+                bc[0] = 0;
+                bc[1] = remaining - (suf - h0);
+            }
         }
         __syncthreads();
         prefix |= (uint32_t)bc[0] << shift;
@@ -433,7 +488,7 @@ __global__ __launch_bounds__(NB_T) void topk_emit_kernel(TopkArgs a) {
     const int g0 = tid * CH, g1 = min(total, g0 + CH);
     int n_gt = 0, n_eq = 0;
     for (int g = g0; g < g1; ++g) {
-        const uint32_t u = a.k_prob[g];
+        const uint32_t u = kp(g);
         n_gt += u > T;
         n_eq += u == T;
     }
@@ -453,7 +508,7 @@ __global__ __launch_bounds__(NB_T) void topk_emit_kernel(TopkArgs a) {
     int r_gt = off_gt + i_gt - n_gt;      // entries > T before this slice
     int r_eq = off_eq + i_eq - n_eq;      // entries == T before this slice
     for (int g = g0; g < g1; ++g) {
-        const uint32_t u = a.k_prob[g];
+        const uint32_t u = kp(g);
         int idx = -1;
         if (u > T) idx = r_gt++;
         else if (u == T) { if (r_eq < remaining) idx = all_gt + r_eq; ++r_eq; }
@@ -522,8 +577,17 @@ extern "C" int ssd_decode_nms_batch(const float* l_, const float* c_, const floa
         hipLaunchKernelGGL(nms_kernel<512>, dim3(C1, 1, B), dim3(512), lds, st, w.s_boxes, w.s_prob, w.cand_cnt, P, iou_threshold, chunk_words, w.kept_pos,
                            w.kept_prob, w.kept_cnt);
     SSD_CHECK_LAUNCH();
-    TopkArgs ta{w.s_boxes, w.s_idx, w.kept_prob, w.kept_pos, w.kept_cnt, w.k_prob, w.k_src, P, C1, top_k, img_wh, boxes, classes, probs, prior_ids, count};
-    hipLaunchKernelGGL(topk_emit_kernel, dim3(1, 1, B), dim3(NB_T), (size_t)top_k * 8, st, ta);
+    const int kp_cap = 16384;                                    // 64 KB of probability bits beside the 2 * top_k selection words
+    {
+        static bool raised = false;
+        if (!raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(topk_emit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+                return SSD_ERR_LAUNCH;
+            raised = true;
+        }
+    }
+    TopkArgs ta{w.s_boxes, w.s_idx, w.kept_prob, w.kept_pos, w.kept_cnt, w.k_prob, w.k_src, P, C1, top_k, kp_cap, img_wh, boxes, classes, probs, prior_ids, count};
+    hipLaunchKernelGGL(topk_emit_kernel, dim3(1, 1, B), dim3(NB_T), (size_t)top_k * 8 + (size_t)kp_cap * 4, st, ta);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
 }
