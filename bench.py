@@ -362,6 +362,7 @@ def roofline_of(net, step, conv_dtype: str, ms: float, layers: bool = False) -> 
     import ctypes as _C
     gemm_tag = "igemm_kernel<64, 64, 2, 2, 1, true"
     fused_tag = "wino4_gemm_out_kernel"
+    x3_tags = {4: "gemm_planes_x3_kernel", 5: "gemm_tn_x3_kernel"}       # Winograd plane GEMMs from three bf16 limbs per f32 operand (csrc/gemm_x3.hip)
     exec_flops = 0.0
     for _ in range(3):
         eng.prof = []
@@ -371,7 +372,7 @@ def roofline_of(net, step, conv_dtype: str, ms: float, layers: bool = False) -> 
         ms_buf, fl_buf, kind_buf = (_C.c_float * 1024)(), (_C.c_double * 1024)(), (_C.c_int * 1024)()
         ng = _l.load().ssd_prof_gemm_collect_kinds(ms_buf, fl_buf, kind_buf, 1024)
         for i in range(max(ng, 0)):
-            a = agg.setdefault(fused_tag if kind_buf[i] == 1 else gemm_tag, [0.0, 0.0, 0])
+            a = agg.setdefault(x3_tags.get(kind_buf[i], fused_tag if kind_buf[i] == 1 else gemm_tag), [0.0, 0.0, 0])
             a[0] += ms_buf[i] * 1e-3; a[1] += fl_buf[i]; a[2] += 1
         for label, tag, flops, e0, e1, executed in eng.prof:
             exec_flops += executed
@@ -395,7 +396,12 @@ def roofline_of(net, step, conv_dtype: str, ms: float, layers: bool = False) -> 
     # dense peak of the dtype the kernel multiplies in; an f32x3 product costs six bf16 MFMAs, so its ceiling in
     # algorithmic f32 FLOPs is a sixth of the bf16 peak
     on_bf16_mfma = "bf16" in tag or (conv_dtype == "bf16" and tag.startswith("conv3x3_halo"))
-    if conv_dtype == "f32" or (conv_dtype == "bf16" and not on_bf16_mfma):
+    if tag in x3_tags.values():
+        peak, peak_note = 2500.0, ("bf16 MFMA dense (v_mfma_f32_32x32x16_bf16): this kernel multiplies f32 operands as three exact bf16 limbs each, six "
+                                   "limb products per f32 product; `achieved` is its EXECUTED bf16 MFMA rate over whole tiles (the f32-equivalent rate "
+                                   "of the Winograd-domain product is a sixth of it, against 157.3 TFLOP/s of the f32 MFMA it replaces; the ops it serves "
+                                   "are the `winograd_3x3` row of by_kernel, in direct-convolution FLOPs)")
+    elif conv_dtype == "f32" or (conv_dtype == "bf16" and not on_bf16_mfma):
         peak, peak_note = PEAK_F32_MFMA_TFLOPS, "f32 MFMA dense"
     elif conv_dtype == "bf16":
         peak, peak_note = 2500.0, "bf16 MFMA dense (v_mfma_f32_32x32x16_bf16); `achieved` counts the direct convolution's FLOPs of the launches, not the tile padding"
@@ -636,7 +642,11 @@ def main():
            "value": round(ips, 2), "unit": "images/sec",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": {"f32": "f32", "f32x3": "f32 (fwd/dgrad products from three bf16 limbs per operand, f32 accumulate)",
+           "dtype": {"f32": "f32" + (" (tensors, accumulators, loss, SGD; the Winograd-domain products of the layers with >= 256 reduction channels are "
+                                      "formed from three EXACT bf16 limbs per f32 operand on the bf16 MFMA -- six limb products per f32 product, dropped "
+                                      "terms <= 2^-26 -- measured no further from f64 than the f32 MFMA; SSD_WINO_X3=0 selects the f32 MFMA)"
+                                      if _ops.wino_x3(4, 256) and net._engine.wino else ""),
+                     "f32x3": "f32 (fwd/dgrad products from three bf16 limbs per operand, f32 accumulate)",
                      "bf16": "bf16 operands (convs), f32 accumulate / loss"}[args.conv_dtype], "data": "synthetic",
            "config": {"workload": (f"SSD300-VGG16 train step (fwd + MultiBox loss + bwd + all-reduce + SGD), "
                                    f"batch {bs}/GPU, 300x300x3, 21 classes, 8732 priors (BASELINE configs[1])") if args.variant == 300 else
@@ -654,7 +664,10 @@ def main():
                       "conv_algorithm": ("f32 throughout; Winograd F(%dx%d,3x3) for forward / dgrad of the 3x3 stride-1 layers with >= %d input "
                                          "channels (the 2x2 max pools fused into its output transform) and for the weight gradients of those with >= %d channels on maps <= %d px, direct MFMA "
                                          "kernels for the rest" % (net._engine.WINO_TILE, net._engine.WINO_TILE, net._engine.WINO_MIN_CI,
-                                                                   net._engine.WINO_WGRAD_MIN_CI, net._engine.WINO_WGRAD_MAX_HW))
+                                                                   net._engine.WINO_WGRAD_MIN_CI, net._engine.WINO_WGRAD_MAX_HW)
+                                         + ("; plane GEMMs with >= 256 reduction channels (and the weight-gradient GEMMs of layers with >= 128 x 128 "
+                                            "channels) on the bf16 MFMA from three exact bf16 limbs per operand (csrc/gemm_x3.hip)"
+                                            if _ops.wino_x3(4, 256) else ""))
                       if (net._engine.wino and args.conv_dtype == "f32") else "direct MFMA kernels",
                       "host_enqueue_ms_per_step": round(host_ms, 2),
                       "shader_clock_mhz_during_timed_steps": round(mhz, 0),

@@ -17,6 +17,9 @@
 #include <type_traits>
 #include "common.h"
 
+int ssd_internal_prof_open(double flops, int kind, hipStream_t st);      // conv_igemm.hip: the per-launch recorder behind ssd_prof_gemm_begin / _collect
+void ssd_internal_prof_close(int slot, hipStream_t st);
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -474,7 +477,10 @@ __attribute__((visibility("hidden"))) int ssd_internal_gemm_batched_x3(const flo
     p.batch_a = batch_a_elems; p.batch_out = (size_t)M * N;
     const size_t nblk = (size_t)p.tiles_m * p.tiles_n * nbatch;
     if (nblk >= (1ull << 31)) return SSD_ERR_BAD_SHAPE;
+    // recorder kind 4: the bf16 MFMA FLOPs the grid executes (six limb products per f32 product, whole 128 x 128 tiles)
+    const int slot = ssd_internal_prof_open(6.0 * 2.0 * (double)nblk * 128.0 * 128.0 * K, 4, st);
     hipLaunchKernelGGL(gemm_planes_x3_kernel, dim3((unsigned)nblk), dim3(256), 0, st, p);
+    ssd_internal_prof_close(slot, st);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
 }
@@ -496,7 +502,10 @@ __attribute__((visibility("hidden"))) int ssd_internal_gemm_tn_x3(const float* a
     q.a_bytes = (unsigned)((size_t)K * lda * 4); q.c_bytes = (unsigned)((size_t)K * ldc * 4);
     const size_t nblk = (size_t)q.tiles_m * q.tiles_n * q.groups;
     if (nblk >= (1ull << 31)) return SSD_ERR_BAD_SHAPE;
+    // recorder kind 5: executed bf16 MFMA FLOPs (whole tiles, whole 16-row steps of every K slice)
+    const int slot = ssd_internal_prof_open(6.0 * 2.0 * (double)nblk * 128.0 * 128.0 * 16.0 * ksteps_per_split, 5, st);
     hipLaunchKernelGGL(gemm_tn_x3_kernel, dim3((unsigned)nblk), dim3(256), 0, st, q);
+    ssd_internal_prof_close(slot, st);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
 }
