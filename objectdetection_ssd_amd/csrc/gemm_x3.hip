@@ -41,6 +41,14 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t srd, unsigned
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)voff, (int)soff, 0));
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// Fragment reads as inline asm with hand-counted lgkmcnt waits (as csrc/conv_bf16.hip): for its own reads the compiler waits lgkmcnt(0) --
+// all twelve -- before the first MFMA; LDS operations retire in issue order, so lgkmcnt(N) with N = reads issued after the ones needed.
+__device__ __forceinline__ bf16x8 lds_read16(unsigned addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 
 // two f32 -> the packed (a, b) bf16 pairs of their three limbs.  Round-to-nearest limbs (v_cvt_pk_bf16_f32): |mid| <= 2^-9 |x|,
 // |lo| <= 2^-17 |x|, both residuals exact (x - bf16(x) has at most 16 significant bits, r1 - bf16(r1) at most 8), so hi + mid + lo = x
@@ -129,6 +137,7 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
 
     const unsigned frag = lr * 32 + ((lh ^ ((lr >> 3) & 1)) << 4);
     const unsigned a_rd = wm * 64 * 32 + frag, b_rd = X3_OPER + wn * 64 * 32 + frag;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
 
     // one step on LDS stage PH: 12 fragment reads, then 24 MFMAs (product-major, smallest limb products first) with the split of the
     // other register set's rows placed by hand between them -- one stage (<= 4 VALU instructions) of one pair per MFMA, pinned by
@@ -136,15 +145,15 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
     auto step = [&](auto ph_tag) {
         constexpr int PH = decltype(ph_tag)::value;
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-        const unsigned char* st = lds + PH * X3_STAGE;
+        const unsigned st = lds_base + PH * X3_STAGE;
         bf16x8 af[3][2], bf[3][2];
 #pragma unroll
-        for (int g = 0; g < 3; ++g)                // in the order the products need them
+        for (int g = 0; g < 3; ++g)                // in the order the products need them: four reads per product group
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int pa = g == 0 ? 2 : (g == 1 ? 0 : 1), pb = g == 0 ? 0 : (g == 1 ? 2 : 1);
-                af[pa][i] = *reinterpret_cast<const bf16x8*>(st + a_rd + pa * X3_LIMB + i * 1024);
-                bf[pb][i] = *reinterpret_cast<const bf16x8*>(st + b_rd + pb * X3_LIMB + i * 1024);
+                af[pa][i] = lds_read16(st + a_rd + pa * X3_LIMB + i * 1024);
+                bf[pb][i] = lds_read16(st + b_rd + pb * X3_LIMB + i * 1024);
             }
         __builtin_amdgcn_sched_barrier(0);
         const f32x4 v0 = ra[PH ^ 1][0], v1 = ra[PH ^ 1][1];
@@ -159,6 +168,10 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
 #pragma unroll
         for (int q = 0; q < 24; ++q) {
             const int pr = q >> 2, i = (q >> 1) & 1, j = q & 1;
+            if (q == 0) wait_lgkm<8>();            // the first product group's four fragments; the other eight stay in flight
+            if (q == 4) wait_lgkm<4>();
+            if (q == 8) wait_lgkm<0>();
+            if (q == 0 || q == 4 || q == 8) __builtin_amdgcn_sched_barrier(0);      // (the MFMA is a pure intrinsic: it would move above the wait)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[pr]][i], bf[PB[pr]][j], acc[i][j], 0, 0, 0);
             if (q >= 2 && q < 22) {                // (the first MFMAs wait for the fragments anyway)
                 const int e = (q - 2) / 5, sg = (q - 2) % 5;
@@ -253,9 +266,12 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* p0, const unsigned char* p1) {
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+// (compiler-visible reads here: as inline asm the two halves of a fragment land in separate register pairs and the copies that join them
+// cost 40 registers -- 208, two workgroups per CU instead of three, 2.53 -> 2.8 ms per step)
+__device__ __forceinline__ bf16x8 tr_pair(unsigned a0, unsigned a1) {
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds_u8*)(size_t)a0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds_u8*)(size_t)a1);
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
@@ -322,10 +338,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(const TnX3Params p) 
                 }
     }
 
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     auto step = [&](auto ph_tag) {
         constexpr int PH = decltype(ph_tag)::value;
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-        const unsigned char* st = lds + PH * X3_STAGE;
+        const unsigned st = lds_base + PH * X3_STAGE;
         bf16x8 af[3][2], bf[3][2];
 #pragma unroll
         for (int g = 0; g < 3; ++g)
