@@ -460,3 +460,56 @@ def test_round2_entry_points_validate_and_size_without_a_gpu():
     job.kind = 9
     assert lib.ssd_weight_job_blocks(C.byref(job)) == -1
     assert lib.ssd_weights_prepare(None, OK_PTR, 1, 1, None) == -3
+
+
+def test_round3_limb_gemm_rules_and_sizes_without_a_gpu():
+    """Host-side rules of the three-limb plane GEMMs (csrc/gemm_x3.hip) with made-up pointers that are never dereferenced: which reduction
+    lengths take them, the environment / tune switch, the size of a limb filter tensor, what the bare GEMM entry points refuse, and the block
+    count of a weight job whose outputs are limb planes (8 elements per thread)."""
+    import ctypes as C
+    import os
+    import subprocess
+    import sys
+    from objectdetection_ssd_amd import _lib
+    lib = _lib.load()
+    OK_PTR, ODD_PTR = 0x10000, 0x10004
+    try:
+        assert lib.ssd_tune_set_wino_x3(1) == 0
+        assert [lib.ssd_wino_uses_x3(4, k) for k in (64, 128, 256, 512, 1024)] == [0, 0, 1, 1, 1]
+        assert lib.ssd_wino_uses_x3(2, 512) == 0                       # F(2x2) (a tuning aid) stays on the f32 MFMA
+        assert lib.ssd_tune_set_wino_x3(0) == 0
+        assert lib.ssd_wino_uses_x3(4, 512) == 0
+    finally:
+        assert lib.ssd_tune_set_wino_x3(-1) == 0
+    # the default comes from the environment, read once per process: on unless SSD_WINO_X3=0
+    code = ("import sys; sys.path.insert(0, %r); from objectdetection_ssd_amd import _lib; print(_lib.load().ssd_wino_uses_x3(4, 512))"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    for env, want in (({}, "1"), ({"SSD_WINO_X3": "0"}, "0"), ({"SSD_WINO_X3": "1"}, "1")):
+        e = {k: v for k, v in os.environ.items() if k != "SSD_WINO_X3"}
+        e.update(env)
+        assert subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=120).stdout.strip() == want
+    # limb filter tensor: K x pad128(rows) elements per plane, 3 limbs of 2 bytes
+    assert lib.ssd_gemm_x3_weights_bytes(512, 512, 36) == 36 * 512 * 512 * 6
+    assert lib.ssd_gemm_x3_weights_bytes(100, 512, 36) == 36 * 512 * 128 * 6
+    assert lib.ssd_gemm_x3_weights_bytes(150, 1024, 1) == 1024 * 256 * 6
+    assert lib.ssd_gemm_x3_weights_bytes(100, 48, 1) == 0                  # K must be a multiple of 32
+    assert lib.ssd_gemm_x3_weights_bytes(0, 512, 1) == 0
+    assert lib.ssd_gemm_x3_split_weights(None, OK_PTR, 128, 256, 1, None) == -3
+    assert lib.ssd_gemm_x3_split_weights(OK_PTR, ODD_PTR, 128, 256, 1, None) == -5
+    assert lib.ssd_gemm_x3_split_weights(OK_PTR, OK_PTR, 128, 40, 1, None) == -1
+    assert lib.ssd_gemm_planes_x3(None, OK_PTR, OK_PTR, 128, 256, 128, 128, 1, None) == -3
+    assert lib.ssd_gemm_planes_x3(OK_PTR, OK_PTR, ODD_PTR, 128, 256, 128, 128, 1, None) == -5
+    assert lib.ssd_gemm_planes_x3(OK_PTR, OK_PTR, OK_PTR, 128, 48, 128, 128, 1, None) == -1          # K % 32
+    assert lib.ssd_gemm_planes_x3(OK_PTR, OK_PTR, OK_PTR, 128, 256, 300, 100, 1, None) == -1         # more columns than the padded filter rows
+    assert lib.ssd_gemm_planes_x3(OK_PTR, OK_PTR, OK_PTR, 0, 256, 128, 128, 1, None) == -1
+    assert lib.ssd_gemm_planes_f32(None, OK_PTR, OK_PTR, 128, 256, 128, 128, 1, None) == -3
+    # weight job with limb outputs: forward K = Ci = 256 as limbs (bit 0), backward K = co_pad = 128 as f32
+    job = _lib.WeightJob()
+    job.w0 = job.w1 = OK_PTR; job.out_fwd = OK_PTR; job.out_bwd = OK_PTR
+    job.co0 = job.co = 128; job.ci = 256; job.taps = 9; job.co_pad = 128; job.kind = 0
+    job.pad0 = 0
+    assert lib.ssd_weight_job_blocks(C.byref(job)) == (128 * 256 + 256 * 128 + 255) // 256
+    job.pad0 = 1
+    assert lib.ssd_weight_job_blocks(C.byref(job)) == (128 * 256 // 8 + 256 * 128 + 255) // 256
+    job.pad0 = 3
+    assert lib.ssd_weight_job_blocks(C.byref(job)) == (128 * 256 // 8 + 256 * 128 // 8 + 255) // 256
