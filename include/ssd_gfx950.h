@@ -280,6 +280,16 @@ int ssd_tune_set_wino_x3(int on);
 size_t ssd_gemm_x3_weights_bytes(int rows, int K, int nbatch);
 int ssd_gemm_x3_split_weights(const float* w, void* w3, int rows, int K, int nbatch, void* stream);
 int ssd_gemm_planes_x3(const float* a, const void* w3, float* out, int M, int K, int N, int n_rows, int nbatch, void* stream);
+/* 1x1 / stride-1 convolutions with long reductions (fc7, seq8.0: Model.py:150-156) on the same limb kernels.  Filters as limb planes:
+ * forward w3 = limbs of w [Co][Ci] (ssd_gemm_x3_split_weights(w, w3, Co, Ci, 1), or a kind-4 job of ssd_weights_prepare: out_fwd rows Co,
+ * K = Ci; out_bwd rows Ci, K = co_pad = limbs of w^T); Ci % 32 == 0 forward, ldy = Co_pad % 32 == 0 for the data gradient (the reduction
+ * runs over all ldy columns of dy: padding columns must be zero).  Epilogues as ssd_conv2d_fwd / ssd_conv2d_dgrad. */
+int ssd_conv1x1_fwd_x3(const float* x, const void* w3, const float* bias, float* y, int ldy, const ssd_conv_geom* g, int relu, void* stream);
+int ssd_conv1x1_dgrad_x3(const float* dy, int ldy, const void* w3t, float* dx, const float* relu_mask, int accumulate, const ssd_conv_geom* g,
+                         void* stream);
+size_t ssd_conv1x1_wgrad_x3_workspace(const ssd_conv_geom* g, int ldy);
+int ssd_conv1x1_wgrad_x3(const float* x, const float* dy, int ldy, float* dw, float* dbias, const ssd_conv_geom* g, void* workspace,
+                         size_t workspace_bytes, void* stream);
 int ssd_gemm_planes_f32(const float* a, const float* w, float* out, int M, int K, int N, int n_rows, int nbatch, void* stream);
 int ssd_has_experimental(void);           /* 1 if built with SSD_EXPERIMENTAL: gemm_nt.hip and wino4_full_kernel (both off by default, forced by ssd_tune_set_gemm_nt(1) / ssd_tune_set_wino_full(1)) are present */
 /* The whole convolution (input transform too) in one kernel where the reduction length is 64 (128 when forced): -1 automatic, 0 never, 1 force.

@@ -278,6 +278,24 @@ class _Engine:
         return (self.wino and not self.bf16 and not self.x3 and g.R == 3 and g.S == 3 and g.stride == 1 and dil_ok and g.pad == g.dil
                 and g.Ci % 32 == 0 and g.Ci >= self.WINO_MIN_CI and g.H >= self.WINO_MIN_HW)
 
+    X31_MIN_PIXELS = 8192         # 1x1 layers on the limb GEMMs from this many output pixels (fc7, seq8.0 at batch 32: 11 552; below, the
+                                  # 128 x 128 tiles leave most CUs idle and the split-K f32 kernel wins)
+
+    def _x31_ok(self, g) -> bool:
+        """f32 mode: this 1x1 / stride-1 convolution runs the three-limb GEMM kernels (forward, data gradient, weight gradient)."""
+        return (self.wino and not self.bf16 and not self.x3 and ops.wino_x3(4, 256) and g.R == 1 and g.S == 1 and g.stride == 1 and g.pad == 0
+                and g.Ci % 32 == 0 and g.Ci >= 256 and g.Co % 32 == 0 and g.Co >= 128 and g.N * g.H * g.W >= self.X31_MIN_PIXELS)
+
+    def _x31_weights(self, key: str, tensors, co_pad: int):
+        """Cached limb planes of a 1x1 filter and of its transpose, refreshed when the parameter changes."""
+        sig = tuple((t.data_ptr(), t._version) for t in tensors)
+        ent = self._wcache.get("x31:" + key)
+        if ent is None or ent[0] != sig:
+            wf, wb = ops.conv1x1_weights_x3(tensors[0].detach().contiguous(), co_pad)
+            ent = (sig, wf, wb)
+            self._wcache["x31:" + key] = ent
+        return ent[1], ent[2]
+
     def _wino_wgrad_ok(self, g, head: bool) -> bool:
         """Weight gradient of this layer in the Winograd domain (else: the fused direct kernels)."""
         return (self._wino_ok(g) and g.H <= self.WINO_WGRAD_MAX_HW and g.Ci >= self.WINO_WGRAD_MIN_CI
@@ -377,6 +395,11 @@ class _Engine:
                         wb = torch.empty((g.Ci, 9, ops.pad64(co_all)), device=dev, dtype=torch.bfloat16)
                         jobs.append(dict(job, kind=3, co_pad=co_all, pad1=ops.pad64(co_all), out_fwd=wf, out_bwd=wb))
                         entries.append((op["p"], "b16", tensors, (wf, wb)))
+                    elif kind == "conv" and self._x31_ok(g):
+                        wf = ops.x3_filter_alloc(co_all, g.Ci, dev)
+                        wb = ops.x3_filter_alloc(g.Ci, co_pad, dev)
+                        jobs.append(dict(job, kind=4, out_fwd=wf, out_bwd=wb))
+                        entries.append((op["p"], "x31", tensors, (wf, wb)))
                     elif self._wino_ok(g) and self.WINO_TILE == 4:
                         uf = ops.wino_filter_alloc(4, co_all, g.Ci, dev)
                         ub = ops.wino_filter_alloc(4, g.Ci, co_pad, dev)
@@ -398,6 +421,8 @@ class _Engine:
                 self._wcache["b16:" + key] = (lsig, bufs[0], bufs[1])
             elif what == "wino":
                 self._wcache["wino:" + key] = (lsig + (ops.wino_x3(4, 256),), bufs[0], bufs[1])
+            elif what == "x31":
+                self._wcache["x31:" + key] = (lsig, bufs[0], bufs[1])
             elif what == "layout":
                 self._wcache[key] = [lsig, None, bufs[0], bufs[1]]
             else:
@@ -527,6 +552,12 @@ class _Engine:
                         aux["planes:" + op["p"]] = res[1]
                     if wb:
                         aux["bits:" + op["p"]] = res[2]
+                    aux[op["y"]] = g
+                    continue
+                if self._x31_ok(g):
+                    w3f, _ = self._x31_weights(op["p"], (P[op["p"] + ".weight"],), op["co"])
+                    T[op["y"]] = self._timed("fwd " + op["p"], "gemm_planes_x3_kernel (1x1)", ops.conv_flops(g),
+                                             lambda: ops.conv1x1_fwd_x3(xin, w3f, bias, g, op["relu"]))
                     aux[op["y"]] = g
                     continue
                 wf, _ = self._layouts(op["p"], (P[op["p"] + ".weight"],), op["co"], False)
@@ -794,6 +825,12 @@ class _Engine:
                         dyp = res[2] if dual else None
                     else:
                         def wg(name=op["p"], xin=xin, dy=dy, g=g):
+                            if self._x31_ok(g):
+                                grads[name + ".weight"], grads[name + ".bias"] = self._timed(
+                                    "wgrad " + name, "gemm_tn_x3_kernel (1x1)", ops.conv_flops(g),
+                                    lambda: ops.conv1x1_wgrad_x3(xin, dy, g, g.Co, True, dw_out=self._gout(name + ".weight"),
+                                                                 db_out=self._gout(name + ".bias")))
+                                return
                             grads[name + ".weight"], grads[name + ".bias"] = self._timed(
                                 "wgrad " + name, ops.wgrad_tile(g, self.bf16) if self.prof is not None else "", ops.conv_flops(g),
                                 lambda: ops.conv2d_wgrad(xin, dy, g, g.Co, True, bf16=self.bf16, dw_out=self._gout(name + ".weight"),
@@ -812,6 +849,12 @@ class _Engine:
                         "dgrad " + op["p"], "winograd_3x3", ops.wino_flops(g),
                         lambda: ops.conv2d_dgrad_wino(None if isinstance(dy, ops.PooledGrad) else dy, ub, g, dx, mask, acc, planes=dyp,
                                                       bits=bits if mask is not None else None)))
+                    continue
+                if self._x31_ok(g) and not to_bf16:
+                    _, w3b = self._x31_weights(op["p"], (P[op["p"] + ".weight"],), op["co"])
+                    deliver(op["x"], lambda dx, acc, mask: self._timed(
+                        "dgrad " + op["p"], "gemm_planes_x3_kernel (1x1)", ops.conv_flops(g),
+                        lambda: ops.conv1x1_dgrad_x3(dy, w3b, g, dx, mask, acc)))
                     continue
                 _, wb = self._layouts(op["p"], (P[op["p"] + ".weight"],), op["co"], True)
                 if to_bf16:

@@ -83,6 +83,10 @@ SIGNATURES = {
     "ssd_gemm_x3_split_weights": (_I, [_P, _P, _I, _I, _I, _P]),
     "ssd_gemm_planes_x3": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ssd_gemm_planes_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ssd_conv1x1_fwd_x3": (_I, [_P, _P, _P, _P, _I, _G, _I, _P]),
+    "ssd_conv1x1_dgrad_x3": (_I, [_P, _I, _P, _P, _P, _I, _G, _P]),
+    "ssd_conv1x1_wgrad_x3_workspace": (_Z, [_G, _I]),
+    "ssd_conv1x1_wgrad_x3": (_I, [_P, _P, _I, _P, _P, _G, _P, _Z, _P]),
     "ssd_has_experimental": (_I, []),
     "ssd_conv3x3_wgrad_bf16t": (_I, [_P, _P, _I, _P, _P, _G, _P, _Z, _P]),
     "ssd_conv1_first_fwd_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),

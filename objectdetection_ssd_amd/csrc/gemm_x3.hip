@@ -35,20 +35,16 @@ struct GemmX3Params {
     int M, K, N, rows_pad;
     int tiles_m, tiles_n, nbatch;
     size_t batch_a, batch_out;          // element strides between problems
+    // epilogue of the 1x1 convolutions (ldo > 0): out[m * ldo + n] = [accumulate: out +] acc (+ bias[n]) -> ReLU -> ReLU mask; planes: ldo = 0
+    const float* __restrict__ bias;
+    const float* __restrict__ mask;     // [M][ldo]: the data gradient passes where mask > 0
+    int ldo, relu, accumulate;
 };
 
 __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t srd, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)voff, (int)soff, 0));
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// Fragment reads as inline asm with hand-counted lgkmcnt waits (as csrc/conv_bf16.hip): for its own reads the compiler waits lgkmcnt(0) --
-// all twelve -- before the first MFMA; LDS operations retire in issue order, so lgkmcnt(N) with N = reads issued after the ones needed.
-__device__ __forceinline__ bf16x8 lds_read16(unsigned addr) {
-    bf16x8 v;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
-    return v;
-}
-template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 
 // two f32 -> the packed (a, b) bf16 pairs of their three limbs.  Round-to-nearest limbs (v_cvt_pk_bf16_f32): |mid| <= 2^-9 |x|,
 // |lo| <= 2^-17 |x|, both residuals exact (x - bf16(x) has at most 16 significant bits, r1 - bf16(r1) at most 8), so hi + mid + lo = x
@@ -79,6 +75,7 @@ constexpr int X3_LIMB = 128 * 32;          // bytes of one limb image: [128 rows
 constexpr int X3_OPER = 3 * X3_LIMB;       // one operand, one stage
 constexpr int X3_STAGE = 2 * X3_OPER;      // A + B
 
+template <bool EPI>             // EPI: the 1x1 convolutions' epilogue (its own instantiation: the plane GEMMs keep their straight store)
 __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Params p) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * X3_STAGE];       // 48 KB: three workgroups per CU
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -137,7 +134,6 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
 
     const unsigned frag = lr * 32 + ((lh ^ ((lr >> 3) & 1)) << 4);
     const unsigned a_rd = wm * 64 * 32 + frag, b_rd = X3_OPER + wn * 64 * 32 + frag;
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
 
     // one step on LDS stage PH: 12 fragment reads, then 24 MFMAs (product-major, smallest limb products first) with the split of the
     // other register set's rows placed by hand between them -- one stage (<= 4 VALU instructions) of one pair per MFMA, pinned by
@@ -145,15 +141,18 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
     auto step = [&](auto ph_tag) {
         constexpr int PH = decltype(ph_tag)::value;
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-        const unsigned st = lds_base + PH * X3_STAGE;
+        // (compiler-visible reads: as inline asm with hand-counted lgkmcnt the first MFMAs started four reads earlier, +3 % in isolation,
+        // but under this kernel's register pressure the allocator may copy a fragment register between the asm read and the wait --
+        // it cannot know the data has not arrived -- and one build of the 1x1 instantiation did exactly that)
+        const unsigned char* st = lds + PH * X3_STAGE;
         bf16x8 af[3][2], bf[3][2];
 #pragma unroll
-        for (int g = 0; g < 3; ++g)                // in the order the products need them: four reads per product group
+        for (int g = 0; g < 3; ++g)                // in the order the products need them
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int pa = g == 0 ? 2 : (g == 1 ? 0 : 1), pb = g == 0 ? 0 : (g == 1 ? 2 : 1);
-                af[pa][i] = lds_read16(st + a_rd + pa * X3_LIMB + i * 1024);
-                bf[pb][i] = lds_read16(st + b_rd + pb * X3_LIMB + i * 1024);
+                af[pa][i] = *reinterpret_cast<const bf16x8*>(st + a_rd + pa * X3_LIMB + i * 1024);
+                bf[pb][i] = *reinterpret_cast<const bf16x8*>(st + b_rd + pb * X3_LIMB + i * 1024);
             }
         __builtin_amdgcn_sched_barrier(0);
         const f32x4 v0 = ra[PH ^ 1][0], v1 = ra[PH ^ 1][1];
@@ -168,10 +167,6 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
 #pragma unroll
         for (int q = 0; q < 24; ++q) {
             const int pr = q >> 2, i = (q >> 1) & 1, j = q & 1;
-            if (q == 0) wait_lgkm<8>();            // the first product group's four fragments; the other eight stay in flight
-            if (q == 4) wait_lgkm<4>();
-            if (q == 8) wait_lgkm<0>();
-            if (q == 0 || q == 4 || q == 8) __builtin_amdgcn_sched_barrier(0);      // (the MFMA is a pure intrinsic: it would move above the wait)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[pr]][i], bf[PB[pr]][j], acc[i][j], 0, 0, 0);
             if (q >= 2 && q < 22) {                // (the first MFMAs wait for the fragments anyway)
                 const int e = (q - 2) / 5, sg = (q - 2) % 5;
@@ -242,8 +237,19 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);       // bits 2 and 5 of m: lh and i
-                const float v = ((lh ^ i) & 1) ? -acc[i][j][r] : acc[i][j][r];               // the row's sign s(m) again
-                if (m < p.M && n < p.N) out[(size_t)m * p.N + n] = v;
+                float v = ((lh ^ i) & 1) ? -acc[i][j][r] : acc[i][j][r];                     // the row's sign s(m) again
+                if (m < p.M && n < p.N) {
+                    if constexpr (!EPI) {
+                        out[(size_t)m * p.N + n] = v;
+                    } else {                                                                 // (same order as igemm_epilogue, conv_igemm.hip)
+                        const size_t idx = (size_t)m * p.ldo + n;
+                        if (p.bias != nullptr) v += p.bias[n];
+                        if (p.accumulate) v += out[idx];
+                        if (p.relu) v = v < 0.f ? 0.f : v;                                   // NaN stays NaN, like torch.relu
+                        if (p.mask != nullptr) v = p.mask[idx] > 0.f ? v : 0.f;
+                        out[idx] = v;
+                    }
+                }
             }
         }
 }
@@ -496,7 +502,7 @@ __attribute__((visibility("hidden"))) int ssd_internal_gemm_batched_x3(const flo
     if (nblk >= (1ull << 31)) return SSD_ERR_BAD_SHAPE;
     // recorder kind 4: the bf16 MFMA FLOPs the grid executes (six limb products per f32 product, whole 128 x 128 tiles)
     const int slot = ssd_internal_prof_open(6.0 * 2.0 * (double)nblk * 128.0 * 128.0 * K, 4, st);
-    hipLaunchKernelGGL(gemm_planes_x3_kernel, dim3((unsigned)nblk), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(gemm_planes_x3_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, st, p);
     ssd_internal_prof_close(slot, st);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
@@ -524,6 +530,124 @@ __attribute__((visibility("hidden"))) int ssd_internal_gemm_tn_x3(const float* a
     hipLaunchKernelGGL(gemm_tn_x3_kernel, dim3((unsigned)nblk), dim3(256), 0, st, q);
     ssd_internal_prof_close(slot, st);
     SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
+// ---- 1x1 / stride-1 convolutions with long reductions (fc7, seq8.0: Model.py:150-156) on the same kernels -----------------------------------
+namespace {
+// out[i] = sum_k slab[k][i], four entries per thread, slices in index order (reproducible)
+__global__ __launch_bounds__(256) void x3_slab_sum_kernel(const float* __restrict__ slab, float* __restrict__ out, size_t n4, int nslab) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 sum = *reinterpret_cast<const f32x4*>(slab + i * 4);
+        for (int k = 1; k < nslab; ++k) sum += *reinterpret_cast<const f32x4*>(slab + (size_t)k * n4 * 4 + i * 4);
+        *reinterpret_cast<f32x4*>(out + i * 4) = sum;
+    }
+}
+// column sums of dy [M][ld] (the bias gradient): block b sums rows b, b + gridDim.x, ... of a column quad per thread -> part[b][ld]
+__global__ __launch_bounds__(256) void x3_colsum_partial_kernel(const float* __restrict__ dy, float* __restrict__ part, size_t M, int ld) {
+    const int q4 = ld >> 2;
+    for (int q = threadIdx.x; q < q4; q += 256) {
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f};
+        for (size_t m = blockIdx.x; m < M; m += gridDim.x) s0 += *reinterpret_cast<const f32x4*>(dy + m * ld + q * 4);
+        *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.x * ld + q * 4) = s0;
+    }
+}
+__global__ __launch_bounds__(256) void x3_colsum_final_kernel(const float* __restrict__ part, float* __restrict__ db, int nblk, int C, int ld) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float t = 0.f;
+    for (int k = 0; k < nblk; ++k) t += part[(size_t)k * ld + c];
+    db[c] = t;
+}
+constexpr int X3_COLSUM_BLOCKS = 256;
+struct X3WgradPlan { int ks, per; size_t slab_floats, part_floats; };
+X3WgradPlan x3_wgrad_plan(const ssd_conv_geom* g, int ldy) {
+    X3WgradPlan w;
+    const size_t M = (size_t)g->N * g->Ho * g->Wo;
+    const int tiles = ssd_cdiv(g->Co, 128) * ssd_cdiv(g->Ci, 128), steps16 = (int)((M + 15) / 16);
+    int ks = 768 / tiles;                          // one round of resident workgroups
+    if (ks > 1) ks &= ~1;
+    if (ks > steps16 / 8) ks = steps16 / 8;
+    if (ks < 1) ks = 1;
+    w.per = ssd_cdiv(steps16, ks);
+    w.ks = ssd_cdiv(steps16, w.per);
+    w.slab_floats = (size_t)w.ks * g->Co * g->Ci;
+    w.part_floats = (size_t)X3_COLSUM_BLOCKS * ldy;
+    return w;
+}
+bool x3_1x1_geom_ok(const ssd_conv_geom* g) {
+    return g && g->R == 1 && g->S == 1 && g->stride == 1 && g->pad == 0 && g->Ho == g->H && g->Wo == g->W && g->N > 0 && g->H > 0 && g->W > 0 &&
+           g->Ci > 0 && g->Co > 0;
+}
+}  // namespace
+
+extern "C" int ssd_conv1x1_fwd_x3(const float* x, const void* w3, const float* bias, float* y, int ldy, const ssd_conv_geom* g, int relu, void* stream) {
+    if (!x || !w3 || !y) return SSD_ERR_NULL;
+    if (!x3_1x1_geom_ok(g) || g->Ci % 32 != 0 || ldy < g->Co) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(x) || !ssd_aligned16(w3) || !ssd_aligned16(y)) return SSD_ERR_ALIGN;
+    const size_t M = (size_t)g->N * g->H * g->W;
+    if (M >= (1ull << 31) || M * g->Ci * 4 >= 0xF0000000ull) return SSD_ERR_BAD_SHAPE;
+    GemmX3Params p{};
+    p.a = x; p.w3 = static_cast<const __bf16*>(w3); p.out = y;
+    p.M = (int)M; p.K = g->Ci; p.N = g->Co; p.rows_pad = ssd_cdiv(g->Co, 128) * 128;
+    p.tiles_m = ssd_cdiv((int)M, 128); p.tiles_n = ssd_cdiv(g->Co, 128); p.nbatch = 1;
+    p.bias = bias; p.mask = nullptr; p.ldo = ldy; p.relu = relu; p.accumulate = 0;
+    hipLaunchKernelGGL(gemm_planes_x3_kernel<true>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), 0, (hipStream_t)stream, p);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
+// dx [M][Ci] = dy [M][ldy] * w (ldy = Co_pad = the reduction length, a multiple of 32; w3t = limbs of w^T: rows Ci, K = Co_pad)
+extern "C" int ssd_conv1x1_dgrad_x3(const float* dy, int ldy, const void* w3t, float* dx, const float* relu_mask, int accumulate,
+                                    const ssd_conv_geom* g, void* stream) {
+    if (!dy || !w3t || !dx) return SSD_ERR_NULL;
+    if (!x3_1x1_geom_ok(g) || ldy % 32 != 0 || ldy < g->Co) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(dy) || !ssd_aligned16(w3t) || !ssd_aligned16(dx) || (relu_mask && !ssd_aligned16(relu_mask))) return SSD_ERR_ALIGN;
+    const size_t M = (size_t)g->N * g->H * g->W;
+    if (M >= (1ull << 31) || M * ldy * 4 >= 0xF0000000ull) return SSD_ERR_BAD_SHAPE;
+    GemmX3Params p{};
+    p.a = dy; p.w3 = static_cast<const __bf16*>(w3t); p.out = dx;
+    p.M = (int)M; p.K = ldy; p.N = g->Ci; p.rows_pad = ssd_cdiv(g->Ci, 128) * 128;
+    p.tiles_m = ssd_cdiv((int)M, 128); p.tiles_n = ssd_cdiv(g->Ci, 128); p.nbatch = 1;
+    p.bias = nullptr; p.mask = relu_mask; p.ldo = g->Ci; p.relu = 0; p.accumulate = accumulate;
+    hipLaunchKernelGGL(gemm_planes_x3_kernel<true>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), 0, (hipStream_t)stream, p);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
+extern "C" size_t ssd_conv1x1_wgrad_x3_workspace(const ssd_conv_geom* g, int ldy) {
+    if (!x3_1x1_geom_ok(g) || ldy < g->Co || ldy % 4 != 0) return 0;
+    const X3WgradPlan w = x3_wgrad_plan(g, ldy);
+    return (w.slab_floats + w.part_floats) * 4 + 256;
+}
+
+// dw [Co][Ci] = dy^T x over the pixels (split-K TN GEMM from limbs + slice sum), dbias = column sums of dy (optional)
+extern "C" int ssd_conv1x1_wgrad_x3(const float* x, const float* dy, int ldy, float* dw, float* dbias, const ssd_conv_geom* g, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    if (!x || !dy || !dw || !workspace) return SSD_ERR_NULL;
+    if (!x3_1x1_geom_ok(g) || g->Ci % 4 != 0 || ldy % 4 != 0 || ldy < g->Co) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(x) || !ssd_aligned16(dy) || !ssd_aligned16(dw) || !ssd_aligned16(workspace)) return SSD_ERR_ALIGN;
+    if (workspace_bytes < ssd_conv1x1_wgrad_x3_workspace(g, ldy)) return SSD_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const X3WgradPlan w = x3_wgrad_plan(g, ldy);
+    const size_t M = (size_t)g->N * g->H * g->W;
+    if (M >= (1ull << 31)) return SSD_ERR_BAD_SHAPE;
+    float* slab = static_cast<float*>(workspace);
+    float* part = slab + w.slab_floats;
+    float* dst = w.ks == 1 && (g->Co * (size_t)g->Ci) % 4 == 0 ? dw : slab;
+    if (int e = ssd_internal_gemm_tn_x3(dy, x, dst, g->Co, g->Ci, (int)M, ldy, g->Ci, 1, w.ks, w.per, M * ldy, M * g->Ci, st)) return e;
+    if (dst != dw) {
+        const size_t n = (size_t)g->Co * g->Ci;
+        if (n % 4 != 0) return SSD_ERR_BAD_SHAPE;
+        const size_t blocks = (n / 4 + 255) / 256;
+        hipLaunchKernelGGL(x3_slab_sum_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, st, slab, dw, n / 4, w.ks);
+        SSD_CHECK_LAUNCH();
+    }
+    if (dbias != nullptr) {
+        hipLaunchKernelGGL(x3_colsum_partial_kernel, dim3(X3_COLSUM_BLOCKS), dim3(256), 0, st, dy, part, M, ldy);
+        hipLaunchKernelGGL(x3_colsum_final_kernel, dim3(ssd_cdiv(g->Co, 256)), dim3(256), 0, st, part, dbias, X3_COLSUM_BLOCKS, g->Co, ldy);
+        SSD_CHECK_LAUNCH();
+    }
     return SSD_OK;
 }
 

@@ -1656,6 +1656,29 @@ __global__ __launch_bounds__(256) void weight_jobs_kernel(const ssd_weight_job* 
             const int t = (int)(rest % T), ci = (int)(rest / T);
             reinterpret_cast<__bf16*>(j.out_bwd)[e] = (__bf16)(co < Co ? src(co, ci, t) : 0.f);
         }
+    } else if (j.kind == 4) {                        // 1x1 filters as limb planes for csrc/gemm_x3.hip: out_fwd rows Co, K = Ci; out_bwd rows Ci, K = co_pad
+        const size_t tf = j.out_fwd == nullptr ? 0 : (size_t)Co * Ci / 8, tb = j.out_bwd == nullptr ? 0 : (size_t)Ci * j.co_pad / 8;
+        const bool fwd = i < tf;
+        if (!fwd && i - tf >= tb) return;
+        const size_t e = fwd ? i : i - tf;
+        const int Nrows = fwd ? Co : Ci, K = fwd ? Ci : j.co_pad;
+        const int K8 = K >> 3, k8 = (int)(e % K8) * 8, n = (int)(e / K8);
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+        bf16x8 h, m, l;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int co = fwd ? n : k8 + q, ci = fwd ? k8 + q : n;
+            const float v = co < Co ? src(co, ci, 0) : 0.f;
+            h[q] = (__bf16)v;                        // round-to-nearest limbs; both residuals are exact (gemm_x3.hip)
+            const float r1 = v - (float)h[q];
+            m[q] = (__bf16)r1;
+            l[q] = (__bf16)(r1 - (float)m[q]);
+        }
+        const size_t limb = (size_t)((Nrows + 127) / 128 * 128) * 16;
+        __bf16* d = reinterpret_cast<__bf16*>(fwd ? j.out_fwd : j.out_bwd) + (size_t)(k8 >> 4) * 3 * limb + (size_t)n * 16 + (k8 & 15);
+        *reinterpret_cast<bf16x8*>(d) = h;
+        *reinterpret_cast<bf16x8*>(d + limb) = m;
+        *reinterpret_cast<bf16x8*>(d + 2 * limb) = l;
     } else {                                         // conv1_1 rows for the im2col GEMM: [Co][32], k = (r*3+s)*3 + c, zero padded
         const size_t total = (size_t)Co * 32;
         if (i < total) {
@@ -1673,6 +1696,11 @@ extern "C" int ssd_weight_job_blocks(const ssd_weight_job* job) {
         elems = (size_t)job->co * job->ci / ((job->pad0 & 1) ? 8 : 1) + (job->out_bwd ? (size_t)job->ci * job->co_pad / ((job->pad0 & 2) ? 8 : 1) : 0);
     else if (job->kind == 1) elems = (size_t)job->co_pad * job->taps * job->ci * (job->out_bwd ? 2 : 1);
     else if (job->kind == 2) elems = (size_t)job->co * 32;
+    else if (job->kind == 4) {
+        if (job->taps != 1 || job->ci % 16 != 0 || job->co_pad % 16 != 0 || job->co_pad < job->co) return -1;
+        elems = (job->out_fwd ? (size_t)job->co * job->ci / 8 : 0) + (job->out_bwd ? (size_t)job->ci * job->co_pad / 8 : 0);
+        if (elems == 0) return -1;
+    }
     else if (job->kind == 3) elems = (size_t)job->co_pad * job->taps * job->ci + (job->out_bwd ? (size_t)job->ci * job->taps * job->pad1 : 0);
     else return -1;
     const size_t b = (elems + 255) / 256;

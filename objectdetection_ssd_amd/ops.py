@@ -870,6 +870,83 @@ def _wino_mo(u: torch.Tensor) -> int:
     return 2 if u.shape[0] == 16 else 4
 
 
+# ---- 1x1 / stride-1 convolutions on the three-limb GEMM kernels (csrc/gemm_x3.hip; fc7, seq8.0) ---------------------------------
+def x3_filter_alloc(rows: int, K: int, device) -> torch.Tensor:
+    """Limb planes of a [rows][K] filter matrix: (K/16, 3, pad128(rows), 16) bf16, zero-filled (padding rows are never written)."""
+    return torch.zeros((K // 16, 3, (rows + 127) // 128 * 128, 16), device=device, dtype=torch.bfloat16)
+
+
+def conv1x1_weights_x3(w_oihw: torch.Tensor, co_pad: int):
+    """(Co,Ci,1,1) -> (limbs of w [Co][Ci], limbs of w^T [Ci][co_pad]) for conv1x1_fwd_x3 / conv1x1_dgrad_x3 (per-layer form of the kind-4
+    weight job)."""
+    _req(w_oihw, "weight")
+    co, ci = int(w_oihw.shape[0]), int(w_oihw.shape[1])
+    if tuple(w_oihw.shape[2:]) != (1, 1) or ci % 32 != 0 or co_pad % 32 != 0 or co_pad < co:
+        raise ValueError("conv1x1_weights_x3: a 1x1 filter with Ci and co_pad multiples of 32")
+    lib = _lib.load()
+    wf = x3_filter_alloc(co, ci, w_oihw.device)
+    check(lib.ssd_gemm_x3_split_weights(w_oihw.data_ptr(), wf.data_ptr(), co, ci, 1, _stream()), "conv1x1_weights_x3")
+    wt = torch.zeros((ci, co_pad), device=w_oihw.device, dtype=torch.float32)
+    wt[:, :co] = w_oihw.reshape(co, ci).t()
+    wb = x3_filter_alloc(ci, co_pad, w_oihw.device)
+    check(lib.ssd_gemm_x3_split_weights(wt.data_ptr(), wb.data_ptr(), ci, co_pad, 1, _stream()), "conv1x1_weights_x3")
+    return wf, wb
+
+
+def _x3_filter(w3: torch.Tensor, name: str, rows: int, K: int) -> None:
+    _req(w3, name, torch.bfloat16)
+    if tuple(w3.shape) != (K // 16, 3, (rows + 127) // 128 * 128, 16):
+        raise ValueError(f"{name}: limb planes do not match the geometry")
+
+
+def conv1x1_fwd_x3(x: torch.Tensor, w3: torch.Tensor, bias: Optional[torch.Tensor], g: ConvGeom, relu: bool) -> torch.Tensor:
+    _req(x, "x")
+    if tuple(x.shape) != (g.N, g.H, g.W, g.Ci):
+        raise ValueError("conv1x1_fwd_x3: x shape does not match geometry")
+    _x3_filter(w3, "w3", g.Co, g.Ci)
+    if bias is not None:
+        _req(bias, "bias")
+    y = torch.empty((g.N, g.H, g.W, g.Co), device=x.device, dtype=torch.float32)
+    check(_lib.load().ssd_conv1x1_fwd_x3(x.data_ptr(), w3.data_ptr(), _ptr(bias), y.data_ptr(), g.Co, C.byref(g), int(relu), _stream()), "conv1x1_fwd_x3")
+    return y
+
+
+def conv1x1_dgrad_x3(dy: torch.Tensor, w3t: torch.Tensor, g: ConvGeom, dx: Optional[torch.Tensor] = None, relu_mask: Optional[torch.Tensor] = None,
+                     accumulate: bool = False) -> torch.Tensor:
+    _req(dy, "dy")
+    ldy = dy.shape[-1]
+    if dy.numel() != g.N * g.H * g.W * ldy:
+        raise ValueError("conv1x1_dgrad_x3: dy size does not match geometry")
+    _x3_filter(w3t, "w3t", g.Ci, ldy)
+    if dx is None:
+        if accumulate:
+            raise ValueError("accumulate needs an existing dx")
+        dx = torch.empty((g.N, g.H, g.W, g.Ci), device=dy.device, dtype=torch.float32)
+    _req(dx, "dx")
+    if relu_mask is not None:
+        _req(relu_mask, "relu_mask")
+    check(_lib.load().ssd_conv1x1_dgrad_x3(dy.data_ptr(), ldy, w3t.data_ptr(), dx.data_ptr(), _ptr(relu_mask), int(accumulate), C.byref(g), _stream()),
+          "conv1x1_dgrad_x3")
+    return dx
+
+
+def conv1x1_wgrad_x3(x: torch.Tensor, dy: torch.Tensor, g: ConvGeom, ldy: int, want_bias: bool = True, dw_out: Optional[torch.Tensor] = None,
+                     db_out: Optional[torch.Tensor] = None):
+    _req(x, "x"); _req(dy, "dy")
+    if tuple(x.shape) != (g.N, g.H, g.W, g.Ci) or dy.numel() != g.N * g.H * g.W * ldy or ldy < g.Co:
+        raise ValueError("conv1x1_wgrad_x3: shapes do not match geometry")
+    lib = _lib.load()
+    nbytes = lib.ssd_conv1x1_wgrad_x3_workspace(C.byref(g), ldy)
+    if nbytes == 0:
+        raise ValueError("conv1x1_wgrad_x3: not a 1x1 / stride 1 geometry")
+    ws = workspace(nbytes, x.device)
+    dw = _grad_dst(dw_out, (g.Co, g.Ci, 1, 1), x.device, "dw_out")
+    db = _grad_dst(db_out, (g.Co,), x.device, "db_out") if want_bias else None
+    check(lib.ssd_conv1x1_wgrad_x3(x.data_ptr(), dy.data_ptr(), ldy, dw.data_ptr(), _ptr(db), C.byref(g), ws.data_ptr(), ws.numel(), _stream()),
+          "conv1x1_wgrad_x3")
+    return dw, db
+
+
 def wino_planes_shape(g: ConvGeom):
     return (36, wino_tiles(g), g.Ci)
 
@@ -1117,7 +1194,7 @@ class WeightTable:
         for a, j in zip(arr, jobs):
             for t in (j["w0"], j.get("w1"), j.get("out_fwd"), j.get("out_bwd")):
                 if t is not None:
-                    _req(t, "weight job tensor", t.dtype if (j["kind"] in (0, 3) and t.dtype == torch.bfloat16) else torch.float32)
+                    _req(t, "weight job tensor", t.dtype if (j["kind"] in (0, 3, 4) and t.dtype == torch.bfloat16) else torch.float32)
                     self.keep.append(t)
             a.w0 = j["w0"].data_ptr()
             a.w1 = j["w1"].data_ptr() if j.get("w1") is not None else j["w0"].data_ptr()

@@ -1082,6 +1082,60 @@ def test_plane_gemm_from_three_bf16_limbs_is_as_exact_as_the_f32_mfma(case):
     assert e3 <= 2.0 * e32 + 1e-9 and e3 <= 2e-6, (e3, e32)
 
 
+X31_CASES = [  # n, h, w, ci, co: fc7's shape class at a small batch, ragged pixel count, Co not a multiple of 128, deep reduction
+    (2, 19, 19, 1024, 1024), (3, 13, 7, 256, 160), (1, 38, 38, 512, 128), (2, 10, 10, 2048, 256),
+]
+
+
+@pytest.mark.parametrize("case", X31_CASES)
+def test_conv1x1_on_the_three_limb_gemms_forward_dgrad_wgrad(case):
+    """1x1 / stride-1 convolutions through csrc/gemm_x3.hip (fc7, seq8.0 in the f32 step): forward with bias + ReLU, data gradient with
+    accumulate + ReLU mask, weight and bias gradient (split-K TN GEMM + slice sum + column sums) against an f64 convolution: within
+    FIXED 1e-6 (forward, data gradient) / 2e-6 (weight gradient) relative L2 (measured 4.7e-7 at K = 1024, 6.4e-7 at K = 2048, where
+    the exact-f32 MFMA kernels read 1.6e-7: 6 x K/16 accumulating MFMAs per output instead of K/2 exact FMA steps -- both are f32
+    summation-order noise, reported side by side in the assertion message); filter limbs from the per-layer split and from the kind-4 weight job must be the same bits."""
+    from objectdetection_ssd_amd import ops
+    n, h, w, ci, co = case
+    dev = _dev()
+    full = (n, h, w, ci, co, 1, 1, 0, 1)
+    x, wt, b = _conv_data(full, seed=311)
+    x = torch.relu(x)
+    x64 = x.double().requires_grad_(True)
+    w64 = wt.double().requires_grad_(True)
+    b64 = b.double().requires_grad_(True)
+    y64 = F.relu(F.conv2d(x64, w64, b64))
+    dy = torch.randn(y64.shape, generator=torch.Generator().manual_seed(312)) * (y64.detach() > 0)
+    y64.backward(dy.double())
+    g = ops.make_geom(*full)
+    xd, dyd, wd, bd = _nhwc(x).to(dev), _nhwc(dy).to(dev), wt.to(dev), b.to(dev)
+    w3f, w3b = ops.conv1x1_weights_x3(wd, co)
+    wf_j, wb_j = ops.x3_filter_alloc(co, ci, dev), ops.x3_filter_alloc(ci, co, dev)
+    ops.WeightTable([dict(kind=4, w0=wd, co0=co, co=co, ci=ci, taps=1, co_pad=co, out_fwd=wf_j, out_bwd=wb_j)], dev).run()
+    assert torch.equal(wf_j.view(torch.int16), w3f.view(torch.int16)) and torch.equal(wb_j.view(torch.int16), w3b.view(torch.int16))
+    rel = lambda a, r: float((a.double().cpu() - r).norm() / r.norm())
+    # forward
+    y3 = ops.conv1x1_fwd_x3(xd, w3f, bd, g, True)
+    y32 = ops.conv2d_fwd(xd, ops.weight_ohwi(wd), bd, g, True)
+    ref = _nhwc(y64.detach())
+    assert rel(y3, ref) <= 1e-6, (rel(y3, ref), rel(y32, ref))
+    assert torch.equal(y3 > 0, y32 > 0) or float(((y3 > 0) != (y32 > 0)).float().mean()) < 1e-5
+    # data gradient: += into an existing tensor, masked by the layer input's ReLU
+    prev = torch.randn(n, h, w, ci, generator=torch.Generator().manual_seed(313)).to(dev)
+    dx3 = ops.conv1x1_dgrad_x3(dyd, w3b, g, dx=prev.clone(), relu_mask=xd, accumulate=True)
+    dx32 = ops.conv2d_dgrad(dyd, ops.weight_ihwo(wd), g, prev.clone(), xd, True)
+    refdx = (prev.cpu().double() + _nhwc(x64.grad)) * (_nhwc(x) > 0)
+    assert rel(dx3, refdx) <= 1e-6, (rel(dx3, refdx), rel(dx32, refdx))
+    dx3n = ops.conv1x1_dgrad_x3(dyd, w3b, g)
+    assert rel(dx3n, _nhwc(x64.grad)) <= 1e-6
+    # weight and bias gradient
+    dw3, db3 = ops.conv1x1_wgrad_x3(xd, dyd, g, co, True)
+    dw32, db32 = ops.conv2d_wgrad(xd, dyd, g, co, True)
+    assert rel(dw3, w64.grad) <= 2e-6, (rel(dw3, w64.grad), rel(dw32, w64.grad))
+    assert rel(db3, b64.grad) <= 2e-6, rel(db3, b64.grad)
+    dwa, dba = ops.conv1x1_wgrad_x3(xd, dyd, g, co, True)
+    assert torch.equal(dwa, dw3) and torch.equal(dba, db3)               # fixed slice order: reproducible
+
+
 DILATED_CASES = [  # n, h, w, ci, co, dilation: fc6's shape class, odd maps, lattices of unequal size, a map smaller than the dilation
     (2, 19, 19, 64, 96, 4), (1, 10, 13, 32, 64, 2), (2, 7, 5, 32, 32, 3), (1, 3, 3, 32, 32, 4), (1, 23, 17, 32, 40, 4), (32, 19, 19, 512, 1024, 4),
 ]
