@@ -11,9 +11,11 @@
 // Structure: 128 x 128 tile, 4 waves (2 x 2, 64 x 64 each = 2 x 2 MFMA tiles), K step 16 (one MFMA depth), two LDS stages, ONE barrier
 // per step (24 MFMAs per wave between barriers).  The weight limbs arrive pre-split and pre-tiled ([k step][limb][row][16]): one
 // LDS-DMA instruction per limb and thread, 4 KB contiguous per limb.  The activation tile is loaded as f32 (two 16-byte loads per
-// thread and step, a step ahead), split in registers (~44 VALU instructions: v_cvt_pk_bf16_f32 / shift / and / sub) and written as three 16-byte LDS
-// stores.  LDS rows are 32 bytes (16 k); the two 16-byte halves of row r are swapped when bit 3 of r is set, so that the 16 lanes
-// of a ds_read_b128 group hit 16 different 16-byte slots (MI355X_MICROARCH.md LDS table).
+// thread and step, two steps ahead into one of two register sets), split in registers (~50 VALU instructions: v_cvt_pk_bf16_f32 / shift /
+// and / sub, placed by hand in the MFMA gaps) and written as three 16-byte LDS stores.  LDS rows are 32 bytes (16 k); the two 16-byte
+// halves of row r are swapped when bit 3 of r is set, so that the 16 lanes of a ds_read_b128 group hit 16 different 16-byte slots
+// (MI355X_MICROARCH.md LDS table).  The same kernel with an epilogue (bias / ReLU / += / ReLU mask, row stride) is the forward and the
+// data gradient of the 1x1 layers with long reductions (fc7, seq8.0); the TN form below is every weight gradient.
 #include <type_traits>
 #include "common.h"
 
