@@ -1,5 +1,5 @@
 """300 train steps over four alternating synthetic batches: step time, loss and allocator state every 50 steps (a stability check:
-the step time must stay flat and the reserved memory must not grow -- 23.9 ms, 18.5 GB reserved on an MI355X).
+the step time must stay flat and the reserved memory must not grow -- 21.2 ms, 18.7 GB reserved on an MI355X).
 
     python tools/long_run.py
 """
