@@ -679,6 +679,27 @@ def main():
             step()
     if not args.no_roofline and rank == 0:
         out["roofline"] = roofline_of(net, step, args.conv_dtype, ms, args.layers)
+    if world == 1 and args.conv_dtype == "f32" and args.variant == 300 and not args.no_bf16_leg and _ops.wino_x3(4, 256) and net._engine.wino:
+        # the same step with EVERY product on the f32 MFMA (the limb GEMMs switched off), a few steps beside the headline: what the
+        # three-limb form buys on this device, and the number to hold against a reader who wants v_mfma_f32_32x32x2_f32 only
+        from objectdetection_ssd_amd import _lib as _l3
+        try:
+            _l3.check(_l3.load().ssd_tune_set_wino_x3(0), "tune")
+            net.invalidate_weight_cache()
+            for _ in range(3):
+                step()
+            fence()
+            m0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            fence()
+            mms = (time.perf_counter() - m0) / args.steps * 1e3
+        finally:
+            _l3.check(_l3.load().ssd_tune_set_wino_x3(-1), "tune")
+            net.invalidate_weight_cache()
+        out["config"]["f32_mfma_only"] = {"images_per_sec": round(bs / mms * 1e3, 1), "ms_per_step": round(mms, 3), "steps": args.steps,
+                                          "note": "same process, same batch, SSD_WINO_X3=0: all Winograd-domain and 1x1 products on v_mfma_f32_32x32x2_f32 / "
+                                                  "16x16x4_f32 (the round-2 arithmetic); `value` uses three exact bf16 limbs per f32 operand for the long reductions"}
     if world == 1 and args.conv_dtype == "f32" and args.variant == 300 and not args.no_bf16_leg:
         # BASELINE configs[2] ("bf16 convs", 32 images per GPU): the same step with bf16-operand forward / dgrad / 3x3-wgrad convolutions
         # (f32 accumulate, f32 loss and optimizer), a few steps beside the headline so that the driver's record holds a number for it.
