@@ -47,6 +47,18 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t srd, unsigned
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)voff, (int)soff, 0));
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// (used by the X3_PIPE experiment below)
+// Workgroup barrier of the K loops: all of this wave's LDS traffic done (its stores visible, its fragment reads returned), then a RAW
+// s_barrier.  __syncthreads() is a fence + barrier, and for the fence the compiler waits vmcnt(0) whenever an LDS-DMA may be in flight --
+// every load requested for later steps, which is the whole point of requesting them early; the counted wait_vmcnt in front of each
+// barrier says exactly which requests the next step needs.
+// (the waits are the BUILTIN, not asm: the compiler's own wait-count pass reads it and so knows that this wave's fragment reads of the
+// step have returned -- after an asm wait it still waited lgkmcnt(0) in front of the next step's first MFMA, i.e. for the reads just issued)
+__device__ __forceinline__ void loop_barrier() {
+    __builtin_amdgcn_s_waitcnt(0xC07F);           // lgkmcnt(0); vmcnt / expcnt fields at their maxima = no wait
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 
 // two f32 -> the packed (a, b) bf16 pairs of their three limbs.  Round-to-nearest limbs (v_cvt_pk_bf16_f32): |mid| <= 2^-9 |x|,
 // |lo| <= 2^-17 |x|, both residuals exact (x - bf16(x) has at most 16 significant bits, r1 - bf16(r1) at most 8), so hi + mid + lo = x
@@ -73,6 +85,15 @@ __device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, u32x4& hi
     lo = u32x4{l[0], l[1], l[2], l[3]};
 }
 
+// Row loads of the K loops as inline asm: 32 bytes of one row into two register quads.  The compiler does not know such a load is pending,
+// so it neither waits for it at the first use (where, once an LDS-DMA is in flight, it waits vmcnt(0) -- the requests just issued for
+// later steps included) nor may anything touch the destination before the counted wait that covers it.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void buf_load32_async(f32x4& d0, f32x4& d1, i32x4 srd, unsigned voff, unsigned soff) {
+    asm volatile("buffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:16"
+                 : "=&v"(d0), "=&v"(d1) : "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+
 constexpr int X3_LIMB = 128 * 32;          // bytes of one limb image: [128 rows][16 k] bf16
 constexpr int X3_OPER = 3 * X3_LIMB;       // one operand, one stage
 constexpr int X3_STAGE = 2 * X3_OPER;      // A + B
@@ -96,6 +117,11 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
     const __amdgpu_buffer_rsrc_t srd_a =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a + (size_t)b * p.batch_a), 0, (int)((size_t)p.M * p.K * 4), 0x00020000);
     const unsigned voff_a = m0 + arow < p.M ? ((unsigned)(m0 + arow) * (unsigned)p.K + ahalf * 8u) * 4u : OOB;
+#ifdef X3_ASM_ALOAD
+    const unsigned long long a_base = reinterpret_cast<unsigned long long>(p.a + (size_t)b * p.batch_a);      // the same descriptor as four words
+    const i32x4 srd_a4 = {__builtin_amdgcn_readfirstlane((int)(unsigned)a_base), __builtin_amdgcn_readfirstlane((int)(unsigned)((a_base >> 32) & 0xffffu)),
+                          __builtin_amdgcn_readfirstlane((int)((size_t)p.M * p.K * 4)), 0x00020000};      // (readfirstlane: provably scalar for the "s" operand)
+#endif
     const unsigned a_wr = arow * 32 + ((ahalf ^ ((arow >> 3) & 1)) << 4);            // byte offset inside a limb image
     // B: thread -> 16-byte slot `tid` of each limb image; the XOR of the image is applied on the source address
     const int brow = tid >> 1, bhalf = (tid & 1) ^ ((brow >> 3) & 1);
@@ -106,9 +132,17 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
     // step s + 1's rows (issued a step earlier) runs in the shadow of step s's MFMAs
     f32x4 ra[2][2];
     auto load_a = [&](int ks, int set) {          // beyond the last step: out-of-range offsets (zeros, no traffic) keep vmcnt uniform
+#ifdef X3_PROBE_NO_ALOAD                     // timing probes (tools/x3_variants.sh): a piece compiled out, results meaningless
+        const unsigned v = OOB;
+#else
         const unsigned v = ks < NK ? voff_a : OOB;
+#endif
+#ifdef X3_ASM_ALOAD
+        buf_load32_async(ra[set][0], ra[set][1], srd_a4, v, (unsigned)ks * 64u);
+#else
         ra[set][0] = buf_load16(srd_a, v, (unsigned)ks * 64u);
         ra[set][1] = buf_load16(srd_a, v + 16u, (unsigned)ks * 64u);
+#endif
     };
     // Sign dither.  The bf16 MFMA's internal sum is truncated, not rounded: against f64 the result carries a bias of about -1.7e-10 of
     // its magnitude per MFMA of the chain, always downwards (tools/x3_bias_probe.py: -3.3e-8 at K = 512, -1.3e-7 at K = 2048, the same
@@ -119,7 +153,11 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
     // the sign s(m), s(m) = (-1)^(bit 2 ^ bit 5 of m): zero mean over any 8 consecutive rows.
     const unsigned a_sign = (unsigned)(((arow >> 2) ^ (arow >> 5)) & 1) << 31;
     auto dma_b = [&](int ks, int stage) {
+#ifdef X3_PROBE_NO_BDMA
+        const __bf16* s = b_src;                  // the same 12 KB every step: L1 / L2 hits
+#else
         const __bf16* s = b_src + (size_t)ks * 3 * limb_elems;
+#endif
         unsigned char* d = lds + stage * X3_STAGE + X3_OPER + wave * 1024;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
@@ -157,6 +195,9 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
                 bf[pb][i] = *reinterpret_cast<const bf16x8*>(st + b_rd + pb * X3_LIMB + i * 1024);
             }
         __builtin_amdgcn_sched_barrier(0);
+#ifdef X3_SETPRIO
+        __builtin_amdgcn_s_setprio(X3_SETPRIO);
+#endif
         const f32x4 v0 = ra[PH ^ 1][0], v1 = ra[PH ^ 1][1];
         float xa[4] = {v0[0], v0[2], v1[0], v1[2]}, xb[4] = {v0[1], v0[3], v1[1], v1[3]};
 #pragma unroll
@@ -170,6 +211,7 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
         for (int q = 0; q < 24; ++q) {
             const int pr = q >> 2, i = (q >> 1) & 1, j = q & 1;
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[pr]][i], bf[PB[pr]][j], acc[i][j], 0, 0, 0);
+#ifndef X3_PROBE_NO_SPLIT
             if (q >= 2 && q < 22) {                // (the first MFMAs wait for the fragments anyway)
                 const int e = (q - 2) / 5, sg = (q - 2) % 5;
                 // (the empty asm pins each stage's results where they are written: pure arithmetic would otherwise sink, at IR level,
@@ -186,8 +228,14 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
                 }
                 if (sg == 4) { lo[e] = pack_rne(r1a[e], r1b[e]); asm volatile("" : "+v"(lo[e])); }
             }
+#else
+            if (q == 2) { for (int e = 0; e < 4; ++e) { hi[e] = __float_as_uint(xa[e]); mid[e] = __float_as_uint(xb[e]); lo[e] = hi[e] ^ mid[e]; } }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
+#ifdef X3_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         unsigned char* d = lds + (PH ^ 1) * X3_STAGE + a_wr;       // the other stage: last read a step ago, a barrier since
         *reinterpret_cast<u32x4*>(d) = u32x4{hi[0], hi[1], hi[2], hi[3]};
         *reinterpret_cast<u32x4*>(d + X3_LIMB) = u32x4{mid[0], mid[1], mid[2], mid[3]};
@@ -198,6 +246,9 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
     dma_b(0, 0);
     load_a(0, 0);
     load_a(1, 1);
+#ifdef X3_ASM_ALOAD
+    wait_vmcnt<0>();
+#endif
     {
         u32x4 hi, mid, lo;
         f32x4 s0 = ra[0][0], s1 = ra[0][1];       // (the compiler waits for set 0 here)
@@ -217,13 +268,23 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
     wait_vmcnt<7>();                              // issue order: B(0), A(0), A(1), B(1), A(2): everything up to A(0) has landed
     __syncthreads();
     for (int ks = 0; ks < NK; ks += 2) {          // NK is even (K % 32 == 0)
+        // (__syncthreads, not a raw barrier: its fence makes the compiler drain every load HERE, a full step after the request; with a
+        // raw barrier it drains them at the first use of the row registers instead -- right after the next requests: 4.6 -> 4.9 ms per step)
         step(std::integral_constant<int, 0>{});   // step ks: reads stage 0, writes A(ks + 1) into stage 1
-        wait_vmcnt<2>();                          // B(ks + 1) has landed; the two row loads issued after it stay in flight
+#ifdef X3_ASM_ALOAD
+        wait_vmcnt<0>();                          // everything requested at the top of this step: the weights of step ks + 1, the rows of ks + 2
+#else
+        wait_vmcnt<2>();                          // B(ks + 1) has landed
+#endif
         __syncthreads();
         if (ks + 2 < NK) dma_b(ks + 2, 0);
         load_a(ks + 3, 1);
         step(std::integral_constant<int, 1>{});   // step ks + 1
+#ifdef X3_ASM_ALOAD
+        wait_vmcnt<0>();
+#else
         wait_vmcnt<2>();
+#endif
         __syncthreads();
         if (ks + 3 < NK) dma_b(ks + 3, 1);
         load_a(ks + 4, 0);
@@ -255,6 +316,205 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
             }
         }
 }
+
+#ifdef X3_PIPE      // EXPERIMENT, not built by default (tools/x3_variants.sh "" "-DX3_PIPE"): measured below
+// ---- the same NT product, software-pipelined: THREE LDS stages, TWO fragment register sets, THREE raw-row register sets.
+// At the top of step t a wave requests the weights of step t + 3 (LDS-DMA into the stage whose fragments it already holds) and the rows of
+// step t + 4 (registers), reads the FRAGMENTS OF STEP t + 1 from LDS, and then issues the 24 MFMAs of step t on the fragments it read a
+// step ago -- no LDS latency in front of them -- with the split of the rows of step t + 2 (requested two steps ago) in their gaps.  One
+// counted wait per step (vmcnt(5): everything but this step's own five requests) and one raw barrier.  72 KB of LDS and ~200 registers:
+// two workgroups per CU.
+// The row loads are inline asm: for its own loads the compiler, once an LDS-DMA is in flight, waits vmcnt(0) in front of the first use
+// -- this step's fresh requests included -- which is exactly the stall the pipeline exists to remove.  An asm load completes later than
+// the compiler believes; nothing may touch its destination registers before the counted wait two steps on.  The parity tests run this
+// very binary on every shape class (a copy of such a register made too early gives garbage, not a small error).
+// Probes on the two-stage kernel (tools/x3_variants.sh) put its skeleton -- no global loads, no split -- at 1.28 PFLOP/s: its three
+// waves per SIMD fall into lock-step (MFMA phase together, LDS / barrier phase together) and every load was drained at every barrier.
+
+template <bool EPI>
+__global__ __launch_bounds__(256, 2) void gemm_planes_x3p_kernel(const GemmX3Params p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * X3_STAGE];       // 72 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int nblk = p.tiles_m * p.tiles_n * p.nbatch;
+    int lid = xcd_swizzle(blockIdx.x, nblk);
+    const int tile_n = lid % p.tiles_n;
+    lid /= p.tiles_n;
+    const int tile_m = lid % p.tiles_m, b = lid / p.tiles_m;
+    const int m0 = tile_m * 128, n0 = tile_n * 128;
+    const int NK = p.K >> 4;
+
+    const int arow = tid >> 1, ahalf = tid & 1;
+    const __amdgpu_buffer_rsrc_t srd_a =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a + (size_t)b * p.batch_a), 0, (int)((size_t)p.M * p.K * 4), 0x00020000);
+    const unsigned long long a_base = reinterpret_cast<unsigned long long>(p.a + (size_t)b * p.batch_a);      // the same descriptor as four words
+    const i32x4 srd_a4 = {__builtin_amdgcn_readfirstlane((int)(unsigned)a_base), __builtin_amdgcn_readfirstlane((int)(unsigned)((a_base >> 32) & 0xffffu)),
+                          __builtin_amdgcn_readfirstlane((int)((size_t)p.M * p.K * 4)), 0x00020000};      // (readfirstlane: provably scalar for the "s" operand)
+    const unsigned voff_a = m0 + arow < p.M ? ((unsigned)(m0 + arow) * (unsigned)p.K + ahalf * 8u) * 4u : OOB;
+    const unsigned a_wr = arow * 32 + ((ahalf ^ ((arow >> 3) & 1)) << 4);
+    const int brow = tid >> 1, bhalf = (tid & 1) ^ ((brow >> 3) & 1);
+    const size_t limb_elems = (size_t)p.rows_pad * 16;
+    const __bf16* b_src = p.w3 + (size_t)b * NK * 3 * limb_elems + (size_t)(n0 + brow) * 16 + bhalf * 8;
+    const unsigned a_sign = (unsigned)(((arow >> 2) ^ (arow >> 5)) & 1) << 31;       // sign dither: see gemm_planes_x3_kernel
+
+    f32x4 ra[3][2];                               // raw rows of three steps in flight
+    auto dma_b = [&](int ks, int stage) {         // beyond the last step: step 0's tile again (never read), so that every wait count is a constant
+        const __bf16* s = b_src + (size_t)(ks < NK ? ks : 0) * 3 * limb_elems;
+        unsigned char* d = lds + stage * X3_STAGE + X3_OPER + wave * 1024;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(s + pl * limb_elems), (lds_void*)(d + pl * X3_LIMB), 16, 0, 0);
+    };
+    auto split_store = [&](f32x4 s0, f32x4 s1, int stage) {  // (prologue only: the loop splits in the MFMA gaps)
+        u32x4 hi, mid, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s0[e] = __uint_as_float(__float_as_uint(s0[e]) ^ a_sign);
+            s1[e] = __uint_as_float(__float_as_uint(s1[e]) ^ a_sign);
+        }
+        split8(s0, s1, hi, mid, lo);
+        unsigned char* d = lds + stage * X3_STAGE + a_wr;
+        *reinterpret_cast<u32x4*>(d) = hi;
+        *reinterpret_cast<u32x4*>(d + X3_LIMB) = mid;
+        *reinterpret_cast<u32x4*>(d + 2 * X3_LIMB) = lo;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const unsigned frag = lr * 32 + ((lh ^ ((lr >> 3) & 1)) << 4);
+    const unsigned a_rd = wm * 64 * 32 + frag, b_rd = X3_OPER + wn * 64 * 32 + frag;
+    bf16x8 af[2][3][2], bf[2][3][2];              // [fragment set][limb][MFMA tile]
+
+    // step (I = position in the unrolled group of six: every stage / set index below is a constant):
+    //   fragments of the NEXT step from stage (I + 1) % 3 into set (I + 1) & 1, 24 MFMAs on set I & 1 with the split of raw set
+    //   (I + 2) % 3 (the rows of two steps on) in their gaps, limbs stored into stage (I + 2) % 3
+    auto step = [&](auto i_tag) {
+        constexpr int I = decltype(i_tag)::value, PH = I & 1, S1 = (I + 1) % 3, S2 = (I + 2) % 3, RS = (I + 2) % 3;
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        {
+            const unsigned char* st = lds + S1 * X3_STAGE;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[PH ^ 1][pl][i] = *reinterpret_cast<const bf16x8*>(st + a_rd + pl * X3_LIMB + i * 1024);
+                    bf[PH ^ 1][pl][i] = *reinterpret_cast<const bf16x8*>(st + b_rd + pl * X3_LIMB + i * 1024);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 v0 = ra[RS][0], v1 = ra[RS][1];
+        float xa[4] = {v0[0], v0[2], v1[0], v1[2]}, xb[4] = {v0[1], v0[3], v1[1], v1[3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            xa[e] = __uint_as_float(__float_as_uint(xa[e]) ^ a_sign);
+            xb[e] = __uint_as_float(__float_as_uint(xb[e]) ^ a_sign);
+        }
+        unsigned hi[4], mid[4], lo[4];
+        float r1a[4], r1b[4];
+#pragma unroll
+        for (int q = 0; q < 24; ++q) {
+            const int pr = q >> 2, i = (q >> 1) & 1, j = q & 1;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PH][PA[pr]][i], bf[PH][PB[pr]][j], acc[i][j], 0, 0, 0);
+            if (q >= 2 && q < 22) {
+                const int e = (q - 2) / 5, sg = (q - 2) % 5;
+                if (sg == 0) { hi[e] = pack_rne(xa[e], xb[e]); asm volatile("" : "+v"(hi[e])); }
+                if (sg == 1) {
+                    r1a[e] = xa[e] - __uint_as_float(hi[e] << 16); r1b[e] = xb[e] - __uint_as_float(hi[e] & 0xffff0000u);
+                    asm volatile("" : "+v"(r1a[e]), "+v"(r1b[e]));
+                }
+                if (sg == 2) { mid[e] = pack_rne(r1a[e], r1b[e]); asm volatile("" : "+v"(mid[e])); }
+                if (sg == 3) {
+                    r1a[e] -= __uint_as_float(mid[e] << 16); r1b[e] -= __uint_as_float(mid[e] & 0xffff0000u);
+                    asm volatile("" : "+v"(r1a[e]), "+v"(r1b[e]));
+                }
+                if (sg == 4) { lo[e] = pack_rne(r1a[e], r1b[e]); asm volatile("" : "+v"(lo[e])); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        unsigned char* d = lds + S2 * X3_STAGE + a_wr;
+        *reinterpret_cast<u32x4*>(d) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+        *reinterpret_cast<u32x4*>(d + X3_LIMB) = u32x4{mid[0], mid[1], mid[2], mid[3]};
+        *reinterpret_cast<u32x4*>(d + 2 * X3_LIMB) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+    };
+    auto rows = [&](int ks) { return ks < NK ? voff_a : OOB; };      // beyond the last step: zeros, no traffic, the same request count
+
+    // prologue: stages 0 and 1 complete, stage 2's weights landed, the rows of steps 2 and 3 in raw sets 2 and 0, the fragments of step 0 in set 0
+    dma_b(0, 0);
+    dma_b(1, 1);
+    dma_b(2, 2);
+    {
+        const f32x4 p00 = buf_load16(srd_a, rows(0), 0u), p01 = buf_load16(srd_a, rows(0) + 16u, 0u);
+        const f32x4 p10 = buf_load16(srd_a, rows(1), 64u), p11 = buf_load16(srd_a, rows(1) + 16u, 64u);
+        split_store(p00, p01, 0);
+        split_store(p10, p11, 1);
+    }
+    buf_load32_async(ra[2][0], ra[2][1], srd_a4, rows(2), 2u * 64u);
+    buf_load32_async(ra[0][0], ra[0][1], srd_a4, rows(3), 3u * 64u);
+    wait_vmcnt<0>();
+    loop_barrier();
+    {
+        const unsigned char* st = lds;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[0][pl][i] = *reinterpret_cast<const bf16x8*>(st + a_rd + pl * X3_LIMB + i * 1024);
+                bf[0][pl][i] = *reinterpret_cast<const bf16x8*>(st + b_rd + pl * X3_LIMB + i * 1024);
+            }
+    }
+    loop_barrier();                               // stage 0 is free again: its fragments are in registers
+#define X3P_STEP(I)                                                                                                       \
+    if (t + I < NK) {                                                                                                     \
+        buf_load32_async(ra[(I + 1) % 3][0], ra[(I + 1) % 3][1], srd_a4, rows(t + I + 4), (unsigned)(t + I + 4) * 64u);   \
+        dma_b(t + I + 3, I % 3);                                                                                          \
+        step(std::integral_constant<int, I>{});                                                                           \
+        wait_vmcnt<5>();      /* everything but this step's own five requests has landed */                                \
+        loop_barrier();                                                                                                   \
+    }
+    for (int t = 0; t < NK; t += 6) {
+        X3P_STEP(0) X3P_STEP(1) X3P_STEP(2) X3P_STEP(3) X3P_STEP(4) X3P_STEP(5)
+    }
+#undef X3P_STEP
+    wait_vmcnt<0>();                              // (LDS-DMA still in flight must not outlive the workgroup)
+
+    float* out = p.out + (size_t)b * p.batch_out;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+                float v = ((lh ^ i) & 1) ? -acc[i][j][r] : acc[i][j][r];
+                if (m < p.M && n < p.N) {
+                    if constexpr (!EPI) {
+                        out[(size_t)m * p.N + n] = v;
+                    } else {
+                        const size_t idx = (size_t)m * p.ldo + n;
+                        if (p.bias != nullptr) v += p.bias[n];
+                        if (p.accumulate) v += out[idx];
+                        if (p.relu) v = v < 0.f ? 0.f : v;
+                        if (p.mask != nullptr) v = p.mask[idx] > 0.f ? v : 0.f;
+                        out[idx] = v;
+                    }
+                }
+            }
+        }
+}
+// Measured against the two-stage kernel on one device (tools/x3_variants.sh, Gaussian operands): conv4_2 0.371 vs 0.365 ms, fc6 0.450 vs
+// 0.449, conv3_2 0.380 vs 0.379 -- nothing where the time is -- and conv5_2 0.098 vs 0.107, c_4 0.101 vs 0.112 on the short grids.  With
+// s_setprio around the MFMAs, a third weight stage and asm fragment reads also at +-0, and the all-zero-operand skeleton 27 % faster than
+// real data at the same instruction stream, the long GEMMs sit at the rate the chip sustains on this data (about 1.0-1.06 PFLOP/s of bf16
+// MFMAs), not at a limit of the loop structure: the simpler kernel stays.
+#endif
 
 // ---- TN form: out[b][split][m][n] = sum_k a[b][k][m] * c[b][k][n]  (the Winograd weight gradient: a = transformed dy planes [tiles][ldy],
 // c = transformed input planes [tiles][Ci], k = tiles; split-K over `ksplit` slices of the tile range) ------------------------------------
@@ -504,7 +764,18 @@ __attribute__((visibility("hidden"))) int ssd_internal_gemm_batched_x3(const flo
     if (nblk >= (1ull << 31)) return SSD_ERR_BAD_SHAPE;
     // recorder kind 4: the bf16 MFMA FLOPs the grid executes (six limb products per f32 product, whole 128 x 128 tiles)
     const int slot = ssd_internal_prof_open(6.0 * 2.0 * (double)nblk * 128.0 * 128.0 * K, 4, st);
+#ifdef X3_PIPE
+    {
+        static bool raised = false;
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_planes_x3p_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 0);
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(gemm_planes_x3p_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, st, p);
+#else
     hipLaunchKernelGGL(gemm_planes_x3_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, st, p);
+#endif
     ssd_internal_prof_close(slot, st);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
