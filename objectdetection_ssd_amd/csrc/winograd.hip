@@ -1574,7 +1574,9 @@ __global__ __launch_bounds__(256) void weight_jobs_kernel(const ssd_weight_job* 
         const int Nrows = fwd ? Co : Ci, K = fwd ? Ci : j.co_pad;
         float* U = fwd ? j.out_fwd : j.out_bwd;
         if (fwd ? x3f : x3b) {
-            const int K8 = K >> 3, k8 = (int)(e % K8) * 8, n = (int)(e / K8);
+            // thread order = (half of a 16-k chunk, row, chunk): the 64 lanes of a store instruction write 1 KB of one limb image
+            // contiguously (two threads per 32-byte row, consecutive rows), not 32-byte pieces 3 limb images apart
+            const int half = (int)(e & 1), n = (int)((e >> 1) % Nrows), k8 = (int)((e >> 1) / Nrows) * 16 + half * 8;
             float g[8][9];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -1662,7 +1664,7 @@ __global__ __launch_bounds__(256) void weight_jobs_kernel(const ssd_weight_job* 
         if (!fwd && i - tf >= tb) return;
         const size_t e = fwd ? i : i - tf;
         const int Nrows = fwd ? Co : Ci, K = fwd ? Ci : j.co_pad;
-        const int K8 = K >> 3, k8 = (int)(e % K8) * 8, n = (int)(e / K8);
+        const int half = (int)(e & 1), n = (int)((e >> 1) % Nrows), k8 = (int)((e >> 1) / Nrows) * 16 + half * 8;      // (store order: as kind 0)
         typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
         bf16x8 h, m, l;
 #pragma unroll
