@@ -3,7 +3,9 @@
 // bits, round-to-nearest: both residual subtractions are exact) and a product block is the six limb products of weight >= 2^-18
 // (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid) on v_mfma_f32_32x32x16_bf16, accumulated in f32; the dropped terms (mid*lo, lo*mid,
 // lo*lo) are <= 2^-26 relative, below the rounding of an f32 product.  Six bf16 MFMAs cost 6/16 of the f32 MFMA block they replace
-// (v_mfma_f32_32x32x2_f32: 256 FLOP/clk/CU against 4096).
+// (v_mfma_f32_32x32x2_f32: 256 FLOP/clk/CU against 4096).  Non-finite operands: x = +-inf splits into (inf, NaN, NaN) -- inf - inf -- so a
+// product that the f32 MFMA would return as +-inf comes out NaN (NaN stays NaN); values below 2^-126 * 2^16 lose their low limbs to the
+// bf16 denormal range (absolute error < 2^-133).  Neither occurs in a step that has not already diverged.
 //
 //   NT form  out[b][m][n] = sum_k a[b][m][k] * w[b][n][k]      (forward / data gradient: a = transformed activation planes [tiles][K],
 //                                                               w = transformed filter planes, split ONCE per step by the weight job)
