@@ -428,6 +428,10 @@ def roofline_of(net, step, conv_dtype: str, ms: float, layers: bool = False) -> 
                        "all_conv_kernels_tflops": round(sum(a[1] for a in agg.values()) / sum(a[0] for a in agg.values()) / 1e12, 2),
                        "by_kernel": {k: {"ms_per_step": round(a[0] / 3 * 1e3, 3), "tflops": round(a[1] / a[0] / 1e12, 2),
                                          "launches_per_step": a[2] // 3} for k, a in sorted(agg.items())}}
+    if tag in x3_tags.values():      # the same launches counted as f32 products (one per six limb MFMAs): algorithmic Winograd-domain FLOPs / time
+        roof["f32_product_tflops"] = round(ach / 6.0, 2)
+        roof["f32_product_note"] = ("achieved / 6: the Winograd-domain f32 products these launches deliver per second; against it the f32 MFMA "
+                                    "peak is 157.3 TFLOP/s and the bf16 peak / 6 = 416.7 -- `frac` is the same fraction either way")
     if layers:                       # per-layer table: mean over the three profiled steps
         per = {}
         for label, tag, flops, dt in rows:
