@@ -915,8 +915,9 @@ def test_weight_job_table_equals_the_per_layer_transforms_bit_for_bit():
         co_, ci_ = wq.shape[0], wq.shape[1]
         jobs.append(dict(kind=0, w0=wq, co0=co_, co=co_, ci=ci_, taps=9, co_pad=cp, out_fwd=ops.wino_filter_alloc(4, co_, ci_, dev),
                          out_bwd=ops.wino_filter_alloc(4, ci_, cp, dev)))
-    assert [jb["out_fwd"].dtype == torch.bfloat16 for jb in jobs[6:]] == [True, False, True]
-    assert [jb["out_bwd"].dtype == torch.bfloat16 for jb in jobs[6:]] == [False, True, True]
+    on = ops.wino_x3(4, 256)                       # (SSD_WINO_X3=0 in the environment: every filter stays f32 and the limb checks below are skipped)
+    assert [jb["out_fwd"].dtype == torch.bfloat16 for jb in jobs[6:]] == [on, False, on]
+    assert [jb["out_bwd"].dtype == torch.bfloat16 for jb in jobs[6:]] == [False, on, on]
     table = ops.WeightTable(jobs, dev)
     assert table.njobs == 9 and table.total_blocks > 9
     table.run()
@@ -928,6 +929,8 @@ def test_weight_job_table_equals_the_per_layer_transforms_bit_for_bit():
                            uf.view(torch.int16) if uf.dtype == torch.bfloat16 else uf)
         assert torch.equal(jb["out_bwd"].view(torch.int16) if ub.dtype == torch.bfloat16 else jb["out_bwd"],
                            ub.view(torch.int16) if ub.dtype == torch.bfloat16 else ub)
+    if not on:
+        return
     # the limbs of a filter plane add up to the f32 transform: hi + mid + lo == U exactly
     lib = __import__("objectdetection_ssd_amd._lib", fromlist=["load"]).load()
     try:
