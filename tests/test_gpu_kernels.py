@@ -929,17 +929,15 @@ def test_weight_job_table_equals_the_per_layer_transforms_bit_for_bit():
                            uf.view(torch.int16) if uf.dtype == torch.bfloat16 else uf)
         assert torch.equal(jb["out_bwd"].view(torch.int16) if ub.dtype == torch.bfloat16 else jb["out_bwd"],
                            ub.view(torch.int16) if ub.dtype == torch.bfloat16 else ub)
-    if not on:
-        return
-    # the limbs of a filter plane add up to the f32 transform: hi + mid + lo == U exactly
-    lib = __import__("objectdetection_ssd_amd._lib", fromlist=["load"]).load()
-    try:
-        assert lib.ssd_tune_set_wino_x3(0) == 0
-        uf32, _ = ops.wino_weights(w_xc, co_pad=288, mo=4)
-    finally:
-        assert lib.ssd_tune_set_wino_x3(-1) == 0
-    lim = jobs[8]["out_fwd"].float().sum(2)[:, :, :288, :].permute(0, 2, 1, 3).reshape(36, 288, 256)
-    assert torch.equal(lim, uf32)
+    if on:   # the limbs of a filter plane add up to the f32 transform: hi + mid + lo == U exactly
+        lib = __import__("objectdetection_ssd_amd._lib", fromlist=["load"]).load()
+        try:
+            assert lib.ssd_tune_set_wino_x3(0) == 0
+            uf32, _ = ops.wino_weights(w_xc, co_pad=288, mo=4)
+        finally:
+            assert lib.ssd_tune_set_wino_x3(-1) == 0
+        lim = jobs[8]["out_fwd"].float().sum(2)[:, :, :288, :].permute(0, 2, 1, 3).reshape(36, 288, 256)
+        assert torch.equal(lim, uf32)
     uf, ub = ops.wino_weights(w_wino, co_pad=128, mo=4)
     assert torch.equal(jobs[0]["out_fwd"], uf) and torch.equal(jobs[0]["out_bwd"], ub)
     uf, ub = ops.wino_weights(headw, co_pad=160, mo=4)
