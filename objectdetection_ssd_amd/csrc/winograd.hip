@@ -1663,7 +1663,7 @@ __global__ __launch_bounds__(256) void weight_jobs_kernel(const ssd_weight_job* 
         const bool fwd = i < tf;
         if (!fwd && i - tf >= tb) return;
         const size_t e = fwd ? i : i - tf;
-        const int Nrows = fwd ? Co : Ci, K = fwd ? Ci : j.co_pad;
+        const int Nrows = fwd ? Co : Ci;             // (K = Ci forward, co_pad backward: Nrows * K / 8 threads)
         const int half = (int)(e & 1), n = (int)((e >> 1) % Nrows), k8 = (int)((e >> 1) / Nrows) * 16 + half * 8;      // (store order: as kind 0)
         typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
         bf16x8 h, m, l;
