@@ -57,7 +57,34 @@ def _compile(src: str, force: bool, verbose: bool) -> str:
             sys.stderr.write(r.stdout + r.stderr)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}")
+    _guard_asm_reads(src, obj, [*COMMON, *PER_FILE.get(src, []), *os.environ.get("SSD_HIPCC_FLAGS", "").split(),
+                                *(["-DSSD_EXPERIMENTAL"] if os.environ.get("SSD_EXPERIMENTAL", "") not in ("", "0") else [])])
     return obj
+
+
+def _guard_asm_reads(src: str, obj: str, flags) -> None:
+    """Sources that read LDS through inline asm with hand-counted waits (conv_bf16.hip's `lds_read16`): the machine code of THIS build
+    is checked for any instruction that touches such a read's destination before a wait retires it (asm_guard.py) -- the register
+    allocator is free to do that, and did once.  A violation fails the build; the verdict is cached beside the object."""
+    from . import asm_guard
+    path = os.path.join(CSRC, src)
+    if os.environ.get("SSD_NO_ASM_GUARD", "") not in ("", "0") or not asm_guard.uses_idiom(path):
+        return
+    stamp = obj + ".guard.ok"
+    if os.path.exists(stamp) and os.path.getmtime(stamp) >= os.path.getmtime(obj):
+        return
+    flags = [f for f in flags if f != "-fPIC"]
+    bad = asm_guard.check_source(_hipcc(), flags, path, OBJ)
+    try:
+        os.remove(os.path.join(OBJ, src.replace(".hip", ".guard.s")))      # tens of MB of text: not needed once checked
+    except OSError:
+        pass
+    if bad:
+        msg = "\n".join(f"  {k}: line {ln}: `{ins}` touches the destination of `{rd}` before a wait retires it" for k, ln, ins, rd in bad[:20])
+        raise RuntimeError(f"asm_guard: {len(bad)} unsafe use(s) of an inline-asm ds_read destination in {src} (this compiler / flag set "
+                           f"moved a fragment register before its s_waitcnt):\n{msg}")
+    with open(stamp, "w") as f:
+        f.write("ok\n")
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

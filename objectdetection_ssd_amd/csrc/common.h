@@ -2,12 +2,22 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/ssd_gfx950.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define SSD_CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return SSD_ERR_LAUNCH; } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a property of (kernel, DEVICE): a call site keeps one bit per device in a flag
+// word of its own (devices 0 .. 63; a race only sets the idempotent attribute twice).
+static inline bool ssd_attr_needed(const std::atomic<unsigned long long>& seen, int& dev) {
+    dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return true;
+    return ((seen.load(std::memory_order_relaxed) >> (dev & 63)) & 1ull) == 0;
+}
+static inline void ssd_attr_done(std::atomic<unsigned long long>& seen, int dev) { seen.fetch_or(1ull << (dev & 63), std::memory_order_relaxed); }
 
 static inline bool ssd_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int ssd_cdiv(int a, int b) { return (a + b - 1) / b; }

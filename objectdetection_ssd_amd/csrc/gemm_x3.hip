@@ -3,9 +3,15 @@
 // bits, round-to-nearest: both residual subtractions are exact) and a product block is the six limb products of weight >= 2^-18
 // (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid) on v_mfma_f32_32x32x16_bf16, accumulated in f32; the dropped terms (mid*lo, lo*mid,
 // lo*lo) are <= 2^-26 relative, below the rounding of an f32 product.  Six bf16 MFMAs cost 6/16 of the f32 MFMA block they replace
-// (v_mfma_f32_32x32x2_f32: 256 FLOP/clk/CU against 4096).  Non-finite operands: x = +-inf splits into (inf, NaN, NaN) -- inf - inf -- so a
-// product that the f32 MFMA would return as +-inf comes out NaN (NaN stays NaN); values below 2^-126 * 2^16 lose their low limbs to the
-// bf16 denormal range (absolute error < 2^-133).  Neither occurs in a step that has not already diverged.
+// (v_mfma_f32_32x32x2_f32: 256 FLOP/clk/CU against 4096).  Non-finite and out-of-range operands -- where this differs from the f32 MFMA:
+//   * x = +-inf splits into (inf, NaN, NaN) -- the residual is inf - inf -- so every output element whose reduction contains x comes out
+//     NaN where the f32 MFMA returns +-inf (or NaN, if it meets a zero); NaN stays NaN.
+//   * a FINITE |x| above the largest bf16 (0x7f7f0000 = 3.3895e38; f32 reaches 3.4028e38) rounds hi to +-inf and gives the same NaN where
+//     the f32 MFMA returns a finite value or an overflowed +-inf.
+//   * values below 2^-126 * 2^16 lose their low limbs to the bf16 denormal range (absolute error < 2^-133).
+// In all three cases the affected output is non-finite (or differs below 1e-39) in BOTH forms' worst case: a step that reaches them has
+// diverged already, and what is pinned is that the limb form never turns a non-finite result into a finite one
+// (tests/test_gpu_kernels.py::test_limb_gemm_non_finite_operands, tests/test_gpu_path.py::test_overflowing_step_is_non_finite_in_both_gemm_forms).
 //
 //   NT form  out[b][m][n] = sum_k a[b][m][k] * w[b][n][k]      (forward / data gradient: a = transformed activation planes [tiles][K],
 //                                                               w = transformed filter planes, split ONCE per step by the weight job)
@@ -768,10 +774,11 @@ __attribute__((visibility("hidden"))) int ssd_internal_gemm_batched_x3(const flo
     const int slot = ssd_internal_prof_open(6.0 * 2.0 * (double)nblk * 128.0 * 128.0 * K, 4, st);
 #ifdef X3_PIPE
     {
-        static bool raised = false;
-        if (!raised) {
+        static std::atomic<unsigned long long> raised{0};
+        int dev;
+        if (ssd_attr_needed(raised, dev)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_planes_x3p_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 0);
-            raised = true;
+            ssd_attr_done(raised, dev);
         }
     }
     hipLaunchKernelGGL(gemm_planes_x3p_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, st, p);

@@ -358,12 +358,13 @@ extern "C" int ssd_multibox_loss(const float* loc, const float* conf, const floa
     SSD_CHECK_LAUNCH();
     const size_t hn_lds = (size_t)P * sizeof(uint32_t);
     if (hn_lds > 48 * 1024) {
-        static bool raised = false;     // idempotent attribute; a race only sets it twice
-        if (!raised) {
+        static std::atomic<unsigned long long> raised{0};     // one bit per device (common.h)
+        int dev;
+        if (ssd_attr_needed(raised, dev)) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(hard_negative_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     150 * 1024) != hipSuccess)
                 return SSD_ERR_LAUNCH;
-            raised = true;
+            ssd_attr_done(raised, dev);
         }
     }
     hipLaunchKernelGGL(hard_negative_kernel, dim3(bs), dim3(HB), hn_lds, st, w.neg, w.part, w.sel, w.stats, P, NB, neg_pos_ratio);

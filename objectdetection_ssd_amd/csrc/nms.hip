@@ -562,12 +562,13 @@ extern "C" int ssd_decode_nms_batch(const float* l_, const float* c_, const floa
     if (chunk_words < 32 * nwcap) return SSD_ERR_BAD_SHAPE;
     const size_t lds = (size_t)(nwcap + chunk_words) * 8;
     if (lds > 48 * 1024) {
-        static bool raised = false;
-        if (!raised) {
+        static std::atomic<unsigned long long> raised{0};     // one bit per device (common.h): the attribute belongs to (kernel, device)
+        int dev;
+        if (ssd_attr_needed(raised, dev)) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
                 return SSD_ERR_LAUNCH;
-            raised = true;
+            ssd_attr_done(raised, dev);
         }
     }
     if (wide)
@@ -579,11 +580,12 @@ extern "C" int ssd_decode_nms_batch(const float* l_, const float* c_, const floa
     SSD_CHECK_LAUNCH();
     const int kp_cap = 16384;                                    // 64 KB of probability bits beside the 2 * top_k selection words
     {
-        static bool raised = false;
-        if (!raised) {
+        static std::atomic<unsigned long long> raised{0};
+        int dev;
+        if (ssd_attr_needed(raised, dev)) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(topk_emit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
                 return SSD_ERR_LAUNCH;
-            raised = true;
+            ssd_attr_done(raised, dev);
         }
     }
     TopkArgs ta{w.s_boxes, w.s_idx, w.kept_prob, w.kept_pos, w.kept_cnt, w.k_prob, w.k_src, P, C1, top_k, kp_cap, img_wh, boxes, classes, probs, prior_ids, count};

@@ -976,7 +976,7 @@ inline bool use_x3(int mo, int K) {
         const char* e = getenv("SSD_WINO_X3");
         g_wino_x3 = (e != nullptr && e[0] == '0') ? 0 : 1;
     }
-    return g_wino_x3 == 1 && mo == 4 && K >= 256 && K % 16 == 0;
+    return g_wino_x3 == 1 && mo == 4 && K >= 256 && K % 32 == 0;      // (the limb GEMM walks K in pairs of 16-deep steps)
 }
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 // GEMMs + output transform in one kernel (wino_fused.hip)?  It removes the write and the read-back of the M planes; what it costs is

@@ -15,6 +15,7 @@ decay applies to both groups, as torch.optim.SGD does there).
 """
 from __future__ import annotations
 
+import weakref
 from typing import List, Optional
 
 import torch
@@ -32,12 +33,31 @@ class FlatSGDDataParallel(torch.optim.Optimizer):
     buffer), so a resumed run continues with its momentum instead of restarting it."""
 
     def __init__(self, model, lr: float = 1e-4, momentum: float = 0.9, weight_decay: float = 5e-4,
-                 bias_lr_mult: float = 2.0, process_group=None, overlap: bool = False, bucket_bytes: int = 16 << 20):
+                 bias_lr_mult: float = 2.0, process_group=None, overlap: Optional[bool] = None, bucket_bytes: int = 16 << 20,
+                 grad_dtype: torch.dtype = torch.float32, time_exchange: bool = False):
         """overlap: start the all-reduce of a slice of the flat gradient buffer as soon as the backward has produced all of it
         (asynchronous collectives on the process group's stream, `bucket_bytes` per slice), instead of one all-reduce after the
-        backward.  Same sums, same result; opt-in until it has been timed on a multi-GPU node."""
+        backward.  Same sums, same result (bitwise: tests/test_ddp_gloo.py at world 2 / 4 / 8).  None (default) = overlapped whenever
+        the process group has more than one rank: against a 10 - 20 ms step the 105 MB exchange is no longer negligible when it
+        is left exposed behind the backward.
+
+        grad_dtype = torch.bfloat16: the WEIGHT gradients travel as bf16 (52.6 MB instead of 105 MB): each slice is rounded once to
+        bf16, summed by the collective in bf16, and widened back into the f32 buffer the optimizer reads (f32 master weights and f32
+        momentum unchanged).  The bias segment and the positive-prior count stay f32 -- the count must be exact.  Meant for the
+        bf16-tensor mode (BASELINE configs[2]), whose gradients already carry bf16-sized rounding; the f32 default is bit-identical
+        to the single all-reduce.
+
+        time_exchange: record HIP events around the points where the COMPUTE stream waits for the collectives, so that
+        `exposed_exchange_ms()` reports how long a step's gradient exchange was not hidden behind the backward."""
         self.model = model
         self.group = process_group
+        if grad_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("grad_dtype must be torch.float32 or torch.bfloat16")
+        self.grad_dtype = grad_dtype
+        self.time_exchange = bool(time_exchange)
+        self._exch_events: list = []
+        if overlap is None:
+            overlap = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
         named = dict(model.named_parameters())
         names = [n for n in model._engine.names if named[n].requires_grad]
         # weights first, biases second: two contiguous segments = two SGD launches (train.py:46-51 groups)
@@ -86,7 +106,19 @@ class FlatSGDDataParallel(torch.optim.Optimizer):
         for p, v in zip(self.params, self.grad_views):
             p.grad = v
         eng = model._engine
-        eng.grad_sink, eng.grad_out, eng.sink_owns_grads, eng.sink_early = self._sink, self._grad_out, True, bool(overlap)
+        # The engine must not keep this optimizer (and its three 105 MB buffers) alive, and must not keep reporting to it once it is
+        # gone: the hooks hold weak references, and when the last outside reference to the optimizer goes -- or `close()` is called --
+        # they are taken off again, unless another optimizer has replaced them meanwhile (the token tells whose hooks are installed).
+        self._closed = False
+        self._token = object()
+        eng.grad_sink, eng.grad_out = _WeakMethod(self, "_sink", self._token), _WeakMethod(self, "_grad_out", self._token)
+        eng.sink_owns_grads, eng.sink_early = True, bool(overlap)
+        try:
+            eng_ref = weakref.ref(eng)
+        except TypeError:                              # (test stand-ins for the engine that cannot be weakly referenced)
+            eng_ref = (lambda e=eng: e)
+        self._finalizer = weakref.finalize(self, FlatSGDDataParallel._detach, eng_ref, self._token)
+        self.flat_grad16 = (torch.zeros(self.n_w, device=dev, dtype=torch.bfloat16) if grad_dtype == torch.bfloat16 else None)
         # -- overlapped exchange: contiguous slices of the weight segment, filled from the back of the network first ------------
         self.overlap = bool(overlap)
         self._handles: list = []
@@ -231,7 +263,9 @@ class FlatSGDDataParallel(torch.optim.Optimizer):
         if grad.data_ptr() != view.data_ptr():
             view.copy_(grad.reshape(view.shape))
         if name in self._arrived:
-            raise RuntimeError(f"gradient of {name} delivered twice in one step (zero_grad() starts a step)")
+            raise RuntimeError(f"gradient of {name} delivered twice in one step: the backward writes (not adds) every gradient into the flat "
+                               "buffer, so one step is ONE backward pass -- zero_grad() starts a step; accumulating micro-batches is "
+                               "not supported by this optimizer (use a larger per-GPU batch: activations are 3.3 GB at 32 images)")
         self._arrived.add(name)
         b = self._bucket_of.get(name) if self.overlap else None
         if b is None:                                  # biases travel with n_pos in the closing collective
@@ -239,7 +273,36 @@ class FlatSGDDataParallel(torch.optim.Optimizer):
         self._left[b] -= 1
         if self._left[b] == 0 and self.world > 1:
             lo, hi = self._bucket_rng[b]
-            self._handles.append(dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._handles.append(self._start_weight_slice(lo, hi))
+
+    def _start_weight_slice(self, lo: int, hi: int):
+        """Asynchronous all-reduce of flat_grad[lo:hi] (inside the weight segment) -> (work handle, lo, hi)."""
+        if self.flat_grad16 is not None:
+            self.flat_grad16[lo:hi].copy_(self.flat_grad[lo:hi])          # one rounding to bf16; the collective sums in bf16
+            return dist.all_reduce(self.flat_grad16[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True), lo, hi
+        return dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True), lo, hi
+
+    def _wait_weight_slice(self, handle) -> None:
+        work, lo, hi = handle
+        work.wait()                                     # the compute stream waits for the collective, the host does not
+        if self.flat_grad16 is not None:
+            self.flat_grad[lo:hi].copy_(self.flat_grad16[lo:hi])          # widened back: the optimizer reads f32
+
+    def _mark(self):
+        if not self.time_exchange or not self.flat_grad.is_cuda:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def exposed_exchange_ms(self, last: int = 0) -> Optional[float]:
+        """Mean time per step the compute stream spent between reaching the gradient exchange's wait point and the moment the last
+        collective (and the bf16 widening, if any) had finished -- the part of the exchange the backward did not hide.  Call after a
+        device synchronisation; needs `time_exchange=True`.  last = only the most recent `last` steps (0 = all recorded)."""
+        ev = self._exch_events[-last:] if last else self._exch_events
+        if not ev:
+            return None
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
 
     def _finish_overlapped(self, n_pos: torch.Tensor) -> None:
         if len(self._arrived) != len(self.names) or any(self._left):
@@ -248,8 +311,13 @@ class FlatSGDDataParallel(torch.optim.Optimizer):
         self.flat_grad[self.n:self.n + 1].copy_(n_pos.reshape(1))
         if self.world > 1:
             tail = dist.all_reduce(self.flat_grad[self.n_w:self.n + 1], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            for h in self._handles + [tail]:
-                h.wait()                                # the compute stream waits for the collectives, the host does not
+            e0 = self._mark()
+            for h in self._handles:
+                self._wait_weight_slice(h)
+            tail.wait()
+            e1 = self._mark()
+            if e0 is not None:
+                self._exch_events.append((e0, e1))
         self._handles = []
         self._left = list(self._need)
         self._arrived.clear()
@@ -259,8 +327,9 @@ class FlatSGDDataParallel(torch.optim.Optimizer):
         """All-reduce the flat buffer once: this rank's gradients of the UN-normalised loss sums (written there by the backward) and
         its positive-prior count (`Losses.ssd(..., with_n_pos=True)`); afterwards `flat_grad[:n] * inv_npos` is the gradient of the
         reference loss at the global batch."""
-        if self.overlap:
+        if self.overlap and (self._arrived or self._handles):
             return self._finish_overlapped(n_pos)
+        # (an overlapped optimizer whose engine reported nothing this step: the caller filled .grad itself -- one all-reduce, as below)
         late = [i for i, n in enumerate(self.names) if n not in self._arrived]
         if late:                                         # gradients the caller put into .grad itself (no engine callback)
             gs = [self.params[i].grad for i in late]
@@ -271,8 +340,33 @@ class FlatSGDDataParallel(torch.optim.Optimizer):
         self._arrived.clear()
         self.flat_grad[self.n:self.n + 1].copy_(n_pos.reshape(1))
         if self.world > 1:
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)    # the one collective per step
+            e0 = self._mark()
+            if self.flat_grad16 is not None:             # bf16 weight payload + the small f32 tail (biases, n_pos)
+                h = self._start_weight_slice(0, self.n_w)
+                tail = dist.all_reduce(self.flat_grad[self.n_w:self.n + 1], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._wait_weight_slice(h)
+                tail.wait()
+            else:
+                dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)    # the one collective per step
+            e1 = self._mark()
+            if e0 is not None:
+                self._exch_events.append((e0, e1))
         torch.reciprocal(self.flat_grad[self.n:self.n + 1], out=self.inv_npos)
+
+    # -- lifetime -----------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _detach(eng_ref, token) -> None:
+        eng = eng_ref()
+        if eng is not None and getattr(eng.grad_sink, "_token", None) is token:
+            eng.grad_sink, eng.grad_out, eng.sink_owns_grads, eng.sink_early = None, None, False, False
+
+    def close(self) -> None:
+        """Take this optimizer's hooks off the model's engine: later backward passes hand their gradients to autograd again (a plain
+        optimizer can follow).  The parameters keep living in the flat buffer -- they are ordinary tensors viewing it -- and their
+        .grad stay views of the flat gradient buffer until the caller resets them (`model.zero_grad(set_to_none=True)`)."""
+        if not self._closed:
+            self._closed = True
+            self._finalizer()
 
     def apply_sgd(self) -> None:
         first = not self._has_momentum
@@ -296,3 +390,16 @@ class FlatSGDDataParallel(torch.optim.Optimizer):
     def reduce_and_step(self, n_pos: torch.Tensor) -> None:
         self.reduce_gradients(n_pos)
         self.apply_sgd()
+
+
+class _WeakMethod:
+    """Bound method through a weak reference to its object: the engine's hooks must not own the optimizer."""
+
+    def __init__(self, obj, name: str, token=None):
+        self._ref, self._name, self._token = weakref.ref(obj), name, token
+
+    def __call__(self, *a, **k):
+        obj = self._ref()
+        if obj is None:
+            raise RuntimeError("the FlatSGDDataParallel this engine reports to no longer exists")
+        return getattr(obj, self._name)(*a, **k)

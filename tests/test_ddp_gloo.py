@@ -44,6 +44,7 @@ def _worker(rank, world, port, q):
                 for p in net.parameters():
                     p.add_(1.0)
         tr = FlatSGDDataParallel(net, lr=0.1)
+        assert tr.overlap, "more than one rank: the overlapped exchange is the default"
         assert tr.names == ["a.weight", "b.weight", "g", "a.bias", "b.bias"]      # weights | biases segments
         assert tr.n_w == 136 + 36 + 8 and tr.n == tr.n_w + 8 + 8
         tr.broadcast_parameters(0)
@@ -238,7 +239,7 @@ def _order_worker(rank, world, port, q):
         from objectdetection_ssd_amd.ddp import FlatSGDDataParallel
         torch.manual_seed(0)
         a, b, c = _Wide(), _Wide(), _Wide()
-        plain = FlatSGDDataParallel(a, lr=0.1)
+        plain = FlatSGDDataParallel(a, lr=0.1, overlap=False)             # the single all-reduce: the reference of this test
         over = FlatSGDDataParallel(b, lr=0.1, overlap=True, bucket_bytes=1024)
         tiny = FlatSGDDataParallel(c, lr=0.1, overlap=True, bucket_bytes=4)            # every weight its own bucket
         assert len(over._bucket_rng) >= 3 and len(tiny._bucket_rng) == len(tiny.w_names)
@@ -323,6 +324,81 @@ def test_overlapped_exchange_bucket_boundaries_and_order_world_4_and_8(world):
     for i, sz in enumerate(ref._sizes):
         np.testing.assert_allclose(out[0][4][ref._offs[i]:ref._offs[i] + sz], total[pos:pos + sz], rtol=1e-5, atol=1e-6)
         pos += sz
+
+
+def _bf16_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gc
+        from objectdetection_ssd_amd.ddp import FlatSGDDataParallel
+        torch.manual_seed(0)
+        a, b, c = _Wide(), _Wide(), _Wide()
+        exact = FlatSGDDataParallel(a, lr=0.1, overlap=False)
+        over16 = FlatSGDDataParallel(b, lr=0.1, overlap=True, bucket_bytes=1024, grad_dtype=torch.bfloat16)
+        one16 = FlatSGDDataParallel(c, lr=0.1, overlap=False, grad_dtype=torch.bfloat16)
+        g = torch.Generator().manual_seed(900 + rank)
+        local = {n: torch.randn(p.shape, generator=g) * (10.0 ** float(torch.randint(-3, 3, (1,), generator=g))) for n, p in zip(exact.names, exact.params)}
+        n_pos = torch.tensor(301.0 + 2 * rank)                       # not representable in bf16 once summed: must travel as f32
+        for tr, net in ((exact, a), (over16, b), (one16, c)):
+            tr.zero_grad()
+            for n in reversed(tr.names):
+                net._engine.grad_sink(n, local[n])
+            tr.reduce_gradients(n_pos)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {n: t.numpy() for n, t in local.items()})
+        # lifetime of the hooks: close() takes them off, a dropped optimizer takes them off, a replaced one is left alone
+        d = _Wide()
+        t1 = FlatSGDDataParallel(d, lr=0.1, overlap=False)
+        assert d._engine.grad_sink is not None and d._engine.sink_owns_grads
+        t1.close()
+        closed = d._engine.grad_sink is None and d._engine.grad_out is None and not d._engine.sink_owns_grads
+        t2 = FlatSGDDataParallel(d, lr=0.1, overlap=False)
+        t3 = FlatSGDDataParallel(d, lr=0.1, overlap=False)          # replaces t2's hooks
+        del t2
+        gc.collect()
+        kept = d._engine.grad_sink is not None and d._engine.grad_sink._token is t3._token
+        del t3
+        gc.collect()
+        dropped = d._engine.grad_sink is None
+        q.put((rank, exact.flat_grad[:exact.n + 1].clone().numpy(), over16.flat_grad[:over16.n + 1].clone().numpy(),
+               one16.flat_grad[:one16.n + 1].clone().numpy(), gathered, (closed, kept, dropped)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bf16_gradient_payload_rounding_and_hook_lifetime_world2():
+    """`FlatSGDDataParallel(grad_dtype=torch.bfloat16)` (the 52.6 MB payload of BASELINE configs[2]): weight gradients are rounded once
+    to bf16, summed by the collective, and widened into the f32 buffer -- every reduced weight gradient is a bf16 value within bf16
+    rounding of the exact sum, equal on both ranks and equal between the overlapped and the single exchange; the bias segment and
+    the positive-prior count are the exact f32 sums.  Plus the life cycle of the engine hooks."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bf16_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from objectdetection_ssd_amd.ddp import FlatSGDDataParallel
+    ref = FlatSGDDataParallel(_Wide(), lr=0.1, overlap=False)
+    for rank, exact, over16, one16, gathered, life in out:
+        assert all(life), life
+        assert np.array_equal(over16, out[0][2]) and np.array_equal(one16, out[0][3])        # both ranks hold the same buffers
+        assert np.array_equal(over16, one16)                                                    # slices or one collective: same rounding points
+        assert exact[ref.n] == over16[ref.n] == 301.0 + 303.0                                   # the count is exact
+        assert np.array_equal(exact[ref.n_w:ref.n], over16[ref.n_w:ref.n])                      # biases travel as f32
+        for i, n in enumerate(ref.names[:len(ref.w_names)]):
+            lo, sz = ref._offs[i], ref._sizes[i]
+            got = torch.from_numpy(over16[lo:lo + sz])
+            g0, g1 = (torch.from_numpy(gathered[r][n]).reshape(-1) for r in range(2))
+            assert torch.equal(got, got.bfloat16().float()), n                                  # what arrived is a bf16 value
+            emu = (g0.bfloat16().float() + g1.bfloat16().float()).bfloat16().float()            # round, add, round
+            assert torch.equal(got, emu), n
+            bound = 2.0 ** -7 * (g0.abs() + g1.abs()) + 1e-30      # unit roundoff 2^-8, twice (inputs, sum)
+            assert bool(((got - torch.from_numpy(exact[lo:lo + sz])).abs() <= bound).all()), n
 
 
 def test_bench_rendezvous_at_eight_ranks():
