@@ -500,6 +500,9 @@ def main():
     ap.add_argument("--grad-dtype", default="auto", choices=("auto", "f32", "bf16"),
                     help="payload of the weight-gradient all-reduce: bf16 = 52.6 MB instead of 105 MB (auto: bf16 with --conv-dtype bf16, else f32)")
     ap.add_argument("--igemm-lds-pad", type=int, default=-1, help="tuning aid: extra dynamic LDS bytes per igemm block (-1 = library default)")
+    ap.add_argument("--graph-step", default="auto", choices=("auto", "on", "off"),
+                    help="replay the train step from one captured HIP graph (ddp.GraphedTrainStep); auto = on with one GPU, off with several "
+                         "(there the eager step overlaps the gradient all-reduce with the backward, which a replay cannot)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--rendezvous-only", action="store_true",
@@ -618,13 +621,26 @@ def main():
     if args.variant == 512:
         x = torch.randn(bs, 3, 512, 512, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
 
-    def step():
+    def eager_step():
         trainer.zero_grad()
         loc, conf = net(x)
         l1, l2, n_pos = Losses.ssd((loc, conf), classes, boxes, norm_mode=1, with_n_pos=True)     # un-normalised sums (ddp.py)
         (l1 + l2).backward()
         trainer.reduce_and_step(n_pos)
         return l1, l2, n_pos
+
+    use_graph = args.graph_step == "on" or (args.graph_step == "auto" and world == 1)
+    gstep = None
+    if use_graph:
+        from objectdetection_ssd_amd.ddp import GraphedTrainStep
+        gstep = GraphedTrainStep(net, trainer, max_boxes_per_image=8, warmup=2)
+
+        def step():
+            return gstep(x, classes, boxes)
+        for _ in range(3):                                 # two eager steps (pools, workspaces, momentum) + the capturing one: set-up, not warm-up
+            step()
+    else:
+        step = eager_step
 
     def fence():
         if world > 1:
@@ -652,13 +668,20 @@ def main():
     ips = bs * world * args.steps / elapsed
     # host-side enqueue time of ONE step into an empty queue (diagnostic: the step is GPU-bound while this stays below
     # ms_per_step; several steps back to back would measure the queue's back-pressure instead)
-    host_ms = 0.0
+    host_ms = host_eager_ms = 0.0
     for _ in range(3):
         fence()
         h0 = time.perf_counter()
         step()
         host_ms += (time.perf_counter() - h0) / 3 * 1e3
     fence()
+    if gstep is not None:
+        for _ in range(3):
+            fence()
+            h0 = time.perf_counter()
+            eager_step()
+            host_eager_ms += (time.perf_counter() - h0) / 3 * 1e3
+        fence()
     n_pos = float(trainer.flat_grad[trainer.n].item())
     loss = (float(l1.item()) + float(l2.item())) / max(float(n_pos_local.item()), 1.0)
     # self-check of the collective path: every rank adds 1 and its own rank id; rank 0 prints what arrived
@@ -710,15 +733,21 @@ def main():
                                             if _ops.wino_x3(4, 256) else ""))
                       if (net._engine.wino and args.conv_dtype == "f32") else "direct MFMA kernels",
                       "host_enqueue_ms_per_step": round(host_ms, 2),
+                      "step_launch": ({"form": "one HIP graph replay per step (ddp.GraphedTrainStep: forward + loss + backward"
+                                               + (" + SGD" if world == 1 else "; all-reduce + SGD issued behind it") + ")",
+                                       "kernel_launches_in_graph": gstep.kernel_nodes,
+                                       "host_enqueue_ms_per_step_eager": round(host_eager_ms, 2),
+                                       "note": "bitwise equal to the eager step (tests/test_gpu_path.py::test_graphed_train_step_is_bitwise_the_eager_step)"}
+                                      if gstep is not None else {"form": "eager: every kernel launched from Python"}),
                       "shader_clock_mhz_during_timed_steps": round(mhz, 0),
                       "f32_mfma_peak_at_that_clock_tflops": round(PEAK_F32_MFMA_TFLOPS * mhz / 2400.0, 1)}}
 
     # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream -----------------
     if not args.no_roofline and rank != 0:
         for _ in range(3):                 # keep the collectives of rank 0's profiling steps matched
-            step()
+            eager_step()
     if not args.no_roofline and rank == 0:
-        out["roofline"] = roofline_of(net, step, args.conv_dtype, ms, args.layers)
+        out["roofline"] = roofline_of(net, eager_step, args.conv_dtype, ms, args.layers)
     if world == 1 and args.conv_dtype == "f32" and args.variant == 300 and not args.no_bf16_leg and _ops.wino_x3(4, 256) and net._engine.wino:
         # the same step with EVERY product on the f32 MFMA (the limb GEMMs switched off), a few steps beside the headline: what the
         # three-limb form buys on this device, and the number to hold against a reader who wants v_mfma_f32_32x32x2_f32 only
@@ -758,7 +787,7 @@ def main():
                                                       "bf16), f32 accumulate / loss / SGD; same batch, same process",
                                               "direct_conv_tflops": round(TRAIN_GFLOP_PER_IMAGE * bs / bms, 2)}
         if not args.no_roofline:
-            out["config"]["bf16_operand_mode"]["roofline"] = roofline_of(net, step, "bf16", bms)
+            out["config"]["bf16_operand_mode"]["roofline"] = roofline_of(net, eager_step, "bf16", bms)
         net.conv_dtype = "f32"
     if world > 1:
         dist.barrier()

@@ -457,6 +457,10 @@ int ssd_preprocess_u8(const uint8_t* arena, const ssd_image_desc* descs_dev, con
  * 100 * d(counter) / d(wall clock) per XCC. */
 int ssd_clock_probe(uint64_t* out32, void* stream);
 
+/* ---- diagnostic (host only): node count of a captured hipGraph_t and how many of the nodes are kernel launches -- what one replay of
+ * the captured train step (ddp.GraphedTrainStep; the loop of train_function.py:80-95) stands for. */
+int ssd_graph_node_counts(void* graph, int* kernel_nodes, int* total_nodes);
+
 /* ---- fused SGD (train.py:53-55: momentum .9, weight decay 5e-4; bias lr 2x) on a flat buffer;
  * grad_scale multiplies the gradient first (1/n_pos_global in data-parallel runs).  Per element, each line rounded once:
  *   g' = fma(weight_decay, p, g * scale);  buf = first_step ? g' : (momentum * buf) + g';  p = fma(-lr, buf, p)

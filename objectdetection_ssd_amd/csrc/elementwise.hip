@@ -454,6 +454,28 @@ extern "C" int ssd_clock_probe(uint64_t* out32, void* stream) {
     return SSD_OK;
 }
 
+// Host-only diagnostic: how many nodes -- and how many of them kernel launches -- a captured HIP graph holds (what one replay of
+// ddp.GraphedTrainStep stands for; bench.py prints it).
+extern "C" int ssd_graph_node_counts(void* graph, int* kernel_nodes, int* total_nodes) {
+    if (!graph || !kernel_nodes || !total_nodes) return SSD_ERR_NULL;
+    size_t n = 0;
+    if (hipGraphGetNodes((hipGraph_t)graph, nullptr, &n) != hipSuccess) return SSD_ERR_LAUNCH;
+    hipGraphNode_t* nodes = n ? new hipGraphNode_t[n] : nullptr;
+    int k = 0;
+    if (n && hipGraphGetNodes((hipGraph_t)graph, nodes, &n) != hipSuccess) {
+        delete[] nodes;
+        return SSD_ERR_LAUNCH;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        hipGraphNodeType t;
+        if (hipGraphNodeGetType(nodes[i], &t) == hipSuccess && t == hipGraphNodeTypeKernel) ++k;
+    }
+    delete[] nodes;
+    *kernel_nodes = k;
+    *total_nodes = (int)n;
+    return SSD_OK;
+}
+
 extern "C" int ssd_im2col_nchw3(const float* x_nchw, float* out, int N, int H, int W, int R, int S, int stride, int pad,
                                 int Ho, int Wo, int Kpad, void* stream) {
     if (!x_nchw || !out) return SSD_ERR_NULL;

@@ -403,3 +403,184 @@ class _WeakMethod:
         if obj is None:
             raise RuntimeError("the FlatSGDDataParallel this engine reports to no longer exists")
         return getattr(obj, self._name)(*a, **k)
+
+
+class GraphedTrainStep:
+    """One train step of the hot path -- forward + MultiBox loss + backward (+ the fused SGD when there is one rank) -- captured once into a
+    HIP graph and replayed: the eager step issues ~250 launches from one Python thread (4-5 ms of host time per step against a
+    10-20 ms step); the replay is one `hipGraphLaunch` plus the handful of copies that bring the batch into the static buffers.
+    The serving loop it replaces is train_function.py:80-95 (`outputs = model(inputs)`, `ssd(outputs, ...)`, `loss.backward()`,
+    `optimizer.step()`).
+
+    Everything the library launches only enqueues on the stream it is given (no allocation, no synchronisation), so the capture
+    needs nothing special from the kernels; what it needs from the host side is fixed shapes:
+
+      * the image batch has the shape of the first call;
+      * the ground truth lives in static buffers of `max_boxes` rows (default 8 per image, VOC's practical maximum is 42 for one
+        image and ~2.4 on average); the per-image offsets `img_start` are data, so any split of <= max_boxes boxes over the images
+        replays correctly -- rows beyond the last offset are never read by the matching, the loss or the gradients;
+      * the number of positive priors stays on the device (it is written into the flat gradient buffer's count slot inside the graph).
+
+    The first `warmup` calls run the step eagerly (they are ordinary training steps: allocator pools, workspaces, weight tables and the
+    momentum buffers come into being), the next call captures and replays.  The graph bakes in lr / momentum / weight decay: it is
+    captured again when the optimizer's groups change (StepLR).  With more than one rank the gradient exchange is ONE all-reduce
+    issued after the graph (a collective started from inside the backward cannot be part of a replay), followed by the two SGD
+    launches; `FlatSGDDataParallel(overlap=...)` is switched off for the life of this object.
+
+    `__call__(x, classes, boxes)` -> (loc_sum, conf_sum, n_pos): 0-dim views of a static device tensor holding this rank's
+    un-normalised loss sums and positive count (`Losses.ssd(..., norm_mode=1, with_n_pos=True)`), overwritten by the next call."""
+
+    def __init__(self, net, trainer: FlatSGDDataParallel, max_boxes_per_image: int = 8, warmup: int = 2, two_streams: bool = False):
+        self.net, self.trainer = net, trainer
+        self.max_per_image, self.warmup = int(max_boxes_per_image), int(warmup)
+        self.two_streams = bool(two_streams)
+        self.graph = None
+        self._sig = None
+        self._calls = 0
+        self.kernel_nodes = None          # launches inside the captured graph (hipGraphGetNodes), filled at capture
+        self._static = None
+        trainer.overlap = False           # the exchange of a replayed step is one all-reduce behind the graph
+        net._engine.sink_early = False
+        self._stream = None
+        self._ring, self._ring_pos = [], 0
+
+    # -- static buffers ------------------------------------------------------------------------------------------------------------
+    def _make_static(self, x: torch.Tensor):
+        dev, bs = x.device, x.shape[0]
+        cap = bs * self.max_per_image
+        self._static = dict(x=torch.empty_like(x), gt=torch.zeros((cap, 4), device=dev), cls=torch.zeros((cap,), device=dev),
+                            start=torch.zeros((bs + 1,), device=dev, dtype=torch.int32))
+        # pinned staging for ground truth that arrives on the host, four steps deep (the host may run that far ahead of the device)
+        self._ring = [dict(gt=torch.zeros((cap, 4)).pin_memory(), cls=torch.zeros((cap,)).pin_memory(),
+                           start=torch.zeros((bs + 1,), dtype=torch.int32).pin_memory(), done=None) for _ in range(4)]
+
+    def _load_batch(self, x, classes, boxes):
+        S = self._static
+        if tuple(x.shape) != tuple(S["x"].shape) or x.dtype != S["x"].dtype:
+            raise ValueError(f"graph step built for images {tuple(S['x'].shape)}, got {tuple(x.shape)}")
+        counts = [int(b.shape[0]) for b in boxes]
+        if len(counts) != x.shape[0] or any(c == 0 for c in counts) or any(int(c.shape[0]) != n for c, n in zip(classes, counts)):
+            raise ValueError("every image needs at least one ground-truth box, and classes / boxes must agree")   # Losses.py:153
+        n = sum(counts)
+        if n > S["gt"].shape[0]:
+            raise ValueError(f"{n} ground-truth boxes in the batch, the graph step holds {S['gt'].shape[0]} (max_boxes_per_image)")
+        S["x"].copy_(x, non_blocking=True)
+        slot = self._ring[self._ring_pos]
+        self._ring_pos = (self._ring_pos + 1) % len(self._ring)
+        if slot["done"] is not None:
+            slot["done"].synchronize()                       # the copy that last read this staging slot (four steps ago)
+        st = slot["start"]
+        st[0] = 0
+        torch.cumsum(torch.tensor(counts, dtype=torch.int32), 0, out=st[1:])
+        if boxes[0].is_cuda:
+            torch.cat([b.reshape(-1, 4).to(torch.float32) for b in boxes], out=S["gt"][:n])
+            torch.cat([c.reshape(-1).to(torch.float32) for c in classes], out=S["cls"][:n])
+        else:
+            torch.cat([b.reshape(-1, 4).to(torch.float32) for b in boxes], out=slot["gt"][:n])
+            torch.cat([c.reshape(-1).to(torch.float32) for c in classes], out=slot["cls"][:n])
+            S["gt"][:n].copy_(slot["gt"][:n], non_blocking=True)
+            S["cls"][:n].copy_(slot["cls"][:n], non_blocking=True)
+        S["start"].copy_(st, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        slot["done"] = ev
+
+    # -- the step, written against the static buffers (what the capture records) ------------------------------------------------------
+    def _body(self, with_sgd: bool):
+        from . import Losses
+        S, net, tr = self._static, self.net, self.trainer
+        eng = net._engine
+        P = net._forward_params()
+        loc, conf, saved = eng.forward(S["x"], P, save=True)
+        pri, pri_xyxy = Losses._priors_on(loc.device, loc.shape[1])
+        out = ops.multibox_loss(loc, conf, S["gt"], S["cls"], S["start"], pri, pri_xyxy, Losses.IOU_THRESHOLD, Losses.NEG_POS_RATIO, 1,
+                                want_grads=True)
+        need = {n: bool(P[n].requires_grad) for n in eng.names}
+        eng.backward(saved, out["dloc"], out["dconf"], P, need)
+        tr.flat_grad[tr.n:tr.n + 1].copy_(out["losses"][2:3])
+        tr._arrived.clear()
+        if with_sgd:
+            torch.reciprocal(tr.flat_grad[tr.n:tr.n + 1], out=tr.inv_npos)
+            tr.apply_sgd()
+        return out["losses"], out["obj"], out["cls"]
+
+    def _signature(self):
+        tr = self.trainer
+        eng = self.net._engine
+        return tuple((g["lr"], g["momentum"], g["weight_decay"]) for g in tr.param_groups) + (
+            tr.world, eng.bf16, eng.bf16_tensors, eng.x3, eng.wino, eng.WINO_TILE, ops.wino_x3(4, 256))
+
+    def _eager(self, x, classes, boxes):
+        from . import Losses
+        tr = self.trainer
+        tr.zero_grad()
+        loc, conf = self.net(x)
+        l1, l2, n_pos = Losses.ssd((loc, conf), classes, boxes, norm_mode=1, with_n_pos=True)
+        (l1 + l2).backward()
+        tr.reduce_and_step(n_pos)
+        return l1.detach(), l2.detach(), n_pos
+
+    def _capture(self):
+        eng, tr = self.net._engine, self.trainer
+        dev = self._static["x"].device
+        single = tr.world == 1
+        keep_tail = eng.overlap_tail
+        if not self.two_streams:
+            eng.overlap_tail = False                          # one stream inside the graph (bit-identical to the two-stream schedule)
+        try:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=dev)
+            s = self._stream
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s), torch.no_grad():       # one untimed pass on the capture stream: its workspaces, the static shapes
+                self._body(with_sgd=False)
+            torch.cuda.current_stream(dev).wait_stream(s)
+            torch.cuda.synchronize(dev)
+            # (that pass wrote gradients and n_pos only: no parameter moved)
+            try:
+                g = torch.cuda.CUDAGraph(keep_graph=True)
+            except TypeError:
+                g = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(g, stream=s):
+                self.losses, self.obj, self.cls = self._body(with_sgd=single)
+            self.graph = g
+            self.kernel_nodes = _graph_kernel_nodes(g)
+            if single:
+                tr.steps -= 1                                 # apply_sgd's bookkeeping ran once during capture without a step being executed
+        finally:
+            eng.overlap_tail = keep_tail
+        self._sig = self._signature()
+
+    def __call__(self, x, classes, boxes):
+        tr = self.trainer
+        self._calls += 1
+        if self._calls <= self.warmup or not tr._has_momentum:
+            return self._eager(x, classes, boxes)
+        if self._static is None:
+            self._make_static(x)
+        self._load_batch(x, classes, boxes)
+        if self.graph is None or self._sig != self._signature():
+            self._capture()
+        self.graph.replay()
+        if tr.world > 1:
+            dist.all_reduce(tr.flat_grad, op=dist.ReduceOp.SUM, group=tr.group)      # the one collective per step
+            torch.reciprocal(tr.flat_grad[tr.n:tr.n + 1], out=tr.inv_npos)
+            tr.apply_sgd()
+        else:
+            tr.steps += 1
+            self.net._engine._wcache.clear()
+        return self.losses[0], self.losses[1], self.losses[2]
+
+
+def _graph_kernel_nodes(graph) -> Optional[int]:
+    """Kernel nodes of a captured torch graph (the launches one replay stands for), through the library's `ssd_graph_node_counts`."""
+    try:
+        raw = graph.raw_cuda_graph()
+    except Exception:
+        return None
+    import ctypes as C
+    from . import _lib
+    kernels, total = C.c_int(0), C.c_int(0)
+    if _lib.load().ssd_graph_node_counts(C.c_void_p(int(raw)), C.byref(kernels), C.byref(total)) != 0:
+        return None
+    return int(kernels.value)

@@ -1083,6 +1083,53 @@ def test_plane_gemm_from_three_bf16_limbs_is_as_exact_as_the_f32_mfma(case):
     assert e3 <= 2.0 * e32 + 1e-9 and e3 <= 2e-6, (e3, e32)
 
 
+def test_limb_gemm_non_finite_operands():
+    """csrc/gemm_x3.hip header, "Non-finite and out-of-range operands": an activation row holding +inf, or a finite value above the
+    largest bf16 (3.3895e38), makes every output of that ROW NaN in the limb form (inf - inf in the split) where the f32 MFMA returns
+    +-inf / a finite overflow; NaN stays NaN; all other rows are bit-identical to the run without the special values -- the limb form
+    never turns a non-finite result into a finite one and never spreads it."""
+    from objectdetection_ssd_amd import _lib
+    lib = _lib.load()
+    M, K, N, P = 256, 256, 128, 2
+    dev = _dev()
+    gen = torch.Generator().manual_seed(77)
+    a = torch.randn(P, M, K, generator=gen)
+    w = torch.randn(P, N, K, generator=gen) / K ** 0.5
+    st = torch.cuda.current_stream().cuda_stream
+    wd = w.to(dev)
+    w3 = torch.zeros(lib.ssd_gemm_x3_weights_bytes(N, K, P), dtype=torch.uint8, device=dev)
+    _lib.check(lib.ssd_gemm_x3_split_weights(wd.data_ptr(), w3.data_ptr(), N, K, P, st), "split")
+
+    def run(act):
+        ad = act.to(dev)
+        o3 = torch.zeros((P, M, N), device=dev)
+        o32 = torch.zeros((P, M, N), device=dev)
+        _lib.check(lib.ssd_gemm_planes_x3(ad.data_ptr(), w3.data_ptr(), o3.data_ptr(), M, K, N, N, P, st), "x3")
+        _lib.check(lib.ssd_gemm_planes_f32(ad.data_ptr(), wd.data_ptr(), o32.data_ptr(), M, K, N, N, P, st), "f32")
+        return o3.cpu(), o32.cpu()
+
+    clean3, clean32 = run(a)
+    assert torch.isfinite(clean3).all() and torch.isfinite(clean32).all()
+    b = a.clone()
+    b[0, 5, 17] = float("inf")
+    b[0, 40, 3] = 3.40e38                 # finite in f32, above the bf16 range
+    b[1, 100, 200] = float("nan")
+    b[1, 7, 9] = -float("inf")
+    hot3, hot32 = run(b)
+    rows = {(0, 5), (0, 40), (1, 100), (1, 7)}
+    for p_ in range(P):
+        for m in range(M):
+            if (p_, m) in rows:
+                assert not torch.isfinite(hot3[p_, m]).any(), (p_, m)          # limb form: the whole row is NaN
+                assert torch.isnan(hot3[p_, m]).all(), (p_, m)
+                assert not torch.isfinite(hot32[p_, m]).any() or (p_, m) == (0, 40)   # f32 MFMA: inf (or NaN); the 3.4e38 row may stay finite
+    keep = torch.ones(P, M, dtype=torch.bool)
+    for p_, m in rows:
+        keep[p_, m] = False
+    assert torch.equal(hot3[keep], clean3[keep]) and torch.equal(hot32[keep], clean32[keep])
+    assert torch.isinf(hot32[0, 5]).all() and torch.isinf(hot32[1, 7]).all() and torch.isnan(hot32[1, 100]).all()
+
+
 X31_CASES = [  # n, h, w, ci, co: fc7's shape class at a small batch, ragged pixel count, Co not a multiple of 128, deep reduction
     (2, 19, 19, 1024, 1024), (3, 13, 7, 256, 160), (1, 38, 38, 512, 128), (2, 10, 10, 2048, 256),
 ]

@@ -513,3 +513,27 @@ def test_round3_limb_gemm_rules_and_sizes_without_a_gpu():
     assert lib.ssd_weight_job_blocks(C.byref(job)) == (128 * 256 // 8 + 256 * 128 + 255) // 256
     job.pad0 = 3
     assert lib.ssd_weight_job_blocks(C.byref(job)) == (128 * 256 // 8 + 256 * 128 // 8 + 255) // 256
+
+
+def test_asm_guard_flags_a_fragment_register_touched_before_its_wait():
+    """build.py's guard for the inline-asm `ds_read` idiom (asm_guard.py): a copy of a read's destination before the covering
+    `s_waitcnt lgkmcnt` is a violation; after it, or after a counted wait that retires that read, it is not; compiler-issued LDS
+    operations count as queue entries."""
+    from objectdetection_ssd_amd import asm_guard as G
+    head = ["\t.type\tk1,@function", "k1:"]
+    rd = lambda dst, addr: ["\t;;#ASMSTART", f"\tds_read_b128 {dst}, {addr}", "\t;;#ASMEND"]
+    ok = head + rd("v[8:11]", "v0") + rd("v[12:15]", "v1") + ["\ts_waitcnt lgkmcnt(1)", "\tv_mov_b32_e32 v40, v9",
+                                                               "\ts_waitcnt lgkmcnt(0)", "\tv_mfma_f32_32x32x16_bf16 a[0:15], v[8:11], v[12:15], a[0:15]", "\ts_endpgm"]
+    assert G.check_assembly(ok) == []
+    early = head + rd("v[8:11]", "v0") + rd("v[12:15]", "v1") + ["\ts_waitcnt lgkmcnt(1)", "\tv_mov_b32_e32 v40, v13", "\ts_endpgm"]
+    bad = G.check_assembly(early)
+    assert len(bad) == 1 and bad[0][0] == "k1" and "v13" in bad[0][2] and "v[12:15]" in bad[0][3]
+    # a compiler-visible ds_read issued after the asm read keeps it in flight under lgkmcnt(1)
+    mixed = head + rd("v[8:11]", "v0") + ["\tds_read_b64 v[20:21], v2", "\ts_waitcnt lgkmcnt(1)", "\tv_add_f32_e32 v30, v8, v8",
+                                          "\ts_waitcnt vmcnt(0)", "\tv_add_f32_e32 v31, v20, v20", "\ts_endpgm"]
+    assert G.check_assembly(mixed) == []                     # lgkmcnt(1) retired the asm read; the compiler read is the compiler's business
+    spill = head + rd("v[8:11]", "v0") + ["\tscratch_store_dwordx4 off, v[8:11], s0", "\ts_waitcnt lgkmcnt(0)", "\ts_endpgm"]
+    assert len(G.check_assembly(spill)) == 1
+    # the raw simm16 form of a wait: 0xC07F = lgkmcnt(0) with the other counters open
+    raw = head + rd("v[8:11]", "v0") + ["\ts_waitcnt 0xc07f", "\tv_mov_b32_e32 v40, v9", "\ts_endpgm"]
+    assert G.check_assembly(raw) == []

@@ -1,0 +1,28 @@
+#!/bin/bash
+# first GPU call of round 4: full -m gpu suite, vendor-library ceiling, default bench line
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests -m gpu -q --maxfail=12 > gpurun_out/a_tests.log 2>&1
+rc=$?
+echo "pytest rc=$rc" >> gpurun_out/a_tests.log
+tail -5 gpurun_out/a_tests.log
+if [ $rc -ge 124 ]; then exit $rc; fi
+timeout -k 10 300 python tools/blas_ceiling.py > gpurun_out/a_blas.log 2>&1
+rc=$?
+cat gpurun_out/a_blas.log | tail -14
+if [ $rc -ge 124 ]; then exit $rc; fi
+timeout -k 10 600 python bench.py --steps 20 --warmup 5 > gpurun_out/a_bench.json 2> gpurun_out/a_bench.err
+echo "bench rc=$?"
+tail -c 1500 gpurun_out/a_bench.err
+python - <<'PY'
+import json
+try:
+    d = json.loads(open('gpurun_out/a_bench.json').read().strip().splitlines()[-1])
+    c = d['config']
+    print('value', d['value'], 'ms', d['ms_per_step'], 'host', c['host_enqueue_ms_per_step'], c.get('step_launch'))
+    print('f32only', c.get('f32_mfma_only', {}).get('ms_per_step'), 'bf16', c.get('bf16_operand_mode', {}).get('ms_per_step'))
+    print('roofline', d['roofline']['frac'], d['roofline']['kernel'])
+    print('cpu', {k: v for k, v in d['cpu_baseline'].items() if k in ('value', 'cores', 'by_threads')})
+    print('loss', d.get('loss_delta_vs_cpu'))
+except Exception as e:
+    print('parse failed', e)
+PY
