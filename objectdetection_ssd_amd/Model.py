@@ -211,6 +211,7 @@ class _Engine:
         self.sink_owns_grads = False   # True (ddp.py): gradients live in the listener's buffer, autograd is handed None for them
         self.sink_early = False        # True: the listener acts on a gradient at once (overlapped all-reduce), so side-stream gradients are joined early
         self._test_side_delay = None   # tests: callable run on the side stream in front of the deferred weight gradients
+        self.grad_tap = None           # tests: dict that receives every activation's finished gradient tensor (name -> dX as the backward stored it)
         self.dual_dy = True       # backward: one pass over dy writes the planes of the weight gradient AND of the data gradient
         self.keep_planes = True   # training forward keeps the F(4x4) input planes of the layers whose weight gradient is Winograd
         self.fuse_pool = True     # Winograd F(4x4) layers in pool_after write the pooled map + argmax only ...
@@ -649,6 +650,8 @@ class _Engine:
             mask = T[name] if (last and name in self.relu_out) else None
             G[name] = fn(G.get(name), k > 0, mask)
             arrived[name] = k + 1
+            if self.grad_tap is not None and last and torch.is_tensor(G[name]):
+                self.grad_tap[name] = G[name]
 
         main = torch.cuda.current_stream(dloc.device)
         # (with a gradient listener every gradient is reported on the caller's stream: no third stream then)

@@ -393,6 +393,53 @@ def _round_store():
     return RoundStore.apply
 
 
+def bf16_spacing(t):
+    """Distance between neighbouring bf16 values at |t| (8 significant bits: 2^(floor(log2|t|) - 7)), as a tensor of t's dtype."""
+    import torch
+    a = t.abs().clamp_min(2.0 ** -126)
+    return torch.pow(torch.full_like(a, 2.0), torch.floor(torch.log2(a)) - 7.0)
+
+
+def _pin_store(name, fwd, bwd, report, kind, gate):
+    """TESTS ONLY (the rounding-pinned comparison of the bf16-tensor mode).  An identity that REPLACES what flows through it by the
+    values ANOTHER evaluation of the same network stored at this point: on the way forward the activation tensor `fwd`, on the way
+    back the gradient tensor `bwd` (None: pass the gradient through).  Every layer of this evaluation then sees exactly the other
+    evaluation's inputs -- the stored bf16 / f32 values, i.e. its rounding DIRECTIONS are pinned like its ReLU / arg-max decisions --
+    and `report[name + ':fwd' | ':bwd']` records how far this evaluation's own value was from the one it is replaced by:
+
+        max over elements of (|own - stored| - 2e-5 * rms(own)) / spacing,   spacing = the bf16 spacing at |stored| (kind 'bf16')
+                                                                              or 1e-5 * max|stored|            (kind 'f32')
+
+    -- for a correct layer <= 0.5 (one rounding to nearest) on a bf16 tensor, <= 1 on an f32 tensor; the rms term covers sums that
+    cancel to (almost) nothing, whose f32 accumulation error is set by the size of the terms, not of the result.
+    gate: bool tensor or None -- the gradient is compared where gate is set only (a post-ReLU tensor's stored gradient is already
+    masked by the ReLU that follows on the way back)."""
+    import torch
+
+    def dev(own, stored, mask):
+        own, stored = own.detach().double(), stored.double()
+        rms = float(own.pow(2).mean().sqrt())
+        space = bf16_spacing(stored) if kind == "bf16" else torch.full_like(stored, 1e-5 * max(float(stored.abs().max()), 1e-30))
+        d = ((own - stored).abs() - 2e-5 * rms) / space
+        if mask is not None:
+            d = d * mask.to(d.dtype)
+        return float(d.max()) if d.numel() else 0.0
+
+    class PinStore(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, z):
+            report[name + ":fwd"] = dev(z, fwd, None)
+            return fwd.to(z.dtype)
+
+        @staticmethod
+        def backward(ctx, g):
+            if bwd is None:
+                return g
+            report[name + ":bwd"] = dev(g if gate is None else g * gate.to(g.dtype), bwd, gate)
+            return bwd.to(g.dtype)
+    return PinStore.apply
+
+
 def _conv_bf16_operands():
     """conv2d of BASELINE.json configs[2] ("bf16 convs"): operands rounded to bf16, products accumulated in f32, bias in f32.
     Forward y = conv(r(x), r(w)) + b; data gradient dx = conv^T(r(dy), r(w)); weight gradient corr(r(x), r(dy)) for the geometries the
@@ -453,7 +500,7 @@ def pinned_max_pool(z, code, k: int, stride: int, pad: int):
 
 
 def ssd300_forward(x, params, return_features: bool = False, variant: int = 300, operand_round: str = None, acts: dict = None,
-                   decisions: dict = None, store_round: bool = False):
+                   decisions: dict = None, store_round: bool = False, pinned: dict = None):
     """x (bs,3,300,300) f32 NCHW torch tensor -> loc (bs,8732,4), conf (bs,8732,21).
     store_round (with operand_round="bf16"): the bf16-TENSOR mode -- the VGG trunk's tensors (conv1_1 .. conv5_3 outputs, the pools'
     outputs, the L2-norm's output) are stored in bf16, and so are their gradients (`_round_store`); fc6 onwards keeps f32 tensors.
@@ -463,6 +510,10 @@ def ssd300_forward(x, params, return_features: bool = False, variant: int = 300,
     other evaluation fused conv -> ReLU -> pool and left no full-resolution mask).  With the decisions pinned the network is one
     fixed linear-in-pieces function: two evaluations differ by arithmetic only, not by a ReLU / arg-max that flipped on a last-bit
     difference (which is a discrete jump of one gradient path).
+    pinned (tests only, with decisions): {"fwd": {tensor name: NCHW values}, "bwd": {tensor name: NCHW gradient}, "bf16": set of the
+    names stored in bf16, "report": {}} -- every named tensor (a1_1 .. a11, p1 .. p5, n4_3) and its gradient are REPLACED by the
+    given values of another evaluation as they pass (`_pin_store`), and `report` receives this evaluation's distance to them,
+    tensor by tensor.  Replaces `store_round`'s own rounding: the other evaluation's rounding directions are followed.
     operand_round="bf16": every convolution multiplies bf16-rounded operands with f32 accumulation (`_conv_bf16_operands`:
     BASELINE.json configs[2]); pools, L2-norm, biases, ReLU and the tensors between layers stay f32.
     acts: optional dict, filled with every post-ReLU activation (NCHW, detached) under the build's tensor names
@@ -483,7 +534,16 @@ def ssd300_forward(x, params, return_features: bool = False, variant: int = 300,
         raise ValueError("store_round needs operand_round='bf16'")
     conv2d = F.conv2d if operand_round is None else _conv_bf16_operands()
     first = {} if operand_round is None else {"wgrad_f32": True}
-    rs = _round_store() if store_round else (lambda t: t)
+    rs_plain = _round_store() if store_round else (lambda t: t)
+
+    def rs(t, name, trunk=True):
+        """the store of tensor `name`: pinned to another evaluation's stored values, rounded to bf16 (trunk tensors of the bf16-tensor
+        mode), or left alone"""
+        if pinned is not None and name in pinned["fwd"]:
+            relu_gate = (pinned["fwd"][name] > 0) if name[0] == "a" else None        # a*: post-ReLU activations; p*, n4_3: no ReLU of their own
+            return _pin_store(name, pinned["fwd"][name], pinned["bwd"].get(name), pinned["report"],
+                              "bf16" if name in pinned["bf16"] else "f32", relu_gate)(t)
+        return rs_plain(t) if trunk else t
     feats = {}
     h = x
     pin_relu = None if decisions is None else decisions["relu"]
@@ -506,7 +566,7 @@ def ssd300_forward(x, params, return_features: bool = False, variant: int = 300,
     n_pool = 0
     for li, idx in enumerate(VGG_CONV_IDX):
         h = rs(relu(conv2d(h, params[f"model.features.{idx}.weight"],
-                           params[f"model.features.{idx}.bias"], padding=1, **(first if li == 0 else {})), _VGG_ACT[li]))
+                           params[f"model.features.{idx}.bias"], padding=1, **(first if li == 0 else {})), _VGG_ACT[li]), _VGG_ACT[li])
         n = li + 1
         if acts is not None:
             acts[_VGG_ACT[li]] = h.detach()
@@ -514,23 +574,24 @@ def ssd300_forward(x, params, return_features: bool = False, variant: int = 300,
             feats["conv4_3"] = h
         if n in pools_after:
             n_pool += 1
-            h = rs(pool(h, f"p{n_pool}", 2, 2, ceil=pools_after[n]))
-    h = rs(pool(h, "p5", 3, 1, pad=1))
+            h = rs(pool(h, f"p{n_pool}", 2, 2, ceil=pools_after[n]), f"p{n_pool}")
+    h = rs(pool(h, "p5", 3, 1, pad=1), "p5")
     c43 = feats["conv4_3"]
     norm = c43.pow(2).sum(dim=1, keepdim=True).sqrt()
-    c43n = rs(c43 / norm * params["rescaling_conv_4_3"])
-    h = relu(conv2d(h, params["conv_fc6.weight"], params["conv_fc6.bias"], padding=4, dilation=4), "a6")
+    c43n = rs(c43 / norm * params["rescaling_conv_4_3"], "n4_3")
+    h = rs(relu(conv2d(h, params["conv_fc6.weight"], params["conv_fc6.bias"], padding=4, dilation=4), "a6"), "a6", trunk=False)
     if acts is not None:
         acts["n4_3"], acts["a6"] = c43n.detach(), h.detach()
-    h = relu(conv2d(h, params["conv_fc7.weight"], params["conv_fc7.bias"]), "a7")
+    h = rs(relu(conv2d(h, params["conv_fc7.weight"], params["conv_fc7.bias"]), "a7"), "a7", trunk=False)
     if acts is not None:
         acts["a7"] = h.detach()
     srcs = [c43n, h]
     for name, _, _, _, stride, pad in (AUX if variant == 300 else AUX_512):
-        h = relu(conv2d(h, params[f"{name}.0.weight"], params[f"{name}.0.bias"]), "a" + name[3:] + "a")
+        h = rs(relu(conv2d(h, params[f"{name}.0.weight"], params[f"{name}.0.bias"]), "a" + name[3:] + "a"), "a" + name[3:] + "a", trunk=False)
         if acts is not None:
             acts["a" + name[3:] + "a"] = h.detach()
-        h = relu(conv2d(h, params[f"{name}.2.weight"], params[f"{name}.2.bias"], stride=stride, padding=pad), "a" + name[3:])
+        h = rs(relu(conv2d(h, params[f"{name}.2.weight"], params[f"{name}.2.bias"], stride=stride, padding=pad), "a" + name[3:]), "a" + name[3:],
+               trunk=False)
         if acts is not None:
             acts["a" + name[3:]] = h.detach()
         srcs.append(h)

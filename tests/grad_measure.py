@@ -165,3 +165,67 @@ def f64_pinned_grads(params, decisions, neg_select):
                                    neg_select=neg_select)
     (a1 + a2).backward()
     return float(a1), float(a2), {k: v.grad for k, v in P.items()}
+
+
+# ---- decision- AND rounding-pinned comparison of the bf16-tensor mode (round-3 review, weak 1) --------------------------------------
+# One fixed bar for all 71 gradients, not produced by tools/grad_bars.py.  What is left between the two sides once every discrete
+# choice of the HIP step is followed -- ReLU masks, arg-max codes, hard negatives and the bf16 value every stored tensor was rounded
+# to -- is f32 accumulation order inside single layers.
+BF16_PINNED_BAR = 1e-4
+
+
+def gpu_pinned_step(net, x, classes, boxes, conv_dtype="bf16"):
+    """One forward + loss + backward of the HIP engine with everything a rounding-pinned oracle run needs exported:
+    -> (decisions, neg_select, pinned dict for O.ssd300_forward, (l1, l2), {param name: gradient})."""
+    from objectdetection_ssd_amd import Losses, ops
+    from objectdetection_ssd_amd.Model import _Elided
+    set_engine(net, "wino", conv_dtype)
+    net.train()
+    eng = net._engine
+    try:
+        P = net._forward_params()
+        eng.grad_tap = {}
+        with torch.no_grad():
+            loc, conf, saved = eng.forward(x, P, save=True)
+            T, aux = saved["T"], saved["aux"]
+            relu, pool, fwd, b16 = {}, {}, {}, set()
+            for op in eng.ops:
+                if op["op"] in ("conv", "conv_first") and op["y"] in eng.relu_out:
+                    t = T[op["y"]]
+                    relu[op["y"]] = None if isinstance(t, _Elided) else (t > 0).permute(0, 3, 1, 2).cpu()
+                elif op["op"] == "pool":
+                    gate = (T[op["y"]] > 0).permute(0, 3, 1, 2).cpu() if isinstance(T[op["x"]], _Elided) else None
+                    pool[op["y"]] = (aux[op["y"]].permute(0, 3, 1, 2).cpu(), gate)
+            for name, t in T.items():
+                if ":" in name or name in ("x", "x_col") or not torch.is_tensor(t):
+                    continue
+                fwd[name] = t.float().permute(0, 3, 1, 2).contiguous().cpu()
+                if t.dtype == torch.bfloat16:
+                    b16.add(name)
+            gt, cls_t, img_start = Losses._pack_targets(classes, boxes, loc.device)
+            pri, pri_xyxy = Losses._priors_on(loc.device, loc.shape[1])
+            out = ops.multibox_loss(loc.contiguous(), conf.contiguous(), gt, cls_t, img_start, pri, pri_xyxy, Losses.IOU_THRESHOLD,
+                                    Losses.NEG_POS_RATIO, 0, want_grads=True)
+            need = {n: True for n in eng.names}
+            grads = eng.backward(saved, out["dloc"], out["dconf"], P, need)
+            torch.cuda.synchronize()
+            bwd = {n: g.float().permute(0, 3, 1, 2).contiguous().cpu() for n, g in eng.grad_tap.items() if n in fwd}
+            neg = ((out["cls"] == O.BG_CLASS) & (out["dconf"].abs().amax(-1) > 0)).cpu()
+            losses = (float(out["losses"][0]), float(out["losses"][1]))
+            grads = {n: g.detach().float().cpu().clone() for n, g in grads.items()}
+    finally:
+        eng.grad_tap = None
+        set_engine(net, "wino", "f32")
+    pinned = {"fwd": fwd, "bwd": bwd, "bf16": b16, "report": {}}
+    return {"relu": relu, "pool": pool}, neg, pinned, losses, grads
+
+
+def f64_rounding_pinned_grads(params, decisions, neg_select, pinned):
+    """f64 CPU evaluation of the bf16-operand oracle network on the f64 case, following the given decisions AND stored values."""
+    x, boxes, classes = f64_case()
+    P = {k: v.detach().clone().double().requires_grad_(True) for k, v in params.items()}
+    loc, conf = O.ssd300_forward(torch.from_numpy(x).double(), P, operand_round="bf16", store_round=True, decisions=decisions, pinned=pinned)
+    a1, a2 = O.multibox_loss_torch(loc, conf, [torch.from_numpy(b) for b in boxes], [torch.from_numpy(c) for c in classes],
+                                   neg_select=neg_select)
+    (a1 + a2).backward()
+    return float(a1), float(a2), {k: v.grad for k, v in P.items()}

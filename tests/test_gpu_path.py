@@ -1584,3 +1584,38 @@ def test_bf16_k64_persistent_kernel_equals_the_general_kernel():
     finally:
         _lib.check(lib.ssd_tune_set_conv_bf16_k64(1), "tune")
     assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1])
+
+
+
+def test_bf16_train_step_vs_decision_and_rounding_pinned_f64_oracle(golden_net):
+    """The whole-step check of the bf16-tensor mode (BASELINE configs[2]) that does not depend on a table measured with the code under
+    test (round-3 review, weak 1).  The f64 oracle with bf16 operand rounding is run FOLLOWING the HIP step's discrete choices: ReLU
+    masks, max-pool arg-max codes, hard negatives -- and the bf16 (or f32) VALUE every activation and every activation gradient was
+    stored as: each layer of the oracle is fed exactly what the HIP layer was fed.  Then
+      (a) layer by layer, the oracle's own result must round to what the HIP kernel stored: within half a bf16 spacing (one
+          round-to-nearest; 1.01 where the build adds two stored contributions) -- a per-layer check of every forward and data-gradient
+          kernel that no flip upstream can blur;
+      (b) all 71 parameter gradients are within ONE fixed relative-L2 bar, 1e-4, of the f64 result (what is left is f32 summation order
+          inside one layer); the losses within 1e-4."""
+    import grad_measure as M
+    net, params, _ = golden_net
+    assert net._engine.bf16_tensors
+    x, boxes, classes = M.f64_case()
+    xd, cl, bx = M._t(x), [M._t(c) for c in classes], [M._t(b) for b in boxes]
+    decisions, neg, pinned, (l1, l2), grads = M.gpu_pinned_step(net, xd, cl, bx, "bf16")
+    assert {"a1_1", "a1_2", "p1", "a4_3", "n4_3", "p5"} <= pinned["bf16"] and "a6" in pinned["fwd"] and "a6" not in pinned["bf16"]
+    assert set(pinned["bwd"]) >= set(pinned["fwd"]) - {"a1_1"} or "a1_1" in pinned["bwd"]
+    a1, a2, g64 = M.f64_rounding_pinned_grads(params, decisions, neg, pinned)
+    rep = pinned["report"]
+    assert len(rep) >= 2 * len(pinned["fwd"]) - 2, sorted(rep)
+    worst = sorted(((v, k) for k, v in rep.items()), reverse=True)
+    print("rounding-pinned layer distances (spacings): " + ", ".join(f"{k} {v:.3f}" for v, k in worst[:8]))
+    two_adds = {"a4_3:bwd", "a7:bwd", "a8:bwd", "a9:bwd", "a10:bwd"}          # tensors with two consumers: two stored contributions
+    bad = [(k, v) for k, v in rep.items() if v > (1.01 if k in two_adds else 0.51 if k.split(":")[0] in pinned["bf16"] else 1.0)]
+    assert not bad, bad
+    assert abs(l1 - a1) <= 1e-4 * max(1, a1) and abs(l2 - a2) <= 1e-4 * max(1, a2), (l1, a1, l2, a2)
+    assert len(g64) == 71 and set(g64) == set(grads)
+    rows = sorted(((M.rel_l2(grads[k], g64[k]), k) for k in g64), reverse=True)
+    print("rounding-pinned bf16 gradient distance: worst " + ", ".join(f"{k} {v:.2e}" for v, k in rows[:6]) + f"; median {rows[35][0]:.2e}")
+    bad = [(k, v) for v, k in rows if v > M.BF16_PINNED_BAR]
+    assert not bad, bad

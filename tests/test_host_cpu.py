@@ -537,3 +537,40 @@ def test_asm_guard_flags_a_fragment_register_touched_before_its_wait():
     # the raw simm16 form of a wait: 0xC07F = lgkmcnt(0) with the other counters open
     raw = head + rd("v[8:11]", "v0") + ["\ts_waitcnt 0xc07f", "\tv_mov_b32_e32 v40, v9", "\ts_endpgm"]
     assert G.check_assembly(raw) == []
+
+
+def test_oracle_pinned_to_its_own_stored_tensors_is_the_unpinned_oracle():
+    """`ssd300_forward(pinned=...)` (the rounding-pinned comparison of the bf16-tensor mode): pinned to the activations of its OWN bf16
+    run the oracle reports zero distance at every tensor and returns the same outputs and gradients; a perturbed stored tensor shows up
+    in the report at that tensor and nowhere upstream."""
+    import ssd_oracle as O
+    params = O.ssd300_random_params(3)
+    x = torch.randn(1, 3, 300, 300, generator=torch.Generator().manual_seed(4))
+    boxes, classes = [torch.tensor([[.1, .2, .6, .7], [.5, .4, .9, .95]])], [torch.tensor([3., 11.])]
+
+    def run(pinned=None):
+        P = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        acts = {}
+        loc, conf = O.ssd300_forward(x, P, operand_round="bf16", store_round=True, acts=acts, pinned=pinned)
+        a1, a2 = O.multibox_loss_torch(loc, conf, boxes, classes)
+        (a1 + a2).backward()
+        return loc.detach(), conf.detach(), {k: v.grad.clone() for k, v in P.items()}, acts
+    loc0, conf0, g0, acts = run()
+    trunk = {n for n in acts if n.startswith(("a1", "a2", "a3", "a4", "a5")) or n == "n4_3"}
+    pin = {"fwd": dict(acts), "bwd": {}, "bf16": trunk, "report": {}}
+    loc1, conf1, g1, _ = run(pin)
+    assert torch.equal(loc0, loc1) and torch.equal(conf0, conf1)
+    assert set(pin["report"]) == {n + ":fwd" for n in acts}
+    # its own unrounded result is within half a bf16 spacing of what it stored (trunk) / equal to it (f32 tensors)
+    assert all(v <= (0.5 if k.split(":")[0] in trunk else 0.0) for k, v in pin["report"].items()), pin["report"]
+    assert max(v for k, v in pin["report"].items() if k.split(":")[0] in trunk) > 0.45
+    # (the gradients pass through an unrounded identity where the unpinned run rounds them: equal forward, close backward)
+    for k in g0:
+        assert float((g0[k] - g1[k]).norm() / g0[k].norm().clamp_min(1e-30)) <= 3e-2, k
+    bad = dict(acts)
+    bad["a3_2"] = acts["a3_2"] * 1.01                                   # 2.6 bf16 spacings off
+    pin2 = {"fwd": bad, "bwd": {}, "bf16": trunk, "report": {}}
+    run(pin2)
+    # a3_2 itself is off, a3_3 was computed from the perturbed a3_2 and is off too; a4_1 sees the stored (clean) a3_3 / p3 again
+    assert pin2["report"]["a3_2:fwd"] > 1.0 and pin2["report"]["a3_3:fwd"] > 1.0
+    assert pin2["report"]["a3_1:fwd"] <= 0.5 and pin2["report"]["a4_1:fwd"] <= 0.5
