@@ -156,7 +156,7 @@ class conv_flop_counter:
     the algorithmic work of one pass, read off the geometry of the calls themselves."""
 
     NAMES = ("conv2d_fwd", "conv2d_fwd_x3", "conv2d_fwd_wino", "conv2d_fwd_wino_pool", "conv2d_dgrad", "conv2d_dgrad_x3", "conv2d_dgrad_wino",
-             "conv2d_wgrad", "conv2d_wgrad_wino")
+             "conv2d_wgrad", "conv2d_wgrad_wino", "wino_wgrad_gemm", "wino_dgrad_adj_gemm")
 
     def __enter__(self):
         from objectdetection_ssd_amd import ops
@@ -494,6 +494,8 @@ def main():
     ap.add_argument("--wino-wgrad-nt", action="store_true", help="tuning aid: Winograd weight gradient on transposed planes (NT GEMM)")
     ap.add_argument("--no-keep-planes", action="store_true", help="tuning aid: the Winograd weight gradient transforms x again")
     ap.add_argument("--no-dual-dy", action="store_true", help="tuning aid: weight and data gradient transform dy separately")
+    ap.add_argument("--no-adjoint-dgrad", action="store_true", help="tuning aid: rotated-filter Winograd data gradients everywhere (second dy plane set)")
+    ap.add_argument("--no-adjoint-chain", action="store_true", help="tuning aid: adjoint data gradients written out as tensors between chained layers")
     ap.add_argument("--overlap-allreduce", action="store_true",
                     help="force the sliced all-reduce that runs while the backward is still running (ddp.py overlap=True; the default whenever N > 1)")
     ap.add_argument("--no-overlap-allreduce", action="store_true", help="one all-reduce of the whole gradient buffer after the backward")
@@ -601,6 +603,10 @@ def main():
         net._engine.keep_planes = False
     if args.no_dual_dy:
         net._engine.dual_dy = False
+    if args.no_adjoint_dgrad:
+        net._engine.adjoint_dgrad = False
+    if args.no_adjoint_chain:
+        net._engine.adjoint_chain = False
     train_gflop = TRAIN_GFLOP_PER_IMAGE
     if args.variant == 512:
         # direct-convolution FLOPs of one SSD512 train step per image, from the geometry of the step's own convolution calls

@@ -255,6 +255,25 @@ int ssd_conv3x3_wino_wgrad_planes(const float* planes, const float* dy, int ldy,
                                   float* dgrad_planes_out, void* workspace, size_t workspace_bytes, void* stream);
 int ssd_conv3x3_wino_dgrad_planes(const float* dy_planes, const float* U_bwd, int Co_pad, float* dx, const float* relu_mask,
                                   int accumulate, const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream);
+/* Data gradient in the ADJOINT Winograd form (round 4; autograd of nn.Conv2d, reference Model.py:135-143 / train_function.py:94).
+ * The forward y = A^T[(G g G^T) (.) (B^T d B)]A is linear in d; transposed, dx = overlap-add over the tiles of the 6x6 patches
+ * B[(G g G^T) (.) (A dy A^T)]B^T: the data gradient multiplies the SAME planes A dy A^T (ssd_wino4_dy_transform's wgrad_planes) the
+ * weight gradient multiplies, so the second plane set B^T dy B (dgrad_planes_out) is neither written nor read, against the forward
+ * filter transform laid out [36][Ci][Co_pad] (ssd_wino_weights_adj; weight jobs: pad0 bit 2; f32 or limb planes by
+ * ssd_wino_uses_x3(4, Co_pad)).  (1) ssd_conv3x3_wino_dgrad_adj_gemm: md_planes (ssd_wino4_adj_planes_floats(g) floats:
+ * 36 x tiles x pad4(Ci)) = y_planes x U_adj, ldy % 32 == 0.  (2a) ssd_wino4_adj_output: dx (N,H,W,Ci) [+=] the overlap-added patches,
+ * ReLU-masked by relu_bits (as left by ssd_conv3x3_wino_fwd_keep_bits) or by the f32 tensor relu_mask (either may be NULL); or
+ * (2b) ssd_wino4_adj_output_to_planes: the same block of dx is not stored but taken, masked, as the dy of the layer BELOW (g_below:
+ * same map, Co = g->Ci) and leaves that layer's planes A dy A^T (36 x tiles x g->Ci) and bias partial sums
+ * (ssd_wino4_bias_partial_floats(g_below, g->Ci); may be NULL): between two chained 3x3 layers the gradient tensor never reaches memory.
+ * 3x3 / stride 1 / pad 1 / dilation 1 only. */
+int ssd_wino_weights_adj(const float* w_oihw, float* U_adj, int Co, int Ci, int Co_pad, void* stream);
+size_t ssd_wino4_adj_planes_floats(const ssd_conv_geom* g);
+int ssd_conv3x3_wino_dgrad_adj_gemm(const float* y_planes, int ldy, const float* U_adj, float* md_planes, const ssd_conv_geom* g, void* stream);
+int ssd_wino4_adj_output(const float* md_planes, float* dx, const float* relu_mask, const uint64_t* relu_bits, int accumulate,
+                         const ssd_conv_geom* g, void* stream);
+int ssd_wino4_adj_output_to_planes(const float* md_planes, const float* relu_mask, const uint64_t* relu_bits, const ssd_conv_geom* g,
+                                   const ssd_conv_geom* g_below, float* y_planes, float* bias_partial, void* stream);
 /* Forward / dgrad of the F(4x4,3x3) entry points: 36 plane GEMMs + output transform in ONE kernel (accumulators of all planes in
  * registers, the M planes never reach memory) where the reduction length is a multiple of 64.  -1 (default): where it is the faster
  * form; 0: never (batched GEMM + output transform kernels); 1: wherever the geometry allows. */

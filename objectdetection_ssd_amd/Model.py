@@ -206,6 +206,7 @@ class _Engine:
             if (len(readers) == 1 and readers[0]["op"] == "pool" and (readers[0]["k"], readers[0]["s"], readers[0]["pad"]) == (2, 2, 0)
                     and op["relu"] and op["co"] % 4 == 0):
                 self.pool_after[op["y"]] = readers[0]
+        self._conv_of = {o["y"]: o for o in self.ops if o["op"] == "conv"}      # producer of an activation, where that is a convolution
         self.grad_sink = None     # callable(name, gradient): called during backward the moment a parameter's gradient is ready
         self.grad_out = None      # callable(names) -> flat f32 tensor or None: where the gradient of these consecutive parameters is to be written
         self.sink_owns_grads = False   # True (ddp.py): gradients live in the listener's buffer, autograd is handed None for them
@@ -219,6 +220,12 @@ class _Engine:
         self.first_fused = True        # conv1_1 forward and weight gradient straight from the NCHW batch (csrc/conv_first.hip), no im2col rows
         self.wino_dilated = True       # fc6 (3x3, dilation 4) in the Winograd domain too: 49 tiles x 36 products per image instead of 361 x 9
         self.relu_bits = True     # training forward: the input transform also leaves the ReLU mask of its input as bits for the dgrad epilogue
+        # Round 4: data gradient of the F(4x4) layers with >= 256 output channels in the ADJOINT Winograd form -- it multiplies the planes
+        # A dy A^T the weight gradient already has (no second plane set B^T dy B), and between two such layers of one resolution
+        # (conv3_3 -> 3_2 -> 3_1, conv4_3 -> 4_2 -> 4_1, conv5_3 -> 5_2 -> 5_1) the gradient tensor itself is never written: the output
+        # transform of the upper layer's data gradient writes the lower layer's dy planes (csrc/winograd.hip wino4_adj_out_kernel)
+        self.adjoint_dgrad = True
+        self.adjoint_chain = True      # False: every adjoint data gradient is written out as a tensor (A/B aid)
         self.prof = None          # bench.py: list collecting (label, kernel tag, flops, start event, end event)
         self.bf16 = False         # True: forward / dgrad / fused-wgrad convolutions multiply bf16-rounded operands (f32 accumulate)
         # bf16 mode: the VGG trunk (conv1_1 ... pool5, the L2-norm and the c_4 head's input) keeps its activations and gradients in bf16 in
@@ -302,13 +309,22 @@ class _Engine:
         return (self._wino_ok(g) and g.H <= self.WINO_WGRAD_MAX_HW and g.Ci >= self.WINO_WGRAD_MIN_CI
                 and (g.H >= 19 if head else g.Co % 4 == 0))
 
-    def _wino_weights(self, key: str, tensors, co_pad: int):
-        """Cached Winograd-domain filters (U_fwd [16][Co][Ci], U_bwd [16][Ci][co_pad]), refreshed when a parameter changes."""
-        sig = tuple((t.data_ptr(), t._version) for t in tensors) + (ops.wino_x3(4, 256),)     # + the GEMM form the filters were laid out for
+    def _adj_ok(self, g) -> bool:
+        """This convolution's data gradient takes the adjoint Winograd form (needs the kept forward planes: its weight gradient is the
+        Winograd one and shares the dy planes; reduction long enough for the plane GEMM kernels, i.e. not the fused K <= 128 kernel)."""
+        return (self.adjoint_dgrad and self.keep_planes and self.dual_dy and not self.overlap_wgrad and self.WINO_TILE == 4 and self._wino_ok(g) and g.dil == 1
+                and self._wino_wgrad_ok(g, False) and g.Co % 32 == 0 and 256 <= g.Co <= 1024 and g.Ci % 4 == 0)
+
+    def _wino_weights(self, key: str, tensors, co_pad: int, adj: bool = False):
+        """Cached Winograd-domain filters (U_fwd [16][Co][Ci], U_bwd [16][Ci][co_pad]), refreshed when a parameter changes.
+        adj: U_bwd in the adjoint form (the forward transform laid out [Ci][co_pad]) instead of the rotated filter's transform."""
+        sig = tuple((t.data_ptr(), t._version) for t in tensors) + (ops.wino_x3(4, 256), bool(adj))     # + the GEMM form the filters were laid out for
         ent = self._wcache.get("wino:" + key)
         if ent is None or ent[0] != sig:
             w = tensors[0] if len(tensors) == 1 else torch.cat(list(tensors), 0)
-            uf, ub = ops.wino_weights(w.detach().contiguous(), co_pad, want_bwd=True, mo=self.WINO_TILE)
+            uf, ub = ops.wino_weights(w.detach().contiguous(), co_pad, want_bwd=not adj, mo=self.WINO_TILE)
+            if adj:
+                ub = ops.wino_adj_weights(w.detach().contiguous(), co_pad)
             ent = (sig, uf, ub)
             self._wcache["wino:" + key] = ent
         return ent[1], ent[2]
@@ -353,7 +369,7 @@ class _Engine:
         caller's stream, after the previous step's last use); the job table is rebuilt only when a parameter's storage or the input
         size changes."""
         sig = (x.shape[2], x.shape[3], self.wino, self.WINO_TILE, self.WINO_MIN_CI, self.WINO_MIN_HW, self.bf16, self.bf16_tensors,
-               ops.wino_x3(4, 256)) + tuple(P[n].data_ptr() for n in self.names)
+               ops.wino_x3(4, 256), self.adjoint_dgrad, self.keep_planes, self.dual_dy, self.overlap_wgrad) + tuple(P[n].data_ptr() for n in self.names)
         if self._wtable is None or self._wtable[0] != sig:
             jobs, entries = [], []
             bs, hw, dev = x.shape[0], {"x": (x.shape[2], x.shape[3])}, x.device
@@ -404,8 +420,9 @@ class _Engine:
                     elif self._wino_ok(g) and self.WINO_TILE == 4:
                         uf = ops.wino_filter_alloc(4, co_all, g.Ci, dev)
                         ub = ops.wino_filter_alloc(4, g.Ci, co_pad, dev)
-                        jobs.append(dict(job, kind=0, out_fwd=uf, out_bwd=ub))
-                        entries.append((op["p"], "wino", tensors, (uf, ub)))
+                        adj = kind == "conv" and self._adj_ok(g)
+                        jobs.append(dict(job, kind=0, out_fwd=uf, out_bwd=ub, adj=adj))
+                        entries.append((op["p"], "wino_adj" if adj else "wino", tensors, (uf, ub)))
                     elif self._wino_ok(g):
                         continue                               # F(2x2) (a tuning aid): transformed per layer as before
                     else:
@@ -420,8 +437,8 @@ class _Engine:
             lsig = tuple((t.data_ptr(), t._version) for t in tensors)
             if what == "b16":
                 self._wcache["b16:" + key] = (lsig, bufs[0], bufs[1])
-            elif what == "wino":
-                self._wcache["wino:" + key] = (lsig + (ops.wino_x3(4, 256),), bufs[0], bufs[1])
+            elif what in ("wino", "wino_adj"):
+                self._wcache["wino:" + key] = (lsig + (ops.wino_x3(4, 256), what == "wino_adj"), bufs[0], bufs[1])
             elif what == "x31":
                 self._wcache["x31:" + key] = (lsig, bufs[0], bufs[1])
             elif what == "layout":
@@ -529,7 +546,7 @@ class _Engine:
                 if xin.dtype == torch.bfloat16:                   # boundary of the bf16 trunk (pool5 -> fc6): the kernels below take f32 tensors
                     xin = T[op["x"] + ":f32"] = ops.cast_f32(xin)
                 if self._wino_ok(g):
-                    uf, _ = self._wino_weights(op["p"], (P[op["p"] + ".weight"],), op["co"])
+                    uf, _ = self._wino_weights(op["p"], (P[op["p"] + ".weight"],), op["co"], adj=save and self._adj_ok(g))
                     pl = self.pool_after.get(op["y"]) if (self.fuse_pool and self.WINO_TILE == 4) else None
                     # training: the transformed input stays for the weight gradient, which multiplies the same planes
                     keep = save and self.keep_planes and self.WINO_TILE == 4 and self._wino_wgrad_ok(g, False)
@@ -650,8 +667,11 @@ class _Engine:
             mask = T[name] if (last and name in self.relu_out) else None
             G[name] = fn(G.get(name), k > 0, mask)
             arrived[name] = k + 1
-            if self.grad_tap is not None and last and torch.is_tensor(G[name]):
-                self.grad_tap[name] = G[name]
+            if self.grad_tap is not None and torch.is_tensor(G[name]):
+                if last:
+                    self.grad_tap[name] = G[name]
+                else:                                        # a partial sum, as stored before the next reader adds to it in place
+                    self.grad_tap[f"{name}:{k + 1}"] = G[name].clone()
 
         main = torch.cuda.current_stream(dloc.device)
         # (with a gradient listener every gradient is reported on the caller's stream: no third stream then)
@@ -805,6 +825,51 @@ class _Engine:
                             and self.dual_dy and aux.get("planes:" + op["p"]) is not None and g.Co % 32 == 0 and g.Co <= 1024
                             and not ops.wino_uses_full(g, 1) and self._wino_ok(g)):
                         dy = dy.materialize()
+                adj = (self._adj_ok(g) and not to_bf16 and aux.get("planes:" + op["p"]) is not None and not (async_wgrad and side_ctx[0] is None)
+                       and not ops.wino_uses_full(g, 1))
+                if isinstance(dy, ops.AdjPlanesGrad) and not adj:
+                    dy = dy.materialize()
+                if adj:
+                    # Adjoint Winograd form: ONE set of dy planes (A dy A^T) feeds the weight gradient's TN GEMMs and the data gradient's
+                    # plane GEMMs; where dy itself is the adjoint data gradient of the layer above (same map, this layer its only reader)
+                    # the planes come straight from that layer's product planes and dy is never a tensor.
+                    name = op["p"]
+                    kept = aux.pop("planes:" + name)
+                    need_w = need[name + ".weight"] or need[name + ".bias"]
+
+                    def dy_planes(dy=dy, g=g, need_w=need_w):
+                        if isinstance(dy, ops.AdjPlanesGrad):
+                            return ops.wino_adj_output_to_planes(dy.md, dy.g, g, dy.relu_mask, dy.bits, want_bias=need_w)
+                        Yp, _, part = ops.wino_dy_transform(dy, g, g.Co, False, need_w)
+                        return Yp, part
+                    if need_w:
+                        def wg_adj(name=name, g=g, kept=kept):
+                            Yp, part = dy_planes()
+                            dw_, db_ = ops.wino_wgrad_gemm(Yp, kept, part, g, g.Co, dw_out=self._gout(name + ".weight"), db_out=self._gout(name + ".bias"))
+                            return Yp, dw_, db_
+                        Y, dw, db = self._timed("wgrad " + name, "winograd_3x3", ops.wino_flops(g), wg_adj)
+                        grads[name + ".weight"], grads[name + ".bias"] = dw, db
+                    else:
+                        Y, _ = dy_planes()
+                    del kept
+                    _, uadj = self._wino_weights(name, (P[name + ".weight"],), op["co"], adj=True)
+                    bits = aux.pop("bits:" + name, None)
+                    below = self._conv_of.get(op["x"]) if self.adjoint_chain else None
+                    gb = aux.get(op["x"]) if below is not None else None
+                    chain = (below is not None and gb is not None and self.consumers[op["x"]] == 1 and op["x"] in self.relu_out
+                             and self._adj_ok(gb) and aux.get("planes:" + below["p"]) is not None and gb.Co == g.Ci
+                             and (gb.N, gb.H, gb.W) == (g.N, g.H, g.W) and T[op["x"]].dtype == torch.float32)
+
+                    def dgrad_adj(dx, acc, mask, Y=Y, uadj=uadj, g=g, bits=bits, chain=chain):
+                        md = ops.wino_dgrad_adj_gemm(Y, uadj, g, g.Co)
+                        use_bits = bits if mask is not None else None
+                        fmask = None if use_bits is not None else mask
+                        if chain and dx is None and not acc and mask is not None:
+                            return ops.AdjPlanesGrad(md, g, fmask, use_bits)         # the layer below reads the planes, not a tensor
+                        return ops.wino_adj_output(md, g, dx, relu_mask=fmask, bits=use_bits, accumulate=acc)
+                    deliver(op["x"], lambda dx, acc, mask: self._timed("dgrad " + name, "winograd_3x3", ops.wino_flops(g),
+                                                                       lambda: dgrad_adj(dx, acc, mask)))
+                    continue
                 if need[op["p"] + ".weight"] or need[op["p"] + ".bias"]:
                     if self._wino_wgrad_ok(g, False) and async_wgrad and side_ctx[0] is None and aux.get("planes:" + op["p"]) is not None \
                             and g.Co % 32 == 0 and g.Co <= 1024:
@@ -846,7 +911,10 @@ class _Engine:
                     if dw is not None:
                         grads[op["p"] + ".weight"], grads[op["p"] + ".bias"] = dw, db
                 if self._wino_ok(g):
-                    _, ub = self._wino_weights(op["p"], (P[op["p"] + ".weight"],), op["co"])
+                    _, ub = self._wino_weights(op["p"], (P[op["p"] + ".weight"],), op["co"], adj=self._adj_ok(g))
+                    if self._adj_ok(g):
+                        raise RuntimeError(f"{op['p']}: its filter planes are laid out for the adjoint data gradient, which needs the forward's kept planes "
+                                           "(the engine's keep_planes / dual_dy / adjoint_dgrad switches must not change between a forward and its backward)")
                     bits = aux.pop("bits:" + op["p"], None) if (dyp is not None or ops.wino_uses_full(g, 1)) else None
                     deliver(op["x"], lambda dx, acc, mask: self._timed(
                         "dgrad " + op["p"], "winograd_3x3", ops.wino_flops(g),

@@ -48,13 +48,13 @@ __global__ void wino_weight_kernel(const float* __restrict__ w, float* __restric
     const size_t total = (size_t)Nrows * K;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int k = (int)(i % K), n = (int)(i / K);
-        const int co = mode == 0 ? n : k, ci = mode == 0 ? k : n;
+        const int co = mode == 0 ? n : k, ci = mode == 0 ? k : n;      // mode 2: the adjoint form -- rows ci, K = co like mode 1, taps NOT rotated
         float g[3][3];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int s = 0; s < 3; ++s)
-                g[r][s] = (co < Co && ci < Ci) ? w[((size_t)co * Ci + ci) * 9 + (mode == 0 ? r * 3 + s : (2 - r) * 3 + (2 - s))] : 0.f;
+                g[r][s] = (co < Co && ci < Ci) ? w[((size_t)co * Ci + ci) * 9 + (mode != 1 ? r * 3 + s : (2 - r) * 3 + (2 - s))] : 0.f;
         float t[4][3];                                       // G g
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
@@ -391,13 +391,13 @@ __global__ void wino4_weight_kernel(const float* __restrict__ w, float* __restri
     const size_t total = (size_t)Nrows * K;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int k = (int)(i % K), n = (int)(i / K);
-        const int co = mode == 0 ? n : k, ci = mode == 0 ? k : n;
+        const int co = mode == 0 ? n : k, ci = mode == 0 ? k : n;      // mode 2: the adjoint form -- rows ci, K = co like mode 1, taps NOT rotated
         float g[3][3];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int s = 0; s < 3; ++s)
-                g[r][s] = (co < Co && ci < Ci) ? w[((size_t)co * Ci + ci) * 9 + (mode == 0 ? r * 3 + s : (2 - r) * 3 + (2 - s))] : 0.f;
+                g[r][s] = (co < Co && ci < Ci) ? w[((size_t)co * Ci + ci) * 9 + (mode != 1 ? r * 3 + s : (2 - r) * 3 + (2 - s))] : 0.f;
         float t[6][3];
 #pragma unroll
         for (int a = 0; a < 6; ++a)
@@ -798,6 +798,183 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
             }
     }
     if (BIAS) {
+        __shared__ f32x4 red[256];
+        red[threadIdx.x] = bsum;
+        __syncthreads();
+        if ((int)threadIdx.x < C4) {
+            f32x4 t = red[threadIdx.x];
+            for (int k = threadIdx.x + C4; k < 256; k += C4) t += red[k];
+            const int c4 = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % C4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c4 * 4 + e < Cvalid) part[(size_t)blockIdx.x * ((Cvalid + 3) / 4 * 4) + c4 * 4 + e] = t[e];
+        }
+    }
+}
+
+// ---- data gradient in the ADJOINT Winograd form (round 4) -----------------------------------------------------------------------------
+// The forward y = A^T [(G g G^T) (.) (B^T d B)] A is linear in d; its transpose maps dy to dx:
+//     dx patch (6x6, corner (4th-1, 4tw-1)) = B [ sum_co (G g G^T)[co][ci] (.) (A dy A^T)[co] ] B^T,    patches OVERLAP-ADDED
+// so the data gradient multiplies the SAME planes A dy A^T the weight gradient multiplies (no second set B^T dy B: 2.25x the gradient
+// tensor neither written nor read), against the FORWARD filter transform laid out [plane][ci][co] (weight job, pad0 bit 2).  Measured
+// against f64 it is as exact as the rotated-filter form (tools: 3.2e-6 vs 3.3e-6 at 256 channels).  What the overlap-add needs from the
+// neighbours of tile (th, tw) is little: B has B[0][:] = (4,0,0,0,0,0) and B[5][:] = (0,0,0,0,0,1), so row 4th of dx receives only plane
+// row 5 of the tile above, row 4th+3 only plane row 0 (x4) of the tile below, likewise the columns, and the four corner pixels one plane
+// each of the diagonal tiles: 36 + 4*6 + 4 plane values per tile, the 28 extra ones from L2 (they are another thread's own planes).
+// A thread = (tile, channel quad) forms its 4x4 block of dx in registers, applies the ReLU mask, and then EITHER stores it (dx / += dx)
+// OR -- MAKE_Y -- takes it as the dy block of the layer below and writes that layer's planes A dy A^T (+ the bias partial sums, as
+// wino4_dy_kernel<true> does): between two chained layers the gradient tensor itself is never written or read.
+template <bool MAKE_Y, bool BIAS>
+__global__ __launch_bounds__(256) void wino4_adj_out_kernel(const float* __restrict__ Md, int N, int H, int W, int C, int TH, int TW,
+                                                            float* __restrict__ dx, int ldo, const float* __restrict__ mask,
+                                                            const unsigned long long* __restrict__ mask_bits, int accumulate,
+                                                            float* __restrict__ Y, float* __restrict__ part, int Cvalid) {
+    const int C4 = C >> 2;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    const size_t tiles = (size_t)N * TH * TW, total = tiles * C4;
+    const size_t plane = tiles * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        const size_t tile = i / C4;
+        const int tw = (int)(tile % TW), th = (int)((tile / TW) % TH), n = (int)(tile / ((size_t)TW * TH));
+        const float* src = Md + tile * C + c4 * 4;
+        auto ld = [&](const float* base, int a, int b) -> f32x4 { return *reinterpret_cast<const f32x4*>(base + (size_t)(a * 6 + b) * plane); };
+        // r[j] = sum_b m[b] B^T[b][j+1]: one plane row against the four interior columns of B^T
+        auto rowx = [&](const f32x4 (&m)[6], f32x4 (&r)[4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int b = 0; b < 6; ++b)
+                    if (W4_BT[b][j + 1] != 0.f) acc += W4_BT[b][j + 1] * m[b];
+                r[j] = acc;
+            }
+        };
+        f32x4 d[4][4];
+#pragma unroll
+        for (int a2 = 0; a2 < 4; ++a2)
+#pragma unroll
+            for (int b2 = 0; b2 < 4; ++b2) d[a2][b2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {                        // the tile's own patch, interior 4x4: sum_a B^T[a][i+1] (M[a][:] B^T)[j+1]
+            f32x4 m[6], r[4];
+#pragma unroll
+            for (int b = 0; b < 6; ++b) m[b] = ld(src, a, b);
+            rowx(m, r);
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2)
+                if (W4_BT[a][i2 + 1] != 0.f) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) d[i2][j] += W4_BT[a][i2 + 1] * r[j];
+                }
+        }
+        const bool up = th > 0, down = th + 1 < TH, left = tw > 0, right = tw + 1 < TW;
+        if (up) {                                            // row 5 of the patch above lands on this tile's row 0
+            const float* s2 = src - (size_t)TW * C;
+            f32x4 m[6], r[4];
+#pragma unroll
+            for (int b = 0; b < 6; ++b) m[b] = ld(s2, 5, b);
+            rowx(m, r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[0][j] += r[j];
+        }
+        if (down) {                                          // row 0 of the patch below (B[0][0] = 4) on row 3
+            const float* s2 = src + (size_t)TW * C;
+            f32x4 m[6], r[4];
+#pragma unroll
+            for (int b = 0; b < 6; ++b) m[b] = ld(s2, 0, b);
+            rowx(m, r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[3][j] += 4.f * r[j];
+        }
+        if (left) {                                          // column 5 of the patch to the left on column 0
+            const float* s2 = src - C;
+            f32x4 m[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) m[a] = ld(s2, a, 5);
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+                    if (W4_BT[a][i2 + 1] != 0.f) acc += W4_BT[a][i2 + 1] * m[a];
+                d[i2][0] += acc;
+            }
+        }
+        if (right) {                                         // column 0 of the patch to the right (x4) on column 3
+            const float* s2 = src + C;
+            f32x4 m[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) m[a] = ld(s2, a, 0);
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+                    if (W4_BT[a][i2 + 1] != 0.f) acc += W4_BT[a][i2 + 1] * m[a];
+                d[i2][3] += 4.f * acc;
+            }
+        }
+        if (up && left) d[0][0] += ld(src - (size_t)(TW + 1) * C, 5, 5);
+        if (up && right) d[0][3] += 4.f * ld(src - (size_t)(TW - 1) * C, 5, 0);
+        if (down && left) d[3][0] += 4.f * ld(src + (size_t)(TW - 1) * C, 0, 5);
+        if (down && right) d[3][3] += 16.f * ld(src + (size_t)(TW + 1) * C, 0, 0);
+
+        const unsigned long long word = mask_bits != nullptr ? mask_bits[i] : ~0ull;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int oh = 4 * th + a;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int ow = 4 * tw + b;
+                const bool in = oh < H && ow < W;
+                f32x4 v = d[a][b];
+                const size_t idx = (((size_t)n * H + oh) * W + ow) * ldo + c4 * 4;
+                if (!MAKE_Y && accumulate && in) v += *reinterpret_cast<const f32x4*>(dx + idx);
+                if (mask_bits != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ((word >> ((a * 4 + b) * 4 + e)) & 1ull) ? v[e] : 0.f;
+                } else if (mask != nullptr && in) {
+                    const f32x4 mk = *reinterpret_cast<const f32x4*>(mask + idx);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+                }
+                if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};        // beyond the map: no such pixel (and, as a dy block, zero)
+                if (!MAKE_Y) {
+                    if (in) *reinterpret_cast<f32x4*>(dx + idx) = v;
+                } else {
+                    d[a][b] = v;
+                }
+            }
+        }
+        if (MAKE_Y) {                                        // the block is the dy of the layer below: its planes A dy A^T (wino4_dy_kernel's sums)
+            f32x4 t[6][4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (BIAS) bsum += (d[0][b] + d[1][b]) + (d[2][b] + d[3][b]);
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (W4_AT[k][a] != 0.f) acc += W4_AT[k][a] * d[k][b];
+                    t[a][b] = acc;
+                }
+            }
+            float* dst = Y + tile * C + c4 * 4;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = 0; b < 6; ++b) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (W4_AT[k][b] != 0.f) acc += W4_AT[k][b] * t[a][k];
+                    *reinterpret_cast<f32x4*>(dst + (size_t)(a * 6 + b) * plane) = acc;
+                }
+        }
+    }
+    if (MAKE_Y && BIAS) {
         __shared__ f32x4 red[256];
         red[threadIdx.x] = bsum;
         __syncthreads();
@@ -1544,6 +1721,82 @@ extern "C" int ssd_wino4_wgrad_gemm(const float* wgrad_planes, const float* x_pl
     return SSD_OK;
 }
 
+// ---- the adjoint-form data gradient (wino4_adj_out_kernel): GEMMs, stand-alone output, output fused with the next dy transform ------
+extern "C" int ssd_wino_weights_adj(const float* w_oihw, float* U_adj, int Co, int Ci, int Co_pad, void* stream) {
+    if (!w_oihw || !U_adj) return SSD_ERR_NULL;
+    if (Co <= 0 || Ci <= 0 || Co_pad < Co) return SSD_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(wino4_weight_kernel, dim3(grid_for((size_t)Ci * Co_pad)), dim3(256), 0, (hipStream_t)stream, w_oihw, U_adj, Co, Ci, Ci, Co_pad, 2,
+                       (int)use_x3(4, Co_pad));
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
+// md_planes [36][tiles][pad4(Ci)] = y_planes [36][tiles][ldy] . U_adj[p] ([Ci][ldy], f32 or limb planes by ssd_wino_uses_x3(4, ldy))
+extern "C" size_t ssd_wino4_adj_planes_floats(const ssd_conv_geom* g) {
+    if (!wino_geom_ok(g) || g->dil != 1) return 0;
+    const LatPlan lp = lat_plan(g->H, g->W, 1);
+    return (size_t)36 * g->N * lp.TH * lp.TW * ((g->Ci + 3) / 4 * 4);
+}
+
+extern "C" int ssd_conv3x3_wino_dgrad_adj_gemm(const float* y_planes, int ldy, const float* U_adj, float* md_planes, const ssd_conv_geom* g,
+                                               void* stream) {
+    if (!y_planes || !U_adj || !md_planes) return SSD_ERR_NULL;
+    if (!wino_geom_ok(g) || g->dil != 1 || ldy % 32 != 0 || ldy < g->Co || g->Ci % 4 != 0) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(y_planes) || !ssd_aligned16(U_adj) || !ssd_aligned16(md_planes)) return SSD_ERR_ALIGN;
+    const LatPlan lp = lat_plan(g->H, g->W, 1);
+    const size_t tiles = (size_t)g->N * lp.TH * lp.TW;
+    if (tiles >= (1ull << 31)) return SSD_ERR_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (use_x3(4, ldy)) return ssd_internal_gemm_batched_x3(y_planes, U_adj, md_planes, (int)tiles, ldy, g->Ci, g->Ci, 36, tiles * ldy, st);
+    return ssd_internal_gemm_batched(y_planes, U_adj, md_planes, (int)tiles, ldy, g->Ci, g->Ci, 36, tiles * ldy, (size_t)g->Ci * ldy, 1, st);
+}
+
+// dx (N,H,W,Ci) [+=] overlap-add of B md B^T, ReLU-masked by the bit words of the forward's input transform or by an f32 tensor
+extern "C" int ssd_wino4_adj_output(const float* md_planes, float* dx, const float* relu_mask, const uint64_t* relu_bits, int accumulate,
+                                    const ssd_conv_geom* g, void* stream) {
+    if (!md_planes || !dx) return SSD_ERR_NULL;
+    if (!wino_geom_ok(g) || g->dil != 1 || g->Ci % 4 != 0) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(md_planes) || !ssd_aligned16(dx) || (relu_mask && !ssd_aligned16(relu_mask)) || (relu_bits && ((uintptr_t)relu_bits & 7)))
+        return SSD_ERR_ALIGN;
+    const LatPlan lp = lat_plan(g->H, g->W, 1);
+    const size_t tiles = (size_t)g->N * lp.TH * lp.TW;
+    hipLaunchKernelGGL((wino4_adj_out_kernel<false, false>), dim3(grid_for(tiles * (g->Ci / 4))), dim3(256), 0, (hipStream_t)stream, md_planes, g->N, g->H,
+                       g->W, g->Ci, lp.TH, lp.TW, dx, g->Ci, relu_mask, reinterpret_cast<const unsigned long long*>(relu_bits), accumulate,
+                       static_cast<float*>(nullptr), static_cast<float*>(nullptr), 0);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
+// The same block of dx, never stored: masked, it IS the dy of the layer below (g_below: same map, Co = g->Ci, its input of that layer
+// being the ReLU output the mask belongs to) -- out come that layer's planes A dy A^T [36][tiles][g->Ci] and its bias partial sums
+// (ssd_wino4_bias_partial_floats(g_below, g->Ci) floats), ready for ssd_wino4_wgrad_gemm and ssd_conv3x3_wino_dgrad_adj_gemm.
+extern "C" int ssd_wino4_adj_output_to_planes(const float* md_planes, const float* relu_mask, const uint64_t* relu_bits, const ssd_conv_geom* g,
+                                              const ssd_conv_geom* g_below, float* y_planes, float* bias_partial, void* stream) {
+    if (!md_planes || !y_planes || !g_below) return SSD_ERR_NULL;
+    if (!wino_geom_ok(g) || !wino_geom_ok(g_below) || g->dil != 1 || g_below->dil != 1 || g->Ci % 4 != 0 || g_below->Co != g->Ci ||
+        g_below->N != g->N || g_below->H != g->H || g_below->W != g->W)
+        return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(md_planes) || !ssd_aligned16(y_planes) || (relu_mask && !ssd_aligned16(relu_mask)) || (relu_bits && ((uintptr_t)relu_bits & 7)) ||
+        (bias_partial && !ssd_aligned16(bias_partial)))
+        return SSD_ERR_ALIGN;
+    const LatPlan lp = lat_plan(g->H, g->W, 1);
+    const size_t tiles = (size_t)g->N * lp.TH * lp.TW;
+    hipStream_t st = (hipStream_t)stream;
+    if (bias_partial) {
+        const int blocks = dy_bias_blocks_for(g_below, g->Ci, tiles);
+        if (blocks == 0) return SSD_ERR_BAD_SHAPE;
+        hipLaunchKernelGGL((wino4_adj_out_kernel<true, true>), dim3(blocks), dim3(256), 0, st, md_planes, g->N, g->H, g->W, g->Ci, lp.TH, lp.TW,
+                           static_cast<float*>(nullptr), g->Ci, relu_mask, reinterpret_cast<const unsigned long long*>(relu_bits), 0, y_planes, bias_partial,
+                           g_below->Co);
+    } else {
+        hipLaunchKernelGGL((wino4_adj_out_kernel<true, false>), dim3(grid_for(tiles * (g->Ci / 4))), dim3(256), 0, st, md_planes, g->N, g->H, g->W, g->Ci,
+                           lp.TH, lp.TW, static_cast<float*>(nullptr), g->Ci, relu_mask, reinterpret_cast<const unsigned long long*>(relu_bits), 0, y_planes,
+                           static_cast<float*>(nullptr), 0);
+    }
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
 // ---- every filter transform / re-layout of a training step in ONE launch ---------------------------------------------------------------
 // A step re-lays ~30 weight tensors (Winograd-domain filters for forward and dgrad, or the OHWI / IHWO copies of the direct kernels):
 // 56 launches of ~9 microseconds in a row.  Here a job table (device memory, built once by the caller while the pointers stay the same)
@@ -1565,6 +1818,7 @@ __global__ __launch_bounds__(256) void weight_jobs_kernel(const ssd_weight_job* 
         // pad0 bit 0 / 1: out_fwd / out_bwd hold limb planes (ssd_wino_uses_x3 of their K): there a thread transforms 8 consecutive k of
         // one row and writes each plane's limbs as three 16-byte stores
         const int x3f = j.pad0 & 1, x3b = (j.pad0 >> 1) & 1;
+        const bool adj = (j.pad0 >> 2) & 1;          // out_bwd in the ADJOINT form: the forward transform G g G^T (taps not rotated), rows ci, K = co
         const size_t nf = (size_t)Co * Ci, nb = (size_t)Ci * j.co_pad;
         const size_t tf = x3f ? nf / 8 : nf, tb = j.out_bwd == nullptr ? 0 : (x3b ? nb / 8 : nb);
         const bool fwd = i < tf;
@@ -1582,7 +1836,7 @@ __global__ __launch_bounds__(256) void weight_jobs_kernel(const ssd_weight_job* 
             for (int q = 0; q < 8; ++q) {
                 const int co = fwd ? n : k8 + q, ci = fwd ? k8 + q : n;
 #pragma unroll
-                for (int t9 = 0; t9 < 9; ++t9) g[q][t9] = co < Co ? src(co, ci, fwd ? t9 : 8 - t9) : 0.f;
+                for (int t9 = 0; t9 < 9; ++t9) g[q][t9] = co < Co ? src(co, ci, (fwd || adj) ? t9 : 8 - t9) : 0.f;
             }
             const size_t limb = (size_t)((Nrows + 127) / 128 * 128) * 16;
             __bf16* base = reinterpret_cast<__bf16*>(U) + (size_t)(k8 >> 4) * 3 * limb + (size_t)n * 16 + (k8 & 15);
@@ -1619,7 +1873,7 @@ __global__ __launch_bounds__(256) void weight_jobs_kernel(const ssd_weight_job* 
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) g[r][s] = co < Co ? src(co, ci, fwd ? r * 3 + s : (2 - r) * 3 + (2 - s)) : 0.f;
+            for (int s = 0; s < 3; ++s) g[r][s] = co < Co ? src(co, ci, (fwd || adj) ? r * 3 + s : (2 - r) * 3 + (2 - s)) : 0.f;
         float t[6][3];
 #pragma unroll
         for (int a = 0; a < 6; ++a)

@@ -1142,6 +1142,95 @@ def wino_dy_transform(dy: torch.Tensor, g: ConvGeom, ldy: int, dgrad_planes: boo
     return Y, Vd, part
 
 
+def wino_adj_weights(w_oihw: torch.Tensor, co_pad: int) -> torch.Tensor:
+    """Filter planes of the adjoint-form data gradient (`wino_dgrad_adj_gemm`): the forward transform G g G^T laid out (36, Ci, co_pad)
+    -- limb planes where `wino_x3(4, co_pad)`."""
+    _req(w_oihw, "w")
+    co, ci = int(w_oihw.shape[0]), int(w_oihw.shape[1])
+    u = wino_filter_alloc(4, ci, co_pad, w_oihw.device)
+    check(_lib.load().ssd_wino_weights_adj(w_oihw.data_ptr(), u.data_ptr(), co, ci, co_pad, _stream()), "wino_weights_adj")
+    return u
+
+
+def wino_dgrad_adj_gemm(y_planes: torch.Tensor, u_adj: torch.Tensor, g: ConvGeom, ldy: int) -> torch.Tensor:
+    """The 36 plane GEMMs of the adjoint-form data gradient: (36, tiles, ldy) planes A dy A^T (`wino_dy_transform`'s first result, the
+    weight gradient's operand) x the adjoint filter planes -> md (36, tiles, Ci)."""
+    _req(y_planes, "y_planes")
+    tiles = wino_planes_shape(g)[1]
+    if tuple(y_planes.shape) != (36, tiles, ldy) or g.Ci % 4 != 0 or ldy % 32 != 0:
+        raise ValueError("wino_dgrad_adj_gemm: planes do not match the geometry")
+    _wino_filter(u_adj, "u_adj", g.Ci, ldy)
+    md = torch.empty((36, tiles, g.Ci), device=y_planes.device, dtype=torch.float32)
+    check(_lib.load().ssd_conv3x3_wino_dgrad_adj_gemm(y_planes.data_ptr(), ldy, u_adj.data_ptr(), md.data_ptr(), C.byref(g), _stream()),
+          "wino_dgrad_adj_gemm")
+    return md
+
+
+def _adj_mask_args(g: ConvGeom, tiles: int, relu_mask, bits):
+    if bits is not None:
+        _req(bits, "bits", torch.int64)
+        if tuple(bits.shape) != (tiles, g.Ci // 4):
+            raise ValueError("adjoint output: one mask word per (tile, channel quad)")
+    if relu_mask is not None:
+        _req(relu_mask, "relu_mask")
+        if relu_mask.numel() != g.N * g.H * g.W * g.Ci:
+            raise ValueError("adjoint output: relu_mask must have dx's shape")
+
+
+def wino_adj_output(md: torch.Tensor, g: ConvGeom, dx: Optional[torch.Tensor] = None, relu_mask: Optional[torch.Tensor] = None,
+                    bits: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """dx (N,H,W,Ci) [+=] the overlap-added 6x6 patches B md B^T, then the ReLU mask (bit words of the forward's input transform, or an
+    f32 tensor > 0)."""
+    _req(md, "md")
+    tiles = wino_planes_shape(g)[1]
+    if tuple(md.shape) != (36, tiles, g.Ci):
+        raise ValueError("wino_adj_output: planes do not match the geometry")
+    _adj_mask_args(g, tiles, relu_mask, bits)
+    if dx is None:
+        if accumulate:
+            raise ValueError("accumulate needs an existing dx")
+        dx = torch.empty((g.N, g.H, g.W, g.Ci), device=md.device, dtype=torch.float32)
+    _req(dx, "dx")
+    if dx.numel() != g.N * g.H * g.W * g.Ci:
+        raise ValueError("wino_adj_output: dx shape")
+    check(_lib.load().ssd_wino4_adj_output(md.data_ptr(), dx.data_ptr(), _ptr(relu_mask) if bits is None else None, _ptr(bits), int(accumulate),
+                                           C.byref(g), _stream()), "wino_adj_output")
+    return dx
+
+
+def wino_adj_output_to_planes(md: torch.Tensor, g: ConvGeom, g_below: ConvGeom, relu_mask: Optional[torch.Tensor] = None,
+                              bits: Optional[torch.Tensor] = None, want_bias: bool = True):
+    """The chained form: the masked dx block of layer `g` is the dy block of the layer below it -> (planes A dy A^T (36, tiles, g.Ci) of
+    `g_below`, its bias partial sums or None), without the gradient tensor in between."""
+    _req(md, "md")
+    tiles = wino_planes_shape(g)[1]
+    if tuple(md.shape) != (36, tiles, g.Ci) or g_below.Co != g.Ci or (g_below.N, g_below.H, g_below.W) != (g.N, g.H, g.W):
+        raise ValueError("wino_adj_output_to_planes: the two layers do not chain")
+    _adj_mask_args(g, tiles, relu_mask, bits)
+    lib = _lib.load()
+    Y = torch.empty((36, tiles, g.Ci), device=md.device, dtype=torch.float32)
+    part = torch.empty((lib.ssd_wino4_bias_partial_floats(C.byref(g_below), g.Ci),), device=md.device, dtype=torch.float32) if want_bias else None
+    check(lib.ssd_wino4_adj_output_to_planes(md.data_ptr(), _ptr(relu_mask) if bits is None else None, _ptr(bits), C.byref(g), C.byref(g_below),
+                                             Y.data_ptr(), _ptr(part), _stream()), "wino_adj_output_to_planes")
+    return Y, part
+
+
+class AdjPlanesGrad:
+    """A data gradient that exists only as the product planes `md` of the adjoint-form GEMMs of layer `g` (plus the ReLU mask of the
+    tensor it is the gradient of): the layer below turns it into its own dy planes (`wino_adj_output_to_planes`) without the tensor
+    being written; `materialize()` is the stand-alone output transform for any other reader."""
+
+    def __init__(self, md: torch.Tensor, g: ConvGeom, relu_mask: Optional[torch.Tensor], bits: Optional[torch.Tensor]):
+        self.md, self.g, self.relu_mask, self.bits = md, g, relu_mask, bits
+
+    @property
+    def shape(self):
+        return (self.g.N, self.g.H, self.g.W, self.g.Ci)
+
+    def materialize(self) -> torch.Tensor:
+        return wino_adj_output(self.md, self.g, None, self.relu_mask, self.bits, False)
+
+
 class PooledGrad:
     """A gradient that exists only as the gradient of the 2x2 / stride-2 max pool behind it: (dpool (N,Hp,Wp,C), argmax codes, pooled forward
     output = the ReLU gate).  `wino_dy_transform` / `conv2d_wgrad_wino` take it in place of dy; `materialize()` is the scatter to memory."""
@@ -1202,8 +1291,10 @@ class WeightTable:
             a.out_bwd = _ptr(j.get("out_bwd"))
             a.co0, a.co, a.ci, a.taps, a.co_pad, a.kind = j["co0"], j["co"], j["ci"], j["taps"], j["co_pad"], j["kind"]
             a.pad1 = j.get("pad1", 0)
-            if j["kind"] == 0:                 # Winograd filters: which outputs are limb tensors (wino_filter_alloc)
+            if j["kind"] == 0:                 # Winograd filters: which outputs are limb tensors (wino_filter_alloc); bit 2: out_bwd in the adjoint form
                 a.pad0 = sum(bit for bit, key in ((1, "out_fwd"), (2, "out_bwd")) if j.get(key) is not None and j[key].dtype == torch.bfloat16)
+                if j.get("adj"):
+                    a.pad0 |= 4
             nb = lib.ssd_weight_job_blocks(C.byref(a))
             if nb <= 0:
                 raise ValueError("bad weight job")

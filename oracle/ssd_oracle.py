@@ -428,6 +428,8 @@ def _pin_store(name, fwd, bwd, report, kind, gate):
     class PinStore(torch.autograd.Function):
         @staticmethod
         def forward(ctx, z):
+            if fwd is None:                      # a branch pin: only the gradient flowing back through THIS reader is replaced
+                return z.view_as(z)
             report[name + ":fwd"] = dev(z, fwd, None)
             return fwd.to(z.dtype)
 
@@ -577,6 +579,10 @@ def ssd300_forward(x, params, return_features: bool = False, variant: int = 300,
             h = rs(pool(h, f"p{n_pool}", 2, 2, ceil=pools_after[n]), f"p{n_pool}")
     h = rs(pool(h, "p5", 3, 1, pad=1), "p5")
     c43 = feats["conv4_3"]
+    if pinned is not None and "a4_3:1" in pinned["bwd"]:
+        # conv4_3's output has two readers; the other evaluation stored the L2-norm's contribution to its gradient (rounded to bf16) before
+        # the pool's was added to it: follow that intermediate value too, so that each of the two roundings is compared on its own
+        c43 = _pin_store("a4_3:1", None, pinned["bwd"]["a4_3:1"], pinned["report"], "bf16" if "a4_3" in pinned["bf16"] else "f32", None)(c43)
     norm = c43.pow(2).sum(dim=1, keepdim=True).sqrt()
     c43n = rs(c43 / norm * params["rescaling_conv_4_3"], "n4_3")
     h = rs(relu(conv2d(h, params["conv_fc6.weight"], params["conv_fc6.bias"], padding=4, dilation=4), "a6"), "a6", trunk=False)

@@ -209,7 +209,7 @@ def gpu_pinned_step(net, x, classes, boxes, conv_dtype="bf16"):
             need = {n: True for n in eng.names}
             grads = eng.backward(saved, out["dloc"], out["dconf"], P, need)
             torch.cuda.synchronize()
-            bwd = {n: g.float().permute(0, 3, 1, 2).contiguous().cpu() for n, g in eng.grad_tap.items() if n in fwd}
+            bwd = {n: g.float().permute(0, 3, 1, 2).contiguous().cpu() for n, g in eng.grad_tap.items() if n.split(":")[0] in fwd}
             neg = ((out["cls"] == O.BG_CLASS) & (out["dconf"].abs().amax(-1) > 0)).cpu()
             losses = (float(out["losses"][0]), float(out["losses"][1]))
             grads = {n: g.detach().float().cpu().clone() for n, g in grads.items()}

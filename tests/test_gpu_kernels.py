@@ -819,6 +819,80 @@ def test_winograd_f4x4_3x3_forward_and_dgrad(case):
     _close(dw_t, dw, tol=2e-5, what=f"winograd F(4x4) wgrad TN vs NT {case}")
 
 
+def _relu_bits(mask_nhwc: torch.Tensor, th: int, tw: int) -> torch.Tensor:
+    """(N,H,W,C) -> (N*th*tw, C/4) int64 words, bit (a*4+b)*4+e = mask[n, 4th+a, 4tw+b, 4c4+e] > 0: what wino4_input_kernel leaves"""
+    n, h, w, c = mask_nhwc.shape
+    pad = torch.zeros(n, 4 * th, 4 * tw, c, dtype=torch.bool)
+    pad[:, :h, :w] = mask_nhwc > 0
+    t = pad.view(n, th, 4, tw, 4, c // 4, 4).permute(0, 1, 3, 5, 2, 4, 6).reshape(n * th * tw, c // 4, 64).to(torch.int64)
+    sh = torch.arange(64, dtype=torch.int64)
+    return (t << sh).sum(-1)                      # bit 63 wraps into the sign: the same 64-bit pattern
+
+
+ADJ_CASES = [(2, 19, 19, 64, 256), (1, 38, 38, 128, 256), (2, 10, 13, 32, 512), (1, 75, 75, 64, 256), (3, 5, 9, 32, 288)]
+
+
+@pytest.mark.parametrize("case", ADJ_CASES)
+def test_adjoint_winograd_data_gradient(case):
+    """The adjoint-form data gradient (csrc/winograd.hip wino4_adj_out_kernel; autograd of nn.Conv2d, reference Model.py:135-143): the
+    planes A dy A^T of the weight gradient x the forward filter transform, 6x6 patches overlap-added by a gather over the neighbouring
+    tiles.  Against an f64 `conv2d_input` within the f32 bar and no further from it than the rotated-filter form; += and ReLU masks (f32
+    tensor and bit words) as the direct kernel applies them; and the CHAINED form -- the masked block taken as the dy of the layer below,
+    written as that layer's planes + bias partial sums -- equals the dy transform of the stored tensor."""
+    from objectdetection_ssd_amd import _lib, ops
+    n, h, w, ci, co = case
+    dev = _dev()
+    full = (n, h, w, ci, co, 3, 1, 1, 1)
+    x, wt, b = _conv_data(full, seed=181)
+    g = ops.make_geom(*full)
+    gen = torch.Generator().manual_seed(182)
+    dy = torch.randn(n, co, h, w, generator=gen) * torch.exp(torch.randn(n, co, h, w, generator=gen))
+    ref = torch.nn.grad.conv2d_input((n, ci, h, w), wt.double(), dy.double(), padding=1)
+    dyd = _nhwc(dy).contiguous().to(dev)
+    uf, ub = ops.wino_weights(wt.to(dev), co, mo=4)
+    uadj = ops.wino_adj_weights(wt.to(dev), co)
+    assert uadj.shape == ub.shape and uadj.dtype == ub.dtype
+    Y, none, _ = ops.wino_dy_transform(dyd, g, co, False, False)
+    assert none is None
+    md = ops.wino_dgrad_adj_gemm(Y, uadj, g, co)
+    dx = ops.wino_adj_output(md, g)
+    dx_rot = ops.conv2d_dgrad_wino(dyd, ub, g)
+    _close(dx, _nhwc(ref), what=f"adjoint dgrad {case}")
+    ea = float((dx.cpu().double() - _nhwc(ref)).norm() / ref.norm())
+    er = float((dx_rot.cpu().double() - _nhwc(ref)).norm() / ref.norm())
+    print(f"adjoint dgrad {case}: rel L2 vs f64 {ea:.2e} (rotated-filter form {er:.2e})")
+    assert ea <= 1.5 * er + 1e-7, (ea, er)
+    # ReLU mask as an f32 tensor and as bit words, and accumulation into an existing gradient
+    act = torch.randn(n, h, w, ci, generator=gen)
+    base = torch.randn(n, h, w, ci, generator=gen)
+    want = torch.where(act > 0, base + dx.cpu(), torch.zeros(()))
+    got = ops.wino_adj_output(md, g, base.clone().to(dev), relu_mask=act.to(dev), accumulate=True)
+    assert torch.equal(got.cpu(), want)
+    th, tw = (h + 3) // 4, (w + 3) // 4
+    bits = _relu_bits(act, th, tw).to(dev)
+    got_b = ops.wino_adj_output(md, g, base.clone().to(dev), bits=bits, accumulate=True)
+    assert torch.equal(got_b.cpu(), want)
+    # chained: the masked block is the dy of a layer below with ci output channels
+    if ci % 32 == 0:
+        g_below = ops.make_geom(n, h, w, 32, ci, 3, 1, 1, 1)
+        dmask = torch.where(act > 0, dx.cpu(), torch.zeros(())).contiguous().to(dev)
+        Y_ref, _, part_ref = ops.wino_dy_transform(dmask, g_below, ci, False, True)
+        Y2, part2 = ops.wino_adj_output_to_planes(md, g, g_below, bits=bits, want_bias=True)
+        Y3, part3 = ops.wino_adj_output_to_planes(md, g, g_below, relu_mask=act.to(dev), want_bias=False)
+        assert part3 is None and torch.equal(Y2, Y3)
+        _close(Y2, Y_ref, tol=1e-6, what=f"chained dy planes {case}")
+        lib = _lib.load()
+        nb = part2.numel() // ci
+        s2, sr = part2.view(nb, ci).double().sum(0), dmask.double().sum((0, 1, 2))
+        # (the partial buffer has rows beyond the launched blocks: compare through the weight-gradient path instead when it is ragged)
+        kept = torch.randn(36, Y2.shape[1], 32, device=dev)
+        dw2, db2 = ops.wino_wgrad_gemm(Y2, kept, part2, g_below, ci)
+        dwr, dbr = ops.wino_wgrad_gemm(Y_ref, kept, part_ref, g_below, ci)
+        _close(dw2, dwr, tol=1e-6, what=f"chained wgrad {case}")
+        _close(db2, dbr, tol=1e-6, what=f"chained bias gradient {case}")
+        assert float((db2.cpu().double() - sr.cpu()).abs().max()) <= 1e-4 * max(1.0, float(sr.abs().max()))
+
+
 @pytest.mark.parametrize("case", [(2, 22, 22, 32, 8, False), (1, 75, 75, 32, 12, True), (2, 9, 13, 64, 4, False), (1, 15, 11, 32, 8, True),
                                   (1, 150, 150, 64, 64, False)])
 def test_winograd_forward_fused_with_maxpool(case):

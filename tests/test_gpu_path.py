@@ -1593,8 +1593,8 @@ def test_bf16_train_step_vs_decision_and_rounding_pinned_f64_oracle(golden_net):
     masks, max-pool arg-max codes, hard negatives -- and the bf16 (or f32) VALUE every activation and every activation gradient was
     stored as: each layer of the oracle is fed exactly what the HIP layer was fed.  Then
       (a) layer by layer, the oracle's own result must round to what the HIP kernel stored: within half a bf16 spacing (one
-          round-to-nearest; 1.01 where the build adds two stored contributions) -- a per-layer check of every forward and data-gradient
-          kernel that no flip upstream can blur;
+          round-to-nearest; conv4_3's gradient has two contributions and two roundings, each followed and checked on its own) -- a
+          per-layer check of every forward and data-gradient kernel that no flip upstream can blur;
       (b) all 71 parameter gradients are within ONE fixed relative-L2 bar, 1e-4, of the f64 result (what is left is f32 summation order
           inside one layer); the losses within 1e-4."""
     import grad_measure as M
@@ -1610,8 +1610,8 @@ def test_bf16_train_step_vs_decision_and_rounding_pinned_f64_oracle(golden_net):
     assert len(rep) >= 2 * len(pinned["fwd"]) - 2, sorted(rep)
     worst = sorted(((v, k) for k, v in rep.items()), reverse=True)
     print("rounding-pinned layer distances (spacings): " + ", ".join(f"{k} {v:.3f}" for v, k in worst[:8]))
-    two_adds = {"a4_3:bwd", "a7:bwd", "a8:bwd", "a9:bwd", "a10:bwd"}          # tensors with two consumers: two stored contributions
-    bad = [(k, v) for k, v in rep.items() if v > (1.01 if k in two_adds else 0.51 if k.split(":")[0] in pinned["bf16"] else 1.0)]
+    assert "a4_3:1" in pinned["bwd"] and "a4_3:1:bwd" in rep
+    bad = [(k, v) for k, v in rep.items() if v > (0.51 if k.split(":")[0] in pinned["bf16"] else 1.0)]
     assert not bad, bad
     assert abs(l1 - a1) <= 1e-4 * max(1, a1) and abs(l2 - a2) <= 1e-4 * max(1, a2), (l1, a1, l2, a2)
     assert len(g64) == 71 and set(g64) == set(grads)
