@@ -106,8 +106,12 @@ constexpr int X3_LIMB = 128 * 32;          // bytes of one limb image: [128 rows
 constexpr int X3_OPER = 3 * X3_LIMB;       // one operand, one stage
 constexpr int X3_STAGE = 2 * X3_OPER;      // A + B
 
-template <bool EPI>             // EPI: the 1x1 convolutions' epilogue (its own instantiation: the plane GEMMs keep their straight store)
-__global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Params p) {
+// M16: the same products on v_mfma_f32_16x16x32_bf16 -- TWO limb products per instruction, the limbs concatenated along the instruction's
+// K = 32: [hi | mid] x [hi | hi] = hi hi + mid hi, [hi | mid] x [mid | mid] = hi mid + mid mid, [hi | lo] x [lo | hi] = hi lo + lo hi (lanes 0-31 of
+// an operand read limb X, lanes 32-63 limb Y of the same 16 k).  Same cycles per FLOP as 32x32x16; the chip can hold a higher clock on this
+// shape (MI355X_MICROARCH.md, DVFS give-back item 7).  20 fragment reads per step instead of 12, 48 MFMAs instead of 24.
+template <bool EPI, bool M16 = false>       // EPI: the 1x1 convolutions' epilogue (its own instantiation: the plane GEMMs keep their straight store)
+__global__ __launch_bounds__(256, M16 ? 2 : 3) void gemm_planes_x3_kernel(const GemmX3Params p) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * X3_STAGE];       // 48 KB: three workgroups per CU
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -173,15 +177,28 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
     };
 
     f32x16 acc[2][2];
+    f32x4 acc4[M16 ? 4 : 1][M16 ? 4 : 1];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < (M16 ? 4 : 1); ++i)
+#pragma unroll
+        for (int j = 0; j < (M16 ? 4 : 1); ++j) acc4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const unsigned frag = lr * 32 + ((lh ^ ((lr >> 3) & 1)) << 4);
     const unsigned a_rd = wm * 64 * 32 + frag, b_rd = X3_OPER + wn * 64 * 32 + frag;
+    // M16: lane = (row r16 of a 16-row block, quarter g4): k half g4 & 1 of limb X (g4 < 2) or limb Y (g4 >= 2)
+    const int r16 = lane & 15, g4 = lane >> 4;
+    const unsigned frag16 = r16 * 32 + (((g4 & 1) ^ ((r16 >> 3) & 1)) << 4);
+    const unsigned up = g4 >> 1;                              // 0: this lane reads the first limb of the pair, 1: the second
+    // A' kinds: 0 = [hi | mid], 1 = [hi | lo];  B' kinds: 0 = [hi | hi], 1 = [mid | mid], 2 = [lo | hi]
+    const unsigned a16[2] = {wm * 64 * 32 + frag16 + up * X3_LIMB, wm * 64 * 32 + frag16 + up * 2 * X3_LIMB};
+    const unsigned b16[3] = {X3_OPER + wn * 64 * 32 + frag16, X3_OPER + wn * 64 * 32 + frag16 + X3_LIMB,
+                             X3_OPER + wn * 64 * 32 + frag16 + (1 - up) * 2 * X3_LIMB};
 
     // one step on LDS stage PH: 12 fragment reads, then 24 MFMAs (product-major, smallest limb products first) with the split of the
     // other register set's rows placed by hand between them -- one stage (<= 4 VALU instructions) of one pair per MFMA, pinned by
@@ -194,6 +211,8 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
         // it cannot know the data has not arrived -- and one build of the 1x1 instantiation did exactly that)
         const unsigned char* st = lds + PH * X3_STAGE;
         bf16x8 af[3][2], bf[3][2];
+        bf16x8 af4[2][4], bf4[3][4];
+        if constexpr (!M16) {
 #pragma unroll
         for (int g = 0; g < 3; ++g)                // in the order the products need them
 #pragma unroll
@@ -206,6 +225,21 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
 #ifdef X3_SETPRIO
         __builtin_amdgcn_s_setprio(X3_SETPRIO);
 #endif
+        } else {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {          // in the order the products need them: [hi|lo] x [lo|hi], then [hi|mid] x [mid|mid], then x [hi|hi]
+                const int ka = g == 0 ? 1 : 0, kb = g == 0 ? 2 : (g == 1 ? 1 : 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (g < 2) af4[ka][i] = *reinterpret_cast<const bf16x8*>(st + a16[ka] + i * 512);
+                    bf4[kb][i] = *reinterpret_cast<const bf16x8*>(st + b16[kb] + i * 512);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef X3_SETPRIO
+            __builtin_amdgcn_s_setprio(X3_SETPRIO);
+#endif
+        }
         const f32x4 v0 = ra[PH ^ 1][0], v1 = ra[PH ^ 1][1];
         float xa[4] = {v0[0], v0[2], v1[0], v1[2]}, xb[4] = {v0[1], v0[3], v1[1], v1[3]};
 #pragma unroll
@@ -215,6 +249,29 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
         }
         unsigned hi[4], mid[4], lo[4];
         float r1a[4], r1b[4];
+        if constexpr (M16) {
+#pragma unroll
+            for (int q = 0; q < 48; ++q) {
+                const int pr = q >> 4, i = (q >> 2) & 3, j = q & 3;
+                const int ka = pr == 0 ? 1 : 0, kb = pr == 0 ? 2 : (pr == 1 ? 1 : 0);
+                acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af4[ka][i], bf4[kb][j], acc4[i][j], 0, 0, 0);
+                if (q >= 4 && q < 44 && (q & 1) == 0) {      // one split stage per two 16-cycle MFMAs
+                    const int sl = (q - 4) >> 1, e = sl / 5, sg = sl % 5;
+                    if (sg == 0) { hi[e] = pack_rne(xa[e], xb[e]); asm volatile("" : "+v"(hi[e])); }
+                    if (sg == 1) {
+                        r1a[e] = xa[e] - __uint_as_float(hi[e] << 16); r1b[e] = xb[e] - __uint_as_float(hi[e] & 0xffff0000u);
+                        asm volatile("" : "+v"(r1a[e]), "+v"(r1b[e]));
+                    }
+                    if (sg == 2) { mid[e] = pack_rne(r1a[e], r1b[e]); asm volatile("" : "+v"(mid[e])); }
+                    if (sg == 3) {
+                        r1a[e] -= __uint_as_float(mid[e] << 16); r1b[e] -= __uint_as_float(mid[e] & 0xffff0000u);
+                        asm volatile("" : "+v"(r1a[e]), "+v"(r1b[e]));
+                    }
+                    if (sg == 4) { lo[e] = pack_rne(r1a[e], r1b[e]); asm volatile("" : "+v"(lo[e])); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < 24; ++q) {
             const int pr = q >> 2, i = (q >> 1) & 1, j = q & 1;
@@ -240,6 +297,7 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
             if (q == 2) { for (int e = 0; e < 4; ++e) { hi[e] = __float_as_uint(xa[e]); mid[e] = __float_as_uint(xb[e]); lo[e] = hi[e] ^ mid[e]; } }
 #endif
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
 #ifdef X3_SETPRIO
         __builtin_amdgcn_s_setprio(0);
@@ -300,29 +358,45 @@ __global__ __launch_bounds__(256, 3) void gemm_planes_x3_kernel(const GemmX3Para
     wait_vmcnt<0>();
 
     float* out = p.out + (size_t)b * p.batch_out;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + lr;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);       // bits 2 and 5 of m: lh and i
-                float v = ((lh ^ i) & 1) ? -acc[i][j][r] : acc[i][j][r];                     // the row's sign s(m) again
-                if (m < p.M && n < p.N) {
-                    if constexpr (!EPI) {
-                        out[(size_t)m * p.N + n] = v;
-                    } else {                                                                 // (same order as igemm_epilogue, conv_igemm.hip)
-                        const size_t idx = (size_t)m * p.ldo + n;
-                        if (p.bias != nullptr) v += p.bias[n];
-                        if (p.accumulate) v += out[idx];
-                        if (p.relu) v = v < 0.f ? 0.f : v;                                   // NaN stays NaN, like torch.relu
-                        if (p.mask != nullptr) v = p.mask[idx] > 0.f ? v : 0.f;
-                        out[idx] = v;
-                    }
-                }
+    auto store = [&](int m, int n, float v) {
+        if (m < p.M && n < p.N) {
+            if constexpr (!EPI) {
+                out[(size_t)m * p.N + n] = v;
+            } else {                                                                 // (same order as igemm_epilogue, conv_igemm.hip)
+                const size_t idx = (size_t)m * p.ldo + n;
+                if (p.bias != nullptr) v += p.bias[n];
+                if (p.accumulate) v += out[idx];
+                if (p.relu) v = v < 0.f ? 0.f : v;                                   // NaN stays NaN, like torch.relu
+                if (p.mask != nullptr) v = p.mask[idx] > 0.f ? v : 0.f;
+                out[idx] = v;
             }
         }
+    };
+    if constexpr (M16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + r16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * 64 + i * 16 + 4 * g4 + r;                    // bits 2 and 5 of m: g4 & 1 and i >> 1
+                    store(m, n, ((g4 ^ (i >> 1)) & 1) ? -acc4[i][j][r] : acc4[i][j][r]); // the row's sign s(m) again
+                }
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + lr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + i * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);   // bits 2 and 5 of m: lh and i
+                    store(m, n, ((lh ^ i) & 1) ? -acc[i][j][r] : acc[i][j][r]);              // the row's sign s(m) again
+                }
+            }
+    }
 }
 
 #ifdef X3_PIPE      // EXPERIMENT, not built by default (tools/x3_variants.sh "" "-DX3_PIPE"): measured below
@@ -758,6 +832,7 @@ extern "C" int ssd_gemm_x3_split_weights(const float* w, void* w3, int rows, int
     return SSD_OK;
 }
 
+static int g_x3_m16 = 0;      // ssd_tune_set_x3_mfma: 1 = the plane GEMMs on v_mfma_f32_16x16x32_bf16 (limb pairs concatenated along K), 0 = 32x32x16
 // Internal (not part of the C ABI): the x3 form of ssd_internal_gemm_batched (conv_igemm.hip); w3 from ssd_gemm_x3_split_weights
 __attribute__((visibility("hidden"))) int ssd_internal_gemm_batched_x3(const float* a, const void* w3, float* out, int M, int K, int N, int n_rows,
                                                                         int nbatch, size_t batch_a_elems, hipStream_t st) {
@@ -783,10 +858,19 @@ __attribute__((visibility("hidden"))) int ssd_internal_gemm_batched_x3(const flo
     }
     hipLaunchKernelGGL(gemm_planes_x3p_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, st, p);
 #else
-    hipLaunchKernelGGL(gemm_planes_x3_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, st, p);
+    if (g_x3_m16) hipLaunchKernelGGL((gemm_planes_x3_kernel<false, true>), dim3((unsigned)nblk), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_planes_x3_kernel<false, false>), dim3((unsigned)nblk), dim3(256), 0, st, p);
 #endif
     ssd_internal_prof_close(slot, st);
     SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
+// Tuning aid: MFMA shape of the limb plane GEMMs (forward / data gradient of the Winograd layers): 32 = v_mfma_f32_32x32x16_bf16 (default),
+// 16 = v_mfma_f32_16x16x32_bf16 with two limb products per instruction.
+extern "C" int ssd_tune_set_x3_mfma(int rows) {
+    if (rows != 16 && rows != 32) return SSD_ERR_BAD_SHAPE;
+    g_x3_m16 = rows == 16;
     return SSD_OK;
 }
 

@@ -1351,8 +1351,11 @@ def test_overlapped_exchange_waits_for_gradients_written_on_the_side_stream():
     assert np.array_equal(res["plain"], res["overlap_delayed"])
 
 
-def test_second_stream_schedule_is_bitwise_the_single_stream_step():
-    """The engine runs the tiny-map group (c_8, seq9 ... c_11: ~60 latency-bound launches per direction) on a second HIP stream beside
+@pytest.mark.parametrize("form", ["adjoint", "rotated + weight-gradient stream"])
+def test_second_stream_schedule_is_bitwise_the_single_stream_step(form):
+    """(form: the default engine, whose >= 256-channel data gradients take the adjoint Winograd form and share the weight gradient's
+    planes -- there is no third stream then -- and the round-3 engine with the rotated-filter form and the weight-gradient stream.)
+    The engine runs the tiny-map group (c_8, seq9 ... c_11: ~60 latency-bound launches per direction) on a second HIP stream beside
     the c_4 / c_7 head convolutions, forward and backward, and the Winograd weight-gradient GEMMs (which nothing in the backward pass
     waits for) on a third beside the data-gradient chain.  Same kernels, same operands, only the stream differs: outputs, losses and
     every gradient must be bit-identical to the single-stream schedule, three steps in a row (events order every cross-stream use)."""
@@ -1360,11 +1363,12 @@ def test_second_stream_schedule_is_bitwise_the_single_stream_step():
     from objectdetection_ssd_amd import Model
     torch.manual_seed(11)
     net = Model.SSD_300().to(DEV)
+    net._engine.adjoint_dgrad = form == "adjoint"
     x, cl, bx = M.bench_batch(bs=4, seed=77)
     res = {}
     for overlap in (True, False, True):
         net._engine.overlap_tail = overlap
-        net._engine.overlap_wgrad = overlap                  # ... and the Winograd weight-gradient GEMMs on a third one
+        net._engine.overlap_wgrad = overlap and form != "adjoint"      # ... and the Winograd weight-gradient GEMMs on a third one
         net._engine.batch_weights = overlap                  # ... and all filter transforms of the step in one launch vs layer by layer
         steps = [M.train_step(net, x, cl, bx) for _ in range(3)]
         for a in steps[1:]:

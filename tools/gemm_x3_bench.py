@@ -32,19 +32,34 @@ def main():
         f32 = lambda: _lib.check(lib.ssd_gemm_planes_f32(a.data_ptr(), w.data_ptr(), o32.data_ptr(), M, K, N, N, P, st), "f32")   # noqa: E731
         x3 = lambda: _lib.check(lib.ssd_gemm_planes_x3(a.data_ptr(), w3.data_ptr(), ox3.data_ptr(), M, K, N, N, P, st), "x3")    # noqa: E731
         res = {}
-        for tag, fn in (("f32", f32), ("x3", x3)):
-            for _ in range(3):
-                fn()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            pa = ops.clock_probe(dev)
-            for _ in range(20):
-                fn()
-            pb = ops.clock_probe(dev)
-            e1.record()
-            torch.cuda.synchronize()
-            res[tag] = e0.elapsed_time(e1) / 20
-            res[tag + "_mhz"] = ops.shader_mhz(pa, pb)
+
+        def x3m16():
+            _lib.check(lib.ssd_tune_set_x3_mfma(16), "tune")
+            try:
+                x3()
+            finally:
+                _lib.check(lib.ssd_tune_set_x3_mfma(32), "tune")
+        runs = {"f32": [], "x3": [], "x3m16": []}
+        for rnd in range(3):                       # interleaved rounds in one process (variants ranked on one device, one minute)
+            for tag, fn in (("f32", f32), ("x3", x3), ("x3m16", x3m16)):
+                for _ in range(3):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                pa = ops.clock_probe(dev)
+                for _ in range(20):
+                    fn()
+                pb = ops.clock_probe(dev)
+                e1.record()
+                torch.cuda.synchronize()
+                runs[tag].append((e0.elapsed_time(e1) / 20, ops.shader_mhz(pa, pb)))
+        for tag, r in runs.items():
+            r.sort()
+            res[tag], res[tag + "_mhz"] = r[1]
+        x3m16()
+        o16 = ox3.clone()
+        x3()
+        e16 = float((o16[0].double() - a[0].double() @ w[0].double().T).norm() / (a[0].double() @ w[0].double().T).norm())
         ref = a[0].double() @ w[0].double().T
         err = {t: float((o[0].double() - ref).norm() / ref.norm()) for t, o in (("f32", o32), ("x3", ox3))}
         last = P - 1
@@ -52,7 +67,7 @@ def main():
         err2 = float((ox3[last].double() - ref2).norm() / ref2.norm())
         fl = 2.0 * M * K * N * P
         print(f"{name:14s} M={M:6d} K={K:4d} N={N:4d}  f32 {res['f32']:.3f} ms {fl / res['f32'] / 1e9:7.1f} TF/s   x3 {res['x3']:.3f} ms "
-              f"{fl / res['x3'] / 1e9:7.1f} TF/s (executed bf16 {6 * fl / res['x3'] / 1e9:7.1f})   err f32 {err['f32']:.2e} x3 {err['x3']:.2e} / {err2:.2e}  clock f32 {res['f32_mhz']:.0f} x3 {res['x3_mhz']:.0f} MHz",
+              f"{fl / res['x3'] / 1e9:7.1f} TF/s (executed bf16 {6 * fl / res['x3'] / 1e9:7.1f})   x3/16x16x32 {res['x3m16']:.3f} ms (executed {6 * fl / res['x3m16'] / 1e9:7.1f}, err {e16:.2e}, {res['x3m16_mhz']:.0f} MHz)   err f32 {err['f32']:.2e} x3 {err['x3']:.2e} / {err2:.2e}  clock f32 {res['f32_mhz']:.0f} x3 {res['x3_mhz']:.0f} MHz",
               flush=True)
 
 
