@@ -426,7 +426,7 @@ def roofline_of(net, step, conv_dtype: str, ms: float, layers: bool = False) -> 
     tag, (tsum, fsum, n) = max(((k, v) for k, v in agg.items() if not k.startswith("winograd")), key=lambda kv: kv[1][0])
     ach = fsum / tsum / 1e12
     traffic = None            # HBM bytes per launch from the committed PMC passes of this round (a pointer: counters cannot be collected in the timed run)
-    traffic_file = "r03_bf16_traffic.json" if conv_dtype == "bf16" else "r03_traffic.json"
+    traffic_file = "r03_bf16_traffic.json" if conv_dtype == "bf16" else "r04_traffic.json"
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", traffic_file)))
         if tj["kernel"] == tag:
@@ -459,7 +459,7 @@ def roofline_of(net, step, conv_dtype: str, ms: float, layers: bool = False) -> 
                       "GEMMs + output transform): `achieved` counts the direct convolution's FLOPs, the GEMMs execute 2.25x fewer")
     roof = {"bound": "mfma", "kernel": tag + ", ...>", "achieved": round(ach, 2),
                        "peak": peak, "peak_note": peak_note, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                       "traffic": traffic, "traffic_unit": f"bytes per launch (profiles/{traffic_file})", "launches_timed": n, "avg_launch_ms": round(tsum / n * 1e3, 4),
+                       "traffic": traffic, "traffic_unit": f"bytes per launch (profiles/{traffic_file}: the PMC passes of this round's profile run -- counters cannot be collected inside this run)", "launches_timed": n, "avg_launch_ms": round(tsum / n * 1e3, 4),
                        "avg_launch_gflop": round(fsum / n / 1e9, 3),
                        "step_executed_gflop": round(exec_flops / 3 / 1e9, 1),
                        "step_executed_frac": round(exec_flops / 3 / (ms * 1e-3) / 1e12 / (2500.0 if conv_dtype == "bf16" else PEAK_F32_MFMA_TFLOPS), 4),
@@ -525,7 +525,7 @@ def main():
                     help="time the train step as ONE captured HIP graph replay per step (ddp.GraphedTrainStep) instead of ~250 eager launches. "
                          "Default off: at batch 32 the step is GPU-bound and the replay measures slower on the device than the eager two-stream "
                          "schedule; the default line reports the replay's numbers beside the headline (config.graph_step)")
-    ap.add_argument("--graph-two-streams", action="store_true", help="capture the tiny-map group on its second stream inside the graph too")
+    ap.add_argument("--graph-one-stream", action="store_true", help="capture the whole step on one stream (default: the tiny-map group on its second stream inside the graph, as in the eager step)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--rendezvous-only", action="store_true",
@@ -660,7 +660,7 @@ def main():
     gstep = None
     if use_graph:
         from objectdetection_ssd_amd.ddp import GraphedTrainStep
-        gstep = GraphedTrainStep(net, trainer, max_boxes_per_image=8, warmup=2, two_streams=args.graph_two_streams)
+        gstep = GraphedTrainStep(net, trainer, max_boxes_per_image=8, warmup=2, two_streams=not args.graph_one_stream)
 
         def step():
             return gstep(x, classes, boxes)
@@ -829,7 +829,7 @@ def main():
         from objectdetection_ssd_amd.ddp import GraphedTrainStep
         note("graph-step leg")
         keep_overlap = trainer.overlap
-        g2 = GraphedTrainStep(net, trainer, max_boxes_per_image=8, warmup=0, two_streams=args.graph_two_streams)
+        g2 = GraphedTrainStep(net, trainer, max_boxes_per_image=8, warmup=0, two_streams=not args.graph_one_stream)
         for _ in range(3):
             g2(x, classes, boxes)
         fence()

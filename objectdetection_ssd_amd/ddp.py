@@ -427,10 +427,15 @@ class GraphedTrainStep:
     issued after the graph (a collective started from inside the backward cannot be part of a replay), followed by the two SGD
     launches; `FlatSGDDataParallel(overlap=...)` is switched off for the life of this object.
 
+    two_streams (default): the tiny-map group (c_8, seq9 ... c_11) is captured on the engine's second stream, as the eager step runs it
+    -- the graph then has two parallel branches (fork / join by events inside the capture); False puts every node on one chain.
+    Measured interleaved with the eager step on one device (tools/ab_graph.py, batch 32, f32): eager 20.41 ms, replay with two branches
+    20.57, replay on one chain 21.03 -- the step is GPU-bound, so the replay buys HOST time (5.1 -> 0.3 ms per step), not device time.
+
     `__call__(x, classes, boxes)` -> (loc_sum, conf_sum, n_pos): 0-dim views of a static device tensor holding this rank's
     un-normalised loss sums and positive count (`Losses.ssd(..., norm_mode=1, with_n_pos=True)`), overwritten by the next call."""
 
-    def __init__(self, net, trainer: FlatSGDDataParallel, max_boxes_per_image: int = 8, warmup: int = 2, two_streams: bool = False):
+    def __init__(self, net, trainer: FlatSGDDataParallel, max_boxes_per_image: int = 8, warmup: int = 2, two_streams: bool = True):
         self.net, self.trainer = net, trainer
         self.max_per_image, self.warmup = int(max_boxes_per_image), int(warmup)
         self.two_streams = bool(two_streams)

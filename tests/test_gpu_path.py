@@ -1513,8 +1513,8 @@ def test_overflowing_step_is_non_finite_in_both_gemm_forms():
     assert abs(res[1][0] - res[0][0]) <= 1e-4 * max(1, abs(res[0][0])) and abs(res[1][1] - res[0][1]) <= 1e-4 * max(1, abs(res[0][1]))
 
 
-@pytest.mark.parametrize("conv_dtype", ["f32", "bf16"])
-def test_graphed_train_step_is_bitwise_the_eager_step(conv_dtype):
+@pytest.mark.parametrize("conv_dtype,two_streams", [("f32", True), ("f32", False), ("bf16", True)])
+def test_graphed_train_step_is_bitwise_the_eager_step(conv_dtype, two_streams):
     """ddp.GraphedTrainStep (the captured form of train_function.py:80-95's loop body): forward + MultiBox loss + backward + fused SGD
     replayed from ONE HIP graph must leave the weights, the momentum and the loss sums bit-identical to the eager step, step after
     step, on batches whose ground-truth counts differ from the captured one (the offsets are data, not shape)."""
@@ -1528,7 +1528,7 @@ def test_graphed_train_step_is_bitwise_the_eager_step(conv_dtype):
         n.conv_dtype = conv_dtype
         nets.append(n)
         trs.append(FlatSGDDataParallel(n, lr=lr, momentum=0.9, weight_decay=5e-4))
-    gstep = GraphedTrainStep(nets[1], trs[1], max_boxes_per_image=8, warmup=2)
+    gstep = GraphedTrainStep(nets[1], trs[1], max_boxes_per_image=8, warmup=2, two_streams=two_streams)
     for it in range(6):
         x = _t(np.random.default_rng(100 + it).standard_normal((bs, 3, 300, 300), dtype=np.float32))
         boxes, classes = synth_gt(np.random.default_rng(200 + it), bs)
