@@ -1,0 +1,174 @@
+// Plane GEMMs from PRE-SPLIT limbs on both sides (round 4 experiment; reached through ssd_gemm_planes_x3v2 only -- not on the step's path yet):
+//
+//     out[b][m][n] = sum_k a[b][m][k] * w[b][n][k],   a and w both given as three exact bf16 limbs per f32 value in the pre-tiled layout
+//     [b][K/16][3][rows_pad128][16] of ssd_gemm_x3_split_weights (csrc/gemm_x3.hip): six limb products per f32 product, f32 accumulate.
+//
+// What it tests: the 128 x 128 kernel of gemm_x3.hip sits at 0.47 MFMA busy -- its three small workgroups per CU meet at their barriers
+// together, and a wave splits its activation rows in registers.  Here
+//   * 256 x 256 tile, 512 threads = 8 waves (2 x 4: wave tile 128 x 64 = 4 x 2 MFMA tiles of v_mfma_f32_32x32x16_bf16), ONE workgroup per CU;
+//   * both operands arrive by LDS-DMA (global_load_lds_dwordx4), no VALU in the loop: a K step of 16 is 48 KB (two operands x three limbs
+//     x 256 rows x 32 bytes), three slots = 144 KB of LDS, six 1-KB DMA instructions per wave and step;
+//   * PING-PONG (cdna_hip_programming.md section 5, the 8-phase template's stagger; MI355X_MICROARCH.md "Two waves per SIMD"): waves 0-3 and
+//     waves 4-7 -- one of each per SIMD -- run half a step apart.  A step is a READ phase (wait for the DMA issued a step ago, 18
+//     ds_read_b128 of this step's fragments, issue the DMA of step + 2) and a MATRIX phase (48 MFMAs, 1536 cycles), a barrier after each;
+//     one group's read phase runs beside the other group's matrix phase, so each SIMD's matrix pipe always has one wave issuing.
+// Slot safety: the DMA of step t + 2 overwrites the slot of step t - 1, whose last reads (the other group's) finished before the barrier
+// that precedes this read phase; data of step t is waited for (vmcnt(0) at the top of read phase t - 1, a full step after its issue) by
+// every wave and published by the barriers in between (rule "read a staged buffer one phase after the wait that retires it").
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+struct X3V2Params {
+    const __bf16* __restrict__ a3;      // [nbatch][K/16][3][rows_a][16]
+    const __bf16* __restrict__ w3;      // [nbatch][K/16][3][rows_w][16]
+    float* __restrict__ out;            // [nbatch][M][N]
+    int M, K, N, rows_a, rows_w;
+    int tiles_m, tiles_n, nbatch;
+    int dither;                         // 1: the rows of a3 were stored with the sign s(m) = (-1)^(bit 2 ^ bit 5 of m) (gemm_x3.hip): undo it on the way out
+};
+
+constexpr int V2_LIMB = 256 * 32;              // bytes of one limb image: [256 rows][16 k] bf16
+constexpr int V2_OPER = 3 * V2_LIMB;           // one operand, one step: 24 KB
+constexpr int V2_STAGE = 2 * V2_OPER;          // A + B: 48 KB
+constexpr int V2_SLOTS = 3;
+
+__global__ __launch_bounds__(512, 1) void gemm_planes_x3v2_kernel(const X3V2Params p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];          // 144 KB (dynamic: above the 64 KB static limit)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;                  // ping-pong group: waves 0-3 lead, waves 4-7 follow half a step behind
+    const int w4 = wave & 3;
+    const int wm = w4 >> 1, wn2 = (w4 & 1) * 2 + grp;      // wave tile: rows wm * 128 .. + 127, columns wn2 * 64 .. + 63 (each group covers all four column blocks over its two wm)
+    const int lr = lane & 31, lh = lane >> 5;
+    const int nblk = p.tiles_m * p.tiles_n * p.nbatch;
+    int lid = xcd_swizzle(blockIdx.x, nblk);
+    const int tile_n = lid % p.tiles_n;
+    lid /= p.tiles_n;
+    const int tile_m = lid % p.tiles_m, b = lid / p.tiles_m;
+    const int m0 = tile_m * 256, n0 = tile_n * 256;
+    const int NK = p.K >> 4;
+
+    // ---- DMA pieces of this wave: 48 one-KB pieces per step (operand, limb, 32-row block), six per wave -----------------------------------
+    // a piece = 32 rows x 32 bytes of one limb image; lane = (row of the piece, 16-byte half); the image's XOR (half ^ bit 3 of the row) is applied
+    // on the source address, the LDS destination is linear (rule 21)
+    const int prow = lane >> 1, phalf = lane & 1;
+    const __bf16* src[6];
+    int dst[6];
+    size_t kstride[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int q = wave * 6 + i;                 // 0..47
+        const int oper = q / 24, r = q % 24, limb = r / 8, blk = r % 8;
+        const int row = blk * 32 + prow;
+        const int half = phalf ^ ((row >> 3) & 1);
+        const int rows = oper == 0 ? p.rows_a : p.rows_w;
+        int grow = (oper == 0 ? m0 : n0) + row;
+        grow = grow < rows ? grow : rows - 1;       // beyond the operand: any valid row (its products are never stored)
+        const __bf16* base = (oper == 0 ? p.a3 : p.w3) + (size_t)b * NK * 3 * rows * 16;
+        src[i] = base + ((size_t)limb * rows + grow) * 16 + half * 8;
+        kstride[i] = (size_t)3 * rows * 16;
+        dst[i] = oper * V2_OPER + limb * V2_LIMB + blk * 1024;
+    }
+    auto issue = [&](int ks, int slot) {
+        unsigned char* base = lds + slot * V2_STAGE;
+        const int k = ks < NK ? ks : NK - 1;        // beyond the last step: re-fetch the last one (never read): every wait count stays a constant
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src[i] + (size_t)k * kstride[i]), (lds_void*)(base + dst[i]), 16, 0, 0);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const unsigned frag = lr * 32 + ((lh ^ ((lr >> 3) & 1)) << 4);
+    const unsigned a_rd = wm * 128 * 32 + frag, b_rd = V2_OPER + wn2 * 64 * 32 + frag;
+
+    // prologue: steps 0 and 1 requested; the follower group enters the loop one barrier late
+    issue(0, 0);
+    issue(1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // step 0 has landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();                             // ... everyone's
+    if (grp == 1) __builtin_amdgcn_s_barrier();               // the stagger: from here on the follower is half a step behind
+
+    for (int ks = 0; ks < NK; ++ks) {
+        const int slot = ks % V2_SLOTS;
+        // ---- read phase -----------------------------------------------------------------------------------------------------------------
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA issued a step ago (step ks + 1): published by the two barriers below
+        const unsigned char* st = lds + slot * V2_STAGE;
+        bf16x8 af[3][4], bf[3][2];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[pl][i] = *reinterpret_cast<const bf16x8*>(st + a_rd + pl * V2_LIMB + i * 1024);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8*>(st + b_rd + pl * V2_LIMB + j * 1024);
+        }
+        issue(ks + 2, (ks + 2) % V2_SLOTS);                   // into the slot of step ks - 1: both groups finished reading it before the barrier above this phase
+        __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0): the fragments are in registers (the DMA stays in flight)
+        __builtin_amdgcn_s_barrier();
+        // ---- matrix phase ---------------------------------------------------------------------------------------------------------------
+        __builtin_amdgcn_s_setprio(1);
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // smallest limb products first (gemm_x3.hip)
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[pr]][i], bf[PB[pr]][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();               // the leader's matching extra barrier: both groups have executed the same number
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    float* out = p.out + (size_t)b * ((size_t)p.M * p.N);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn2 * 64 + j * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 128 + i * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);       // bits 2 and 5 of m: lh and i & 1
+                float v = acc[i][j][r];
+                if (p.dither && ((lh ^ i) & 1)) v = -v;
+                if (m < p.M && n < p.N) out[(size_t)m * p.N + n] = v;
+            }
+        }
+}
+
+}  // namespace
+
+// Experiment entry (declared in include/ssd_gfx950.h): both operands as limb planes of ssd_gemm_x3_split_weights (rows_pad = ceil128 of M / n_rows).
+extern "C" int ssd_gemm_planes_x3v2(const void* a3, const void* w3, float* out, int M, int K, int N, int n_rows, int nbatch, int dither, void* stream) {
+    if (!a3 || !w3 || !out) return SSD_ERR_NULL;
+    if (M <= 0 || N <= 0 || K <= 0 || K % 32 != 0 || n_rows < N || nbatch <= 0) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(a3) || !ssd_aligned16(w3) || !ssd_aligned16(out)) return SSD_ERR_ALIGN;
+    X3V2Params p{};
+    p.a3 = static_cast<const __bf16*>(a3); p.w3 = static_cast<const __bf16*>(w3); p.out = out;
+    p.M = M; p.K = K; p.N = N; p.rows_a = ssd_cdiv(M, 128) * 128; p.rows_w = ssd_cdiv(n_rows, 128) * 128;
+    p.tiles_m = ssd_cdiv(M, 256); p.tiles_n = ssd_cdiv(N, 256); p.nbatch = nbatch; p.dither = dither ? 1 : 0;
+    const size_t nblk = (size_t)p.tiles_m * p.tiles_n * nbatch;
+    if (nblk >= (1ull << 31)) return SSD_ERR_BAD_SHAPE;
+    static std::atomic<unsigned long long> raised{0};
+    int dev;
+    if (ssd_attr_needed(raised, dev)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_planes_x3v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, V2_SLOTS * V2_STAGE) !=
+            hipSuccess)
+            return SSD_ERR_LAUNCH;
+        ssd_attr_done(raised, dev);
+    }
+    hipLaunchKernelGGL(gemm_planes_x3v2_kernel, dim3((unsigned)nblk), dim3(512), V2_SLOTS * V2_STAGE, (hipStream_t)stream, p);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}

@@ -32,6 +32,10 @@ def main():
         f32 = lambda: _lib.check(lib.ssd_gemm_planes_f32(a.data_ptr(), w.data_ptr(), o32.data_ptr(), M, K, N, N, P, st), "f32")   # noqa: E731
         x3 = lambda: _lib.check(lib.ssd_gemm_planes_x3(a.data_ptr(), w3.data_ptr(), ox3.data_ptr(), M, K, N, N, P, st), "x3")    # noqa: E731
         res = {}
+        a3 = torch.empty(lib.ssd_gemm_x3_weights_bytes(M, K, P), dtype=torch.uint8, device=dev)     # the activation operand as limb planes too
+        _lib.check(lib.ssd_gemm_x3_split_weights(a.data_ptr(), a3.data_ptr(), M, K, P, st), "split a")
+        ov2 = torch.empty(P, M, N, device=dev)
+        v2 = lambda: _lib.check(lib.ssd_gemm_planes_x3v2(a3.data_ptr(), w3.data_ptr(), ov2.data_ptr(), M, K, N, N, P, 0, st), "x3v2")   # noqa: E731
 
         def x3m16():
             _lib.check(lib.ssd_tune_set_x3_mfma(16), "tune")
@@ -39,9 +43,9 @@ def main():
                 x3()
             finally:
                 _lib.check(lib.ssd_tune_set_x3_mfma(32), "tune")
-        runs = {"f32": [], "x3": [], "x3m16": []}
+        runs = {"f32": [], "x3": [], "x3m16": [], "v2": []}
         for rnd in range(3):                       # interleaved rounds in one process (variants ranked on one device, one minute)
-            for tag, fn in (("f32", f32), ("x3", x3), ("x3m16", x3m16)):
+            for tag, fn in (("f32", f32), ("x3", x3), ("x3m16", x3m16), ("v2", v2)):
                 for _ in range(3):
                     fn()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -56,6 +60,10 @@ def main():
         for tag, r in runs.items():
             r.sort()
             res[tag], res[tag + "_mhz"] = r[1]
+        v2()
+        torch.cuda.synchronize()
+        ev2 = float((ov2[0].double() - a[0].double() @ w[0].double().T).norm() / (a[0].double() @ w[0].double().T).norm())
+        ev2l = float((ov2[P - 1].double() - a[P - 1].double() @ w[P - 1].double().T).norm() / (a[P - 1].double() @ w[P - 1].double().T).norm())
         x3m16()
         o16 = ox3.clone()
         x3()
@@ -67,7 +75,7 @@ def main():
         err2 = float((ox3[last].double() - ref2).norm() / ref2.norm())
         fl = 2.0 * M * K * N * P
         print(f"{name:14s} M={M:6d} K={K:4d} N={N:4d}  f32 {res['f32']:.3f} ms {fl / res['f32'] / 1e9:7.1f} TF/s   x3 {res['x3']:.3f} ms "
-              f"{fl / res['x3'] / 1e9:7.1f} TF/s (executed bf16 {6 * fl / res['x3'] / 1e9:7.1f})   x3/16x16x32 {res['x3m16']:.3f} ms (executed {6 * fl / res['x3m16'] / 1e9:7.1f}, err {e16:.2e}, {res['x3m16_mhz']:.0f} MHz)   err f32 {err['f32']:.2e} x3 {err['x3']:.2e} / {err2:.2e}  clock f32 {res['f32_mhz']:.0f} x3 {res['x3_mhz']:.0f} MHz",
+              f"{fl / res['x3'] / 1e9:7.1f} TF/s (executed bf16 {6 * fl / res['x3'] / 1e9:7.1f})   x3/16x16x32 {res['x3m16']:.3f} ms (executed {6 * fl / res['x3m16'] / 1e9:7.1f}, err {e16:.2e}, {res['x3m16_mhz']:.0f} MHz)   v2 256x256 ping-pong {res['v2']:.3f} ms (executed {6 * fl / res['v2'] / 1e9:7.1f}, err {ev2:.2e} / {ev2l:.2e}, {res['v2_mhz']:.0f} MHz)   err f32 {err['f32']:.2e} x3 {err['x3']:.2e} / {err2:.2e}  clock f32 {res['f32_mhz']:.0f} x3 {res['x3_mhz']:.0f} MHz",
               flush=True)
 
 
