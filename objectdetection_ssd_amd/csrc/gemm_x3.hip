@@ -832,6 +832,9 @@ extern "C" int ssd_gemm_x3_split_weights(const float* w, void* w3, int rows, int
     return SSD_OK;
 }
 
+int ssd_internal_gemm_batched_x3s(const float* a, const void* w3, float* out, int M, int K, int N, int n_rows, int nbatch, size_t batch_a_elems,
+                                  hipStream_t st);       // csrc/gemm_x3v2.hip: 256 x 256 tiles, two wave groups in ping-pong
+static int g_x3_big = 1;       // ssd_tune_set_x3_big: 0 = every launch on the 128 x 128 kernel, 1 = the large launches on the 256 x 256 ping-pong kernel, 2 = all that fit
 static int g_x3_m16 = 0;      // ssd_tune_set_x3_mfma: 1 = the plane GEMMs on v_mfma_f32_16x16x32_bf16 (limb pairs concatenated along K), 0 = 32x32x16
 // Internal (not part of the C ABI): the x3 form of ssd_internal_gemm_batched (conv_igemm.hip); w3 from ssd_gemm_x3_split_weights
 __attribute__((visibility("hidden"))) int ssd_internal_gemm_batched_x3(const float* a, const void* w3, float* out, int M, int K, int N, int n_rows,
@@ -845,6 +848,15 @@ __attribute__((visibility("hidden"))) int ssd_internal_gemm_batched_x3(const flo
     p.batch_a = batch_a_elems; p.batch_out = (size_t)M * N;
     const size_t nblk = (size_t)p.tiles_m * p.tiles_n * nbatch;
     if (nblk >= (1ull << 31)) return SSD_ERR_BAD_SHAPE;
+    // The large launches (conv3_2 ... conv4_3, fc6 and their data gradients: N >= 256 columns, >= 8 row tiles) take the 256 x 256 ping-pong kernel
+    // (csrc/gemm_x3v2.hip); short grids and narrow N keep the 128 x 128 tiles, which quantise better (measured: tools/gemm_x3_bench.py).
+    if (K >= 64 && N % 4 == 0 && ((g_x3_big == 1 && N >= 256 && M >= 2048) || g_x3_big == 2)) {
+        const size_t nblk2 = (size_t)ssd_cdiv(M, 256) * ssd_cdiv(N, 256) * nbatch;
+        const int slot2 = ssd_internal_prof_open(6.0 * 2.0 * (double)nblk2 * 256.0 * 256.0 * K, 4, st);
+        const int e = ssd_internal_gemm_batched_x3s(a, w3, out, M, K, N, n_rows, nbatch, batch_a_elems, st);
+        ssd_internal_prof_close(slot2, st);
+        return e;
+    }
     // recorder kind 4: the bf16 MFMA FLOPs the grid executes (six limb products per f32 product, whole 128 x 128 tiles)
     const int slot = ssd_internal_prof_open(6.0 * 2.0 * (double)nblk * 128.0 * 128.0 * K, 4, st);
 #ifdef X3_PIPE
@@ -863,6 +875,13 @@ __attribute__((visibility("hidden"))) int ssd_internal_gemm_batched_x3(const flo
 #endif
     ssd_internal_prof_close(slot, st);
     SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
+// Tuning aid: 0 = every limb plane GEMM on the 128 x 128 kernel, 1 (default) = the large launches on the 256 x 256 ping-pong kernel, 2 = every launch
+extern "C" int ssd_tune_set_x3_big(int mode) {
+    if (mode < 0 || mode > 2) return SSD_ERR_BAD_SHAPE;
+    g_x3_big = mode;
     return SSD_OK;
 }
 

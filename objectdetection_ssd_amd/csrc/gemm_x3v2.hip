@@ -147,6 +147,222 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_x3v2_kernel(const X3V2Para
         }
 }
 
+
+// ---- the same structure with the activation operand as it lies in memory today: f32 planes [M][K], split in the kernel ----------------------
+// (no change to the transform kernels, the kept planes or the weight-gradient GEMMs.)  A thread owns 8 consecutive k of one row per step, as in
+// gemm_x3.hip: the rows of step t + 3 are requested in read phase t (two 16-byte buffer loads into one of two register sets), the rows of
+// step t + 2 are split into limbs IN THE SHADOW of matrix phase t's MFMAs (hand-placed stages, <= 4 VALU per 32-cycle MFMA), and the limbs go to
+// LDS slot (t + 2) % 3 in read phase t + 1 -- a full step before either group reads them.  The weights arrive by LDS-DMA as above (three pieces
+// per wave and step).  The row's sign dither s(m) of gemm_x3.hip is applied before the split and undone in the epilogue.
+// Epilogue: a wave's 128 x 64 result goes through LDS (the ring is free by then) in two halves and leaves as 16-byte stores, 256 contiguous
+// bytes per row -- a quarter of the store instructions of the direct form, which at one workgroup per CU are not hidden behind anything.
+constexpr unsigned V2_OOB = 0xFFFFFF00u;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct X3SParams {
+    const float* __restrict__ a;        // [nbatch][M][K] f32
+    const __bf16* __restrict__ w3;      // [nbatch][K/16][3][rows_w][16]
+    float* __restrict__ out;            // [nbatch][M][N]
+    int M, K, N, rows_w;
+    int tiles_m, tiles_n, nbatch;
+    size_t batch_a, batch_out;
+};
+
+__device__ __forceinline__ unsigned v2_pack(float a, float b) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 h = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, h);
+}
+
+__global__ __launch_bounds__(512, 1) void gemm_planes_x3s_kernel(const X3SParams p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];          // 144 KB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, w4 = wave & 3;
+    const int wm = w4 >> 1, wn2 = (w4 & 1) * 2 + grp;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int nblk = p.tiles_m * p.tiles_n * p.nbatch;
+    int lid = xcd_swizzle(blockIdx.x, nblk);
+    const int tile_n = lid % p.tiles_n;
+    lid /= p.tiles_n;
+    const int tile_m = lid % p.tiles_m, b = lid / p.tiles_m;
+    const int m0 = tile_m * 256, n0 = tile_n * 256;
+    const int NK = p.K >> 4;
+
+    // A: thread -> (row, half): 8 consecutive k of one row per step (buffer loads: rows beyond M read as zero, no traffic)
+    const int arow = tid >> 1, ahalf = tid & 1;
+    const __amdgpu_buffer_rsrc_t srd_a =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a + (size_t)b * p.batch_a), 0, (int)((size_t)p.M * p.K * 4), 0x00020000);
+    const unsigned voff_a = m0 + arow < p.M ? ((unsigned)(m0 + arow) * (unsigned)p.K + ahalf * 8u) * 4u : V2_OOB;
+    const unsigned a_wr = arow * 32 + ((ahalf ^ ((arow >> 3) & 1)) << 4);
+    const unsigned a_sign = (unsigned)(((arow >> 2) ^ (arow >> 5)) & 1) << 31;
+    f32x4 ra[2][2];
+    auto load_a = [&](int ks, int set) {
+        const unsigned v = ks < NK ? voff_a : V2_OOB;
+        ra[set][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_a, (int)v, ks * 64, 0));
+        ra[set][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_a, (int)(v + 16u), ks * 64, 0));
+    };
+    // B: 24 one-KB pieces per step (limb, 32-row block), three per wave
+    const int prow = lane >> 1, phalf = lane & 1;
+    const __bf16* bsrc[3];
+    int bdst[3];
+    const size_t bk = (size_t)3 * p.rows_w * 16;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int q = wave * 3 + i, limb = q / 8, blk = q % 8;
+        const int row = blk * 32 + prow;
+        const int half = phalf ^ ((row >> 3) & 1);
+        int grow = n0 + row;
+        grow = grow < p.rows_w ? grow : p.rows_w - 1;
+        bsrc[i] = p.w3 + (size_t)b * NK * bk + ((size_t)limb * p.rows_w + grow) * 16 + half * 8;
+        bdst[i] = V2_OPER + limb * V2_LIMB + blk * 1024;
+    }
+    auto issue_b = [&](int ks, int slot) {
+        unsigned char* base = lds + slot * V2_STAGE;
+        const int k = ks < NK ? ks : NK - 1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(bsrc[i] + (size_t)k * bk), (lds_void*)(base + bdst[i]), 16, 0, 0);
+    };
+    unsigned hi[4], mid[4], lo[4];
+    auto split_now = [&](int set) {               // prologue only: the loop splits in the MFMA gaps
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x4 v = ra[set][e >> 1];
+            const float xa = __uint_as_float(__float_as_uint(v[(e & 1) * 2]) ^ a_sign), xb = __uint_as_float(__float_as_uint(v[(e & 1) * 2 + 1]) ^ a_sign);
+            hi[e] = v2_pack(xa, xb);
+            const float ra1 = xa - __uint_as_float(hi[e] << 16), rb1 = xb - __uint_as_float(hi[e] & 0xffff0000u);
+            mid[e] = v2_pack(ra1, rb1);
+            lo[e] = v2_pack(ra1 - __uint_as_float(mid[e] << 16), rb1 - __uint_as_float(mid[e] & 0xffff0000u));
+        }
+    };
+    auto store_limbs = [&](int slot) {
+        unsigned char* d = lds + slot * V2_STAGE + a_wr;
+        *reinterpret_cast<u32x4*>(d) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+        *reinterpret_cast<u32x4*>(d + V2_LIMB) = u32x4{mid[0], mid[1], mid[2], mid[3]};
+        *reinterpret_cast<u32x4*>(d + 2 * V2_LIMB) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const unsigned frag = lr * 32 + ((lh ^ ((lr >> 3) & 1)) << 4);
+    const unsigned a_rd = wm * 128 * 32 + frag, b_rd = V2_OPER + wn2 * 64 * 32 + frag;
+
+    // prologue: weights of steps 0 and 1 requested; rows of steps 0, 1 loaded and split (step 0 -> slot 0, step 1 stays in the limb registers for
+    // read phase 0), rows of step 2 in flight
+    issue_b(0, 0);
+    issue_b(1, 1);
+    load_a(0, 0);
+    load_a(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    split_now(0);
+    store_limbs(0);
+    split_now(1);
+    load_a(2, 0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+
+    for (int ks = 0; ks < NK; ++ks) {
+        const int slot = ks % V2_SLOTS;
+        // ---- read phase: limbs of step ks + 1 to LDS, fragments of step ks, requests for steps ks + 2 (weights) and ks + 3 (rows) ---------------
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // everything requested a step ago: the weights of ks + 1, the rows of ks + 2
+        store_limbs((ks + 1) % V2_SLOTS);
+        const unsigned char* st = lds + slot * V2_STAGE;
+        bf16x8 af[3][4], bf[3][2];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[pl][i] = *reinterpret_cast<const bf16x8*>(st + a_rd + pl * V2_LIMB + i * 1024);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8*>(st + b_rd + pl * V2_LIMB + j * 1024);
+        }
+        issue_b(ks + 2, (ks + 2) % V2_SLOTS);
+        const int cur = ks & 1;                               // register set holding the rows of step ks + 2 (requested in read phase ks - 1 / prologue)
+        // the rows of step ks + 3 go into the OTHER set, whose rows (step ks + 1) were split a phase ago
+        if (cur == 0) load_a(ks + 3, 1); else load_a(ks + 3, 0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        // ---- matrix phase: 48 MFMAs, the split of the rows of step ks + 2 in their gaps --------------------------------------------------------
+        __builtin_amdgcn_s_setprio(1);
+        const f32x4 v0 = cur == 0 ? ra[0][0] : ra[1][0], v1 = cur == 0 ? ra[0][1] : ra[1][1];
+        float xa[4] = {v0[0], v0[2], v1[0], v1[2]}, xb[4] = {v0[1], v0[3], v1[1], v1[3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            xa[e] = __uint_as_float(__float_as_uint(xa[e]) ^ a_sign);
+            xb[e] = __uint_as_float(__float_as_uint(xb[e]) ^ a_sign);
+        }
+        float r1a[4], r1b[4];
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < 48; ++q) {
+            const int pr = q >> 3, i = (q >> 1) & 3, j = q & 1;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[pr]][i], bf[PB[pr]][j], acc[i][j], 0, 0, 0);
+            if (q >= 2 && q < 42 && (q & 1) == 0) {          // one split stage per two MFMAs
+                const int sl = (q - 2) >> 1, e = sl / 5, sg = sl % 5;
+                if (sg == 0) { hi[e] = v2_pack(xa[e], xb[e]); asm volatile("" : "+v"(hi[e])); }
+                if (sg == 1) {
+                    r1a[e] = xa[e] - __uint_as_float(hi[e] << 16); r1b[e] = xb[e] - __uint_as_float(hi[e] & 0xffff0000u);
+                    asm volatile("" : "+v"(r1a[e]), "+v"(r1b[e]));
+                }
+                if (sg == 2) { mid[e] = v2_pack(r1a[e], r1b[e]); asm volatile("" : "+v"(mid[e])); }
+                if (sg == 3) {
+                    r1a[e] -= __uint_as_float(mid[e] << 16); r1b[e] -= __uint_as_float(mid[e] & 0xffff0000u);
+                    asm volatile("" : "+v"(r1a[e]), "+v"(r1b[e]));
+                }
+                if (sg == 4) { lo[e] = v2_pack(r1a[e], r1b[e]); asm volatile("" : "+v"(lo[e])); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                             // every wave is out of the loop: the ring can hold the result tiles
+
+    // ---- epilogue through LDS: per wave 64 rows x 64 columns at a time (row stride 68 floats: 16-byte aligned, conflict-light) -------------------
+    float* out = p.out + (size_t)b * p.batch_out;
+    float* mine = reinterpret_cast<float*>(lds) + wave * (64 * 68);
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+            const int i = h2 * 2 + i2;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i2 * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+                    const float v = ((lh ^ i) & 1) ? -acc[i][j][r] : acc[i][j][r];       // the row's sign s(m) again (bits 2 and 5 of m: lh and i & 1)
+                    mine[row * 68 + j * 32 + lr] = v;
+                }
+        }
+        // same wave writes and reads: the LDS queue is in order
+        const int c4 = lane & 15, rr = lane >> 4;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int row = t * 4 + rr;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(mine + row * 68 + c4 * 4);
+            const int m = m0 + wm * 128 + h2 * 64 + row, n = n0 + wn2 * 64 + c4 * 4;
+            if (m < p.M) {
+                float* po = out + (size_t)m * p.N + n;
+                if (n + 3 < p.N) *reinterpret_cast<f32x4*>(po) = v;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.N) po[e] = v[e];
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // Experiment entry (declared in include/ssd_gfx950.h): both operands as limb planes of ssd_gemm_x3_split_weights (rows_pad = ceil128 of M / n_rows).
@@ -169,6 +385,31 @@ extern "C" int ssd_gemm_planes_x3v2(const void* a3, const void* w3, float* out, 
         ssd_attr_done(raised, dev);
     }
     hipLaunchKernelGGL(gemm_planes_x3v2_kernel, dim3((unsigned)nblk), dim3(512), V2_SLOTS * V2_STAGE, (hipStream_t)stream, p);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
+// Internal (csrc/gemm_x3.hip dispatches here for the large launches): a [nbatch][M][K] f32 split in the kernel, w3 limb planes.
+__attribute__((visibility("hidden"))) int ssd_internal_gemm_batched_x3s(const float* a, const void* w3, float* out, int M, int K, int N, int n_rows,
+                                                                         int nbatch, size_t batch_a_elems, hipStream_t st) {
+    if (K % 32 != 0 || K < 48 || M <= 0 || N <= 0 || N % 4 != 0 || n_rows <= 0 || nbatch <= 0) return SSD_ERR_BAD_SHAPE;
+    if ((size_t)M * K * 4 >= 0xF0000000ull) return SSD_ERR_BAD_SHAPE;
+    X3SParams p{};
+    p.a = a; p.w3 = static_cast<const __bf16*>(w3); p.out = out;
+    p.M = M; p.K = K; p.N = N; p.rows_w = ssd_cdiv(n_rows, 128) * 128;
+    p.tiles_m = ssd_cdiv(M, 256); p.tiles_n = ssd_cdiv(N, 256); p.nbatch = nbatch;
+    p.batch_a = batch_a_elems; p.batch_out = (size_t)M * N;
+    const size_t nblk = (size_t)p.tiles_m * p.tiles_n * nbatch;
+    if (nblk >= (1ull << 31)) return SSD_ERR_BAD_SHAPE;
+    static std::atomic<unsigned long long> raised{0};
+    int dev;
+    if (ssd_attr_needed(raised, dev)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_planes_x3s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, V2_SLOTS * V2_STAGE) !=
+            hipSuccess)
+            return SSD_ERR_LAUNCH;
+        ssd_attr_done(raised, dev);
+    }
+    hipLaunchKernelGGL(gemm_planes_x3s_kernel, dim3((unsigned)nblk), dim3(512), V2_SLOTS * V2_STAGE, st, p);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
 }

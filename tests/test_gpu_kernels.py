@@ -1117,7 +1117,7 @@ X3_GEMM_CASES = [  # M, K, N, planes: full tiles; ragged rows and a cut column t
 ]
 
 
-@pytest.mark.parametrize("mfma", [32, 16])
+@pytest.mark.parametrize("mfma", [32, 16, 256])
 @pytest.mark.parametrize("case", X3_GEMM_CASES)
 def test_plane_gemm_from_three_bf16_limbs_is_as_exact_as_the_f32_mfma(case, mfma):
     """csrc/gemm_x3.hip: out[b] = a[b] * w[b]^T with every f32 operand split exactly into three bf16 limbs and six limb products per block
@@ -1145,11 +1145,20 @@ def test_plane_gemm_from_three_bf16_limbs_is_as_exact_as_the_f32_mfma(case, mfma
     guard = 7.0
     o3 = torch.full((P, M, N), guard, device=dev)
     o32 = torch.full((P, M, N), guard, device=dev)
-    _lib.check(lib.ssd_tune_set_x3_mfma(mfma), "tune")        # 16: two limb products per v_mfma_f32_16x16x32_bf16 (limbs concatenated along K)
+    # 16: two limb products per v_mfma_f32_16x16x32_bf16 (limbs concatenated along K); 256: the 256 x 256 ping-pong kernel forced on every shape
+    # it takes (csrc/gemm_x3v2.hip) -- held bit-identical to the 128 x 128 kernel: same products in the same order per accumulator
+    _lib.check(lib.ssd_tune_set_x3_mfma(16 if mfma == 16 else 32), "tune")
+    _lib.check(lib.ssd_tune_set_x3_big(2 if mfma == 256 else 0), "tune")
     try:
         _lib.check(lib.ssd_gemm_planes_x3(ad.data_ptr(), w3.data_ptr(), o3.data_ptr(), M, K, N, N, P, st), "x3")
+        if mfma == 256:
+            o_small = torch.full((P, M, N), guard, device=dev)
+            _lib.check(lib.ssd_tune_set_x3_big(0), "tune")
+            _lib.check(lib.ssd_gemm_planes_x3(ad.data_ptr(), w3.data_ptr(), o_small.data_ptr(), M, K, N, N, P, st), "x3")
+            assert torch.equal(o3, o_small), "256 x 256 ping-pong kernel differs from the 128 x 128 kernel"
     finally:
         _lib.check(lib.ssd_tune_set_x3_mfma(32), "tune")
+        _lib.check(lib.ssd_tune_set_x3_big(1), "tune")
     _lib.check(lib.ssd_gemm_planes_f32(ad.data_ptr(), wd.data_ptr(), o32.data_ptr(), M, K, N, N, P, st), "f32")
     ref = torch.bmm(a.double(), w.double().transpose(1, 2))
     scale = torch.bmm(a.double().abs(), w.double().abs().transpose(1, 2))            # sum_k |a||w|: what an f32 sum's error is relative to

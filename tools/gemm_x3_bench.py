@@ -37,15 +37,27 @@ def main():
         ov2 = torch.empty(P, M, N, device=dev)
         v2 = lambda: _lib.check(lib.ssd_gemm_planes_x3v2(a3.data_ptr(), w3.data_ptr(), ov2.data_ptr(), M, K, N, N, P, 0, st), "x3v2")   # noqa: E731
 
+        def x3():
+            _lib.check(lib.ssd_tune_set_x3_big(0), "tune")
+            _lib.check(lib.ssd_gemm_planes_x3(a.data_ptr(), w3.data_ptr(), ox3.data_ptr(), M, K, N, N, P, st), "x3")
+
+        def x3s():
+            _lib.check(lib.ssd_tune_set_x3_big(2), "tune")
+            try:
+                _lib.check(lib.ssd_gemm_planes_x3(a.data_ptr(), w3.data_ptr(), os_.data_ptr(), M, K, N, N, P, st), "x3s")
+            finally:
+                _lib.check(lib.ssd_tune_set_x3_big(0), "tune")
+        os_ = torch.empty(P, M, N, device=dev)
+
         def x3m16():
             _lib.check(lib.ssd_tune_set_x3_mfma(16), "tune")
             try:
                 x3()
             finally:
                 _lib.check(lib.ssd_tune_set_x3_mfma(32), "tune")
-        runs = {"f32": [], "x3": [], "x3m16": [], "v2": []}
+        runs = {"f32": [], "x3": [], "x3m16": [], "v2": [], "x3s": []}
         for rnd in range(3):                       # interleaved rounds in one process (variants ranked on one device, one minute)
-            for tag, fn in (("f32", f32), ("x3", x3), ("x3m16", x3m16), ("v2", v2)):
+            for tag, fn in (("f32", f32), ("x3", x3), ("x3m16", x3m16), ("v2", v2), ("x3s", x3s)):
                 for _ in range(3):
                     fn()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -64,6 +76,12 @@ def main():
         torch.cuda.synchronize()
         ev2 = float((ov2[0].double() - a[0].double() @ w[0].double().T).norm() / (a[0].double() @ w[0].double().T).norm())
         ev2l = float((ov2[P - 1].double() - a[P - 1].double() @ w[P - 1].double().T).norm() / (a[P - 1].double() @ w[P - 1].double().T).norm())
+        x3s()
+        torch.cuda.synchronize()
+        x3()
+        torch.cuda.synchronize()
+        es = float((os_[0].double() - a[0].double() @ w[0].double().T).norm() / (a[0].double() @ w[0].double().T).norm())
+        same = bool(torch.equal(os_, ox3))
         x3m16()
         o16 = ox3.clone()
         x3()
@@ -75,7 +93,7 @@ def main():
         err2 = float((ox3[last].double() - ref2).norm() / ref2.norm())
         fl = 2.0 * M * K * N * P
         print(f"{name:14s} M={M:6d} K={K:4d} N={N:4d}  f32 {res['f32']:.3f} ms {fl / res['f32'] / 1e9:7.1f} TF/s   x3 {res['x3']:.3f} ms "
-              f"{fl / res['x3'] / 1e9:7.1f} TF/s (executed bf16 {6 * fl / res['x3'] / 1e9:7.1f})   x3/16x16x32 {res['x3m16']:.3f} ms (executed {6 * fl / res['x3m16'] / 1e9:7.1f}, err {e16:.2e}, {res['x3m16_mhz']:.0f} MHz)   v2 256x256 ping-pong {res['v2']:.3f} ms (executed {6 * fl / res['v2'] / 1e9:7.1f}, err {ev2:.2e} / {ev2l:.2e}, {res['v2_mhz']:.0f} MHz)   err f32 {err['f32']:.2e} x3 {err['x3']:.2e} / {err2:.2e}  clock f32 {res['f32_mhz']:.0f} x3 {res['x3_mhz']:.0f} MHz",
+              f"{fl / res['x3'] / 1e9:7.1f} TF/s (executed bf16 {6 * fl / res['x3'] / 1e9:7.1f})   x3/16x16x32 {res['x3m16']:.3f} ms (executed {6 * fl / res['x3m16'] / 1e9:7.1f}, err {e16:.2e}, {res['x3m16_mhz']:.0f} MHz)   v2 256x256 ping-pong {res['v2']:.3f} ms (executed {6 * fl / res['v2'] / 1e9:7.1f}, err {ev2:.2e} / {ev2l:.2e}, {res['v2_mhz']:.0f} MHz)   x3s 256x256 in-kernel split {res['x3s']:.3f} ms (executed {6 * fl / res['x3s'] / 1e9:7.1f}, err {es:.2e}, bitwise == x3: {same})   err f32 {err['f32']:.2e} x3 {err['x3']:.2e} / {err2:.2e}  clock f32 {res['f32_mhz']:.0f} x3 {res['x3_mhz']:.0f} MHz",
               flush=True)
 
 
