@@ -289,7 +289,9 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_x3s_kernel(const X3SParams
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
         // ---- matrix phase: 48 MFMAs, the split of the rows of step ks + 2 in their gaps --------------------------------------------------------
+#ifndef X3S_NO_SETPRIO
         __builtin_amdgcn_s_setprio(1);
+#endif
         const f32x4 v0 = cur == 0 ? ra[0][0] : ra[1][0], v1 = cur == 0 ? ra[0][1] : ra[1][1];
         float xa[4] = {v0[0], v0[2], v1[0], v1[2]}, xb[4] = {v0[1], v0[3], v1[1], v1[3]};
 #pragma unroll
@@ -303,7 +305,12 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_x3s_kernel(const X3SParams
         for (int q = 0; q < 48; ++q) {
             const int pr = q >> 3, i = (q >> 1) & 3, j = q & 1;
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[pr]][i], bf[PB[pr]][j], acc[i][j], 0, 0, 0);
+#ifdef X3S_NO_SPLIT
+            if (q == 2) { for (int e = 0; e < 4; ++e) { hi[e] = __float_as_uint(xa[e]); mid[e] = __float_as_uint(xb[e]); lo[e] = hi[e] ^ mid[e]; } }
+            if (false) {
+#else
             if (q >= 2 && q < 42 && (q & 1) == 0) {          // one split stage per two MFMAs
+#endif
                 const int sl = (q - 2) >> 1, e = sl / 5, sg = sl % 5;
                 if (sg == 0) { hi[e] = v2_pack(xa[e], xb[e]); asm volatile("" : "+v"(hi[e])); }
                 if (sg == 1) {
@@ -317,14 +324,36 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_x3s_kernel(const X3SParams
                 }
                 if (sg == 4) { lo[e] = v2_pack(r1a[e], r1b[e]); asm volatile("" : "+v"(lo[e])); }
             }
+#ifndef X3S_FREE_SCHED
             __builtin_amdgcn_sched_barrier(0);
+#endif
         }
+#ifndef X3S_NO_SETPRIO
         __builtin_amdgcn_s_setprio(0);
+#endif
         __builtin_amdgcn_s_barrier();
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                             // every wave is out of the loop: the ring can hold the result tiles
+#ifdef X3S_DIRECT_EPI
+    {
+        float* outd = p.out + (size_t)b * p.batch_out;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn2 * 64 + j * 32 + lr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 128 + i * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+                    const float v = ((lh ^ i) & 1) ? -acc[i][j][r] : acc[i][j][r];
+                    if (m < p.M && n < p.N) outd[(size_t)m * p.N + n] = v;
+                }
+            }
+        return;
+    }
+#endif
 
     // ---- epilogue through LDS: per wave 64 rows x 64 columns at a time (row stride 68 floats: 16-byte aligned, conflict-light) -------------------
     float* out = p.out + (size_t)b * p.batch_out;

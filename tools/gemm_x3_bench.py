@@ -92,6 +92,10 @@ def main():
         ref2 = a[last].double() @ w[last].double().T
         err2 = float((ox3[last].double() - ref2).norm() / ref2.norm())
         fl = 2.0 * M * K * N * P
+        if os.environ.get("X3_BRIEF"):
+            print(f"{name:14s} x3 {res['x3']:.3f}  x3m16 {res['x3m16']:.3f}  v2 {res['v2']:.3f}  x3s {res['x3s']:.3f} ms   (executed x3s {6 * fl / res['x3s'] / 1e9:6.0f} TF/s, == x3: {same})",
+                  flush=True)
+            continue
         print(f"{name:14s} M={M:6d} K={K:4d} N={N:4d}  f32 {res['f32']:.3f} ms {fl / res['f32'] / 1e9:7.1f} TF/s   x3 {res['x3']:.3f} ms "
               f"{fl / res['x3'] / 1e9:7.1f} TF/s (executed bf16 {6 * fl / res['x3'] / 1e9:7.1f})   x3/16x16x32 {res['x3m16']:.3f} ms (executed {6 * fl / res['x3m16'] / 1e9:7.1f}, err {e16:.2e}, {res['x3m16_mhz']:.0f} MHz)   v2 256x256 ping-pong {res['v2']:.3f} ms (executed {6 * fl / res['v2'] / 1e9:7.1f}, err {ev2:.2e} / {ev2l:.2e}, {res['v2_mhz']:.0f} MHz)   x3s 256x256 in-kernel split {res['x3s']:.3f} ms (executed {6 * fl / res['x3s'] / 1e9:7.1f}, err {es:.2e}, bitwise == x3: {same})   err f32 {err['f32']:.2e} x3 {err['x3']:.2e} / {err2:.2e}  clock f32 {res['f32_mhz']:.0f} x3 {res['x3_mhz']:.0f} MHz",
               flush=True)

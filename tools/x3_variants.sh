@@ -5,10 +5,10 @@ set -e
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $ROOT
 for flags in "$@"; do
-  touch objectdetection_ssd_amd/csrc/gemm_x3.hip
+  touch objectdetection_ssd_amd/csrc/gemm_x3.hip objectdetection_ssd_amd/csrc/gemm_x3v2.hip
   SSD_HIPCC_FLAGS="$flags" python3 -c "from objectdetection_ssd_amd import build; build.build()" > /dev/null
   echo "== flags: [$flags]"
-  python3 tools/gemm_x3_bench.py | cut -c1-128
+  python3 tools/gemm_x3_bench.py | ${X3_FILTER:-cut -c1-128}
 done
-touch objectdetection_ssd_amd/csrc/gemm_x3.hip
+touch objectdetection_ssd_amd/csrc/gemm_x3.hip objectdetection_ssd_amd/csrc/gemm_x3v2.hip
 python3 -c "from objectdetection_ssd_amd import build; build.build()" > /dev/null
