@@ -150,9 +150,10 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_x3v2_kernel(const X3V2Para
 
 // ---- the same structure with the activation operand as it lies in memory today: f32 planes [M][K], split in the kernel ----------------------
 // (no change to the transform kernels, the kept planes or the weight-gradient GEMMs.)  A thread owns 8 consecutive k of one row per step, as in
-// gemm_x3.hip: the rows of step t + 3 are requested in read phase t (two 16-byte buffer loads into one of two register sets), the rows of
-// step t + 2 are split into limbs IN THE SHADOW of matrix phase t's MFMAs (hand-placed stages, <= 4 VALU per 32-cycle MFMA), and the limbs go to
-// LDS slot (t + 2) % 3 in read phase t + 1 -- a full step before either group reads them.  The weights arrive by LDS-DMA as above (three pieces
+// gemm_x3.hip: the rows of step t + 3 are requested in read phase t (two 16-byte buffer loads), and in read phase t + 1 -- while the OTHER
+// group's waves hold the matrix pipe -- they are split into limbs and stored to LDS slot (t + 3) % 3, two steps before either group reads them;
+// the matrix phase is 48 MFMAs and nothing else.  (First version: split in the MFMA gaps of the wave's own matrix phase, pinned by
+// sched_barrier as in gemm_x3.hip: 0.372 ms on conv4_2 against 0.338 for the 128 x 128 kernel; without the pins 0.337; this form: see DESIGN.)  The weights arrive by LDS-DMA as above (three pieces
 // per wave and step).  The row's sign dither s(m) of gemm_x3.hip is applied before the split and undone in the epilogue.
 // Epilogue: a wave's 128 x 64 result goes through LDS (the ring is free by then) in two halves and leaves as 16-byte stores, 256 contiguous
 // bytes per row -- a quarter of the store instructions of the direct form, which at one workgroup per CU are not hidden behind anything.
@@ -253,8 +254,7 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_x3s_kernel(const X3SParams
     const unsigned frag = lr * 32 + ((lh ^ ((lr >> 3) & 1)) << 4);
     const unsigned a_rd = wm * 128 * 32 + frag, b_rd = V2_OPER + wn2 * 64 * 32 + frag;
 
-    // prologue: weights of steps 0 and 1 requested; rows of steps 0, 1 loaded and split (step 0 -> slot 0, step 1 stays in the limb registers for
-    // read phase 0), rows of step 2 in flight
+    // prologue: weights of steps 0 and 1 requested; rows of steps 0 and 1 loaded, split and stored (slots 0, 1); rows of step 2 in flight
     issue_b(0, 0);
     issue_b(1, 1);
     load_a(0, 0);
@@ -263,6 +263,7 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_x3s_kernel(const X3SParams
     split_now(0);
     store_limbs(0);
     split_now(1);
+    store_limbs(1);
     load_a(2, 0);
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();
@@ -270,9 +271,12 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_x3s_kernel(const X3SParams
 
     for (int ks = 0; ks < NK; ++ks) {
         const int slot = ks % V2_SLOTS;
-        // ---- read phase: limbs of step ks + 1 to LDS, fragments of step ks, requests for steps ks + 2 (weights) and ks + 3 (rows) ---------------
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // everything requested a step ago: the weights of ks + 1, the rows of ks + 2
-        store_limbs((ks + 1) % V2_SLOTS);
+        // ---- read phase (beside the other group's matrix phase): the rows of step ks + 2 -- requested a step ago -- are split and stored, the
+        // fragments of step ks read, the weights of step ks + 2 and the rows of step ks + 3 requested.  Slot (ks + 2) % 3 held step ks - 1, which
+        // both groups finished reading before the barrier in front of this phase.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        split_now(0);
+        store_limbs((ks + 2) % V2_SLOTS);
         const unsigned char* st = lds + slot * V2_STAGE;
         bf16x8 af[3][4], bf[3][2];
 #pragma unroll
@@ -283,54 +287,18 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_x3s_kernel(const X3SParams
             for (int j = 0; j < 2; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8*>(st + b_rd + pl * V2_LIMB + j * 1024);
         }
         issue_b(ks + 2, (ks + 2) % V2_SLOTS);
-        const int cur = ks & 1;                               // register set holding the rows of step ks + 2 (requested in read phase ks - 1 / prologue)
-        // the rows of step ks + 3 go into the OTHER set, whose rows (step ks + 1) were split a phase ago
-        if (cur == 0) load_a(ks + 3, 1); else load_a(ks + 3, 0);
+        load_a(ks + 3, 0);
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
-        // ---- matrix phase: 48 MFMAs, the split of the rows of step ks + 2 in their gaps --------------------------------------------------------
-#ifndef X3S_NO_SETPRIO
+        // ---- matrix phase: 48 MFMAs, nothing else ----------------------------------------------------------------------------------------
         __builtin_amdgcn_s_setprio(1);
-#endif
-        const f32x4 v0 = cur == 0 ? ra[0][0] : ra[1][0], v1 = cur == 0 ? ra[0][1] : ra[1][1];
-        float xa[4] = {v0[0], v0[2], v1[0], v1[2]}, xb[4] = {v0[1], v0[3], v1[1], v1[3]};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            xa[e] = __uint_as_float(__float_as_uint(xa[e]) ^ a_sign);
-            xb[e] = __uint_as_float(__float_as_uint(xb[e]) ^ a_sign);
-        }
-        float r1a[4], r1b[4];
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
         for (int q = 0; q < 48; ++q) {
             const int pr = q >> 3, i = (q >> 1) & 3, j = q & 1;
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[pr]][i], bf[PB[pr]][j], acc[i][j], 0, 0, 0);
-#ifdef X3S_NO_SPLIT
-            if (q == 2) { for (int e = 0; e < 4; ++e) { hi[e] = __float_as_uint(xa[e]); mid[e] = __float_as_uint(xb[e]); lo[e] = hi[e] ^ mid[e]; } }
-            if (false) {
-#else
-            if (q >= 2 && q < 42 && (q & 1) == 0) {          // one split stage per two MFMAs
-#endif
-                const int sl = (q - 2) >> 1, e = sl / 5, sg = sl % 5;
-                if (sg == 0) { hi[e] = v2_pack(xa[e], xb[e]); asm volatile("" : "+v"(hi[e])); }
-                if (sg == 1) {
-                    r1a[e] = xa[e] - __uint_as_float(hi[e] << 16); r1b[e] = xb[e] - __uint_as_float(hi[e] & 0xffff0000u);
-                    asm volatile("" : "+v"(r1a[e]), "+v"(r1b[e]));
-                }
-                if (sg == 2) { mid[e] = v2_pack(r1a[e], r1b[e]); asm volatile("" : "+v"(mid[e])); }
-                if (sg == 3) {
-                    r1a[e] -= __uint_as_float(mid[e] << 16); r1b[e] -= __uint_as_float(mid[e] & 0xffff0000u);
-                    asm volatile("" : "+v"(r1a[e]), "+v"(r1b[e]));
-                }
-                if (sg == 4) { lo[e] = v2_pack(r1a[e], r1b[e]); asm volatile("" : "+v"(lo[e])); }
-            }
-#ifndef X3S_FREE_SCHED
-            __builtin_amdgcn_sched_barrier(0);
-#endif
         }
-#ifndef X3S_NO_SETPRIO
         __builtin_amdgcn_s_setprio(0);
-#endif
         __builtin_amdgcn_s_barrier();
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
