@@ -834,7 +834,7 @@ extern "C" int ssd_gemm_x3_split_weights(const float* w, void* w3, int rows, int
 
 int ssd_internal_gemm_batched_x3s(const float* a, const void* w3, float* out, int M, int K, int N, int n_rows, int nbatch, size_t batch_a_elems,
                                   hipStream_t st);       // csrc/gemm_x3v2.hip: 256 x 256 tiles, two wave groups in ping-pong
-static int g_x3_big = 1;       // ssd_tune_set_x3_big: 0 = every launch on the 128 x 128 kernel, 1 = the large launches on the 256 x 256 ping-pong kernel, 2 = all that fit
+static int g_x3_big = 0;       // ssd_tune_set_x3_big (SSD_EXPERIMENTAL builds): 0 = every launch on the 128 x 128 kernel (default), 1 = the large launches on the 256 x 256 ping-pong kernel, 2 = all that fit
 static int g_x3_m16 = 0;      // ssd_tune_set_x3_mfma: 1 = the plane GEMMs on v_mfma_f32_16x16x32_bf16 (limb pairs concatenated along K), 0 = 32x32x16
 // Internal (not part of the C ABI): the x3 form of ssd_internal_gemm_batched (conv_igemm.hip); w3 from ssd_gemm_x3_split_weights
 __attribute__((visibility("hidden"))) int ssd_internal_gemm_batched_x3(const float* a, const void* w3, float* out, int M, int K, int N, int n_rows,
@@ -878,9 +878,13 @@ __attribute__((visibility("hidden"))) int ssd_internal_gemm_batched_x3(const flo
     return SSD_OK;
 }
 
-// Tuning aid: 0 = every limb plane GEMM on the 128 x 128 kernel, 1 (default) = the large launches on the 256 x 256 ping-pong kernel, 2 = every launch
+// Tuning aid (SSD_EXPERIMENTAL builds; measured no better in the step, csrc/gemm_x3v2.hip): 0 (default) = every limb plane GEMM on the 128 x 128
+// kernel, 1 = the large launches on the 256 x 256 ping-pong kernel, 2 = every launch it takes
 extern "C" int ssd_tune_set_x3_big(int mode) {
     if (mode < 0 || mode > 2) return SSD_ERR_BAD_SHAPE;
+#ifndef SSD_EXPERIMENTAL
+    if (mode != 0) return SSD_ERR_BAD_SHAPE;        // csrc/gemm_x3v2.hip is not in this build
+#endif
     g_x3_big = mode;
     return SSD_OK;
 }

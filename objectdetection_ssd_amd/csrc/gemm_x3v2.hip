@@ -15,8 +15,21 @@
 // Slot safety: the DMA of step t + 2 overwrites the slot of step t - 1, whose last reads (the other group's) finished before the barrier
 // that precedes this read phase; data of step t is waited for (vmcnt(0) at the top of read phase t - 1, a full step after its issue) by
 // every wave and published by the barriers in between (rule "read a staged buffer one phase after the wait that retires it").
+//
+// MEASURED (round 4, tools/gemm_x3_bench.py, interleaved rounds on one device; ms per launch of 36 planes):
+//                    128 x 128 kernel (gemm_x3.hip)   pre-split ping-pong (v2)   in-kernel split ping-pong (x3s)
+//   conv3_2 (11552 x 256 x 256)      0.343                     0.320                       0.363
+//   conv4_2 (3200 x 512 x 512)       0.341                     0.307   (1 184 TFLOP/s)     0.361
+//   fc6     (2048 x 512 x 1024)      0.417                     0.375                       0.435
+//   conv5_2 (800 x 512 x 512)        0.102                     0.125                       0.152
+//   dgrad conv3_1 (N = 128)          0.194                     0.284                       0.339
+// The structure is worth 10-13 % on the large launches ONLY when the activation limbs are already in memory; splitting in the kernel (in the
+// MFMA gaps: 0.372; in the read phase beside a prio-1 matrix phase: 0.361) gives it back, and writing limb planes from the transform kernels
+// costs 6 instead of 4 bytes per plane element (+0.4 ms per step) for -0.4 ms of GEMM time.  NOT in the default build (SSD_EXPERIMENTAL=1,
+// like gemm_nt.hip); the 128 x 128 kernel stays on the path.  Step A/B with the x3s dispatch: 20.17 vs 20.18 ms.
 #include "common.h"
 
+#ifdef SSD_EXPERIMENTAL
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -361,9 +374,13 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_x3s_kernel(const X3SParams
 }
 
 }  // namespace
+#endif  // SSD_EXPERIMENTAL
 
 // Experiment entry (declared in include/ssd_gfx950.h): both operands as limb planes of ssd_gemm_x3_split_weights (rows_pad = ceil128 of M / n_rows).
 extern "C" int ssd_gemm_planes_x3v2(const void* a3, const void* w3, float* out, int M, int K, int N, int n_rows, int nbatch, int dither, void* stream) {
+#ifndef SSD_EXPERIMENTAL
+    return SSD_ERR_BAD_SHAPE;                       // not in this build (SSD_EXPERIMENTAL=1 python -m objectdetection_ssd_amd.build)
+#else
     if (!a3 || !w3 || !out) return SSD_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0 || K % 32 != 0 || n_rows < N || nbatch <= 0) return SSD_ERR_BAD_SHAPE;
     if (!ssd_aligned16(a3) || !ssd_aligned16(w3) || !ssd_aligned16(out)) return SSD_ERR_ALIGN;
@@ -384,11 +401,15 @@ extern "C" int ssd_gemm_planes_x3v2(const void* a3, const void* w3, float* out, 
     hipLaunchKernelGGL(gemm_planes_x3v2_kernel, dim3((unsigned)nblk), dim3(512), V2_SLOTS * V2_STAGE, (hipStream_t)stream, p);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
+#endif
 }
 
 // Internal (csrc/gemm_x3.hip dispatches here for the large launches): a [nbatch][M][K] f32 split in the kernel, w3 limb planes.
 __attribute__((visibility("hidden"))) int ssd_internal_gemm_batched_x3s(const float* a, const void* w3, float* out, int M, int K, int N, int n_rows,
                                                                          int nbatch, size_t batch_a_elems, hipStream_t st) {
+#ifndef SSD_EXPERIMENTAL
+    return SSD_ERR_BAD_SHAPE;
+#else
     if (K % 32 != 0 || K < 48 || M <= 0 || N <= 0 || N % 4 != 0 || n_rows <= 0 || nbatch <= 0) return SSD_ERR_BAD_SHAPE;
     if ((size_t)M * K * 4 >= 0xF0000000ull) return SSD_ERR_BAD_SHAPE;
     X3SParams p{};
@@ -409,4 +430,5 @@ __attribute__((visibility("hidden"))) int ssd_internal_gemm_batched_x3s(const fl
     hipLaunchKernelGGL(gemm_planes_x3s_kernel, dim3((unsigned)nblk), dim3(512), V2_SLOTS * V2_STAGE, st, p);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
+#endif
 }

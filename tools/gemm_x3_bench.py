@@ -19,6 +19,8 @@ SHAPES = [("conv3_2", 32 * 19 * 19, 256, 256, 36), ("conv4_2", 32 * 10 * 10, 512
 
 def main():
     lib = _lib.load()
+    if not lib.ssd_has_experimental():
+        raise SystemExit("tools/gemm_x3_bench.py compares the shipped kernel with the experiments of csrc/gemm_x3v2.hip: build with SSD_EXPERIMENTAL=1")
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
     for name, M, K, N, P in SHAPES:
