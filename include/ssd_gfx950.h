@@ -285,7 +285,7 @@ int ssd_tune_set_wino_fused(int mode);
  * dither = 1: a3's rows carry the sign s(m) of csrc/gemm_x3.hip and the result is multiplied by it again. */
 int ssd_gemm_planes_x3v2(const void* a3, const void* w3, float* out, int M, int K, int N, int n_rows, int nbatch, int dither, void* stream);
 int ssd_tune_set_x3_big(int mode);         /* limb plane GEMMs: 0 (default) = always the 128 x 128 kernel; SSD_EXPERIMENTAL builds only: 1 = launches with N >= 256 and M >= 2048 on the 256 x 256 ping-pong kernel (csrc/gemm_x3v2.hip), 2 = every launch it takes */
-int ssd_tune_set_x3_mfma(int rows);        /* limb plane GEMMs (csrc/gemm_x3.hip): 32 (default) = v_mfma_f32_32x32x16_bf16, 16 = v_mfma_f32_16x16x32_bf16, two limb products per instruction */
+int ssd_tune_set_x3_mfma(int rows);        /* limb plane GEMMs (csrc/gemm_x3.hip): 32 (default) = v_mfma_f32_32x32x16_bf16; SSD_EXPERIMENTAL builds only: 16 = v_mfma_f32_16x16x32_bf16, two limb products per instruction */
 /* The plane GEMMs of the layers that do not take the one-kernel form: persistent 128 x 128 LDS-DMA kernel (gemm_nt.hip) instead of the
  * generic 64 x 64 implicit-GEMM kernel.  1: wherever K % 32 == 0 and K >= 64; -1 (default) / 0: never -- measured no faster (both kernels
  * sit at the device's sustained f32 MFMA rate); kept, tested bit-identical, as the evidence for that statement. */

@@ -870,8 +870,11 @@ __attribute__((visibility("hidden"))) int ssd_internal_gemm_batched_x3(const flo
     }
     hipLaunchKernelGGL(gemm_planes_x3p_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, st, p);
 #else
+#ifdef SSD_EXPERIMENTAL
     if (g_x3_m16) hipLaunchKernelGGL((gemm_planes_x3_kernel<false, true>), dim3((unsigned)nblk), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gemm_planes_x3_kernel<false, false>), dim3((unsigned)nblk), dim3(256), 0, st, p);
+    else
+#endif
+    hipLaunchKernelGGL((gemm_planes_x3_kernel<false, false>), dim3((unsigned)nblk), dim3(256), 0, st, p);
 #endif
     ssd_internal_prof_close(slot, st);
     SSD_CHECK_LAUNCH();
@@ -893,6 +896,9 @@ extern "C" int ssd_tune_set_x3_big(int mode) {
 // 16 = v_mfma_f32_16x16x32_bf16 with two limb products per instruction.
 extern "C" int ssd_tune_set_x3_mfma(int rows) {
     if (rows != 16 && rows != 32) return SSD_ERR_BAD_SHAPE;
+#ifndef SSD_EXPERIMENTAL
+    if (rows == 16) return SSD_ERR_BAD_SHAPE;       // measured within noise of the 32x32x16 form: SSD_EXPERIMENTAL builds only
+#endif
     g_x3_m16 = rows == 16;
     return SSD_OK;
 }
