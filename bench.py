@@ -175,7 +175,7 @@ class conv_flop_counter:
     the algorithmic work of one pass, read off the geometry of the calls themselves."""
 
     NAMES = ("conv2d_fwd", "conv2d_fwd_x3", "conv2d_fwd_wino", "conv2d_fwd_wino_pool", "conv2d_dgrad", "conv2d_dgrad_x3", "conv2d_dgrad_wino",
-             "conv2d_wgrad", "conv2d_wgrad_wino", "wino_wgrad_gemm", "wino_dgrad_adj_gemm")
+             "conv2d_wgrad", "conv2d_wgrad_wino", "wino_wgrad_gemm", "wino_dgrad_adj_gemm", "conv2d_fwd_wino_from_planes")
 
     def __enter__(self):
         from objectdetection_ssd_amd import ops
@@ -513,6 +513,7 @@ def main():
     ap.add_argument("--wino-wgrad-nt", action="store_true", help="tuning aid: Winograd weight gradient on transposed planes (NT GEMM)")
     ap.add_argument("--no-keep-planes", action="store_true", help="tuning aid: the Winograd weight gradient transforms x again")
     ap.add_argument("--no-dual-dy", action="store_true", help="tuning aid: weight and data gradient transform dy separately")
+    ap.add_argument("--no-first-wino", action="store_true", help="tuning aid: conv1_1 writes its activation tensor, conv1_2 transforms it (two kernels)")
     ap.add_argument("--no-adjoint-dgrad", action="store_true", help="tuning aid: rotated-filter Winograd data gradients everywhere (second dy plane set)")
     ap.add_argument("--no-adjoint-chain", action="store_true", help="tuning aid: adjoint data gradients written out as tensors between chained layers")
     ap.add_argument("--overlap-allreduce", action="store_true",
@@ -624,6 +625,8 @@ def main():
         net._engine.keep_planes = False
     if args.no_dual_dy:
         net._engine.dual_dy = False
+    if args.no_first_wino:
+        net._engine.first_wino = False
     if args.no_adjoint_dgrad:
         net._engine.adjoint_dgrad = False
     if args.no_adjoint_chain:

@@ -255,6 +255,16 @@ int ssd_conv3x3_wino_wgrad_planes(const float* planes, const float* dy, int ldy,
                                   float* dgrad_planes_out, void* workspace, size_t workspace_bytes, void* stream);
 int ssd_conv3x3_wino_dgrad_planes(const float* dy_planes, const float* U_bwd, int Co_pad, float* dx, const float* relu_mask,
                                   int accumulate, const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream);
+/* conv1_1 written as the next layer's Winograd input (round 4; Model.py:135 features[0:4]: Conv2d(3,64) -> ReLU -> Conv2d(64,64)).  In
+ * training nothing but conv1_2 reads conv1_1's activation, so ssd_conv1_first_wino_fwd leaves it as the F(4x4) input planes
+ * (36 x N*ceil(H/4)*ceil(W/4) x 64 f32) + the ReLU bit words of ssd_conv3x3_wino_fwd_keep_bits, bit-identical to ssd_conv1_first_fwd followed
+ * by that layer's input transform, and the 64-channel activation (737 MB at batch 32) is neither written nor read.
+ * ssd_conv3x3_wino_fwd_from_planes is the forward of a layer whose planes are given: plane GEMMs + output transform (+ the fused 2x2 pool
+ * when y_pooled is not NULL; then y may be NULL). */
+int ssd_conv1_first_wino_fwd(const float* x_nchw, const float* w_rows, const float* bias, float* planes, uint64_t* relu_bits, int N, int H, int W,
+                             void* stream);
+int ssd_conv3x3_wino_fwd_from_planes(const float* planes, const float* U_fwd, const float* bias, float* y, int ldy, float* y_pooled, uint8_t* argmax,
+                                     const ssd_conv_geom* g, int relu, int ceil_mode, void* workspace, size_t workspace_bytes, void* stream);
 /* Data gradient in the ADJOINT Winograd form (round 4; autograd of nn.Conv2d, reference Model.py:135-143 / train_function.py:94).
  * The forward y = A^T[(G g G^T) (.) (B^T d B)]A is linear in d; transposed, dx = overlap-add over the tiles of the 6x6 patches
  * B[(G g G^T) (.) (A dy A^T)]B^T: the data gradient multiplies the SAME planes A dy A^T (ssd_wino4_dy_transform's wgrad_planes) the

@@ -132,6 +132,8 @@ class _Elided:
     """Stands in the activation table for a tensor that a fused kernel consumed without writing it: shape only.  In the backward it
     takes the ReLU-mask slot of its pool, which then gates by the pooled output (`maxpool_bwd(..., y_gate=)`)."""
 
+    dtype = torch.float32
+
     def __init__(self, shape):
         self.shape = tuple(shape)
 
@@ -225,6 +227,9 @@ class _Engine:
         # (conv3_3 -> 3_2 -> 3_1, conv4_3 -> 4_2 -> 4_1, conv5_3 -> 5_2 -> 5_1) the gradient tensor itself is never written: the output
         # transform of the upper layer's data gradient writes the lower layer's dy planes (csrc/winograd.hip wino4_adj_out_kernel)
         self.adjoint_dgrad = True
+        # Round 4: conv1_1 writes conv1_2's Winograd input planes (+ ReLU bits) itself; its 64-channel activation -- read by nothing else --
+        # is never stored (csrc/conv_first.hip conv_first_wino_kernel; bit-identical planes)
+        self.first_wino = True
         self.adjoint_chain = True      # False: every adjoint data gradient is written out as a tensor (A/B aid)
         self.prof = None          # bench.py: list collecting (label, kernel tag, flops, start event, end event)
         self.bf16 = False         # True: forward / dgrad / fused-wgrad convolutions multiply bf16-rounded operands (f32 accumulate)
@@ -314,6 +319,16 @@ class _Engine:
         Winograd one and shares the dy planes; reduction long enough for the plane GEMM kernels, i.e. not the fused K <= 128 kernel)."""
         return (self.adjoint_dgrad and self.keep_planes and self.dual_dy and not self.overlap_wgrad and self.WINO_TILE == 4 and self._wino_ok(g) and g.dil == 1
                 and self._wino_wgrad_ok(g, False) and g.Co % 32 == 0 and 256 <= g.Co <= 1024 and g.Ci % 4 == 0)
+
+    def _first_wino_ok(self, op, bs, x) -> bool:
+        """conv1_1's output goes straight into the input planes of the layer behind it: that layer is its only reader and an F(4x4) one."""
+        if not (self.first_wino and self.wino and self.WINO_TILE == 4 and self.consumers.get(op["y"], 0) == 1):
+            return False
+        nxt = next((o for o in self.ops if o["op"] == "conv" and o["x"] == op["y"]), None)
+        if nxt is None or nxt["ci"] != 64:
+            return False
+        g = ops.make_geom(bs, x.shape[2], x.shape[3], nxt["ci"], nxt["co"], nxt["k"], nxt["s"], nxt["pad"], nxt["dil"])
+        return self._wino_ok(g) and g.dil == 1 and g.Co % 4 == 0 and not ops.wino_uses_full(g, 0)
 
     def _wino_weights(self, key: str, tensors, co_pad: int, adj: bool = False):
         """Cached Winograd-domain filters (U_fwd [16][Co][Ci], U_bwd [16][Ci][co_pad]), refreshed when a parameter changes.
@@ -522,6 +537,14 @@ class _Engine:
                     T[op["y"]] = self._timed("fwd " + op["p"], "conv_first_fwd_kernel", flops1,
                                              lambda: ops.conv1_first_fwd_bf16(x, ent[2], bias, True))
                     col = None
+                elif (self.first_fused and not self.bf16 and not self.x3 and self._first_wino_ok(op, bs, x)
+                      and (not save or (self.relu_bits and self.dual_dy and self.keep_planes))):
+                    # ... and, where its only reader is a Winograd layer, straight into that layer's input planes: no activation tensor at all
+                    pre = self._timed("fwd " + op["p"], "conv_first_fwd_kernel", flops1,
+                                      lambda: ops.conv1_first_wino_fwd(x, ent[2], bias, want_bits=save and self.relu_bits))
+                    T[op["y"]] = _Elided((bs, x.shape[2], x.shape[3], 64))
+                    aux["preplanes:" + op["y"]] = pre
+                    col = None
                 elif self.first_fused and not self.bf16 and not self.x3:
                     # one kernel from the NCHW batch: halo tile in LDS, K = 27 on the MFMA, bias + ReLU; the weight gradient's rows ride along
                     T[op["y"]], col = self._timed("fwd " + op["p"], "conv_first_fwd_kernel", flops1,
@@ -552,6 +575,24 @@ class _Engine:
                     keep = save and self.keep_planes and self.WINO_TILE == 4 and self._wino_wgrad_ok(g, False)
                     # the mask is only ever applied to a post-ReLU input (deliver() below): pool outputs and the image are not gated here
                     wb = keep and self.relu_bits and self.dual_dy and op["x"] in self.relu_out and g.Co % 32 == 0
+                    pre = aux.pop("preplanes:" + op["x"], None)
+                    if pre is not None:
+                        # the producer of this layer's input left the input planes (and the ReLU bits): GEMMs + output transform only
+                        planes, pbits = pre
+                        if pl is not None:
+                            yp, am = self._timed("fwd " + op["p"], "winograd_3x3", ops.wino_flops(g),
+                                                 lambda: ops.conv2d_fwd_wino_from_planes(planes, uf, bias, g, True, pool_ceil=pl["ceil"], want_argmax=save))
+                            T[op["y"]] = _Elided((bs, g.H, g.W, op["co"]))
+                            T[pl["y"]], aux[pl["y"]] = yp, am
+                        else:
+                            T[op["y"]] = self._timed("fwd " + op["p"], "winograd_3x3", ops.wino_flops(g),
+                                                     lambda: ops.conv2d_fwd_wino_from_planes(planes, uf, bias, g, op["relu"]))
+                        aux[op["y"]] = g
+                        if keep:
+                            aux["planes:" + op["p"]] = planes
+                        if wb and pbits is not None:
+                            aux["bits:" + op["p"]] = pbits
+                        continue
                     if pl is not None:
                         res = self._timed("fwd " + op["p"], "winograd_3x3", ops.wino_flops(g),
                                           lambda: ops.conv2d_fwd_wino_pool(xin, uf, bias, g, pl["ceil"], want_argmax=save, keep_planes=keep,
@@ -916,10 +957,17 @@ class _Engine:
                         raise RuntimeError(f"{op['p']}: its filter planes are laid out for the adjoint data gradient, which needs the forward's kept planes "
                                            "(the engine's keep_planes / dual_dy / adjoint_dgrad switches must not change between a forward and its backward)")
                     bits = aux.pop("bits:" + op["p"], None) if (dyp is not None or ops.wino_uses_full(g, 1)) else None
-                    deliver(op["x"], lambda dx, acc, mask: self._timed(
-                        "dgrad " + op["p"], "winograd_3x3", ops.wino_flops(g),
-                        lambda: ops.conv2d_dgrad_wino(None if isinstance(dy, ops.PooledGrad) else dy, ub, g, dx, mask, acc, planes=dyp,
-                                                      bits=bits if mask is not None else None)))
+                    def dgrad_rot(dx, acc, mask, dy=dy, ub=ub, g=g, dyp=dyp, bits=bits, name=op["p"]):
+                        if isinstance(mask, _Elided):            # the gated activation was never stored (conv1_1 -> planes): only its bits exist
+                            if bits is None:
+                                raise RuntimeError(f"{name}: its input was not stored and no ReLU bits were kept for its data gradient")
+                            mask_t = None
+                        else:
+                            mask_t = mask
+                        return ops.conv2d_dgrad_wino(None if isinstance(dy, ops.PooledGrad) else dy, ub, g, dx, mask_t, acc, planes=dyp,
+                                                     bits=bits if mask is not None else None)
+                    deliver(op["x"], lambda dx, acc, mask: self._timed("dgrad " + op["p"], "winograd_3x3", ops.wino_flops(g),
+                                                                       lambda: dgrad_rot(dx, acc, mask)))
                     continue
                 if self._x31_ok(g) and not to_bf16:
                     _, w3b = self._x31_weights(op["p"], (P[op["p"] + ".weight"],), op["co"])

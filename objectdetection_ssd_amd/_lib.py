@@ -123,6 +123,8 @@ SIGNATURES = {
     "ssd_wino4_bias_partial_floats": (_Z, [_G, _I]),
     "ssd_wino4_dy_transform": (_I, [_P, _I, _G, _P, _P, _P, _P]),
     "ssd_wino_weights_adj": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ssd_conv1_first_wino_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ssd_conv3x3_wino_fwd_from_planes": (_I, [_P, _P, _P, _P, _I, _P, _P, _G, _I, _I, _P, _Z, _P]),
     "ssd_wino4_adj_planes_floats": (_Z, [_G]),
     "ssd_conv3x3_wino_dgrad_adj_gemm": (_I, [_P, _I, _P, _P, _G, _P]),
     "ssd_wino4_adj_output": (_I, [_P, _P, _P, _P, _I, _G, _P]),

@@ -145,6 +145,149 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
 }
 
 
+// ---- conv1_1 + ReLU written DIRECTLY as the F(4x4,3x3) input planes of conv1_2 (round 4) ---------------------------------------------------
+// In training the only reader of conv1_1's output is conv1_2 (Model.py:135 features[0:4]), a Winograd layer: its input transform reads the
+// 737 MB activation (batch 32) that this kernel has just written, and nothing else ever needs it -- the backward gates conv1_2's data gradient
+// through the ReLU BITS the transform leaves, conv1_2's weight gradient multiplies the kept planes, conv1_1's own weight gradient reads x and
+// dy.  So a workgroup computes the 6 x 66 patch of a1_1 under one tile row segment of 16 tiles (rows 4 th - 1 .. 4 th + 4, the 64 columns + one on
+// each side; 2.25x conv1_1's small MFMA work: K = 27), parks it in LDS, and writes V = B^T d B for its 16 tiles x 64 channels and the bit words.
+// Positions outside the map are ZERO in the patch (conv1_2's zero padding), not conv1_1 evaluated out there.  The MFMA chain per output
+// element and the transform's sums are those of conv_first_fwd_kernel and wino4_input_kernel (csrc/winograd.hip): planes and bits are
+// bit-identical to the two-kernel form (tests/test_gpu_kernels.py::test_conv1_1_written_as_winograd_planes).
+constexpr int FT = 16, FPR = 6, FPC = 4 * FT + 2, FXR = FPR + 2, FXC = FPC + 2, FXPLANE = FXR * FXC;     // tiles / patch rows x cols / input halo
+constexpr int FPS = 68;                                               // floats per patch pixel in LDS: 64 channels + 4 (16-byte aligned, spreads the banks)
+constexpr int FW_XS = 3 * FXPLANE + 64, FW_WS = 64 * 33, FW_PATCH = FPR * FPC * FPS;
+constexpr size_t FW_LDS_BYTES = (size_t)(FW_XS + FW_WS + FW_PATCH) * 4;
+__device__ constexpr float FW_BT[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
+                                          {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+__device__ __forceinline__ constexpr int ftap_off(int k) {
+    const int kk = k < 27 ? k : 26;
+    return (kk % 3) * FXPLANE + (kk / 9) * FXC + (kk / 3) % 3;
+}
+
+__global__ __launch_bounds__(384) void conv_first_wino_kernel(const float* __restrict__ x, const float* __restrict__ wrows, const float* __restrict__ bias,
+                                                              float* __restrict__ V, unsigned long long* __restrict__ bits, int N, int H, int W,
+                                                              int TH, int TW, int nblk_w) {
+    extern __shared__ __attribute__((aligned(16))) float fw_lds[];
+    float* xs = fw_lds;
+    float* ws = fw_lds + FW_XS;
+    float* patch = fw_lds + FW_XS + FW_WS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bx = blockIdx.x;
+    const int twb = bx % nblk_w, th = (bx / nblk_w) % TH, n = bx / (nblk_w * TH);
+    const int h0 = 4 * th - 1, w0 = 64 * twb - 1;                        // map position of patch element (0, 0)
+    const size_t HWs = (size_t)H * W;
+    for (int e = tid; e < FW_XS; e += 384) {
+        float v = 0.f;
+        if (e < 3 * FXPLANE) {
+            const int c = e / FXPLANE, rem = e - c * FXPLANE, r = rem / FXC, cc = rem - r * FXC;
+            const int ih = h0 - 1 + r, iw = w0 - 1 + cc;
+            if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = x[((size_t)n * 3 + c) * HWs + (size_t)ih * W + iw];
+        }
+        xs[e] = v;
+    }
+    if (tid < 256) {
+        const f32x4 w0v = *reinterpret_cast<const f32x4*>(wrows + tid * 4), w1v = *reinterpret_cast<const f32x4*>(wrows + 1024 + tid * 4);
+        const int r0 = tid >> 3, c0 = (tid & 7) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ws[r0 * 33 + c0 + e] = w0v[e];
+            ws[(r0 + 32) * 33 + c0 + e] = w1v[e];
+        }
+    }
+    const int lr = lane & 31, lh = lane >> 5;
+    __syncthreads();
+    {
+        // wave = patch row; three blocks of 32 columns (the third holds columns 64, 65 and 30 unused ones) x two halves of the 64 channels
+        float bw[2][14];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 14; ++q) bw[i][q] = ws[(32 * i + lr) * 33 + 2 * q + lh];
+        f32x16 acc[3][2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+        const int base = wave * FXC + lr;
+#pragma unroll
+        for (int q = 0; q < 14; ++q) {
+            const int off = lh ? ftap_off(2 * q + 1) : ftap_off(2 * q);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float a = xs[base + 32 * j + off];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[i][q], acc[j][i], 0, 0, 0);
+            }
+        }
+        const int oh = h0 + wave;
+        float bv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) bv[i] = bias != nullptr ? bias[32 * i + lr] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pc = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (pc < FPC) {
+                        const int ow = w0 + pc;
+                        float v = acc[j][i][r] + bv[i];
+                        v = v < 0.f ? 0.f : v;                               // NaN stays NaN, like torch.relu
+                        if ((unsigned)oh >= (unsigned)H || (unsigned)ow >= (unsigned)W) v = 0.f;     // conv1_2's zero padding
+                        patch[(wave * FPC + pc) * FPS + 32 * i + lr] = v;
+                    }
+                }
+    }
+    __syncthreads();
+    if (tid < 256) {
+        const int t = tid >> 4, c4 = tid & 15;
+        const int tw = FT * twb + t;
+        if (tw < TW) {
+            const size_t tiles = (size_t)N * TH * TW, plane = tiles * 64;
+            const size_t tile = ((size_t)n * TH + th) * TW + tw;
+            f32x4 tt[6][6];                                          // B^T d, one patch column at a time (wino4_input_kernel's order)
+            unsigned long long word = 0ull;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                f32x4 d[6];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    d[a] = *reinterpret_cast<const f32x4*>(patch + ((a * FPC) + 4 * t + b) * FPS + c4 * 4);
+                    if (a >= 1 && a <= 4 && b >= 1 && b <= 4) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) word |= (unsigned long long)(d[a][e] > 0.f) << (((a - 1) * 4 + (b - 1)) * 4 + e);
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 6; ++k)
+                        if (FW_BT[a][k] != 0.f) acc2 += FW_BT[a][k] * d[k];
+                    tt[a][b] = acc2;
+                }
+            }
+            float* dst = V + tile * 64 + c4 * 4;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = 0; b < 6; ++b) {
+                    f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 6; ++k)
+                        if (FW_BT[b][k] != 0.f) acc2 += FW_BT[b][k] * tt[a][k];
+                    *reinterpret_cast<f32x4*>(dst + (size_t)(a * 6 + b) * plane) = acc2;
+                }
+            if (bits != nullptr) bits[tile * 16 + c4] = word;
+        }
+    }
+}
+
+
 // Weight + bias gradient of conv1_1 from the NCHW input itself (no [pixel][32] rows in memory):
 //   dw[co][k] = sum_p dy[p][co] * x[p + tap(k)][c(k)],  k = (r*3+s)*3 + c < 27;   column 27 multiplies ones: db[co] = sum_p dy[p][co].
 // Same 4 x 64 pixel tiles and halo image as the forward kernel; the reduction runs over the pixels: per 32-pixel block of its tile row a
@@ -275,6 +418,30 @@ extern "C" int ssd_conv1_first_fwd(const float* x_nchw, const float* w_rows, con
     return conv1_first_fwd_impl(x_nchw, w_rows, bias, y_nhwc, col_out, N, H, W, relu, stream, false);
 }
 // bf16-tensor mode: x and the filter rounded to bf16 (f32 accumulate), y stored as bf16 NHWC
+// conv1_1 (+ bias + ReLU) as the F(4x4) input planes of the 64 -> 64 convolution behind it: V [36][N * TH * TW][64] f32 (TH = ceil(H / 4),
+// TW = ceil(W / 4): ssd_conv3x3_wino_*'s tile grid at dilation 1) and, optionally, the ReLU bit words (N * TH * TW x 16).
+extern "C" int ssd_conv1_first_wino_fwd(const float* x_nchw, const float* w_rows, const float* bias, float* planes, uint64_t* relu_bits, int N,
+                                        int H, int W, void* stream) {
+    if (!x_nchw || !w_rows || !planes) return SSD_ERR_NULL;
+    if (N <= 0 || H <= 0 || W <= 0) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(w_rows) || !ssd_aligned16(planes) || (relu_bits && ((uintptr_t)relu_bits & 7))) return SSD_ERR_ALIGN;
+    const int TH_ = (H + 3) / 4, TW_ = (W + 3) / 4, nbw = (TW_ + FT - 1) / FT;
+    const size_t nblk = (size_t)N * TH_ * nbw;
+    if (nblk >= (1ull << 31) || (size_t)N * TH_ * TW_ >= (1ull << 31)) return SSD_ERR_BAD_SHAPE;
+    static std::atomic<unsigned long long> raised{0};
+    int dev;
+    if (ssd_attr_needed(raised, dev)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FW_LDS_BYTES) !=
+            hipSuccess)
+            return SSD_ERR_LAUNCH;
+        ssd_attr_done(raised, dev);
+    }
+    hipLaunchKernelGGL(conv_first_wino_kernel, dim3((unsigned)nblk), dim3(384), FW_LDS_BYTES, (hipStream_t)stream, x_nchw, w_rows, bias, planes,
+                       reinterpret_cast<unsigned long long*>(relu_bits), N, H, W, TH_, TW_, nbw);
+    SSD_CHECK_LAUNCH();
+    return SSD_OK;
+}
+
 extern "C" int ssd_conv1_first_fwd_bf16(const float* x_nchw, const float* w_rows, const float* bias, void* y_nhwc_bf16, int N, int H, int W,
                                         int relu, void* stream) {
     return conv1_first_fwd_impl(x_nchw, w_rows, bias, y_nhwc_bf16, nullptr, N, H, W, relu, stream, true);

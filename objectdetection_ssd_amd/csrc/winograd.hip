@@ -1334,6 +1334,28 @@ extern "C" int ssd_conv3x3_wino_fwd_pool_bits(const float* x, const float* U_fwd
                      (hipStream_t)stream, &po, planes_keep, nullptr, reinterpret_cast<unsigned long long*>(relu_bits_out));
 }
 
+// Forward of an F(4x4) layer whose input planes already exist (written by the producer of its input: ssd_conv1_first_wino_fwd): the plane
+// GEMMs + output transform only.  y_pooled != NULL: conv -> ReLU -> 2x2 / stride-2 max pool (ssd_conv3x3_wino_fwd_pool's outputs), else y
+// (N,H,W,ldy) with bias (+ ReLU).
+extern "C" int ssd_conv3x3_wino_fwd_from_planes(const float* planes, const float* U_fwd, const float* bias, float* y, int ldy, float* y_pooled,
+                                                uint8_t* argmax, const ssd_conv_geom* g, int relu, int ceil_mode, void* workspace,
+                                                size_t workspace_bytes, void* stream) {
+    if (!planes || !U_fwd || !workspace || (!y && !y_pooled)) return SSD_ERR_NULL;
+    if (!wino_geom_ok(g) || g->dil != 1 || g->Ci % 32 != 0 || g->Co % 4 != 0) return SSD_ERR_BAD_SHAPE;
+    if (!ssd_aligned16(planes) || !ssd_aligned16(U_fwd) || !ssd_aligned16(workspace) || (y && !ssd_aligned16(y)) || (y_pooled && !ssd_aligned16(y_pooled)) ||
+        (bias && !ssd_aligned16(bias)) || (argmax && ((uintptr_t)argmax & 3)))
+        return SSD_ERR_ALIGN;
+    if (y_pooled) {
+        const PooledOut po = {y_pooled, argmax, ceil_mode ? (g->H + 1) / 2 : g->H / 2, ceil_mode ? (g->W + 1) / 2 : g->W / 2};
+        if (po.Ho <= 0 || po.Wo <= 0) return SSD_ERR_BAD_SHAPE;
+        return wino_conv(4, nullptr, g->Ci, U_fwd, g->Co, nullptr, g->Co, g->Co, bias, nullptr, 1, 0, g->N, g->H, g->W, workspace, workspace_bytes,
+                         (hipStream_t)stream, &po, nullptr, planes);
+    }
+    if (ldy < g->Co || ldy % 4 != 0) return SSD_ERR_BAD_SHAPE;
+    return wino_conv(4, nullptr, g->Ci, U_fwd, g->Co, y, ldy, g->Co, bias, nullptr, relu, 0, g->N, g->H, g->W, workspace, workspace_bytes,
+                     (hipStream_t)stream, nullptr, nullptr, planes);
+}
+
 extern "C" int ssd_conv3x3_wino_dgrad(const float* dy, int ldy, const float* U_bwd, int Co_pad, float* dx, const float* relu_mask,
                                       int accumulate, const ssd_conv_geom* g, int mo, void* workspace, size_t workspace_bytes,
                                       void* stream) {

@@ -441,6 +441,26 @@ def conv1_first_fwd(x_nchw: torch.Tensor, w_rows: torch.Tensor, bias: Optional[t
     return y, col
 
 
+def conv1_first_wino_fwd(x_nchw: torch.Tensor, w_rows: torch.Tensor, bias: Optional[torch.Tensor], want_bits: bool = True):
+    """conv1_1 + bias + ReLU left as the F(4x4) input planes of the 64 -> 64 convolution behind it -> (planes (36, tiles, 64), ReLU bit
+    words (tiles, 16) int64 or None): what `conv1_first_fwd` + that layer's input transform would have produced, bit for bit, without the
+    activation tensor in between."""
+    _req(x_nchw, "x"); _req(w_rows, "w_rows")
+    n, c, h, w = x_nchw.shape
+    if c != 3 or w_rows.numel() != 64 * 32:
+        raise ValueError("conv1_first_wino_fwd expects 3 input channels and (64, 32) filter rows")
+    if bias is not None:
+        _req(bias, "bias")
+        if bias.numel() != 64:
+            raise ValueError("conv1_first_wino_fwd: 64 biases")
+    tiles = n * ((h + 3) // 4) * ((w + 3) // 4)
+    planes = torch.empty((36, tiles, 64), device=x_nchw.device, dtype=torch.float32)
+    bits = torch.empty((tiles, 16), device=x_nchw.device, dtype=torch.int64) if want_bits else None
+    check(_lib.load().ssd_conv1_first_wino_fwd(x_nchw.data_ptr(), w_rows.data_ptr(), _ptr(bias), planes.data_ptr(), _ptr(bits), n, h, w, _stream()),
+          "conv1_first_wino_fwd")
+    return planes, bits
+
+
 def conv1_first_wgrad(x_nchw: torch.Tensor, dy: torch.Tensor, want_bias: bool = True):
     """Weight / bias gradient of conv1_1 from the NCHW input: -> (dw (64,32,1,1) rows for `first_weight_grad`, dbias (64,) or None)."""
     _req(x_nchw, "x"); _req(dy, "dy")
@@ -1028,6 +1048,34 @@ def conv2d_fwd_wino_pool(x: torch.Tensor, u_fwd: torch.Tensor, bias: Optional[to
     if want_bits:
         return y, am, planes, bits
     return (y, am, planes) if keep_planes else (y, am)
+
+
+def conv2d_fwd_wino_from_planes(planes: torch.Tensor, u_fwd: torch.Tensor, bias: Optional[torch.Tensor], g: ConvGeom, relu: bool = True,
+                                pool_ceil: Optional[bool] = None, want_argmax: bool = True):
+    """Forward of an F(4x4) layer whose input planes exist already (`conv1_first_wino_fwd`): plane GEMMs + output transform.
+    pool_ceil None -> y (N,H,W,Co); True / False -> (pooled y, argmax or None) of the fused conv -> ReLU -> 2x2 / stride-2 pool."""
+    _req(planes, "planes")
+    if _wino_mo(u_fwd) != 4 or tuple(planes.shape) != tuple(wino_planes_shape(g)) or g.Co % 4 != 0:
+        raise ValueError("conv2d_fwd_wino_from_planes: planes / filters do not match the geometry")
+    _wino_filter(u_fwd, "u_fwd", g.Co, g.Ci)
+    if bias is not None:
+        _req(bias, "bias")
+    lib = _lib.load()
+    nbytes = lib.ssd_conv3x3_wino_workspace(C.byref(g), 0, 4)
+    if nbytes == 0:
+        raise ValueError("conv2d_fwd_wino_from_planes: not a 3x3 / stride 1 / pad 1 geometry")
+    ws = workspace(nbytes, planes.device, "wino")
+    if pool_ceil is None:
+        y = torch.empty((g.N, g.H, g.W, g.Co), device=planes.device, dtype=torch.float32)
+        check(lib.ssd_conv3x3_wino_fwd_from_planes(planes.data_ptr(), u_fwd.data_ptr(), _ptr(bias), y.data_ptr(), g.Co, None, None, C.byref(g), int(relu),
+                                                   0, ws.data_ptr(), ws.numel(), _stream()), "conv2d_fwd_wino_from_planes")
+        return y
+    ho, wo = pool_out(g.H, 2, 2, 0, pool_ceil), pool_out(g.W, 2, 2, 0, pool_ceil)
+    y = torch.empty((g.N, ho, wo, g.Co), device=planes.device, dtype=torch.float32)
+    am = torch.empty((g.N, ho, wo, g.Co), device=planes.device, dtype=torch.uint8) if want_argmax else None
+    check(lib.ssd_conv3x3_wino_fwd_from_planes(planes.data_ptr(), u_fwd.data_ptr(), _ptr(bias), None, 0, y.data_ptr(), _ptr(am), C.byref(g), 1,
+                                               int(pool_ceil), ws.data_ptr(), ws.numel(), _stream()), "conv2d_fwd_wino_from_planes")
+    return y, am
 
 
 def conv2d_dgrad_wino(dy: Optional[torch.Tensor], u_bwd: torch.Tensor, g: ConvGeom, dx: Optional[torch.Tensor] = None,

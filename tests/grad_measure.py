@@ -129,6 +129,31 @@ def layerwise_forward_distance(net, params, conv_dtype):
 PINNED_BAR = {"direct": 1e-5, "wino": 5e-5}
 
 
+def unpack_relu_bits(bits, n, h, w, c):
+    """(tiles, c/4) int64 words of the Winograd input transform (bit (a*4+b)*4+e = x[4th+a][4tw+b][4c4+e] > 0) -> bool mask (n, c, h, w)"""
+    th, tw = (h + 3) // 4, (w + 3) // 4
+    b = bits.cpu().view(n, th, tw, c // 4, 1)
+    sh = torch.arange(64, dtype=torch.int64).view(1, 1, 1, 1, 64)
+    m = ((b >> sh) & 1).bool().view(n, th, tw, c // 4, 4, 4, 4)            # (n, th, tw, c4, a, b, e)
+    m = m.permute(0, 3, 6, 1, 4, 2, 5).reshape(n, c, 4 * th, 4 * tw)      # (n, c4, e, th, a, tw, b)
+    return m[:, :, :h, :w].contiguous()
+
+
+def _relu_mask_of(eng, T, aux, op):
+    """ReLU mask (N,C,H,W bool) of a convolution's output as the engine can reproduce it: from the stored activation, from the ReLU bit words
+    the next layer's input transform kept when the activation itself was never stored (conv1_1 -> planes), or None (gate carried by a pool)."""
+    from objectdetection_ssd_amd.Model import _Elided
+    t = T[op["y"]]
+    if not isinstance(t, _Elided):
+        return (t > 0).permute(0, 3, 1, 2).cpu()
+    nxt = next((o for o in eng.ops if o["op"] == "conv" and o["x"] == op["y"]), None)
+    bits = aux.get("bits:" + nxt["p"]) if nxt is not None else None
+    if bits is None or any(o["op"] == "pool" and o["x"] == op["y"] for o in eng.ops):
+        return None
+    n, h, w, c = t.shape
+    return unpack_relu_bits(bits, n, h, w, c)
+
+
 def gpu_decisions(net, x, classes, boxes):
     """The discrete choices of the HIP forward + loss on this batch: ReLU masks and max-pool arg-max codes as the engine saved
     them for its backward, and the hard negatives its loss kernel selected -> (decisions for O.ssd300_forward, neg_select)."""
@@ -142,8 +167,7 @@ def gpu_decisions(net, x, classes, boxes):
     relu, pool = {}, {}
     for op in eng.ops:
         if op["op"] in ("conv", "conv_first") and op["y"] in eng.relu_out:
-            t = T[op["y"]]
-            relu[op["y"]] = None if isinstance(t, _Elided) else (t > 0).permute(0, 3, 1, 2).cpu()
+            relu[op["y"]] = _relu_mask_of(eng, T, aux, op)
         elif op["op"] == "pool":
             gate = (T[op["y"]] > 0).permute(0, 3, 1, 2).cpu() if isinstance(T[op["x"]], _Elided) else None
             pool[op["y"]] = (aux[op["y"]].permute(0, 3, 1, 2).cpu(), gate)

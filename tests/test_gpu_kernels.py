@@ -819,6 +819,39 @@ def test_winograd_f4x4_3x3_forward_and_dgrad(case):
     _close(dw_t, dw, tol=2e-5, what=f"winograd F(4x4) wgrad TN vs NT {case}")
 
 
+@pytest.mark.parametrize("case", [(2, 300, 300), (1, 37, 70), (3, 8, 8), (1, 129, 66)])
+def test_conv1_1_written_as_winograd_planes(case):
+    """csrc/conv_first.hip conv_first_wino_kernel (Model.py:135 features[0:4]): conv1_1 + ReLU left as the F(4x4) input planes + ReLU bit
+    words of the 64 -> 64 layer behind it must be, bit for bit, what conv1_1's own kernel followed by that layer's input transform writes
+    -- on the full 300 x 300 map, on maps that are no multiple of 4 or of the 64-column workgroup strip, and on a map smaller than a strip;
+    and the layer's forward from those planes (plain and with the fused 2x2 pool) equals its forward from the activation."""
+    from objectdetection_ssd_amd import ops
+    n, h, w = case
+    dev = _dev()
+    gen = torch.Generator().manual_seed(7 + h)
+    x = torch.randn(n, 3, h, w, generator=gen).to(dev)
+    w1 = (torch.randn(64, 3, 3, 3, generator=gen) / 5.0).to(dev)
+    b1 = torch.randn(64, generator=gen).to(dev)
+    w2 = (torch.randn(64, 64, 3, 3, generator=gen) / 24.0).to(dev)
+    b2 = torch.randn(64, generator=gen).to(dev)
+    rows = ops.first_weight_rows(w1)
+    y1, _ = ops.conv1_first_fwd(x, rows, b1, True)
+    g = ops.make_geom(n, h, w, 64, 64, 3, 1, 1, 1)
+    uf, _ = ops.wino_weights(w2, 64, want_bwd=False, mo=4)
+    y2, planes_ref, bits_ref = ops.conv2d_fwd_wino(y1, uf, b2, g, True, keep_planes=True, want_bits=True)
+    planes, bits = ops.conv1_first_wino_fwd(x, rows, b1, want_bits=True)
+    assert planes.shape == planes_ref.shape and bits.shape == bits_ref.shape
+    assert torch.equal(bits, bits_ref), "ReLU bit words differ"
+    assert torch.equal(planes, planes_ref), "input planes differ"
+    assert torch.equal(ops.conv2d_fwd_wino_from_planes(planes, uf, b2, g, True), y2)
+    for ceil in (False, True):
+        yp_ref, am_ref = ops.conv2d_fwd_wino_pool(y1, uf, b2, g, ceil)
+        yp, am = ops.conv2d_fwd_wino_from_planes(planes, uf, b2, g, True, pool_ceil=ceil)
+        assert torch.equal(yp, yp_ref) and torch.equal(am, am_ref)
+    p2, none = ops.conv1_first_wino_fwd(x, rows, b1, want_bits=False)
+    assert none is None and torch.equal(p2, planes)
+
+
 def _relu_bits(mask_nhwc: torch.Tensor, th: int, tw: int) -> torch.Tensor:
     """(N,H,W,C) -> (N*th*tw, C/4) int64 words, bit (a*4+b)*4+e = mask[n, 4th+a, 4tw+b, 4c4+e] > 0: what wino4_input_kernel leaves"""
     n, h, w, c = mask_nhwc.shape

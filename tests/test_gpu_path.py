@@ -1623,3 +1623,36 @@ def test_bf16_train_step_vs_decision_and_rounding_pinned_f64_oracle(golden_net):
     print("rounding-pinned bf16 gradient distance: worst " + ", ".join(f"{k} {v:.2e}" for v, k in rows[:6]) + f"; median {rows[35][0]:.2e}")
     bad = [(k, v) for v, k in rows if v > M.BF16_PINNED_BAR]
     assert not bad, bad
+
+
+
+def test_first_layer_into_planes_is_bitwise_the_two_kernel_step():
+    """`_Engine.first_wino` (round 4): conv1_1 writes conv1_2's Winograd input planes and ReLU bits itself and its activation tensor is never
+    stored.  Same arithmetic, same order: outputs, losses and all 71 gradients of a train step equal the engine with the two separate
+    kernels bit for bit (batch 3 of 300 x 300), and so does the inference forward."""
+    import grad_measure as M
+    from objectdetection_ssd_amd import Model
+    from objectdetection_ssd_amd.Model import _Elided
+    torch.manual_seed(14)
+    net = Model.SSD_300().to(DEV)
+    x, cl, bx = M.bench_batch(bs=3, seed=79)
+    res = {}
+    for on in (True, False):
+        net._engine.first_wino = on
+        res[on] = M.train_step(net, x, cl, bx)
+        with torch.no_grad():
+            _, _, saved = net._engine.forward(x, net._forward_params(), save=True)
+        assert isinstance(saved["T"]["a1_1"], _Elided) == on
+    net._engine.first_wino = True
+    a, b = res[True], res[False]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3]
+    assert set(a[4]) == set(b[4]) and len(a[4]) == 71
+    for k in a[4]:
+        assert torch.equal(a[4][k], b[4][k]), k
+    net.eval()
+    with torch.no_grad():
+        l1, c1 = net(x)
+        net._engine.first_wino = False
+        l0, c0 = net(x)
+        net._engine.first_wino = True
+    assert torch.equal(l0, l1) and torch.equal(c0, c1)
