@@ -956,7 +956,7 @@ class _Engine:
                     if self._adj_ok(g):
                         raise RuntimeError(f"{op['p']}: its filter planes are laid out for the adjoint data gradient, which needs the forward's kept planes "
                                            "(the engine's keep_planes / dual_dy / adjoint_dgrad switches must not change between a forward and its backward)")
-                    bits = aux.pop("bits:" + op["p"], None) if (dyp is not None or ops.wino_uses_full(g, 1)) else None
+                    bits = aux.pop("bits:" + op["p"], None) if (dyp is not None or ops.wino_uses_full(g, 1) or isinstance(T[op["x"]], _Elided)) else None
                     def dgrad_rot(dx, acc, mask, dy=dy, ub=ub, g=g, dyp=dyp, bits=bits, name=op["p"]):
                         if isinstance(mask, _Elided):            # the gated activation was never stored (conv1_1 -> planes): only its bits exist
                             if bits is None:

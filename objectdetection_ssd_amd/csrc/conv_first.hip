@@ -154,7 +154,11 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
 // Positions outside the map are ZERO in the patch (conv1_2's zero padding), not conv1_1 evaluated out there.  The MFMA chain per output
 // element and the transform's sums are those of conv_first_fwd_kernel and wino4_input_kernel (csrc/winograd.hip): planes and bits are
 // bit-identical to the two-kernel form (tests/test_gpu_kernels.py::test_conv1_1_written_as_winograd_planes).
-constexpr int FT = 16, FPR = 6, FPC = 4 * FT + 2, FXR = FPR + 2, FXC = FPC + 2, FXPLANE = FXR * FXC;     // tiles / patch rows x cols / input halo
+#ifndef FW_FT
+#define FW_FT 8        // tiles per workgroup.  16: 123 KB of LDS = one workgroup per CU, nothing overlaps its load / MFMA / transform phases (measured: the
+#endif                 // fused kernel slower than the two it replaces); 8: 68 KB, two workgroups per CU cover each other's phases
+constexpr int FT = FW_FT, FNB = (4 * FT + 2 + 31) / 32;              // column blocks of 32 per patch row
+constexpr int FPR = 6, FPC = 4 * FT + 2, FXR = FPR + 2, FXC = FPC + 2, FXPLANE = FXR * FXC;     // tiles / patch rows x cols / input halo
 constexpr int FPS = 68;                                               // floats per patch pixel in LDS: 64 channels + 4 (16-byte aligned, spreads the banks)
 constexpr int FW_XS = 3 * FXPLANE + 64, FW_WS = 64 * 33, FW_PATCH = FPR * FPC * FPS;
 constexpr size_t FW_LDS_BYTES = (size_t)(FW_XS + FW_WS + FW_PATCH) * 4;
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(384) void conv_first_wino_kernel(const float* __res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bx = blockIdx.x;
     const int twb = bx % nblk_w, th = (bx / nblk_w) % TH, n = bx / (nblk_w * TH);
-    const int h0 = 4 * th - 1, w0 = 64 * twb - 1;                        // map position of patch element (0, 0)
+    const int h0 = 4 * th - 1, w0 = 4 * FT * twb - 1;                    // map position of patch element (0, 0)
     const size_t HWs = (size_t)H * W;
     for (int e = tid; e < FW_XS; e += 384) {
         float v = 0.f;
@@ -198,15 +202,15 @@ __global__ __launch_bounds__(384) void conv_first_wino_kernel(const float* __res
     const int lr = lane & 31, lh = lane >> 5;
     __syncthreads();
     {
-        // wave = patch row; three blocks of 32 columns (the third holds columns 64, 65 and 30 unused ones) x two halves of the 64 channels
+        // wave = patch row; FNB blocks of 32 columns (the last holds the two halo columns and 30 unused ones) x two halves of the 64 channels
         float bw[2][14];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int q = 0; q < 14; ++q) bw[i][q] = ws[(32 * i + lr) * 33 + 2 * q + lh];
-        f32x16 acc[3][2];
+        f32x16 acc[FNB][2];
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < FNB; ++j)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(384) void conv_first_wino_kernel(const float* __res
         for (int q = 0; q < 14; ++q) {
             const int off = lh ? ftap_off(2 * q + 1) : ftap_off(2 * q);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
+            for (int j = 0; j < FNB; ++j) {
                 const float a = xs[base + 32 * j + off];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[i][q], acc[j][i], 0, 0, 0);
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(384) void conv_first_wino_kernel(const float* __res
 #pragma unroll
         for (int i = 0; i < 2; ++i) bv[i] = bias != nullptr ? bias[32 * i + lr] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < FNB; ++j)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(384) void conv_first_wino_kernel(const float* __res
                 }
     }
     __syncthreads();
-    if (tid < 256) {
+    if (tid < 16 * FT) {
         const int t = tid >> 4, c4 = tid & 15;
         const int tw = FT * twb + t;
         if (tw < TW) {
