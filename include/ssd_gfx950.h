@@ -255,7 +255,9 @@ int ssd_conv3x3_wino_wgrad_planes(const float* planes, const float* dy, int ldy,
                                   float* dgrad_planes_out, void* workspace, size_t workspace_bytes, void* stream);
 int ssd_conv3x3_wino_dgrad_planes(const float* dy_planes, const float* U_bwd, int Co_pad, float* dx, const float* relu_mask,
                                   int accumulate, const ssd_conv_geom* g, void* workspace, size_t workspace_bytes, void* stream);
-/* conv1_1 written as the next layer's Winograd input (round 4; Model.py:135 features[0:4]: Conv2d(3,64) -> ReLU -> Conv2d(64,64)).  In
+/* conv1_1 written as the next layer's Winograd input (round 4 EXPERIMENT: ssd_conv1_first_wino_fwd returns SSD_ERR_BAD_SHAPE unless built
+ * with SSD_EXPERIMENTAL=1 -- bit-identical but measured slower than the two kernels it replaces; Model.py:135 features[0:4]:
+ * Conv2d(3,64) -> ReLU -> Conv2d(64,64)).  In
  * training nothing but conv1_2 reads conv1_1's activation, so ssd_conv1_first_wino_fwd leaves it as the F(4x4) input planes
  * (36 x N*ceil(H/4)*ceil(W/4) x 64 f32) + the ReLU bit words of ssd_conv3x3_wino_fwd_keep_bits, bit-identical to ssd_conv1_first_fwd followed
  * by that layer's input transform, and the 64-channel activation (737 MB at batch 32) is neither written nor read.

@@ -227,9 +227,10 @@ class _Engine:
         # (conv3_3 -> 3_2 -> 3_1, conv4_3 -> 4_2 -> 4_1, conv5_3 -> 5_2 -> 5_1) the gradient tensor itself is never written: the output
         # transform of the upper layer's data gradient writes the lower layer's dy planes (csrc/winograd.hip wino4_adj_out_kernel)
         self.adjoint_dgrad = True
-        # Round 4: conv1_1 writes conv1_2's Winograd input planes (+ ReLU bits) itself; its 64-channel activation -- read by nothing else --
-        # is never stored (csrc/conv_first.hip conv_first_wino_kernel; bit-identical planes)
-        self.first_wino = True
+        # Round 4 experiment (SSD_EXPERIMENTAL builds): conv1_1 writes conv1_2's Winograd input planes (+ ReLU bits) itself; its 64-channel
+        # activation -- read by nothing else -- is never stored (csrc/conv_first.hip conv_first_wino_kernel; bit-identical planes).  Measured
+        # SLOWER than the two kernels it replaces (0.96 vs 0.25 + 0.52 ms; step 20.16 vs 19.97): off
+        self.first_wino = False
         self.adjoint_chain = True      # False: every adjoint data gradient is written out as a tensor (A/B aid)
         self.prof = None          # bench.py: list collecting (label, kernel tag, flops, start event, end event)
         self.bf16 = False         # True: forward / dgrad / fused-wgrad convolutions multiply bf16-rounded operands (f32 accumulate)
@@ -322,7 +323,7 @@ class _Engine:
 
     def _first_wino_ok(self, op, bs, x) -> bool:
         """conv1_1's output goes straight into the input planes of the layer behind it: that layer is its only reader and an F(4x4) one."""
-        if not (self.first_wino and self.wino and self.WINO_TILE == 4 and self.consumers.get(op["y"], 0) == 1):
+        if not (self.first_wino and ops.has_experimental() and self.wino and self.WINO_TILE == 4 and self.consumers.get(op["y"], 0) == 1):
             return False
         nxt = next((o for o in self.ops if o["op"] == "conv" and o["x"] == op["y"]), None)
         if nxt is None or nxt["ci"] != 64:

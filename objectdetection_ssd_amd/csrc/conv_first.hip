@@ -145,7 +145,13 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
 }
 
 
-// ---- conv1_1 + ReLU written DIRECTLY as the F(4x4,3x3) input planes of conv1_2 (round 4) ---------------------------------------------------
+// ---- conv1_1 + ReLU written DIRECTLY as the F(4x4,3x3) input planes of conv1_2 (round 4; SSD_EXPERIMENTAL builds only) ---------------------
+// MEASURED: correct and bit-identical, but SLOWER than the two kernels it replaces: 0.964 ms against conv1_1 0.248 + conv1_2's input transform
+// 0.52 (bench.py --layers, batch 32); in the step 20.16 against 19.97 ms (8 tiles per workgroup), 20.36 against 20.25 (16 tiles).  The 1.47 GB it
+// keeps out of HBM are worth 0.3 ms, but a 6 x 34 patch costs 3x conv1_1's MFMA work (6 rows for 4, two 32-column blocks for 34 columns) and the
+// workgroup's load / MFMA / LDS / transform phases do not overlap at two workgroups per CU.  Kept as the tested starting point (the two halo
+// columns as ONE gathered MFMA block per workgroup would halve the MFMA work); `_Engine.first_wino` is off.
+#ifdef SSD_EXPERIMENTAL
 // In training the only reader of conv1_1's output is conv1_2 (Model.py:135 features[0:4]), a Winograd layer: its input transform reads the
 // 737 MB activation (batch 32) that this kernel has just written, and nothing else ever needs it -- the backward gates conv1_2's data gradient
 // through the ReLU BITS the transform leaves, conv1_2's weight gradient multiplies the kept planes, conv1_1's own weight gradient reads x and
@@ -290,6 +296,7 @@ __global__ __launch_bounds__(384) void conv_first_wino_kernel(const float* __res
         }
     }
 }
+#endif  // SSD_EXPERIMENTAL
 
 
 // Weight + bias gradient of conv1_1 from the NCHW input itself (no [pixel][32] rows in memory):
@@ -426,6 +433,9 @@ extern "C" int ssd_conv1_first_fwd(const float* x_nchw, const float* w_rows, con
 // TW = ceil(W / 4): ssd_conv3x3_wino_*'s tile grid at dilation 1) and, optionally, the ReLU bit words (N * TH * TW x 16).
 extern "C" int ssd_conv1_first_wino_fwd(const float* x_nchw, const float* w_rows, const float* bias, float* planes, uint64_t* relu_bits, int N,
                                         int H, int W, void* stream) {
+#ifndef SSD_EXPERIMENTAL
+    return SSD_ERR_BAD_SHAPE;                       // not in this build (SSD_EXPERIMENTAL=1 python -m objectdetection_ssd_amd.build): measured slower
+#else
     if (!x_nchw || !w_rows || !planes) return SSD_ERR_NULL;
     if (N <= 0 || H <= 0 || W <= 0) return SSD_ERR_BAD_SHAPE;
     if (!ssd_aligned16(w_rows) || !ssd_aligned16(planes) || (relu_bits && ((uintptr_t)relu_bits & 7))) return SSD_ERR_ALIGN;
@@ -444,6 +454,7 @@ extern "C" int ssd_conv1_first_wino_fwd(const float* x_nchw, const float* w_rows
                        reinterpret_cast<unsigned long long*>(relu_bits), N, H, W, TH_, TW_, nbw);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
+#endif
 }
 
 extern "C" int ssd_conv1_first_fwd_bf16(const float* x_nchw, const float* w_rows, const float* bias, void* y_nhwc_bf16, int N, int H, int W,

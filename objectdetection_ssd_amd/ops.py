@@ -441,6 +441,11 @@ def conv1_first_fwd(x_nchw: torch.Tensor, w_rows: torch.Tensor, bias: Optional[t
     return y, col
 
 
+def has_experimental() -> bool:
+    """the library was built with SSD_EXPERIMENTAL=1 (the kernels that measured no better than the shipped ones)"""
+    return bool(_lib.load().ssd_has_experimental())
+
+
 def conv1_first_wino_fwd(x_nchw: torch.Tensor, w_rows: torch.Tensor, bias: Optional[torch.Tensor], want_bits: bool = True):
     """conv1_1 + bias + ReLU left as the F(4x4) input planes of the 64 -> 64 convolution behind it -> (planes (36, tiles, 64), ReLU bit
     words (tiles, 16) int64 or None): what `conv1_first_fwd` + that layer's input transform would have produced, bit for bit, without the

@@ -1631,8 +1631,10 @@ def test_first_layer_into_planes_is_bitwise_the_two_kernel_step():
     stored.  Same arithmetic, same order: outputs, losses and all 71 gradients of a train step equal the engine with the two separate
     kernels bit for bit (batch 3 of 300 x 300), and so does the inference forward."""
     import grad_measure as M
-    from objectdetection_ssd_amd import Model
+    from objectdetection_ssd_amd import Model, ops
     from objectdetection_ssd_amd.Model import _Elided
+    if not ops.has_experimental():
+        pytest.skip("conv_first_wino_kernel is compiled only with SSD_EXPERIMENTAL=1 (off by default: measured slower)")
     torch.manual_seed(14)
     net = Model.SSD_300().to(DEV)
     x, cl, bx = M.bench_batch(bs=3, seed=79)
@@ -1643,7 +1645,7 @@ def test_first_layer_into_planes_is_bitwise_the_two_kernel_step():
         with torch.no_grad():
             _, _, saved = net._engine.forward(x, net._forward_params(), save=True)
         assert isinstance(saved["T"]["a1_1"], _Elided) == on
-    net._engine.first_wino = True
+    net._engine.first_wino = False
     a, b = res[True], res[False]
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3]
     assert set(a[4]) == set(b[4]) and len(a[4]) == 71
@@ -1651,8 +1653,8 @@ def test_first_layer_into_planes_is_bitwise_the_two_kernel_step():
         assert torch.equal(a[4][k], b[4][k]), k
     net.eval()
     with torch.no_grad():
+        net._engine.first_wino = True
         l1, c1 = net(x)
         net._engine.first_wino = False
         l0, c0 = net(x)
-        net._engine.first_wino = True
     assert torch.equal(l0, l1) and torch.equal(c0, c1)
