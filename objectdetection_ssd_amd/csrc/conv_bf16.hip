@@ -211,7 +211,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(const HaloParams p
     constexpr int A_BYTES = A_ROWS * 128;
     constexpr int B_PIECES = BN / 8, BPW = B_PIECES / 8;   // weight-tile pieces per stage / per wave
     constexpr int B_BYTES = BN * 128;
-    constexpr int NSLOT = 3;
+    // Weight ring.  3 slots (round 3): stage s + 2 is requested during stage s and is published by the barrier that ENDS stage s + 1, so the
+    // first weight fragments of a stage can only be read AFTER that barrier -- ~200 cycles of LDS latency with the matrix pipe idle, per stage
+    // of 16 MFMAs, in all eight waves at once.  4 slots (round 4, CB_RING4): stage s + 3 is requested during stage s; stage s + 1's weights
+    // were published one barrier earlier, so its first fragments are requested BEFORE the barrier that ends stage s, like the pixel fragments.
+#ifdef CB_RING3
+    constexpr int NSLOT = 3, AHEAD = 2;
+#else
+    constexpr int NSLOT = 4, AHEAD = 3;
+#endif
     static_assert(B_PIECES % 8 == 0 && BPW >= 1, "every wave issues the same number of weight pieces");
     static_assert(MODE == 2 || (PH * PW == BM && HH * HW <= A_ROWS), "patch / halo size");
     static_assert((ADBL ? 2 : 1) * A_BYTES + NSLOT * B_BYTES <= 160 * 1024, "LDS");
@@ -325,14 +333,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(const HaloParams p
     const int KC = p.K >> 6, NS = KC * 9;
     const int row_pitch = MODE == 2 ? p.Wp : HW;
 
-    // ---- prologue: halo of chunk 0, weight tiles of stages 0 and 1 ---------------------------------------------------------
+    // ---- prologue: halo of chunk 0, weight tiles of stages 0 .. AHEAD - 1 ---------------------------------------------------------
 #pragma unroll
     for (int i = 0; i < APW; ++i) issue_a(i, 0, 0, true);
 #pragma unroll
     for (int i = 0; i < BPW; ++i) issue_b(i, 0, 0, 0, true);
 #pragma unroll
     for (int i = 0; i < BPW; ++i) issue_b(i, 1, 0, 1, true);  // NS >= 9
-    wait_vmcnt<BPW>();                                       // everything but stage 1's weights has landed
+    if (AHEAD == 3) {
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) issue_b(i, 2, 0, 2, true);
+    }
+    wait_vmcnt<BPW>();                                       // everything but the last requested stage's weights has landed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
@@ -364,6 +376,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(const HaloParams p
     };
     tap_setup(0);
     if (NSET == 2) load_x(0, As, 0);
+    if (NSET == 2 && AHEAD == 3) load_w(0, Bs, 0);
 
     // Stage = (chunk, tap): 4 k-steps of TM x TN MFMAs.  The fragments of k-step ks+1 are requested before the MFMAs of k-step ks, the
     // stage's DMA instructions sit BETWEEN the k-steps (an LDS-DMA holds the wave's issue port for ~100 cycles: issued in a block at the
@@ -378,8 +391,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(const HaloParams p
         for (int t = 0; t < 9; ++t) {
             const int s = kc * 9 + t;
             const unsigned char* Bb = Bs + (s % NSLOT) * B_BYTES;
-            const int t2 = t + 2 >= 9 ? t + 2 - 9 : t + 2, kc2 = t + 2 >= 9 ? kc + 1 : kc;
-            if (NSET == 2) load_w(0, Bb, 0);
+            const int t2 = t + AHEAD >= 9 ? t + AHEAD - 9 : t + AHEAD, kc2 = t + AHEAD >= 9 ? kc + 1 : kc;
+            if (NSET == 2 && AHEAD == 2) load_w(0, Bb, 0);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int cur = NSET == 2 ? (ks & 1) : 0, nxt = cur ^ 1;
@@ -397,12 +410,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(const HaloParams p
                     if (ADBL && t < APW) issue_a(t, kc + 1, (kc + 1) & 1, next_chunk);      // one halo piece of the next chunk per stage
                     if (KS == 1) {
 #pragma unroll
-                        for (int i = 0; i < BPW; ++i) issue_b(i, s + 2, kc2, t2, s + 2 < NS);
+                        for (int i = 0; i < BPW; ++i) issue_b(i, s + AHEAD, kc2, t2, s + AHEAD < NS);
                     }
                 } else {
 #pragma unroll
                     for (int i = 0; i < BPW; ++i)
-                        if (i % (KS - 1) == ks - 1) issue_b(i, s + 2, kc2, t2, s + 2 < NS);
+                        if (i % (KS - 1) == ks - 1) issue_b(i, s + AHEAD, kc2, t2, s + AHEAD < NS);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -421,9 +434,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(const HaloParams p
                 asm volatile("" ::: "memory");
                 tap_setup(0);
                 if (NSET == 2) load_x(0, An, 0);
+                if (NSET == 2 && AHEAD == 3) load_w(0, Bs + ((s + 1) % NSLOT) * B_BYTES, 0);
             } else {
                 tap_setup(t == 8 ? 0 : t + 1);
                 if (NSET == 2) load_x(0, t == 8 ? An : Ab, 0);               // (after the last stage: a read nobody uses)
+                // 4-slot ring: stage s + 1's weights landed during stage s - 1 and were published by the barrier that ended it
+                if (NSET == 2 && AHEAD == 3) load_w(0, Bs + ((s + 1) % NSLOT) * B_BYTES, 0);
                 // all but what this stage issued has landed: stage s+1's weights, the halo pieces of earlier stages
                 wait_vm(((ADBL && t < APW) ? 1 : 0) + BPW);
                 __builtin_amdgcn_s_barrier();
