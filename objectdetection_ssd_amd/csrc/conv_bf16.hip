@@ -211,14 +211,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_kernel(const HaloParams p
     constexpr int A_BYTES = A_ROWS * 128;
     constexpr int B_PIECES = BN / 8, BPW = B_PIECES / 8;   // weight-tile pieces per stage / per wave
     constexpr int B_BYTES = BN * 128;
-    // Weight ring.  3 slots (round 3): stage s + 2 is requested during stage s and is published by the barrier that ENDS stage s + 1, so the
-    // first weight fragments of a stage can only be read AFTER that barrier -- ~200 cycles of LDS latency with the matrix pipe idle, per stage
-    // of 16 MFMAs, in all eight waves at once.  4 slots (round 4, CB_RING4): stage s + 3 is requested during stage s; stage s + 1's weights
-    // were published one barrier earlier, so its first fragments are requested BEFORE the barrier that ends stage s, like the pixel fragments.
-#ifdef CB_RING3
-    constexpr int NSLOT = 3, AHEAD = 2;
-#else
+    // Weight ring.  3 slots: stage s + 2 is requested during stage s and is published by the barrier that ENDS stage s + 1, so the first
+    // weight fragments of a stage can only be read AFTER that barrier.  Round-4 experiment (-DCB_RING4, tools/cb_variants.sh): 4 slots, stage
+    // s + 3 requested during stage s, stage s + 1's weights published one barrier earlier and its first fragments requested BEFORE the barrier
+    // that ends stage s, like the pixel fragments -- measured no faster (forward layers 2.15-2.21 ms against 2.06-2.15, data gradients 1.96
+    // against 1.92-1.94, step 13.09 against 13.04 ms on a 1 815 MHz device): that latency is not what holds the kernel; default stays 3.
+#ifdef CB_RING4
     constexpr int NSLOT = 4, AHEAD = 3;
+#else
+    constexpr int NSLOT = 3, AHEAD = 2;
 #endif
     static_assert(B_PIECES % 8 == 0 && BPW >= 1, "every wave issues the same number of weight pieces");
     static_assert(MODE == 2 || (PH * PW == BM && HH * HW <= A_ROWS), "patch / halo size");

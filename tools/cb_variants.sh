@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of compile-time variants of csrc/conv_bf16.hip on one device: rebuild with each flag set, run tools/conv_bf16_bench.py and (last) the step.
-#   bash tools/cb_variants.sh "" "-DCB_RING3"
+#   bash tools/cb_variants.sh "" "-DCB_RING4"
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $ROOT
