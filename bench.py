@@ -547,6 +547,11 @@ def main():
     ap.add_argument("--grad-dtype", default="auto", choices=("auto", "f32", "bf16"),
                     help="payload of the weight-gradient all-reduce: bf16 = 52.6 MB instead of 105 MB (auto: bf16 with --conv-dtype bf16, else f32)")
     ap.add_argument("--igemm-lds-pad", type=int, default=-1, help="tuning aid: extra dynamic LDS bytes per igemm block (-1 = library default)")
+    ap.add_argument("--spinup-seconds", type=float, default=3.0,
+                    help="run untimed steps for this long BEFORE the --warmup steps: a device that has been idle starts the process at a low "
+                         "shader clock and takes seconds to reach the clock it then holds (measured on this pool: the same step 23.96 ms in the "
+                         "first half second of load, 20.08 ms two seconds later); the timed region is still exactly --steps steps after "
+                         "--warmup steps.  0 = none.  Reported in config.spinup")
     ap.add_argument("--graph-step", default="off", choices=("on", "off"),
                     help="time the train step as ONE captured HIP graph replay per step (ddp.GraphedTrainStep) instead of ~250 eager launches. "
                          "Default off: at batch 32 the step is GPU-bound and the replay measures slower on the device than the eager two-stream "
@@ -706,6 +711,21 @@ def main():
         torch.cuda.synchronize()
 
     from objectdetection_ssd_amd import ops as _ops
+    spin_steps, spin_t0 = 0, time.perf_counter()
+    if args.spinup_seconds > 0:
+        note(f"spin-up: untimed steps for {args.spinup_seconds:.1f} s (device clock ramp)")
+        while True:
+            for _ in range(5):
+                step()
+            spin_steps += 5
+            torch.cuda.synchronize()
+            go = time.perf_counter() - spin_t0 < args.spinup_seconds
+            if world > 1:                                  # one decision for all ranks, so that every rank issues the same collectives
+                t = torch.tensor([1 if go else 0], device=dev, dtype=torch.int32)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                go = bool(t.item())
+            if not go:
+                break
     note(f"{args.warmup} warm-up + {args.steps} timed steps")
     for _ in range(args.warmup):
         step()
@@ -792,6 +812,9 @@ def main():
                                             "channels) on the bf16 MFMA from three exact bf16 limbs per operand (csrc/gemm_x3.hip)"
                                             if _ops.wino_x3(4, 256) else ""))
                       if (net._engine.wino and args.conv_dtype == "f32") else "direct MFMA kernels",
+                      "spinup": {"seconds": args.spinup_seconds, "untimed_steps": spin_steps,
+                                 "note": "untimed steps run before the warm-up steps so that the timed region sees the shader clock the device HOLDS under "
+                                         "this load, not the ramp from idle (bench.py --spinup-seconds; 0 disables)"},
                       "host_enqueue_ms_per_step": round(host_ms, 2),
                       "step_launch": ({"form": "one HIP graph replay per step (ddp.GraphedTrainStep: forward + loss + backward"
                                                + (" + SGD" if world == 1 else "; all-reduce + SGD issued behind it") + ")",
