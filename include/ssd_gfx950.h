@@ -419,7 +419,10 @@ int ssd_heads_gather(const float* dloc, const float* dconf, float* packed, int l
  *          dloc/dconf = d(loc_loss+conf_loss)/d(loc|conf) (may both be NULL: forward only).
  * norm_mode 0: reference normalisation (divide by batch n_pos).
  * norm_mode 1: un-normalised sums (loc: sum|d|/4, conf: sum CE) and gradients of those,
- *              for data-parallel runs that divide by the global n_pos after the all-reduce. */
+ *              for data-parallel runs that divide by the global n_pos after the all-reduce.
+ * Three kernel launches (per-prior matching + cross entropy, wide; per-image forced matches + hard-negative selection; losses +
+ * gradients, wide); ssd_tune_set_loss_form(0) selects the four-launch form of rounds 1-3 (cross-check). */
+int ssd_tune_set_loss_form(int three_launch);
 size_t ssd_multibox_loss_workspace(int bs, int P, int n_gt);
 int ssd_multibox_loss(const float* loc, const float* conf, const float* gt_boxes, const float* gt_classes,
                       const int32_t* img_start, int bs, int n_gt, const float* priors_cxcywh,

@@ -65,6 +65,7 @@ SIGNATURES = {
     "ssd_clock_probe": (_I, [_P, _P]),
     "ssd_tune_set_x3_mfma": (_I, [_I]),
     "ssd_tune_set_x3_big": (_I, [_I]),
+    "ssd_tune_set_loss_form": (_I, [_I]),
     "ssd_gemm_planes_x3v2": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ssd_graph_node_counts": (_I, [_P, _P, _P]),
     "ssd_photometric_workspace": (_Z, [_I]),

@@ -1641,3 +1641,74 @@ def test_conv1_1_and_nine_tap_weight_gradient_on_bf16_tensors():
         dwa, dba = ops.conv3x3_wgrad_bf16t(xa.to(dev), da.to(dev), geom, ldy, True)
         dwb, dbb = ops.conv2d_wgrad(xa.float().to(dev), da.float().to(dev), geom, ldy, True, bf16=True)
         assert torch.equal(dwa, dwb) and torch.equal(dba, dbb)
+
+
+# ---- MultiBox loss: the three-launch form (wide per-prior kernel, one workgroup per image, wide gradients) against the four-launch form of rounds 1-3 --------------------
+# (Losses.py:119-199.)  obj / cls / the selected hard negatives must be IDENTICAL; the sums differ by their order of addition only.
+LOSS_FORM_CASES = [
+    # bs, P, C, boxes per image (min, max), what
+    (32, 8732, 21, 1, 8, "SSD300 at batch 32"),
+    (3, 8732, 21, 9, 40, "more boxes than one pass of the per-box arg-max takes"),
+    (2, 24564, 21, 1, 6, "SSD512 prior count"),
+    (2, 1000, 64, 1, 3, "64 classes, a last chunk of 40 priors"),
+    (1, 36000, 64, 2, 2, "the largest image the entry takes: 144 KB of values in LDS"),
+    (4, 777, 5, 1, 2, "ragged everything"),
+]
+
+
+def _loss_inputs(bs, P, C, nmin, nmax, seed):
+    g = torch.Generator().manual_seed(seed)
+    cxcy = torch.rand(P, 2, generator=g)
+    wh = torch.rand(P, 2, generator=g) * 0.5 + 0.03
+    pri = torch.cat([cxcy, wh], 1)
+    pri_xyxy = torch.cat([cxcy - wh / 2, cxcy + wh / 2], 1)
+    boxes, classes, start = [], [], [0]
+    for i in range(bs):
+        n = int(torch.randint(nmin, nmax + 1, (1,), generator=g))
+        c = torch.rand(n, 2, generator=g) * 0.6 + 0.2
+        s = torch.rand(n, 2, generator=g) * 0.4 + 0.05
+        b = torch.cat([c - s / 2, c + s / 2], 1)
+        if n >= 2:
+            b[1] = b[0]                                   # two identical boxes: ties in both arg-max directions
+        if i == 0:
+            b[0] = pri_xyxy[5]                            # a box that IS a prior (IoU exactly 1)
+        boxes.append(b)
+        classes.append(torch.randint(0, C - 1, (n,), generator=g).float())
+        start.append(start[-1] + n)
+    loc = torch.randn(bs, P, 4, generator=g)
+    conf = torch.randn(bs, P, C, generator=g) * 2.0
+    n_eq = conf[:, 1::7].shape[1]
+    conf[:, ::7][:, :n_eq] = conf[:, 1::7]                             # equal rows -> equal CE values: the tie rule of the selection
+    return loc, conf, torch.cat(boxes), torch.cat(classes), torch.tensor(start, dtype=torch.int32), pri, pri_xyxy
+
+
+@pytest.mark.parametrize("norm_mode", [0, 1])
+@pytest.mark.parametrize("case", LOSS_FORM_CASES, ids=[c[-1] for c in LOSS_FORM_CASES])
+def test_multibox_loss_three_launch_form_equals_the_four_launch_form(case, norm_mode):
+    from objectdetection_ssd_amd import _lib, ops
+    bs, P, C, nmin, nmax, _ = case
+    dev = _dev()
+    args = [t.to(dev) for t in _loss_inputs(bs, P, C, nmin, nmax, seed=bs * 1000 + C)]
+    lib = _lib.load()
+    outs = {}
+    try:
+        for form in (0, 1):
+            _lib.check(lib.ssd_tune_set_loss_form(form), "tune")
+            o = ops.multibox_loss(*args, iou_threshold=0.5, neg_pos_ratio=3, norm_mode=norm_mode)
+            torch.cuda.synchronize()
+            outs[form] = {k: v.cpu() for k, v in o.items()}
+    finally:
+        _lib.check(lib.ssd_tune_set_loss_form(1), "tune")
+    a, b = outs[0], outs[1]
+    assert torch.equal(a["obj"], b["obj"]) and torch.equal(a["cls"], b["cls"])
+    assert float(a["losses"][2]) == float(b["losses"][2]) and float(a["losses"][2]) >= bs       # n_pos: every box forces one prior
+    # the same priors carry a conf gradient (positives + selected negatives), the loc gradient is a sign pattern: equal up to the 1/n_pos scale
+    assert torch.equal(a["dconf"] != 0, b["dconf"] != 0)
+    assert torch.equal(a["dloc"], b["dloc"])
+    _close(b["dconf"], a["dconf"], 1e-6, "dconf")
+    for q in (0, 1):
+        ra, rb = float(a["losses"][q]), float(b["losses"][q])
+        assert abs(ra - rb) <= 2e-6 * max(1.0, abs(ra)), (q, ra, rb)
+    # forward-only call (no gradient buffers) gives the same losses
+    o = ops.multibox_loss(*args, iou_threshold=0.5, neg_pos_ratio=3, norm_mode=norm_mode, want_grads=False)
+    assert torch.equal(o["losses"].cpu(), b["losses"]) and torch.equal(o["cls"].cpu(), b["cls"])
