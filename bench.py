@@ -451,7 +451,7 @@ def roofline_of(net, step, conv_dtype: str, ms: float, layers: bool = False) -> 
     tag, (tsum, fsum, n) = max(((k, v) for k, v in agg.items() if not k.startswith("winograd")), key=lambda kv: kv[1][0])
     ach = fsum / tsum / 1e12
     traffic = None            # HBM bytes per launch from the committed PMC passes of this round (a pointer: counters cannot be collected in the timed run)
-    traffic_file = "r03_bf16_traffic.json" if conv_dtype == "bf16" else "r04_traffic.json"
+    traffic_file = "r04_bf16_traffic.json" if conv_dtype == "bf16" else "r04_traffic.json"
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", traffic_file)))
         if tj["kernel"] == tag:

@@ -15,11 +15,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R
 cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
 echo "stats done"
 P1="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU GRBM_GUI_ACTIVE"
-rocprofv3 --kernel-trace --pmc $P1 --output-format csv -d $OUT/p1 -- python3 $ROOT/bench.py --steps 1 --warmup 1 $ARGS > /dev/null 2> $OUT/p1.err
+rocprofv3 --kernel-trace --pmc $P1 --output-format csv -d $OUT/p1 -- python3 $ROOT/bench.py --steps 1 --warmup 1 --spinup-seconds 0 $ARGS > /dev/null 2> $OUT/p1.err
 echo "p1 done"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/p2 -- python3 $ROOT/bench.py --steps 1 --warmup 1 $ARGS > /dev/null 2> $OUT/p2.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/p2 -- python3 $ROOT/bench.py --steps 1 --warmup 1 --spinup-seconds 0 $ARGS > /dev/null 2> $OUT/p2.err
 echo "p2 done"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/p3 -- python3 $ROOT/bench.py --steps 1 --warmup 1 $ARGS > /dev/null 2> $OUT/p3.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/p3 -- python3 $ROOT/bench.py --steps 1 --warmup 1 --spinup-seconds 0 $ARGS > /dev/null 2> $OUT/p3.err
 echo "p3 done"
 for p in p1 p2 p3; do
   f=$(ls $OUT/$p/*/*counter_collection.csv | head -1)

@@ -34,7 +34,7 @@ def main():
         "write_size_kb_sum": write_kb,
         "l2_hit_rate": round(b["TCC_HIT_sum"] / (b["TCC_HIT_sum"] + b["TCC_MISS_sum"]), 3),
         "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum in separate passes over `bench.py --steps 1 --warmup 1` "
-                  f"(8 steps in the process; profiles/{tag}_pmc_p2.txt, {tag}_pmc_p3.txt); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches (gfx950: "
+                  f"(all steps of the process: the sums and the launch count come from the same pass; profiles/{tag}_pmc_p2.txt, {tag}_pmc_p3.txt); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches (gfx950: "
                   "FETCH_SIZE counts 64 B per 128-B request for 16-B-per-lane streaming reads, MI355X_MICROARCH.md section HBM)",
     }
     print(json.dumps(out, indent=1))
