@@ -1712,3 +1712,39 @@ def test_multibox_loss_three_launch_form_equals_the_four_launch_form(case, norm_
     # forward-only call (no gradient buffers) gives the same losses
     o = ops.multibox_loss(*args, iou_threshold=0.5, neg_pos_ratio=3, norm_mode=norm_mode, want_grads=False)
     assert torch.equal(o["losses"].cpu(), b["losses"]) and torch.equal(o["cls"].cpu(), b["cls"])
+
+
+def test_weight_job_table_bf16_copies_are_the_rounded_permutes():
+    """Job kind 3 of ssd_weights_prepare (the bf16-tensor mode's filter copies, Model.py:135-143 / 176-184): OHWI [co][taps][ci] and IHWO
+    [ci][taps][pad1] bf16 copies of OIHW f32 masters, written from one read of 32 x 32-channel bricks.  Pure rounding + data movement:
+    bit-exact against torch's own permute + round-to-nearest-even cast, with a head's two filter pieces, ragged channel counts and 1 tap."""
+    from objectdetection_ssd_amd import ops
+    dev = _dev()
+    g_ = torch.Generator().manual_seed(33)
+    rnd = lambda *s: torch.randn(*s, generator=g_).to(dev)
+    cases = [
+        ((rnd(512, 256, 3, 3),), 512, 512),                       # a trunk layer
+        ((rnd(16, 512, 3, 3), rnd(84, 512, 3, 3)), 100, 128),      # the c_4 head: two pieces, 100 filters, K of the data gradient 128
+        ((rnd(70, 80, 3, 3),), 70, 128),                          # ragged bricks both ways
+        ((rnd(96, 160, 1, 1),), 96, 128),                         # one tap
+    ]
+    jobs = []
+    for pieces, co_all, pad1 in cases:
+        ci, taps = pieces[0].shape[1], pieces[0].shape[2] * pieces[0].shape[3]
+        jobs.append(dict(kind=3, w0=pieces[0], w1=pieces[1] if len(pieces) > 1 else None, co0=pieces[0].shape[0], co=co_all, ci=ci, taps=taps,
+                         co_pad=co_all, pad1=pad1,
+                         out_fwd=torch.full((co_all, taps, ci), float("nan"), device=dev, dtype=torch.bfloat16),
+                         out_bwd=torch.full((ci, taps, pad1), float("nan"), device=dev, dtype=torch.bfloat16)))
+    jobs.append(dict(jobs[0], out_fwd=torch.full((512, 9, 256), float("nan"), device=dev, dtype=torch.bfloat16), out_bwd=None))   # forward copy only
+    table = ops.WeightTable(jobs, dev)
+    table.run()
+    torch.cuda.synchronize()
+    for jb, (pieces, co_all, pad1) in zip(jobs, cases + [cases[0]]):
+        w = torch.cat(pieces)
+        co, ci, r, s_ = w.shape
+        ref_f = w.permute(0, 2, 3, 1).reshape(co, r * s_, ci).to(torch.bfloat16)
+        assert torch.equal(jb["out_fwd"].view(torch.int16), ref_f.view(torch.int16))
+        if jb["out_bwd"] is not None:
+            ref_b = torch.zeros(ci, r * s_, pad1, device=dev, dtype=torch.bfloat16)
+            ref_b[:, :, :co] = w.permute(1, 2, 3, 0).reshape(ci, r * s_, co).to(torch.bfloat16)
+            assert torch.equal(jb["out_bwd"].view(torch.int16), ref_b.view(torch.int16))
