@@ -453,8 +453,13 @@ def test_round2_entry_points_validate_and_size_without_a_gpu():
     job.w0 = job.w1 = OK_PTR; job.out_fwd = OK_PTR; job.out_bwd = OK_PTR
     job.co0 = job.co = 128; job.ci = 64; job.taps = 9; job.co_pad = 128; job.kind = 0
     assert lib.ssd_weight_job_blocks(C.byref(job)) == (128 * 64 + 64 * 128 + 255) // 256
-    job.kind = 1
-    assert lib.ssd_weight_job_blocks(C.byref(job)) == (2 * 128 * 9 * 64 + 255) // 256
+    job.kind = 1                                                                                  # one block per 32 x 32-channel brick
+    assert lib.ssd_weight_job_blocks(C.byref(job)) == (128 // 32) * (64 // 32)
+    job.kind = 3; job.pad1 = 192                                                                  # bf16 copies: the data gradient's K may exceed co_pad
+    assert lib.ssd_weight_job_blocks(C.byref(job)) == (192 // 32) * (64 // 32)
+    job.taps = 25
+    assert lib.ssd_weight_job_blocks(C.byref(job)) == -1
+    job.taps = 9
     job.kind = 2; job.co = job.co0 = 64; job.ci = 3
     assert lib.ssd_weight_job_blocks(C.byref(job)) == 64 * 32 // 256
     job.kind = 9
