@@ -22,9 +22,9 @@
 //
 // Position spaces ("mode"):
 //   0  2-D patches of 8 x 32 (BM = 256) or 16 x 32 (BM = 512) output pixels    (300^2, 150^2 maps)
-//   1  2-D patches of 16 x 16                                                    (75^2)
+//   1  2-D patches of 16 x 16                                                    (maps 95 ... 127 wide, and 75^2 with 64 output channels)
 //   2  flat: q runs over [image][H+1][W+1] (one zero row between images, one zero column between rows), a tile is BM
-//      consecutive q; positions on a zero row / column compute garbage that is never stored   (38^2, 19^2, 10^2 ...)
+//      consecutive q; positions on a zero row / column compute garbage that is never stored   (75^2, 38^2, 19^2, 10^2 ...)
 #include <type_traits>
 #include "common.h"
 
@@ -693,8 +693,13 @@ int launch_shape(HaloParams& p, hipStream_t st) {
 
 int dispatch(HaloParams& p, hipStream_t st) {
     int mode = g_force_mode;
-    if (mode < 0) mode = p.W + 2 <= 63 ? 2 : ((p.W >= 128 && p.H >= 128) ? 0 : 1);
-    if (mode == 2 && p.W + 2 > 63) mode = 1;
+    // flat space (mode 2) while the halo of a 256-position tile -- 256 + 2 (W + 1) + 2 rows -- fits the buffers: 6 pieces per wave (384 rows)
+    // up to W = 62, 7 pieces (448 rows; two such buffers + the weight ring are exactly the CU's 160 KB) up to W = 94.  Round 4: the
+    // 75 x 75 maps (conv3_x) moved here from the 16 x 16 patches: 1 444 blocks instead of 1 600 (no 80 x 80 cover of a 75 x 75 map);
+    // measured interleaved (tools/conv_bf16_bench.py): conv3_2 forward 0.290 -> 0.274 ms, data gradient 0.265 -> 0.245, conv3_1's 0.140 -> 0.120.
+    const int flat_rows = 256 + 2 * (p.W + g_flat_gap) + 2;
+    if (mode < 0) mode = flat_rows <= 448 ? 2 : ((p.W >= 128 && p.H >= 128) ? 0 : 1);
+    if (mode == 2 && flat_rows > 448) mode = 1;
     int bn = g_force_bn;
     if (bn < 0) bn = p.Nout <= 64 ? 64 : 128;
     if (bn == 64 && mode == 0 && p.K == 64 && p.Nout <= 64 && g_k64 != 0) {
@@ -709,6 +714,7 @@ int dispatch(HaloParams& p, hipStream_t st) {
         return SSD_OK;
     }
     if (bn == 64) {
+        if (mode == 2 && flat_rows > 384) mode = 1;               // (the 64-channel flat form has the 6-piece buffers only)
         // 64 output channels: wave tile 64 x 64 over 512 positions (16 x 32 patches; one halo buffer, K has one or two chunks here)
         if (mode == 0) return launch<2, 2, 8, 1, 0, 16, 10, false>(p, st);
         if (mode == 1) return launch<2, 1, 4, 2, 1, 16, 6, true>(p, st);
@@ -716,6 +722,7 @@ int dispatch(HaloParams& p, hipStream_t st) {
     }
     if (mode == 0) return launch<2, 2, 4, 2, 0, 8, 6, true>(p, st);
     if (mode == 1) return launch<2, 2, 4, 2, 1, 16, 6, true>(p, st);
+    if (flat_rows > 384) return launch<2, 2, 4, 2, 2, 0, 7, true>(p, st);
     return launch<2, 2, 4, 2, 2, 0, 6, true>(p, st);
 }
 

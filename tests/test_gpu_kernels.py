@@ -1512,7 +1512,11 @@ HALO_BF16_CASES = [
     (2, 128, 3, 13, 11, 128, 128, 128),      # flat: tiles span images
     (2, 128, 2, 38, 38, 64, 128, 100),       # flat at a real map size, head-like rows
     (2, 64, 2, 19, 19, 128, 64, 64),
-    (-1, -1, 1, 75, 75, 64, 128, 128),       # automatic choice: 16x16 patches
+    (-1, -1, 1, 75, 75, 64, 128, 128),       # automatic choice: flat with the 7-piece halo buffers (two of them + the weight ring = 160 KB)
+    (-1, -1, 2, 75, 75, 256, 256, 256),      # ... four chunks, tiles spanning the two images
+    (2, 128, 1, 9, 94, 64, 128, 128),        # ... the widest map the flat form takes
+    (-1, -1, 1, 75, 75, 64, 64, 64),         # 64 output channels at 75 x 75: 16x16 patches (the 64-channel flat form has the 6-piece buffers)
+    (1, 128, 1, 75, 75, 64, 128, 128),       # 16x16 patches forced at 75 x 75 (what rounds 1-3 ran)
     (-1, -1, 1, 10, 10, 64, 128, 128),       # automatic: flat
 ]
 

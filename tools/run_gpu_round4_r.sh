@@ -1,6 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out
-for gap in 2 1 2 1; do
-echo "== gap $gap"
-SSD_CONV_BF16_GAP=$gap timeout -k 10 300 python tools/conv_bf16_bench.py 32 2>&1 | grep -E "conv4|conv5|c_4|c_7|total" || exit 1
+for f7 in 0 1 0 1; do
+echo "== flat7 $f7"
+SSD_CONV_BF16_FLAT7=$f7 timeout -k 10 300 python tools/conv_bf16_bench.py 32 2>&1 | grep -E "conv3|total" || exit 1
 done
