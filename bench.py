@@ -83,6 +83,77 @@ def host_cores():
     return n
 
 
+_LIVE_PMC = None     # {"fetch": {kernel: (kb_sum, dispatches)}, "write": {...}, "note": str} from live_traffic_passes(), or None
+
+
+def live_traffic_passes(argv_tail, timeout_s: float = 150.0):
+    """HBM-side traffic of THIS invocation's kernels: two `rocprofv3 --pmc` passes (FETCH_SIZE; WRITE_SIZE -- separate passes, counters only,
+    MI355X_MICROARCH.md section HBM) over a short run of this same file, started as CHILD processes before this process touches the GPU
+    (one GPU user at a time; the program itself after `--`).  Returns per-kernel sums or a note saying why not.  Any failure -- no profiler
+    on the box, a non-zero exit, the time limit -- leaves the committed file of the round as the source, and the line says so."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return {"note": "rocprofv3 not found on this box"}
+    tmp = tempfile.mkdtemp(prefix="ssd_bench_pmc_", dir="/tmp")
+    out = {"note": ""}
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for key, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])):
+            d = os.path.join(tmp, key)
+            cmd = [prof, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.abspath(__file__), *argv_tail]
+            t0 = time.perf_counter()
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = p.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)            # the process group this call started, nothing else
+                p.wait()
+                return {"note": f"the {key} pass exceeded {timeout_s:.0f} s and was stopped"}
+            if rc != 0:
+                return {"note": f"the {key} pass exited with code {rc}"}
+            files = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
+            if not files:
+                return {"note": f"the {key} pass wrote no counter file"}
+            acc = {}
+            with open(files[0]) as f:
+                for r in csv.DictReader(f):
+                    if r["Counter_Name"] != counters[0]:
+                        continue
+                    k = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
+                    k = re.sub(r"\(.*", "", k).replace("void ", "")
+                    a = acc.setdefault(k, [0.0, set()])
+                    a[0] += float(r["Counter_Value"])
+                    a[1].add(r["Dispatch_Id"])
+            out[key] = {k: (v[0], len(v[1])) for k, v in acc.items()}
+            out["note"] += f"{key} pass {time.perf_counter() - t0:.0f} s; "
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def live_traffic_of(tag: str):
+    """(bytes per launch, launches) of the kernel instantiation with the largest fetch sum whose name starts with `tag`, from the live passes."""
+    if not _LIVE_PMC or "fetch" not in _LIVE_PMC or "write" not in _LIVE_PMC:
+        return None
+    keys = [k for k in _LIVE_PMC["fetch"] if k.startswith(tag) and k in _LIVE_PMC["write"]]
+    if not keys:
+        return None
+    k = max(keys, key=lambda q: _LIVE_PMC["fetch"][q][0])
+    (fkb, nf), (wkb, nw) = _LIVE_PMC["fetch"][k], _LIVE_PMC["write"][k]
+    if nf != nw or nf == 0:
+        return None
+    # gfx950: FETCH_SIZE counts 64 B per 128-B request of a 16-B-per-lane streaming read -> doubled (MI355X_MICROARCH.md section HBM)
+    return round((2 * fkb + wkb) * 1024 / nf, -4), nf, k
+
+
 def cpu_baseline(max_threads: int = 16, variant: int = 300, bs_big: int = PER_GPU_BATCH, all_cores_budget_s: float = 45.0):
     """SURVEY.md section 8(d) / BASELINE.md section 4: the oracle (CPU restatement of the reference path: the same ATen CPU kernels
     the reference dispatches to) timed on this box's host cores for the same synthetic step at bs=2 and bs=32, fwd / loss / bwd / SGD
@@ -450,14 +521,25 @@ def roofline_of(net, step, conv_dtype: str, ms: float, layers: bool = False) -> 
     # but not eligible -- a roofline row has to be one kernel that the rocprof summary can be held against
     tag, (tsum, fsum, n) = max(((k, v) for k, v in agg.items() if not k.startswith("winograd")), key=lambda kv: kv[1][0])
     ach = fsum / tsum / 1e12
-    traffic = None            # HBM bytes per launch from the committed PMC passes of this round (a pointer: counters cannot be collected in the timed run)
+    # HBM bytes per launch of the dominant kernel: from the counter passes this invocation ran as child processes before its timed run
+    # (live_traffic_passes), else from the committed PMC passes of the round's profile run (a pointer, and the line says which)
+    traffic = None
     traffic_file = "r04_bf16_traffic.json" if conv_dtype == "bf16" else "r04_traffic.json"
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", traffic_file)))
-        if tj["kernel"] == tag:
-            traffic = tj["bytes_per_launch"]
-    except Exception:
-        pass
+    traffic_src = f"profiles/{traffic_file}: the PMC passes of this round's profile run, not this invocation"
+    live = live_traffic_of(tag) if conv_dtype == (_LIVE_PMC or {}).get("conv_dtype") else None
+    if live is not None:
+        traffic = live[0]
+        traffic_src = (f"LIVE: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, two child runs of this bench.py invocation before its timed run "
+                       f"({live[1]} launches of {live[2]}; (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / launches; {_LIVE_PMC['note'].strip()})")
+    else:
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", traffic_file)))
+            if tj["kernel"] == tag:
+                traffic = tj["bytes_per_launch"]
+            if _LIVE_PMC is not None and _LIVE_PMC.get("note"):
+                traffic_src += f" (live passes: {_LIVE_PMC['note'].strip()})"
+        except Exception:
+            pass
     # dense peak of the dtype the kernel multiplies in; an f32x3 product costs six bf16 MFMAs, so its ceiling in
     # algorithmic f32 FLOPs is a sixth of the bf16 peak
     on_bf16_mfma = "bf16" in tag or (conv_dtype == "bf16" and tag.startswith("conv3x3_halo"))
@@ -484,7 +566,7 @@ def roofline_of(net, step, conv_dtype: str, ms: float, layers: bool = False) -> 
                       "GEMMs + output transform): `achieved` counts the direct convolution's FLOPs, the GEMMs execute 2.25x fewer")
     roof = {"bound": "mfma", "kernel": tag + ", ...>", "achieved": round(ach, 2),
                        "peak": peak, "peak_note": peak_note, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                       "traffic": traffic, "traffic_unit": f"bytes per launch (profiles/{traffic_file}: the PMC passes of this round's profile run -- counters cannot be collected inside this run)", "launches_timed": n, "avg_launch_ms": round(tsum / n * 1e3, 4),
+                       "traffic": traffic, "traffic_unit": f"bytes per launch ({traffic_src})", "launches_timed": n, "avg_launch_ms": round(tsum / n * 1e3, 4),
                        "avg_launch_gflop": round(fsum / n / 1e9, 3),
                        "step_executed_gflop": round(exec_flops / 3 / 1e9, 1),
                        "step_executed_frac": round(exec_flops / 3 / (ms * 1e-3) / 1e12 / (2500.0 if conv_dtype == "bf16" else PEAK_F32_MFMA_TFLOPS), 4),
@@ -515,6 +597,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--live-traffic", default="auto", choices=("auto", "on", "off"),
+                    help="roofline.traffic from two rocprofv3 --pmc passes run by this invocation as child processes BEFORE its timed run "
+                         "(auto: at N = 1 for the SSD300 train workload when a GPU and rocprofv3 are present; adds about half a minute); off: the committed "
+                         "file of the round")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-bf16-leg", action="store_true", help="skip the short bf16-operand run reported in config.bf16_operand_mode")
     ap.add_argument("--layers", action="store_true", help="print the per-launch table to stderr")
@@ -597,6 +683,16 @@ def main():
             print(json.dumps({"rendezvous": True, "n_gpus": world, "backend": dist.get_backend(), "ranks_counted": int(t.item())}))
         dist.destroy_process_group()
         return
+    global _LIVE_PMC
+    if (args.live_traffic != "off" and world_env == 1 and args.workload == "train" and args.variant == 300 and torch.cuda.device_count() > 0):
+        # (device_count() does not initialise the GPU on this image; is_available() below does -- the children run before it)
+        note("live traffic: two rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE)")
+        # the same engine flags as this run (later options win): one step, every kernel on one stream, none of the extra legs
+        tail = sys.argv[1:] + ["--steps", "1", "--warmup", "1", "--spinup-seconds", "0", "--no-cpu-baseline", "--no-bf16-leg", "--no-overlap-tail",
+                               "--live-traffic", "off", "--graph-step", "off"]
+        _LIVE_PMC = live_traffic_passes(tail)
+        _LIVE_PMC["conv_dtype"] = args.conv_dtype
+        note("live traffic: " + (_LIVE_PMC.get("note") or "done"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the gfx950 HIP extension is the only compute path")
     if args.one_device:

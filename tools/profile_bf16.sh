@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_${TAG}_bf16
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--conv-dtype bf16 --no-cpu-baseline --no-overlap-tail"
+ARGS="--conv-dtype bf16 --live-traffic off --no-cpu-baseline --no-overlap-tail"
 python3 $ROOT/bench.py --steps 10 --warmup 3 --conv-dtype bf16 --no-cpu-baseline --layers > $OUT/bench_plain.json 2> $OUT/layers.txt
 echo "plain done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 10 --warmup 3 $ARGS > $OUT/bench.json 2> $OUT/bench.err
