@@ -56,7 +56,8 @@ _T0 = time.perf_counter()
 
 def note(msg: str) -> None:
     """progress line on stderr (the JSON line on stdout stays the only stdout output): a run that prints nothing for minutes looks hung"""
-    print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+    if os.environ.get("RANK", "0") == "0":
+        print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def cpu_quota_cores():
