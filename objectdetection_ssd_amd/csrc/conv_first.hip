@@ -25,24 +25,56 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // BF16 (the bf16-tensor mode, BASELINE.json configs[2]): x and the filter are rounded to bf16 on their way into LDS -- the products
 // of two bf16 values are exact in the f32 MFMA, so this is the bf16-operand convolution with f32 accumulation -- and y is stored
 // as bf16 NHWC (`y` then points to bf16).
+// PERSISTENT (round 4): a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...  The filter rows go to registers once; the halo of
+// the NEXT tile is requested before this tile's MFMAs and parked in the other LDS buffer after them, so that a tile's loads, its MFMAs
+// and its 64 KB of stores overlap those of its neighbours in time instead of queueing behind the ~2 us of first-load latency every
+// one-tile workgroup paid (0.224 -> 0.165 ms at batch 32; same MFMA chain per output element: bit-identical results).
 template <bool BF16>
 __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wrows,
                                                              const float* __restrict__ bias, float* __restrict__ y, float* __restrict__ col,
-                                                             int N, int H, int W, int tiles_h, int tiles_w, int relu) {
+                                                             int N, int H, int W, int tiles_h, int tiles_w, int relu, int ntiles) {
     auto rnd = [](float v) { return BF16 ? (float)(__bf16)v : v; };
-    __shared__ float xs[3 * PLANE + 8];
+    constexpr int XS = 3 * PLANE + 8;
+    constexpr int EPT = (3 * PLANE + 255) / 256;                       // halo elements per thread
+    __shared__ float xs2[2][XS];
     __shared__ float ws[64 * 33];
     __shared__ __attribute__((aligned(16))) float ys[4 * 32 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bx = blockIdx.x;
-    const int twi = bx % tiles_w, thi = (bx / tiles_w) % tiles_h, n = bx / (tiles_w * tiles_h);
-    const int h0 = thi * TH, w0 = twi * TW;
     const size_t HWs = (size_t)H * W;
-    for (int e = tid; e < 3 * PLANE; e += 256) {
-        const int c = e / PLANE, rem = e - c * PLANE, r = rem / HW_, cc = rem - r * HW_;
-        const int ih = h0 - 1 + r, iw = w0 - 1 + cc;
-        xs[e] = ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) ? rnd(x[((size_t)n * 3 + c) * HWs + (size_t)ih * W + iw]) : 0.f;
+    // this thread's halo elements e = tid + 256 u: (channel, halo row, halo column) never change, only the tile origin does
+    int e_c[EPT], e_r[EPT], e_cc[EPT];
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        const int e = tid + 256 * u;
+        const int c = e / PLANE, rem = e - c * PLANE, r = rem / HW_;
+        e_c[u] = e < 3 * PLANE ? c : -1;
+        e_r[u] = r;
+        e_cc[u] = rem - r * HW_;
     }
+    auto origin = [&](int t, int& n, int& h0, int& w0) {
+        const int twi = t % tiles_w, thi = (t / tiles_w) % tiles_h;
+        n = t / (tiles_w * tiles_h);
+        h0 = thi * TH;
+        w0 = twi * TW;
+    };
+    float hv[EPT];
+    auto fetch = [&](int t) {
+        int n, h0, w0;
+        origin(t, n, h0, w0);
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            const int ih = h0 - 1 + e_r[u], iw = w0 - 1 + e_cc[u];
+            hv[u] = (e_c[u] >= 0 && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+                        ? rnd(x[((size_t)n * 3 + e_c[u]) * HWs + (size_t)ih * W + iw]) : 0.f;
+        }
+    };
+    auto park = [&](float* xs) {
+#pragma unroll
+        for (int u = 0; u < EPT; ++u)
+            if (e_c[u] >= 0) xs[tid + 256 * u] = hv[u];
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) fetch(tile);
     // the 64 x 32 filter rows: two coalesced 16-byte loads per thread into LDS (row stride 33: the fragment reads below walk the rows)
     {
         const f32x4 w0v = *reinterpret_cast<const f32x4*>(wrows + tid * 4), w1v = *reinterpret_cast<const f32x4*>(wrows + 1024 + tid * 4);
@@ -53,6 +85,7 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
             ws[(r0 + 32) * 33 + c0 + e] = rnd(w1v[e]);
         }
     }
+    if (tile < ntiles) park(xs2[0]);
     const int lr = lane & 31, lh = lane >> 5;
     __syncthreads();
     float bw[2][14];                                                   // B operand: w[co = 32 i + lr][k = 2 q + lh]
@@ -60,87 +93,96 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int q = 0; q < 14; ++q) bw[i][q] = ws[(32 * i + lr) * 33 + 2 * q + lh];
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
-    const int base = wave * HW_ + lr;                                  // the wave's tile row, this lane's pixel of a 32-pixel block
-#pragma unroll
-    for (int q = 0; q < 14; ++q) {
-        const int off = lh ? tap_off(2 * q + 1) : tap_off(2 * q);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float a = xs[base + 32 * j + off];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[i][q], acc[j][i], 0, 0, 0);
-        }
-    }
-
-    // C/D map: channel = 32 i + (lane & 31), pixel of the block = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): a lane holds single channels of
-    // 16 pixels.  Stored like that (4 bytes per lane, 128-byte runs) the kernel writes at ~3 TB/s; so each 32-pixel block goes through
-    // a per-wave LDS image [pixel][64 ch] and leaves as 16 bytes per lane, 1 KB (four whole pixels) per instruction.
-    const int oh = h0 + wave;
-    float* ysw = ys + wave * (32 * 64);
     float bv[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) bv[i] = bias != nullptr ? bias[32 * i + lr] : 0.f;
+
+    for (int it = 0; tile < ntiles; ++it, tile += gridDim.x) {
+        const float* xs = xs2[it & 1];
+        int n, h0, w0;
+        origin(tile, n, h0, w0);
+        const int next = tile + gridDim.x;
+        if (next < ntiles) fetch(next);                                // in flight across this tile's MFMAs
+        f32x16 acc[2][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[j][i][r] + bv[i];
-                if (relu) v = v < 0.f ? 0.f : v;                       // NaN stays NaN, like torch.relu
-                ysw[((r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + 32 * i + lr] = v;
+                for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+        const int base = wave * HW_ + lr;                              // the wave's tile row, this lane's pixel of a 32-pixel block
+#pragma unroll
+        for (int q = 0; q < 14; ++q) {
+            const int off = lh ? tap_off(2 * q + 1) : tap_off(2 * q);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float a = xs[base + 32 * j + off];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[i][q], acc[j][i], 0, 0, 0);
             }
-        // same wave writes and reads: the LDS queue is in order, no barrier
-        if (oh < H) {
-            if constexpr (BF16) {                                      // 8 lanes per pixel (128 bytes of bf16), 8 pixels per instruction
-                __bf16* po = reinterpret_cast<__bf16*>(y) + (((size_t)n * H + oh) * W + w0 + 32 * j) * 64 + (lane & 7) * 8;
+        }
+
+        // C/D map: channel = 32 i + (lane & 31), pixel of the block = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): a lane holds single channels of
+        // 16 pixels.  Stored like that (4 bytes per lane, 128-byte runs) the kernel writes at ~3 TB/s; so each 32-pixel block goes through
+        // a per-wave LDS image [pixel][64 ch] and leaves as 16 bytes per lane, 1 KB (four whole pixels) per instruction.
+        const int oh = h0 + wave;
+        float* ysw = ys + wave * (32 * 64);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int px = 8 * t + (lane >> 3);
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(ysw + px * 64 + (lane & 7) * 8);
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(ysw + px * 64 + (lane & 7) * 8 + 4);
-                    if (w0 + 32 * j + px < W)
-                        *reinterpret_cast<bf16x8*>(po + (size_t)px * 64) = bf16x8{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3],
-                                                                                  (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[j][i][r] + bv[i];
+                    if (relu) v = v < 0.f ? 0.f : v;                   // NaN stays NaN, like torch.relu
+                    ysw[((r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + 32 * i + lr] = v;
                 }
-            } else {
-                float* po = y + (((size_t)n * H + oh) * W + w0 + 32 * j) * 64 + (lane & 15) * 4;
+            // same wave writes and reads: the LDS queue is in order, no barrier
+            if (oh < H) {
+                if constexpr (BF16) {                                  // 8 lanes per pixel (128 bytes of bf16), 8 pixels per instruction
+                    __bf16* po = reinterpret_cast<__bf16*>(y) + (((size_t)n * H + oh) * W + w0 + 32 * j) * 64 + (lane & 7) * 8;
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int px = 4 * t + (lane >> 4);
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(ysw + px * 64 + (lane & 15) * 4);
-                    if (w0 + 32 * j + px < W) *reinterpret_cast<f32x4*>(po + (size_t)px * 64) = v;
+                    for (int t = 0; t < 4; ++t) {
+                        const int px = 8 * t + (lane >> 3);
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(ysw + px * 64 + (lane & 7) * 8);
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(ysw + px * 64 + (lane & 7) * 8 + 4);
+                        if (w0 + 32 * j + px < W)
+                            *reinterpret_cast<bf16x8*>(po + (size_t)px * 64) = bf16x8{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3],
+                                                                                      (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+                    }
+                } else {
+                    float* po = y + (((size_t)n * H + oh) * W + w0 + 32 * j) * 64 + (lane & 15) * 4;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const int px = 4 * t + (lane >> 4);
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(ysw + px * 64 + (lane & 15) * 4);
+                        if (w0 + 32 * j + px < W) *reinterpret_cast<f32x4*>(po + (size_t)px * 64) = v;
+                    }
                 }
             }
         }
-    }
-    if (col != nullptr) {                                              // uniform: the [pixel][32] rows of the weight gradient
-        // 8 threads per pixel (128 contiguous bytes), 32 pixels per pass; a thread keeps its 16-byte chunk, i.e. its four taps
-        const int chunk = tid & 7;
-        int toff[4];
+        if (col != nullptr) {                                          // uniform: the [pixel][32] rows of the weight gradient
+            // 8 threads per pixel (128 contiguous bytes), 32 pixels per pass; a thread keeps its 16-byte chunk, i.e. its four taps
+            const int chunk = tid & 7;
+            int toff[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = chunk * 4 + e;
-            toff[e] = k < 27 ? (k % 3) * PLANE + (k / 9) * HW_ + (k / 3) % 3 : -1;
-        }
+            for (int e = 0; e < 4; ++e) {
+                const int k = chunk * 4 + e;
+                toff[e] = k < 27 ? (k % 3) * PLANE + (k / 9) * HW_ + (k / 3) % 3 : -1;
+            }
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int pix = it * 32 + (tid >> 3), py = pix >> 6, px = pix & 63;
-            if (h0 + py < H && w0 + px < W) {
-                f32x4 v;
+            for (int pi = 0; pi < 8; ++pi) {
+                const int pix = pi * 32 + (tid >> 3), py = pix >> 6, px = pix & 63;
+                if (h0 + py < H && w0 + px < W) {
+                    f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = toff[e] >= 0 ? xs[py * HW_ + px + toff[e]] : 0.f;
-                *reinterpret_cast<f32x4*>(col + ((((size_t)n * H + h0 + py) * W + w0 + px) * 8 + chunk) * 4) = v;
+                    for (int e = 0; e < 4; ++e) v[e] = toff[e] >= 0 ? xs[py * HW_ + px + toff[e]] : 0.f;
+                    *reinterpret_cast<f32x4*>(col + ((((size_t)n * H + h0 + py) * W + w0 + px) * 8 + chunk) * 4) = v;
+                }
             }
         }
+        if (next < ntiles) park(xs2[(it + 1) & 1]);                    // (the buffer the PREVIOUS tile read: every wave passed the barrier below since)
+        __syncthreads();
     }
 }
 
@@ -407,6 +449,10 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_reduce_kernel(const floa
 
 }  // namespace
 
+// Workgroups of the persistent forward kernel.  Measured at batch 32 (bench.py --layers; 12 000 tiles): one workgroup per tile 0.224 ms; grids of
+// 512 / 1 024 / 1 536 workgroups 0.164-0.168 ms; 256, 640, 768, 1 280 (tile strides that put the concurrently written tiles on fewer
+// channels) 0.183-0.208.  bf16 output: 0.247 -> 0.20 ms.
+constexpr long long g_first_grid = 1024;
 static int conv1_first_fwd_impl(const float* x_nchw, const float* w_rows, const float* bias, void* y_nhwc, float* col_out, int N, int H,
                                 int W, int relu, void* stream, bool bf16) {
     if (!x_nchw || !w_rows || !y_nhwc) return SSD_ERR_NULL;
@@ -415,12 +461,14 @@ static int conv1_first_fwd_impl(const float* x_nchw, const float* w_rows, const 
     const int tiles_h = ssd_cdiv(H, TH), tiles_w = ssd_cdiv(W, TW);
     const long long blocks = (long long)N * tiles_h * tiles_w;
     if (blocks >= (1ll << 31)) return SSD_ERR_BAD_SHAPE;
+    // persistent: three workgroups fit a CU (LDS: two halo buffers + filter + the four waves' output images = 51 KB)
+    const unsigned grid = (unsigned)(blocks < g_first_grid ? blocks : g_first_grid);
     if (bf16)
-        hipLaunchKernelGGL(conv_first_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_nchw, w_rows, bias,
-                           static_cast<float*>(y_nhwc), col_out, N, H, W, tiles_h, tiles_w, relu);
+        hipLaunchKernelGGL(conv_first_fwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x_nchw, w_rows, bias,
+                           static_cast<float*>(y_nhwc), col_out, N, H, W, tiles_h, tiles_w, relu, (int)blocks);
     else
-        hipLaunchKernelGGL(conv_first_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_nchw, w_rows, bias,
-                           static_cast<float*>(y_nhwc), col_out, N, H, W, tiles_h, tiles_w, relu);
+        hipLaunchKernelGGL(conv_first_fwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x_nchw, w_rows, bias,
+                           static_cast<float*>(y_nhwc), col_out, N, H, W, tiles_h, tiles_w, relu, (int)blocks);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
 }
