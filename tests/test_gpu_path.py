@@ -1658,3 +1658,18 @@ def test_first_layer_into_planes_is_bitwise_the_two_kernel_step():
         net._engine.first_wino = False
         l0, c0 = net(x)
     assert torch.equal(l0, l1) and torch.equal(c0, c1)
+
+
+def test_rccl_calls_of_the_data_parallel_step_run_with_one_rank():
+    """The N > 1 path has only ever had one GPU at a time to run on, so its collectives were rehearsed over gloo.  This runs the SAME calls on
+    RCCL (backend "nccl" with device_id, as bench.py forms it) with a one-rank group and the N > 1 branches forced: parameter broadcast, the
+    overlapped sliced all-reduce in f32 and in bf16 payload, barrier, the int32 MAX all-reduce of bench.py's spin-up.  One rank moves no
+    bytes between GPUs; what it proves is that every call is one RCCL accepts (dtype, device, stream use) -- in a child process, because a
+    process group is process-global state."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "nccl_single_rank.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "rccl single-rank path ok" in r.stdout, (r.returncode, r.stdout[-600:], r.stderr[-1200:])
+    assert r.stdout.count("backend nccl") == 2
