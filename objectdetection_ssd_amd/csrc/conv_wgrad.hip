@@ -660,7 +660,9 @@ WgradPlan plan_wgrad(const ssd_conv_geom* g, bool bf16 = false) {
                                                : g->N * ssd_cdiv(g->Ho, SHAPES[pl.shape][0]) * ssd_cdiv(g->Wo, SHAPES[pl.shape][1]);
         const int per_split = pl.tiles_co * pl.tiles_ci;
         const int bpc = g_force_blocks_per_cu > 0 ? g_force_blocks_per_cu : 2;       // exactly the 2 resident blocks per CU: no tail round
-        int ns = ssd_cdiv(256 * bpc, per_split);
+        // (rounded DOWN: 48 tiles per split -- the c_7 head, 150 x 1024 channels -- gave 11 splits = 528 blocks, sixteen of them a second
+        // round behind the 512 resident ones; 10 splits = 480 blocks is one round)
+        int ns = (256 * bpc) / per_split;
         const int max_by_m = npatch / 4 > 0 ? npatch / 4 : 1;                        // at least 4 patches per block
         if (ns > max_by_m) ns = max_by_m;
         if (ns > 1024) ns = 1024;
