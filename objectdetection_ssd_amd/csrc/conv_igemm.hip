@@ -1143,6 +1143,18 @@ int launch_igemm_bf16(IgemmParams& p, hipStream_t st) {
 }
 
 int plan_ksplit(int M, int Nout, int Ca, int taps);
+// K slices of a bf16-operand launch on 128 x 128 tiles (1 = none): only where those tiles are chosen (>= 300 of them), fill less than two
+// thirds of the 768 resident workgroups, and every slice keeps at least 32 K steps; the slab is capped at 128 MB
+int plan_ksplit128(int M, int Nout, int Ca, int taps) {
+    if (g_force_ksplit == 1) return 1;
+    const long b128 = (long)ssd_cdiv(M, 128) * ssd_cdiv(Nout, 128);
+    const int kt = taps * (Ca / BK);
+    if (Nout <= 64 || b128 < 300 || b128 > 512 || kt < 64) return 1;
+    int k = (int)(768 / b128);
+    if (k > kt / 32) k = kt / 32;
+    while (k > 1 && (size_t)k * M * Nout * 4 > ((size_t)128 << 20)) --k;
+    return k < 2 ? 1 : ssd_cdiv(kt, ssd_cdiv(kt, k));
+}
 
 int dispatch_igemm_bf16(IgemmParams& p, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0) {
     int t = g_bf16_tile;
@@ -1152,6 +1164,16 @@ int dispatch_igemm_bf16(IgemmParams& p, hipStream_t st, void* ws = nullptr, size
         // 128x64 for the 64-channel outputs, 64x64 for the small maps
         const long b128 = (long)ssd_cdiv(p.M, 128) * ssd_cdiv(p.Nout, 128);
         t = p.Nout <= 64 ? 2 : (b128 >= 300 ? 1 : 3);
+    }
+    if (t == 1 && ws != nullptr) {
+        // 128 x 128 tiles, three workgroups per CU = 768 resident: a grid that fills less than two thirds of them with a deep K loop
+        // (fc6's data gradient in the bf16 mode: 364 blocks, 288 K steps) runs in K slices (round 4: 0.254 -> 0.202 ms with the reduction)
+        const int k = plan_ksplit128(p.M, p.Nout, p.Ca, p.R * p.S);
+        if (k > 1 && (size_t)k * p.M * p.Nout * sizeof(float) <= ws_bytes) {
+            p.ksplit = k;
+            p.kt_per_split = ssd_cdiv(p.R * p.S * (p.Ca / BK), k);
+            p.slab = static_cast<float*>(ws);
+        }
     }
     if (t == 3 && ws != nullptr) {                              // 64 x 64 tiles on a small grid with a deep K loop: K slices + the f32 path's reduction
         const int k = plan_ksplit(p.M, p.Nout, p.Ca, p.R * p.S);
@@ -1221,12 +1243,12 @@ extern "C" size_t ssd_conv2d_igemm_workspace(const ssd_conv_geom* g, int directi
     if (direction == 0) {
         if (g->Ci % 32 != 0) return 0;
         const int M = g->N * g->Ho * g->Wo;
-        const int k = plan_ksplit(M, g->Co, g->Ci, taps);
-        return k > 1 ? (size_t)k * M * g->Co * sizeof(float) : 0;
+        const int k = plan_ksplit(M, g->Co, g->Ci, taps), k2 = plan_ksplit128(M, g->Co, g->Ci, taps), km = k > k2 ? k : k2;
+        return km > 1 ? (size_t)km * M * g->Co * sizeof(float) : 0;     // (the bf16-operand path's 128 x 128 rule or the 64 x 64 rule, whichever wants more)
     }
     const int M = g->N * g->H * g->W, co_pad = (g->Co + 31) / 32 * 32;
-    const int k = plan_ksplit(M, g->Ci, co_pad, taps);
-    return k > 1 ? (size_t)k * M * g->Ci * sizeof(float) : 0;
+    const int k = plan_ksplit(M, g->Ci, co_pad, taps), k2 = plan_ksplit128(M, g->Ci, co_pad, taps), km = k > k2 ? k : k2;
+    return km > 1 ? (size_t)km * M * g->Ci * sizeof(float) : 0;
 }
 extern "C" int ssd_conv2d_fwd_ws(const float* x, const float* w_ohwi, const float* bias, float* y, int ldy, const ssd_conv_geom* g,
                                  int relu, void* workspace, size_t workspace_bytes, void* stream) {

@@ -659,7 +659,7 @@ WgradPlan plan_wgrad(const ssd_conv_geom* g, bool bf16 = false) {
         const int npatch = (bf16 && g->R == 1) ? ssd_cdiv(M, 128)                    // the bf16 patch kernel's 1x1 form: 128 consecutive pixels
                                                : g->N * ssd_cdiv(g->Ho, SHAPES[pl.shape][0]) * ssd_cdiv(g->Wo, SHAPES[pl.shape][1]);
         const int per_split = pl.tiles_co * pl.tiles_ci;
-        const int bpc = g_force_blocks_per_cu > 0 ? g_force_blocks_per_cu : 2;       // exactly the 2 resident blocks per CU: no tail round
+        const int bpc = g_force_blocks_per_cu > 0 ? g_force_blocks_per_cu : 2;       // exactly the 2 resident blocks per CU: no tail round (3 for the one-tap bf16 form, whose registers would allow it, measured no faster: fc7 0.103 -> 0.108 ms)
         // (rounded DOWN: 48 tiles per split -- the c_7 head, 150 x 1024 channels -- gave 11 splits = 528 blocks, sixteen of them a second
         // round behind the 512 resident ones; 10 splits = 480 blocks is one round)
         int ns = (256 * bpc) / per_split;
