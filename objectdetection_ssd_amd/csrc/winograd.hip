@@ -1405,7 +1405,9 @@ WinoWgradPlan wino_wgrad_plan(const ssd_conv_geom* g, int ldy, int mo) {
     }
     if (w.x3) {
         // one round of resident blocks (3 per CU): as many K slices as keep the grid within 768 blocks, an even count (partial sums
-        // are written and read back: no more slices than that), at least 8 steps of 16 tiles each
+        // are written and read back: no more slices than that), at least 8 steps of 16 tiles each.  (Round 4, tools/grid_audit.py: the
+        // 512 x 512-channel layers are 576 blocks = three quarters of a round; 2 / 4 slices -- 1 152 / 2 304 blocks, the latter three exact
+        // rounds -- measured: conv4 0.40 -> 0.37 / 0.39 ms, conv5 0.136 -> 0.144 / 0.183, the step 20.07 -> 20.15 / 20.25: not taken.)
         const int bp128 = ((g->Co + 127) / 128) * ((g->Ci + 127) / 128) * w.P, steps16 = (int)((w.tiles + 15) / 16);
         int k3 = 768 / bp128;
         if (k3 > 1) k3 &= ~1;
