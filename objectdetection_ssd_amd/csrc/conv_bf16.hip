@@ -702,6 +702,11 @@ int dispatch(HaloParams& p, hipStream_t st) {
     if (mode == 2 && flat_rows > 448) mode = 1;
     int bn = g_force_bn;
     if (bn < 0) bn = p.Nout <= 64 ? 64 : 128;
+    // a launch whose 128-channel tiles would occupy at most half of the CUs (the c_7 head's forward: 50 position tiles x 2 = 100 blocks with
+    // 144 stages each) takes 64-channel tiles: 150 blocks of half the length (measured 0.107 -> 0.072 ms)
+    if (g_force_bn < 0 && bn == 128 && mode == 2 && flat_rows <= 384 &&
+        ssd_cdiv(p.N * (p.H + 1) * (p.W + g_flat_gap), 256) * ssd_cdiv(p.Nout, 128) <= 128)
+        bn = 64;
     if (bn == 64 && mode == 0 && p.K == 64 && p.Nout <= 64 && g_k64 != 0) {
         p.npw = ssd_cdiv(p.W, 32);
         p.nph = ssd_cdiv(p.H, 8);
