@@ -612,6 +612,41 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// The same sums for layers with FEW output channels and MANY splits (conv1_2: 64 x 1 blocks above, each thread adding 512 slabs one
+// dependent round of 8 loads after the other: 67 us, latency-bound on a quarter of the CUs).  Block = (co, 64-channel chunk, TAP); the four
+// waves take a quarter of the splits each (same eight-accumulator order within a quarter), the quarters are added in fixed order.
+__global__ __launch_bounds__(256) void wgrad_reduce_tap_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Co, int Ci, int T,
+                                                               int nsplit, const float* __restrict__ bias_slab, float* __restrict__ db) {
+    __shared__ float part[4][64];
+    const int chunks = (Ci + 63) / 64;
+    const int t = blockIdx.x % T, rest = blockIdx.x / T;
+    const int co = rest / chunks, ci0 = (rest % chunks) * 64;
+    const int nci = min(64, Ci - ci0);
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const size_t total = (size_t)Co * T * Ci;
+    const int per = (nsplit + 3) / 4, k0 = q * per, k1 = min(nsplit, k0 + per);
+    float s = 0.f;
+    if (c < nci) {
+        const size_t i = ((size_t)co * T + t) * Ci + ci0 + c;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int k = k0;
+        for (; k + 8 <= k1; k += 8)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += slab[(size_t)(k + u) * total + i];
+        for (int u = 0; k < k1; ++k, ++u) a[u] += slab[(size_t)k * total + i];
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    part[q][c] = s;
+    __syncthreads();
+    if (q == 0 && c < nci) dw[((size_t)co * Ci + ci0 + c) * T + t] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+    if (db != nullptr && ci0 == 0 && t == 0 && threadIdx.x < 64) {   // wave 0: lanes stride over the splits, fixed shuffle tree
+        float b = 0.f;
+        for (int k = threadIdx.x; k < nsplit; k += 64) b += bias_slab[(size_t)k * Co + co];
+        b = wave_sum(b);
+        if (threadIdx.x == 0) db[co] = b;
+    }
+}
+
 int g_force_bt = -1, g_force_wnbuf = -1, g_force_blocks_per_cu = -1;   // tuning aid (ssd_tune_set_wgrad)
 
 struct WgradPlan {
@@ -763,8 +798,13 @@ static int conv2d_wgrad_impl(const float* x, const float* dy, int ldy, float* dw
     }
     SSD_CHECK_LAUNCH();
     if (T > 49) return SSD_ERR_BAD_SHAPE;                      // the reduction's LDS tile holds up to 7x7 taps
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g->Co * ssd_cdiv(g->Ci, 64)), dim3(256), 0, st, p.slab, dw_oihw, g->Co, g->Ci, T,
-                       pl.nsplit, dbias ? p.bias_slab : nullptr, dbias);
+    const int rblocks = g->Co * ssd_cdiv(g->Ci, 64);
+    if (rblocks < 512 && pl.nsplit >= 32)                       // few blocks, long sums: one block per tap as well
+        hipLaunchKernelGGL(wgrad_reduce_tap_kernel, dim3(rblocks * T), dim3(256), 0, st, p.slab, dw_oihw, g->Co, g->Ci, T, pl.nsplit,
+                           dbias ? p.bias_slab : nullptr, dbias);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, st, p.slab, dw_oihw, g->Co, g->Ci, T,
+                           pl.nsplit, dbias ? p.bias_slab : nullptr, dbias);
     SSD_CHECK_LAUNCH();
     return SSD_OK;
 }
