@@ -6,6 +6,7 @@
 // v_mfma_f32_32x32x2_f32, the A operand read straight from the halo image (k = (r*3+s)*3 + c selects a constant LDS offset, lanes
 // walk the pixels) -- and bias + ReLU + the NHWC store close it.  When the weight gradient wants them (training), the same workgroup
 // also writes its [pixel][32] rows from the halo image, so that the separate unfold pass and its read of x disappear as well.
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -363,41 +364,81 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     float* dsw = ds + wave * (32 * 64);
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int twi = tile % tiles_w, thi = (tile / tiles_w) % tiles_h, n = tile / (tiles_w * tiles_h);
-        const int h0 = thi * TH, w0 = twi * TW;
-        // dy of this wave's tile row first (two blocks of 32 pixels: lane = (pixel 4 t + lane / 16, channel quad lane % 16); zero outside
-        // the image): 16 loads in flight while the halo image is fetched
+    // Round 4: the NEXT tile's operands are requested while this tile is multiplied -- the dy registers of a 32-pixel block as soon as that
+    // block has been parked in LDS, the halo pixels behind them -- so that a tile's ~2 us of load latency hides under the previous tile's
+    // 64 MFMAs per wave instead of in front of its own (same sums in the same order: bit-identical).
+    constexpr int EPT = (3 * PLANE + 255) / 256;                       // halo elements per thread
+    int e_c[EPT], e_r[EPT], e_cc[EPT];
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        const int e = tid + 256 * u;
+        const int c = e / PLANE, rem = e - c * PLANE, r = rem / HW_;
+        e_c[u] = e < 3 * PLANE ? c : -1;
+        e_r[u] = r;
+        e_cc[u] = rem - r * HW_;
+    }
+    typedef typename std::conditional<DY_BF16, bf16x4, f32x4>::type dy4;
+    dy4 dv[2][8];
+    float hv[EPT];
+    auto origin = [&](int t, int& n, int& h0, int& w0) {
+        const int twi = t % tiles_w, thi = (t / tiles_w) % tiles_h;
+        n = t / (tiles_w * tiles_h);
+        h0 = thi * TH;
+        w0 = twi * TW;
+    };
+    // dy of this wave's tile row, block j of 32 pixels: lane = (pixel 4 t + lane / 16, channel quad lane % 16); zero outside the image
+    auto fetch_dy = [&](int t_, int j) {
+        int n, h0, w0;
+        origin(t_, n, h0, w0);
         const int oh = h0 + wave;
-        f32x4 dv[2][8];
+        const size_t so = (((size_t)n * H + oh) * W + w0 + 32 * j) * 64 + (lane & 15) * 4;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const size_t so = (((size_t)n * H + oh) * W + w0 + 32 * j) * 64 + (lane & 15) * 4;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int px = 4 * t + (lane >> 4);
-                dv[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (oh < H && w0 + 32 * j + px < W) {
-                    if constexpr (DY_BF16) {
-                        const bf16x4 b = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(dy) + so + (size_t)px * 64);
-                        dv[j][t] = f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
-                    } else {
-                        dv[j][t] = *reinterpret_cast<const f32x4*>(dy + so + (size_t)px * 64);
-                    }
-                }
+        for (int t = 0; t < 8; ++t) {
+            const int px = 4 * t + (lane >> 4);
+            if constexpr (DY_BF16) dv[j][t] = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+            else dv[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (oh < H && w0 + 32 * j + px < W) {
+                if constexpr (DY_BF16) dv[j][t] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(dy) + so + (size_t)px * 64);
+                else dv[j][t] = *reinterpret_cast<const f32x4*>(dy + so + (size_t)px * 64);
             }
         }
-        __syncthreads();                                               // the previous tile's halo image is no longer read
-        for (int e = tid; e < 3 * PLANE; e += 256) {
-            const int c = e / PLANE, rem = e - c * PLANE, r = rem / HW_, cc = rem - r * HW_;
-            const int ih = h0 - 1 + r, iw = w0 - 1 + cc;
-            xs[e] = ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) ? x[((size_t)n * 3 + c) * HWs + (size_t)ih * W + iw] : 0.f;
+    };
+    auto fetch_halo = [&](int t_) {
+        int n, h0, w0;
+        origin(t_, n, h0, w0);
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            const int ih = h0 - 1 + e_r[u], iw = w0 - 1 + e_cc[u];
+            hv[u] = (e_c[u] >= 0 && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+                        ? x[((size_t)n * 3 + e_c[u]) * HWs + (size_t)ih * W + iw] : 0.f;
         }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) {
+        fetch_dy(tile, 0);
+        fetch_dy(tile, 1);
+        fetch_halo(tile);
+    }
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        __syncthreads();                                               // the previous tile's halo image is no longer read
+#pragma unroll
+        for (int u = 0; u < EPT; ++u)
+            if (e_c[u] >= 0) xs[tid + 256 * u] = hv[u];
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) *reinterpret_cast<f32x4*>(dsw + (4 * t + (lane >> 4)) * 64 + (lane & 15) * 4) = dv[j][t];
+            for (int t = 0; t < 8; ++t) {
+                f32x4 v;
+                if constexpr (DY_BF16) v = f32x4{(float)dv[j][t][0], (float)dv[j][t][1], (float)dv[j][t][2], (float)dv[j][t][3]};
+                else v = dv[j][t];
+                *reinterpret_cast<f32x4*>(dsw + (4 * t + (lane >> 4)) * 64 + (lane & 15) * 4) = v;
+            }
+            if (next < ntiles) {                                       // this block's registers are free again: the next tile's block j
+                fetch_dy(next, j);
+                if (j == 1) fetch_halo(next);
+            }
             // the wave reads what it wrote itself: the LDS queue is in order
             const int bbase = wave * HW_ + 32 * j + my_off;
 #pragma unroll
